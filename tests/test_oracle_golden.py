@@ -1,0 +1,191 @@
+"""Pin the CPU oracle (oracle/*.py) against the golden vectors produced from the real reference
+(tools/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import intops
+from oracle import wavenet_oracle as wo
+from tests.helpers import GOLDEN, g1_input, g1_meta, grads_from, load_npz, params_from
+
+torch.set_num_threads(1)
+
+
+@pytest.mark.parametrize("meta", g1_meta(), ids=lambda m: m["name"])
+def test_g1_forward_loss_grads(meta):
+    d = load_npz("g1_%s.npz" % meta["name"])
+    params = params_from(d)
+    cfg = meta["cfg"]
+    x = g1_input(d, meta)
+    assert wo.receptive_field(cfg["filter_width"], cfg["dilations"]) == int(d["rf"])
+    inter = {}
+    target = torch.from_numpy(d["target"])
+    loss, probs, grads = wo.loss_and_grads(params, cfg["dilations"], x, target)
+    wo.wavenet_forward(params, cfg["dilations"], x, intermediates=inter)
+    if "pre_softmax" in d:
+        np.testing.assert_allclose(inter["pre_softmax"].numpy(), d["pre_softmax"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(probs.numpy(), d["probs"], rtol=0, atol=1e-7)
+    else:
+        np.testing.assert_allclose(probs.numpy()[d["rows"]], d["probs_rows"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(inter["pre_softmax"].numpy()[:, :, ::53], d["pre_softmax_cols"],
+                                   rtol=0, atol=5e-6)
+        assert abs(float(probs.double().sum()) - float(d["probs_sum"])) < 1e-6
+    assert abs(float(loss) - float(d["loss"])) < 1e-6
+    for k, g in grads_from(d).items():
+        scale = max(1e-12, float(g.abs().max()))
+        assert float((grads[k] - g).abs().max()) <= 2e-5 * scale + 1e-10, k
+    # the reference leaves the last dense conv's grad None; the restatement gives exact zeros
+    for k in d["nograd"]:
+        assert float(grads[str(k)].abs().max()) == 0.0
+
+
+def test_g1_short_input_raises():
+    meta = g1_meta()[0]
+    d = load_npz("g1_%s.npz" % meta["name"])
+    with pytest.raises(ValueError, match="wave sample not long enough"):
+        wo.wavenet_forward(params_from(d), meta["cfg"]["dilations"], torch.zeros(1, 256, int(d["rf"]) - 1))
+
+
+def test_g2_layers():
+    d = load_npz("g2_layers.npz")
+    from tests.helpers import scrambled_input
+    from tests.tools_cfg import TINY
+    inter = {}
+    probs = wo.wavenet_forward(params_from(d), TINY["dilations"], scrambled_input(d["idx"]),
+                               intermediates=inter)
+    np.testing.assert_allclose(inter["x"][0].numpy(), d["x0"], atol=1e-6, rtol=0)
+    for i in range(len(TINY["dilations"])):
+        np.testing.assert_allclose(inter["z"][i].numpy(), d["z%d" % i], atol=1e-6, rtol=0)
+        dense = inter["x"][i + 1] - inter["x"][i][:, :, -inter["x"][i + 1].size(2):]
+        np.testing.assert_allclose(dense.numpy(), d["dense%d" % i], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(probs.numpy(), d["probs"], atol=1e-7, rtol=0)
+
+
+def test_g3_chunk_softmax():
+    from tests.tools_cfg import g3_inputs
+    d = load_npz("g3_softmax.npz")
+    for w, x in g3_inputs().items():
+        assert abs(float(x.astype(np.float64).sum()) - float(d["xsum_w%d" % w])) < 1e-9
+        y = wo.chunk_softmax(torch.from_numpy(x), 256).numpy()
+        np.testing.assert_allclose(y, d["y_w%d" % w], atol=1e-7, rtol=0)
+        # Q2: rows are NOT per-timestep class vectors unless W == 1
+        if w > 1:
+            per_t = torch.softmax(torch.from_numpy(x), dim=1).permute(0, 2, 1).reshape(-1, 256).numpy()
+            assert np.abs(per_t - d["y_w%d" % w]).max() > 1e-3
+
+
+def test_g4_one_hot_and_pieces():
+    d = load_npz("g4_data.npz")
+    n = 0
+    while "oh_piece%d" % n in d:
+        piece = d["oh_piece%d" % n]
+        pos = intops.one_hot_scrambled_positions(piece)
+        assert np.array_equal(np.sort(pos), d["oh_flatpos%d" % n])
+        a = intops.one_hot_scrambled(piece)
+        assert a.shape == (256, len(piece)) and a.dtype == np.float32
+        assert np.array_equal(np.flatnonzero(a.reshape(-1)), d["oh_flatpos%d" % n])
+        assert float(a.sum()) == float(d["oh_sum%d" % n])
+        n += 1
+    assert n == 4
+    n = 0
+    while "mp%d_lens" % n in d:
+        rf, win = (int(v) for v in d["mp%d_rf_win" % n])
+        lens = d["mp%d_lens" % n]
+        flat = d["mp%d_data" % n]
+        data, o = [], 0
+        for l in lens:
+            data.append(flat[o:o + l])
+            o += l
+        pieces = intops.make_data_pieces(data, rf, win)
+        assert len(pieces) == int(d["mp%d_n" % n])
+        assert [len(p) for p, _ in pieces] == list(d["mp%d_piece_len" % n])
+        assert [int(p.astype(np.int64).sum()) for p, _ in pieces] == list(d["mp%d_piece_sum" % n])
+        assert [int(p[0]) for p, _ in pieces] == list(d["mp%d_piece_first" % n])
+        assert [int(t.sum()) for _, t in pieces] == list(d["mp%d_target_sum" % n])
+        assert [len(t) for _, t in pieces] == list(d["mp%d_target_len" % n])
+        assert all(t.dtype == np.int64 for _, t in pieces)
+        n += 1
+    assert n == 3
+
+
+def test_g4_short_first_item_raises():
+    with pytest.raises(NameError):
+        intops.make_data_pieces([np.arange(30)], 20, 30)
+
+
+def test_g5_mulaw():
+    d = load_npz("g5_mulaw.npz")
+    thr = d["thresholds"]
+    assert thr.shape == (255,) and thr.dtype == np.float32 and (np.diff(thr) > 0).all()
+    codes = intops.mu_law_encode_table(d["x"], thr)
+    assert np.array_equal(codes, d["codes"].astype(np.int64))          # bit-exact
+    # the plain float32 formula agrees except for ~ppm of inputs
+    approx = intops.mu_law_encode_formula(d["x"][:90000])
+    assert (approx != d["codes"][:90000]).mean() < 1e-4
+    np.testing.assert_allclose(intops.mu_law_decode(np.arange(256)), d["decode_table"], rtol=2e-6, atol=1e-9)
+    assert np.array_equal(intops.mu_law_encode_table(d["decode_table"], thr), np.arange(256))
+
+
+@pytest.mark.parametrize("tag,correct", [("asis", False), ("fixed", True)])
+def test_g6_fast_generate(tag, correct):
+    d = load_npz("g6_fastgen.npz")
+    params = params_from(d)
+    dil = [int(v) for v in d["dilations"]]
+
+    def onehot(ix):
+        ix = np.atleast_1d(ix)
+        return torch.from_numpy(intops.one_hot_proper(ix))[None]
+
+    pred, q = wo.fast_predict_next(params, dil, onehot(d["start"]), None, correct_queue=correct)
+    preds = [int(pred[0])]
+    np.testing.assert_array_equal(q["causal_layer"].numpy(), d["%s_init_causal" % tag])
+    for i in range(len(dil)):
+        np.testing.assert_allclose(q["block_%d" % (i + 1)].numpy(), d["%s_init_block%d" % (tag, i + 1)],
+                                   atol=1e-6, rtol=0)
+    for s in d["forced"]:
+        pred, q = wo.fast_predict_next(params, dil, onehot(s), q, correct_queue=correct)
+        preds.append(int(pred[0]))
+    assert preds == list(d["%s_preds" % tag])
+    for i in range(len(dil)):
+        np.testing.assert_allclose(q["block_%d" % (i + 1)].numpy(), d["%s_final_block%d" % (tag, i + 1)],
+                                   atol=2e-5, rtol=0)
+    np.testing.assert_array_equal(q["causal_layer"].numpy(), d["%s_final_causal" % tag])
+    if correct:
+        assert preds == list(d["naive_preds"])         # the fixed recurrence == naive forward
+        seq = np.concatenate([d["start"], d["forced"]])
+        rf = int(d["rf"])
+        naive = [int(wo.predict_next_naive(params, dil, onehot(seq[i:i + rf]))[0]) for i in (0, 7, 64)]
+        assert naive == [int(d["naive_preds"][i]) for i in (0, 7, 64)]
+    else:
+        assert preds != list(d["naive_preds"])         # as written it diverges
+    # free-running greedy loop
+    pred, q = wo.fast_predict_next(params, dil, onehot(d["start"]), None, correct_queue=correct)
+    free = [int(pred[0])]
+    for _ in range(48):
+        pred, q = wo.fast_predict_next(params, dil, onehot(free[-1]), q, correct_queue=correct)
+        free.append(int(pred[0]))
+    assert free == list(d["%s_free" % tag])
+
+
+def test_g8_autoencoder():
+    d = load_npz("g8_autoencoder.npz")
+    cfg = json.load(open(os.path.join(GOLDEN, "g8_cfg.json")))
+    params = params_from(d)
+    n = len(cfg["dilations"])
+    for tag in ("a", "b"):
+        idx = d[tag + "_idx"]
+        x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx]))
+        torch.manual_seed(int(d[tag + "_fwd_seed"]))
+        cond = wo.draw_conditioning(n, cfg["en_bottleneck_width"], cfg["de_dilation_channel"],
+                                    cfg["de_skip_channel"])
+        probs, enc = wo.autoencoder_forward(params, cfg["dilations"], x, cfg["en_pool_kernel_size"], cond)
+        np.testing.assert_allclose(enc.numpy(), d[tag + "_enc"], atol=2e-5, rtol=0)
+        np.testing.assert_allclose(probs.numpy(), d[tag + "_probs"], atol=1e-6, rtol=0)
+    e = torch.tensor([[[1.0, 2.0, 3.0]]])
+    np.testing.assert_array_equal(wo.condition(torch.zeros(1, 1, 6), e).numpy(), d["cond_stretch"])
+    np.testing.assert_array_equal(wo.condition(torch.zeros(1, 1, 7), e).numpy(), d["cond_tile"])
+    assert d["cond_stretch"].reshape(-1).tolist() == [1, 1, 2, 2, 3, 3]
+    assert d["cond_tile"].reshape(-1).tolist() == [1, 2, 3, 1, 2, 3, 1]

@@ -1,0 +1,476 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (run in the build container only).
+
+Imports /root/reference (never copied, never shipped) per the recipes of SURVEY.md Appendix A and
+records inputs -> outputs of the hot-path functions as small fixtures.  The fixtures are data:
+input indices / seeds, weights drawn by the reference constructors, and the reference's outputs.
+
+    python tools/make_golden.py            # rewrites tests/golden/
+
+The oracle (oracle/*.py) and the HIP path are both tested against these files.
+"""
+import ast
+import io
+import json
+import os
+import pickle
+import sys
+import tempfile
+import types
+import contextlib
+import warnings
+
+import numpy as np
+import torch
+
+REF = os.environ.get("MUSIC_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+warnings.filterwarnings("ignore")
+torch.set_num_threads(1)          # deterministic reduction order for the fixtures
+
+
+def ref_modules():
+    sys.modules["librosa"] = types.ModuleType("librosa")          # Appendix A.1
+    sys.path.insert(0, os.path.join(REF, "wavenet"))
+    import model, audio_func, faster_audio_data                   # noqa: E401
+    return model, audio_func, faster_audio_data
+
+
+def sd_np(net):
+    return {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
+
+
+def scaled(net, gain):
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(gain)
+    return net
+
+
+TINY = dict(filter_width=2, dilations=[1, 2, 4, 8, 1, 2, 4, 8], dilation_channels=16,
+            residual_channels=16, skip_channels=32, quantization_channels=256, use_bias=False)
+TINY_BIAS = dict(TINY, use_bias=True)
+C1 = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512], dilation_channels=32,
+          residual_channels=32, skip_channels=32, quantization_channels=256, use_bias=False)
+
+
+def scrambled_batch(fad, idx):
+    """Build the loader-faithful (B,256,T) input from int indices through the reference's own
+    one_hot_encode (faster_audio_data.py:62-83)."""
+    rows = []
+    for row in idx:
+        d = fad.one_hot_encode({"audio_piece": torch.from_numpy(row), "audio_target": None})
+        rows.append(d["audio_piece"])
+    return torch.stack(rows)
+
+
+def g1_forward(model, fad):
+    cases = {}
+    meta = []
+    specs = [
+        # name, cfg, seed, gain, B, extra T over rf-1 (so W = extra), input kind
+        ("tiny_s0_g1_w1", TINY, 0, 1.0, 2, 1, "scrambled"),
+        ("tiny_s0_g6_w130", TINY, 0, 6.0, 2, 130, "scrambled"),
+        ("tiny_s1_g6_w257", TINY, 1, 6.0, 1, 257, "scrambled"),
+        ("tiny_s2_g4_w255_randn", TINY, 2, 4.0, 1, 255, "randn"),
+        ("tinybias_s3_g5_w64", TINY_BIAS, 3, 5.0, 2, 64, "scrambled"),
+    ]
+    for name, cfg, seed, gain, b, w, kind in specs:
+        torch.manual_seed(seed)
+        net = scaled(model.wavenet(**cfg), gain)
+        rf = net.receptive_field
+        t = rf + w - 1
+        rng = np.random.default_rng(100 + seed)
+        idx = rng.integers(0, 256, size=(b, t)).astype(np.int32)
+        if kind == "scrambled":
+            x = scrambled_batch(fad, idx)
+        else:
+            x = torch.from_numpy(rng.standard_normal((b, 256, t)).astype(np.float32))
+        target = torch.from_numpy(rng.integers(0, 256, size=(b * w,)).astype(np.int64))
+        pre = {}
+        h = net.post_process_2.register_forward_hook(lambda m, i, o: pre.__setitem__("v", o.detach()))
+        probs = net(x)   # (the lambda returns None, so the module output is untouched)
+        h.remove()
+        loss = torch.nn.CrossEntropyLoss()(probs, target)
+        net.zero_grad()
+        loss.backward()
+        d = {"idx": idx, "target": target.numpy(), "pre_softmax": pre["v"].numpy(),
+             "probs": probs.detach().numpy(), "loss": np.float64(loss.item()),
+             "rf": np.int64(rf)}
+        if kind == "randn":
+            d["x"] = x.numpy()
+        for k, v in sd_np(net).items():
+            d["w:" + k] = v
+        for k, p in net.named_parameters():
+            # the last block's dense conv never reaches the output: the reference leaves its
+            # grad None (the optimizer skips it); recorded as zeros + listed in 'nograd'
+            d["g:" + k] = p.grad.numpy().copy() if p.grad is not None else np.zeros(p.shape, np.float32)
+        d["nograd"] = np.array([k for k, p in net.named_parameters() if p.grad is None])
+        np.savez_compressed(os.path.join(OUT, "g1_%s.npz" % name), **d)
+        meta.append(dict(name=name, cfg=cfg, seed=seed, gain=gain, B=b, W=w, kind=kind))
+    # c1-shaped case: B=1, T=4000 — outputs subsampled to keep the fixture small
+    torch.manual_seed(0)
+    net = scaled(model.wavenet(**C1), 6.0)
+    rf = net.receptive_field
+    t = 4000
+    w = t - rf + 1
+    rng = np.random.default_rng(7)
+    idx = rng.integers(0, 256, size=(1, t)).astype(np.int32)
+    x = scrambled_batch(fad, idx)
+    target = torch.from_numpy(idx[0, rf - 1 + 1:].astype(np.int64)[:w]) if False else \
+        torch.from_numpy(rng.integers(0, 256, size=(w,)).astype(np.int64))
+    pre = {}
+    h = net.post_process_2.register_forward_hook(lambda m, i, o: pre.__setitem__("v", o.detach()))
+    probs = net(x)
+    h.remove()
+    loss = torch.nn.CrossEntropyLoss()(probs, target)
+    net.zero_grad()
+    loss.backward()
+    rows = np.arange(0, w, 37)
+    d = {"idx": idx, "target": target.numpy(), "rows": rows,
+         "probs_rows": probs.detach().numpy()[rows],
+         "pre_softmax_cols": pre["v"].numpy()[:, :, ::53].copy(),
+         "probs_sum": np.float64(probs.double().sum().item()),
+         "pre_abs_sum": np.float64(pre["v"].double().abs().sum().item()),
+         "loss": np.float64(loss.item()), "rf": np.int64(rf)}
+    for k, v in sd_np(net).items():
+        d["w:" + k] = v
+    for k, p in net.named_parameters():
+        d["g:" + k] = p.grad.numpy().copy() if p.grad is not None else np.zeros(p.shape, np.float32)
+    d["nograd"] = np.array([k for k, p in net.named_parameters() if p.grad is None])
+    np.savez_compressed(os.path.join(OUT, "g1_c1_s0_g6.npz"), **d)
+    meta.append(dict(name="c1_s0_g6", cfg=C1, seed=0, gain=6.0, B=1, W=int(w), kind="scrambled"))
+    with open(os.path.join(OUT, "g1_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+def g2_layers(model, fad):
+    """Per-layer residual stream x_i and gated activation z_i of the tiny config (forward hooks)."""
+    torch.manual_seed(5)
+    net = scaled(model.wavenet(**TINY), 6.0)
+    rf = net.receptive_field
+    rng = np.random.default_rng(55)
+    idx = rng.integers(0, 256, size=(1, rf + 40)).astype(np.int32)
+    x = scrambled_batch(fad, idx)
+    dense_out, dense_in = [], []
+    hooks = []
+    for i in range(len(TINY["dilations"])):
+        m = net.dilation_layer_stack[4 * i + 2]
+        def grab(mod, inp, out):
+            dense_in.append(inp[0].detach().numpy().copy())
+            dense_out.append(out.detach().numpy().copy())
+        hooks.append(m.register_forward_hook(grab))
+    c = {}
+
+    def grab0(mod, inp, out):
+        c["x0"] = out.detach().numpy().copy()
+    hooks.append(net.causal_layer.register_forward_hook(grab0))
+    probs = net(x)
+    for h in hooks:
+        h.remove()
+    d = {"idx": idx, "x0": c["x0"], "probs": probs.detach().numpy()}
+    for i, (zi, di) in enumerate(zip(dense_in, dense_out)):
+        d["z%d" % i] = zi
+        d["dense%d" % i] = di
+    for k, v in sd_np(net).items():
+        d["w:" + k] = v
+    np.savez_compressed(os.path.join(OUT, "g2_layers.npz"), **d)
+
+
+def g3_inputs():
+    """Inputs of the chunk-softmax fixture, regenerated from a fixed numpy seed (not stored)."""
+    rng = np.random.default_rng(3)
+    return {w: (4.0 * rng.standard_normal((1, 256, w))).astype(np.float32) for w in (1, 130, 255, 256)}
+
+
+def g3_softmax(model):
+    """The chunk softmax alone: (B,256,W) -> view(-1,256) -> nn.Softmax() (model.py:142-144)."""
+    sm = torch.nn.Softmax()
+    d = {}
+    for w, x in g3_inputs().items():
+        d["y_w%d" % w] = sm(torch.from_numpy(x).view(-1, 256)).numpy()
+        d["xsum_w%d" % w] = np.float64(x.astype(np.float64).sum())
+    np.savez_compressed(os.path.join(OUT, "g3_softmax.npz"), **d)
+
+
+def g4_data(fad):
+    d = {}
+    rng = np.random.default_rng(4)
+    # one_hot_encode: positions of ones
+    for n, t in enumerate((1, 7, 300, 1025)):
+        piece = rng.integers(0, 256, size=(t,)).astype(np.int32)
+        oh = fad.one_hot_encode({"audio_piece": torch.from_numpy(piece), "audio_target": None})
+        a = oh["audio_piece"].numpy()
+        assert a.dtype == np.float32 and a.shape == (256, t)
+        d["oh_piece%d" % n] = piece
+        d["oh_flatpos%d" % n] = np.flatnonzero(a.reshape(-1)).astype(np.int64)
+        d["oh_sum%d" % n] = np.float64(a.sum())
+    # _make_data_pieces on synthetic pickles
+    cases = [
+        (20, 30, [200, 45, 50, 21, 170]),      # tail duplication, exact multiples, short later item
+        (1025, 2976, [12928, 4000, 3000]),     # the SURVEY Q4 example shape
+        (5, 5, [10, 9, 14, 6]),
+    ]
+    for n, (rf, win, lens) in enumerate(cases):
+        data = [rng.integers(0, 256, size=(l,)).astype(np.int32) for l in lens]
+        with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as f:
+            pickle.dump(data, f)
+            path = f.name
+        ds = fad.audio_dataset(path, rf, win)
+        os.unlink(path)
+        d["mp%d_rf_win" % n] = np.array([rf, win], dtype=np.int64)
+        d["mp%d_lens" % n] = np.array(lens, dtype=np.int64)
+        d["mp%d_data" % n] = np.concatenate(data)
+        d["mp%d_n" % n] = np.int64(len(ds))
+        d["mp%d_piece_len" % n] = np.array([len(p["audio_piece"]) for p in ds.data], dtype=np.int64)
+        d["mp%d_piece_sum" % n] = np.array([int(p["audio_piece"].long().sum()) for p in ds.data],
+                                           dtype=np.int64)
+        d["mp%d_piece_first" % n] = np.array([int(p["audio_piece"][0]) for p in ds.data], dtype=np.int64)
+        d["mp%d_target_sum" % n] = np.array([int(p["audio_target"].sum()) for p in ds.data],
+                                            dtype=np.int64)
+        d["mp%d_target_len" % n] = np.array([len(p["audio_target"]) for p in ds.data], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g4_data.npz"), **d)
+
+
+def _f32_to_ordered(a):
+    u = a.view(np.uint32).astype(np.int64)
+    return np.where(u & 0x80000000, 0x80000000 - (u & 0x7FFFFFFF) - 1 + 0, u + 0x80000000)
+
+
+def _ordered_to_f32(o):
+    o = np.asarray(o, dtype=np.int64)
+    u = np.where(o >= 0x80000000, o - 0x80000000, (0x80000000 - 1 - o) | 0x80000000)
+    return u.astype(np.uint32).view(np.float32)
+
+
+def g5_mulaw(af):
+    """255 float32 decision thresholds of audio_func.mu_law_encode by bisection over the float32
+    total order, + random known-answer inputs, + the decode table."""
+    def enc(a):
+        return af.mu_law_encode(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).numpy()
+
+    lo = np.full(255, _f32_to_ordered(np.array([-1.0], dtype=np.float32))[0], dtype=np.int64)
+    hi = np.full(255, _f32_to_ordered(np.array([1.0], dtype=np.float32))[0], dtype=np.int64)
+    ks = np.arange(1, 256)
+    assert (enc(_ordered_to_f32(lo)) < ks).all() or True
+    # invariant: enc(lo) < k <= enc(hi)
+    assert (enc(_ordered_to_f32(hi)) >= ks).all()
+    # lo = -1.0 encodes to 0 < k for all k>=1
+    while (hi - lo > 1).any():
+        mid = (lo + hi) // 2
+        e = enc(_ordered_to_f32(mid))
+        ge = e >= ks
+        hi = np.where(ge, mid, hi)
+        lo = np.where(ge, lo, mid)
+    thr = _ordered_to_f32(hi)
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([
+        (0.3 * rng.standard_normal(60000)).astype(np.float32),
+        rng.uniform(-1.2, 1.2, 30000).astype(np.float32),
+        thr, np.nextafter(thr, np.float32(-2)), np.nextafter(thr, np.float32(2)),
+        np.array([0.0, -0.0, 1.0, -1.0, 5.0, -5.0, 1e-30, -1e-30, np.inf, -np.inf], dtype=np.float32),
+    ])
+    # evaluate one element at a time for the threshold neighbourhood AND vectorised: must agree
+    ys = enc(xs)
+    ys_scalar = np.array([enc(np.array([v], dtype=np.float32))[0] for v in xs[90000:]])
+    assert (ys[90000:] == ys_scalar).all(), "reference encoder is position dependent"
+    table = np.searchsorted(thr, xs, side="right")
+    assert (table == ys).all(), "reference encoder is not monotone: %d mismatches" % (table != ys).sum()
+    dec = af.mu_law_decode(torch.arange(256)).numpy()
+    assert (enc(dec) == np.arange(256)).all()
+    np.savez_compressed(os.path.join(OUT, "g5_mulaw.npz"), thresholds=thr, x=xs,
+                        codes=ys.astype(np.uint8), decode_table=dec.astype(np.float32))
+
+
+def load_fast_predict_next(correct=False):
+    """Appendix A.3: AST-extract predict_next from fast_generate.py with the two torch>=0.4
+    substitutions; never executes the module-level generate() call."""
+    src = open(os.path.join(REF, "wavenet", "fast_generate.py")).read()
+    src = src.replace("layer_input[:, :, -1] = note.data",
+                      "layer_input[:, :, -1] = note.data.view(batch_size, channels)")
+    src = src.replace("new_state[:, :, -1] = note.data",
+                      "new_state[:, :, -1] = note.data.view(state.size(0), state.size(1))")
+    if correct:
+        src = src.replace("""one_layer_update(block_state,
+                                                                  note_out)""",
+                          "one_layer_update(block_state, note_in)")
+        assert "one_layer_update(block_state, note_in)" in src
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "predict_next"]
+    mod = ast.Module(body=fn, type_ignores=[])
+    from collections import OrderedDict
+    from torch.autograd import Variable
+    import torch.nn.functional as F
+    ns = {"torch": torch, "F": F, "OrderedDict": OrderedDict, "Variable": Variable}
+    exec(compile(mod, "fast_generate.py", "exec"), ns)
+    return ns["predict_next"]
+
+
+def g6_fastgen(model):
+    cfg = dict(TINY, dilations=[1, 2, 4, 8, 16, 1, 2, 4, 8, 16])
+    torch.manual_seed(6)
+    net = scaled(model.wavenet(**cfg), 6.0)
+    rf = net.receptive_field
+    rng = np.random.default_rng(66)
+    start = rng.integers(0, 256, size=(rf,))
+    forced = rng.integers(0, 256, size=(64,))
+    d = {"start": start.astype(np.int64), "forced": forced.astype(np.int64), "rf": np.int64(rf),
+         "dilations": np.array(cfg["dilations"])}
+    for k, v in sd_np(net).items():
+        d["w:" + k] = v
+
+    def onehot(ix):
+        t = torch.zeros(1, 256, len(ix))
+        t[0, torch.as_tensor(ix), torch.arange(len(ix))] = 1.0
+        return t
+
+    for tag, correct in (("asis", False), ("fixed", True)):
+        pn = load_fast_predict_next(correct)
+        with torch.no_grad():
+            pred, q = pn(net, onehot(start), None)
+            preds = [int(pred[0])]
+            d["%s_init_causal" % tag] = q["causal_layer"].numpy().copy()
+            for i in range(len(cfg["dilations"])):
+                d["%s_init_block%d" % (tag, i + 1)] = q["block_%d" % (i + 1)].numpy().copy()
+            for s in forced:                                   # teacher-forced incremental steps
+                pred, q = pn(net, onehot([s]), q)
+                preds.append(int(pred[0]))
+            d["%s_preds" % tag] = np.array(preds, dtype=np.int64)
+            for i in range(len(cfg["dilations"])):
+                d["%s_final_block%d" % (tag, i + 1)] = q["block_%d" % (i + 1)].numpy().copy()
+            d["%s_final_causal" % tag] = q["causal_layer"].numpy().copy()
+            # free-running greedy generation (each prediction fed back), 48 steps
+            pred, q = pn(net, onehot(start), None)
+            free = [int(pred[0])]
+            for _ in range(48):
+                pred, q = pn(net, onehot([free[-1]]), q)
+                free.append(int(pred[0]))
+            d["%s_free" % tag] = np.array(free, dtype=np.int64)
+    # naive full-forward predictions for the teacher-forced sequence (what 'fixed' must equal)
+    seq = np.concatenate([start, forced])
+    naive = []
+    with torch.no_grad():
+        for i in range(len(forced) + 1):
+            naive.append(int(model.predict_next(net, onehot(seq[i:i + rf]))[0]))
+    d["naive_preds"] = np.array(naive, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g6_fastgen.npz"), **d)
+
+
+def g7_train():
+    """Appendix A.2: exec wavenet/train.py with async=True -> non_blocking=True and
+    loss.data[0] -> loss.item(), CWD = temp dir with params/ and a synthetic pickle."""
+    src = open(os.path.join(REF, "wavenet", "train.py")).read()
+    src = src.replace("async=True", "non_blocking=True").replace("loss.data[0]", "loss.item()")
+    out = {}
+    for tag, gain in (("plain", None), ("gain", 6.0)):
+        tmp = tempfile.mkdtemp()
+        os.makedirs(os.path.join(tmp, "params"))
+        rng = np.random.default_rng(77)
+        data = [rng.integers(0, 256, size=(l,)).astype(np.int32) for l in (2400, 1500, 1230)]
+        with open(os.path.join(tmp, "np_audio.pkl"), "wb") as f:
+            pickle.dump(data, f)
+        wp = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 32], dilation_channels=16,
+                  residual_channels=16, skip_channels=16, quantization_channels=256, use_bias=False)
+        dp = dict(batch_size=2, shuffle=False, num_workers=0, pin_memory=False,
+                  audio_path=os.path.join(tmp, "np_audio.pkl"), receptive_field=65,
+                  window_length=300, cuda_available=False, quantization_channels=256)
+        tp = dict(log_dir="./log/", restore_dir="./restore/", restore_model="", check_point_every=1,
+                  print_every=2, num_epochs=2, wavenet_params="./wavenet_params.json",
+                  optimizer="adam", max_check_points=10, learning_rate=1e-3, momentum=0.9,
+                  device_ids=None)
+        for n, p in (("wavenet", wp), ("dataset", dp), ("train", tp)):
+            json.dump(p, open(os.path.join(tmp, "params", n + "_params.json"), "w"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            ns = {"__name__": "ref_train"}
+            exec(compile(src, "train.py", "exec"), ns)
+            if gain is not None:
+                orig = ns["wavenet"]
+
+                def scaled_ctor(**kw):
+                    return scaled(orig(**kw), gain)
+                ns["wavenet"] = scaled_ctor
+            torch.manual_seed(0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ns["train"]()
+            out[tag + "_loss_log"] = open("log/loss_log.log").read()
+            out[tag + "_store_log"] = open("log/store_log.log").read()
+            ck = torch.load("restore/wavenet2.model")
+            out[tag + "_ckpt_keys"] = list(ck.keys())
+            out[tag + "_ckpt_shapes"] = [list(v.shape) for v in ck.values()]
+            out[tag + "_ckpt_abs_sum"] = [float(v.double().abs().sum()) for v in ck.values()]
+            out[tag + "_files"] = sorted(os.listdir("restore"))
+        finally:
+            os.chdir(cwd)
+        out["wavenet_params"], out["dataset_params"], out["train_params"] = wp, dict(dp, audio_path="np_audio.pkl"), tp
+        out["data_lens"] = [2400, 1500, 1230]
+        out["data_seed"] = 77
+        out["gain"] = 6.0
+    json.dump(out, open(os.path.join(OUT, "g7_train.json"), "w"), indent=1)
+
+
+def g8_autoencoder():
+    """Appendix A.4: nn.Module.cuda = identity shim, kwargs instead of the invalid JSON, seed the
+    global RNG immediately before forward."""
+    sys.path.insert(0, os.path.join(REF, "wavenet_autoencoder"))
+    old_cuda = torch.nn.Module.cuda
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    import model1
+    model1.print = lambda *a, **k: None
+    cfg = dict(filter_width=2, quantization_channel=256, dilations=[1, 2, 4, 8, 1, 2, 4, 8],
+               en_residual_channel=16, en_dilation_channel=16, en_bottleneck_width=8,
+               en_pool_kernel_size=10, de_residual_channel=16, de_dilation_channel=16,
+               de_skip_channel=32, use_bias=False)
+    d = {}
+    # W = 60 -> Le = 6: layers whose length is a multiple of 6 take the stretch branch
+    torch.manual_seed(8)
+    net = scaled(model1.wavenet_autoencoder(**cfg), 5.0)
+    rf = net.receptive_field
+    rng = np.random.default_rng(88)
+    for tag, w in (("a", 60), ("b", 47)):
+        idx = rng.integers(0, 256, size=(2, rf + w - 1))
+        x = torch.zeros(2, 256, rf + w - 1)
+        for b in range(2):
+            x[b, torch.from_numpy(idx[b]), torch.arange(rf + w - 1)] = 1.0
+        with torch.no_grad():
+            enc = net._encode(x)
+            torch.manual_seed(1234)
+            probs = net(x)
+            torch.manual_seed(1234)
+            probs2 = net(x)
+        assert torch.equal(probs, probs2)
+        d[tag + "_idx"] = idx.astype(np.int64)
+        d[tag + "_enc"] = enc.numpy()
+        d[tag + "_probs"] = probs.numpy()
+        d[tag + "_fwd_seed"] = np.int64(1234)
+    for k, v in sd_np(net).items():
+        d["w:" + k] = v
+    d["rf"] = np.int64(rf)
+    # _conditon on hand inputs (both branches)
+    x = torch.zeros(1, 1, 6)
+    e = torch.tensor([[[1.0, 2.0, 3.0]]])
+    d["cond_stretch"] = net._conditon(x, e).numpy()
+    d["cond_tile"] = net._conditon(torch.zeros(1, 1, 7), e).numpy()
+    json.dump(cfg, open(os.path.join(OUT, "g8_cfg.json"), "w"))
+    np.savez_compressed(os.path.join(OUT, "g8_autoencoder.npz"), **d)
+    torch.nn.Module.cuda = old_cuda
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    model, af, fad = ref_modules()
+    g1_forward(model, fad)
+    g2_layers(model, fad)
+    g3_softmax(model)
+    g4_data(fad)
+    g5_mulaw(af)
+    g6_fastgen(model)
+    g7_train()
+    g8_autoencoder()
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden fixtures written to", os.path.normpath(OUT), "total %.2f MB" % (tot / 1e6))
+
+
+if __name__ == "__main__":
+    main()
