@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio samples/sec trained, 30-layer WaveNet @16 kHz (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torch.distributed, backend nccl = RCCL); weak scaling, 8 clips x 16000 samples
+per GPU.  One "step" = on-device one-hot build + forward + CrossEntropy-on-probabilities +
+backward + gradient all-reduce (N > 1) + Adam, i.e. wavenet/train.py:171-182 of the reference, with
+the int32 sample codes already resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 3, dilation_channels=64,
+           residual_channels=64, skip_channels=256, quantization_channels=256, use_bias=False)
+B_LOCAL, T = 8, 16000
+HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec); 6.29e12 measured copy
+
+
+def synth_codes(rank, b, t):
+    """rng(1234+rank), 0.3*N(0,1) clipped to [-1,1] -> canonical mu-law codes."""
+    rng = np.random.default_rng(1234 + rank)
+    a = np.clip(0.3 * rng.standard_normal((b, t + 1)), -1.0, 1.0).astype(np.float32)
+    tabs = np.load(os.path.join(ROOT, "music_amd", "mulaw_tables.npz"))
+    from music_amd import _lib
+    from music_amd._lib import call, ptr
+    ad = torch.from_numpy(a).cuda()
+    thr = torch.from_numpy(tabs["thresholds"]).cuda()
+    codes = torch.empty(a.size, dtype=torch.uint8, device="cuda")
+    call("wn_mulaw_encode_tbl", ptr(ad), ptr(thr), ptr(codes), a.size, _lib.stream())
+    return codes.view(b, t + 1).to(torch.int32)
+
+
+def stack_bytes(dil, r, d, b, t):
+    """SURVEY §8(d) algorithmic bytes of the dilated-conv stack, fp32, per step (B clips)."""
+    L = [t - 1]
+    for x in dil:
+        L.append(L[-1] - x)
+    w = L[-1]
+    fwd = 4 * sum(r * L[i] + r * L[i + 1] + d * w for i in range(len(dil)))
+    bwd = 4 * sum(r * L[i + 1] + r * L[i] + d * w + r * L[i] for i in range(len(dil)))
+    return fwd * b, bwd * b
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (== the reference's ATen-CPU op sequence, pinned by tests/golden) timed on
+    this host: full training step (forward + CE + backward + Adam) on ONE clip of 16000 samples."""
+    from oracle import wavenet_oracle as wo
+    from oracle import intops
+    torch.manual_seed(0)
+    from music_amd.model import wavenet
+    net = wavenet(**CFG)
+    params = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-4)
+    rng = np.random.default_rng(1234)
+    codes = rng.integers(0, 256, size=(T + 1,))
+    x = torch.from_numpy(intops.one_hot_scrambled(codes[:T]))[None]
+    rf = 3071
+    target = torch.from_numpy(codes[rf:rf + T - rf + 1].astype(np.int64))
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        t0 = time.time()
+        opt.zero_grad()
+        loss = wo.ce_on_probs(wo.wavenet_forward(params, CFG["dilations"], x), target)
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": T / best, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d full training steps (fwd+CE+bwd+Adam) of the 30-layer config on 1 clip x 16000 samples, "
+                      "torch CPU threads=%d, best of %d after 1 warm-up" % (len(times), cores, max(1, len(times) - 1))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="f16x3,bf16x3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="print the per-phase GPU time table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" %
+                             (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from music_amd.model import wavenet
+    torch.manual_seed(0)                               # identical replicas on every rank
+    net = wavenet(**CFG)
+    net.precision = tuple(args.precision.split(","))
+    net = net.cuda()
+    eng = net._engine_for(torch.device("cuda", local))
+    eng.adam_init(lr=1e-4)
+    codes = synth_codes(rank, B_LOCAL, T)
+    rf = net.receptive_field
+    W = T - rf + 1
+    piece = codes[:, :T].contiguous()
+    target = codes[:, rf:rf + W].to(torch.int64).contiguous().view(-1)
+
+    def step():
+        x = eng.onehot(piece, scrambled=True)
+        loss = eng.loss_and_grad(x, target)
+        if world > 1:
+            dist.all_reduce(eng.flat_grad)
+            eng.mark("allreduce")
+        eng.adam_step(gscale=1.0 / world)
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    eng.marks = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    marks, eng.marks = eng.marks, None
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+
+    # per-phase GPU time from the HIP events recorded on the launch stream inside the timed region
+    phase = {}
+    for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+        phase[n1] = phase.get(n1, 0.0) + e0.elapsed_time(e1)
+    phase = {k: v / args.steps for k, v in phase.items()}       # ms per step
+    if args.phases and rank == 0:
+        print(json.dumps({"phase_ms_per_step": phase}), file=sys.stderr)
+
+    fwd_b, bwd_b = stack_bytes(CFG["dilations"], 64, 64, B_LOCAL, T)
+    n_layers = len(CFG["dilations"])
+    stack_fwd_s = phase.get("stack_fwd", float("nan")) * 1e-3
+    achieved = fwd_b / stack_fwd_s / 1e9 if stack_fwd_s == stack_fwd_s and stack_fwd_s > 0 else None
+    out = {
+        "metric": "audio samples/sec trained (whole node), 30-layer WaveNet @16kHz",
+        "value": world * B_LOCAL * T * args.steps / dt,
+        "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (f16/bf16 2-term split operands, 3 MFMA per product, f32 accumulate)"
+                 if args.precision == "f16x3,bf16x3" else args.precision,
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: 30-layer (3x dilations 1..512) WaveNet, 64 res/dil, 256 skip, "
+                               "batch 8x16000 per GPU, full train step (one-hot + fwd + CE + bwd + all-reduce + Adam)",
+                   "global_batch": world * B_LOCAL, "seq_len": T, "parallelism": "dp%d" % world,
+                   "precision": args.precision, "final_loss": float(loss.item())},
+        "roofline": {"bound": "hbm", "kernel": "resblock_fwd_k (30 launches/step)",
+                     "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": (achieved * 1e9 / HBM_PEAK) if achieved else None, "traffic": None,
+                     "algorithmic_bytes_per_launch": fwd_b / n_layers,
+                     "avg_launch_ms": phase.get("stack_fwd", float("nan")) / n_layers,
+                     "stack_fwd_bwd_frac": ((fwd_b + bwd_b) / ((phase.get("stack_fwd", 0) + phase.get("stack_bwd", 0)) * 1e-3) / HBM_PEAK)
+                     if phase.get("stack_bwd") else None},
+        "phase_ms_per_step": {k: round(v, 4) for k, v in phase.items()},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+/* libwavenet_hip.so — C ABI of the MI355X (gfx950) WaveNet hot path.
+ *
+ * The reference (deep-art-project/Music) is pure Python/PyTorch: it has no FFI, plugin table or
+ * operator registry for this path.  The drop-in boundary is therefore the
+ * torch.nn.Module surface of wavenet/model.py, which music_amd/model.py mirrors; that module calls
+ * ONLY the entry points below (through ctypes, music_amd/_lib.py).  Each entry point names the
+ * reference code it replaces.  INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Rules of the ABI
+ *   - plain C types only: device pointers, sizes, a stream handle (hipStream_t passed as void*);
+ *   - returns 0 on success, a negative code on error (wn_last_error() gives the text); no C++
+ *     exceptions cross the boundary;
+ *   - no allocation, no synchronisation, no retained pointers: all workspace is the caller's,
+ *     every call only enqueues work on `stream` (safe under hipGraph stream capture);
+ *   - re-entrant across devices/streams: no global mutable state besides the last-error text.
+ *
+ * Data layout: activations are float32 [clip][channel][time] with time
+ * contiguous, in ABSOLUTE time (column t = index of the newest input sample the value depends
+ * on), all with one row pitch (multiple of 4 floats) and 16-byte aligned bases, allocated with
+ * >= 64 floats of slack in front of and >= 256 behind the addressed range.  Channel counts are
+ * padded to a multiple of 32 with zero weights.  "mode" selects the arithmetic of the
+ * channel-mixing products on the v_mfma_f32_16x16x32 matrix cores:
+ *   WN_F16X3 / WN_BF16X3 : operands split x = hi + lo in f16 / bf16, 3 MFMAs per product,
+ *                          fp32 accumulate (fp32-grade, the default: fwd F16X3, bwd BF16X3)
+ *   WN_F16X1 / WN_BF16X1 : plain 16-bit operands, fp32 accumulate.
+ */
+#ifndef WAVENET_HIP_H
+#define WAVENET_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* wn_stream_t;                 /* hipStream_t */
+enum { WN_F16X3 = 0, WN_F16X1 = 1, WN_BF16X3 = 2, WN_BF16X1 = 3 };
+#define WN_ABI_VERSION 1
+#define WN_CE_NUM_PARTIALS 1024
+
+int wn_version(void);
+const char* wn_last_error(void);
+
+/* Weight packing: flat fp32 parameter buffer -> MFMA A-fragment order, 16-bit hi(/lo) pieces.
+ * idx[p] = offset of the source weight in `flat` (or -1 = structural zero) for logical position
+ * p = (fragment, lane, j); n = number of logical positions (multiple of 512).
+ * Replaces nothing in the reference (cuDNN consumes nn.Conv1d weights directly). */
+int wn_pack_weights(const float* flat, const int32_t* idx, uint16_t* out, int n, int mode,
+                    wn_stream_t stream);
+
+/* Generic channel-mixing product over time:
+ *   out[b][m][t+out_shift] = mask( bias[m] + resid[b][m][t] (t >= resid_lo)
+ *        + sum_k W[m][k]      * pre(in0[b][k][t+shift0])            (k <  32*ks0)
+ *        + sum_k W[m][K0 + k] * pre(in1[b][k][t+shift1]) )          (k <  32*ks1)
+ * for t in [t_lo, t_hi); pre = relu if relu_in; mask keeps values where mask[b][m][t] > 0.
+ * input columns (t+shift) outside [in_lo,in_hi) read as 0 and are never dereferenced.  Replaces: causal nn.Conv1d (wavenet/model.py:104),
+ * the skip 1x1 convs + Python sum (model.py:127-134), post_process_1/2 (model.py:136-138) and
+ * their autograd backward (data gradients). */
+int wn_chan_gemm(const float* in0, const float* in1, int64_t in_bstride, int in_pitch, int in_lo, int in_hi,
+                 int shift0, int shift1, int ks0, int ks1, const uint16_t* wpack, int mt, int m_valid,
+                 float* out, int64_t out_bstride, int out_pitch, int out_shift, const float* bias,
+                 const float* resid, int64_t resid_bstride, int resid_pitch, int resid_lo,
+                 const float* mask, int64_t mask_bstride, int mask_pitch,
+                 int t_lo, int t_hi, int relu_in, int batch, int mode, wn_stream_t stream);
+
+/* Fused gated residual block, forward (wavenet/model.py:111-129 for one dilation d):
+ *   [f;g] = Wfg [x(t-d); x(t)] ; z = tanh f * sigmoid g ; x_out = Wd z + x(t) on [t_lo,t_hi);
+ *   z is stored on [z_lo, t_hi) (the crop the skip product needs).  ch = padded channels (32|64). */
+int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bstride, int64_t z_bstride,
+                    int pitch, const uint16_t* wfg, const uint16_t* wd, const float* bias_f,
+                    const float* bias_g, const float* bias_d, int n_f, int n_d, int ch, int d,
+                    int t_lo, int t_hi, int z_lo, int write_x, int batch, int mode, wn_stream_t stream);
+
+/* Fused gated residual block, backward recompute half (autograd of model.py:118-124, SURVEY
+ * Appendix B): recomputes f,g,z from x_in; dz = Wd^T dy (+ dz_crop on t >= z_lo);
+ * writes dfg = [df; dg] (2*ch rows) and z (ch rows) on [t_lo,t_hi).  dy may be NULL. */
+int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* dfg, float* z,
+                    int64_t x_bstride, int64_t dz_bstride, int64_t dfg_bstride, int64_t z_bstride,
+                    int pitch, const uint16_t* wfg, const uint16_t* wdT, const float* bias_f,
+                    const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
+                    int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
+
+/* Weight gradient: C[m][n] += sum_{b, t in [t_lo,t_hi)} A[b][m][t+a_shift] * B_tap[b][n][t+b_shift_tap]
+ * C columns [0, 16*nt_per_tap) come from b0, the next 16*nt_per_tap from b1 (if not NULL).
+ * C (fp32, leading dimension ldc) is accumulated with atomics: zero it first.
+ * Replaces the weight half of autograd's conv backward (wavenet/train.py:181). */
+int wn_wgrad(const float* a, int64_t a_bstride, int a_pitch, int a_shift, int a_cols,
+             const float* b0, const float* b1, int64_t b_bstride, int b_pitch, int b_shift0,
+             int b_shift1, int b_cols, int nt_per_tap, int mt, int relu_b, float* c, int ldc,
+             int t_lo, int t_hi, int chunk, int batch, int mode, wn_stream_t stream);
+
+/* out[row] = sum_{b,t} a[b][row][t+a_shift]  (bias gradients, use_bias=true) */
+int wn_bias_grad(const float* a, int64_t a_bstride, int a_pitch, int a_shift, int rows, int t_lo,
+                 int t_hi, int batch, float* out, wn_stream_t stream);
+
+/* The reference's chunk softmax: rows of 256 CONSECUTIVE floats of the (B,256,W) buffer
+ * (wavenet/model.py:142-144). */
+int wn_chunk_softmax256_fwd(const float* x, float* y, int64_t nrows, wn_stream_t stream);
+int wn_chunk_softmax256_bwd(const float* y, const float* dy, float* dx, int64_t nrows, wn_stream_t stream);
+/* Fused chunk softmax + nn.CrossEntropyLoss applied to the PROBABILITIES (wavenet/train.py:146,179;
+ * SURVEY Q1) + both backward steps.  probs/dx may be NULL.  loss_part: WN_CE_NUM_PARTIALS floats,
+ * their sum is the mean loss. */
+int wn_chunk_softmax256_ce(const float* x, const int64_t* target, float* probs, float* dx,
+                           float* loss_part, int64_t nrows, float inv_n, wn_stream_t stream);
+
+/* torch.optim.Adam step on a flat buffer (wavenet/train.py:39-42,182); g is multiplied by gscale. */
+int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float bias_corr1, float bias_corr2, float gscale,
+                 wn_stream_t stream);
+/* flat_grad[i] = packed[idx[i]] (idx<0 -> 0): dense wgrad results -> state_dict (out,in,k) layout. */
+int wn_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, wn_stream_t stream);
+
+/* One-hot input on device from int32 codes (B,T) -> float32 (B,Q,T).  scrambled=1 reproduces
+ * faster_audio_data.one_hot_encode's reshape (wavenet/faster_audio_data.py:77-81);
+ * scrambled=0 is the textbook layout fast_generate.py:159-160 builds. */
+int wn_onehot(const int32_t* codes, float* out, int batch, int q, int t, int scrambled, wn_stream_t stream);
+
+/* mu-law (wavenet/audio_func.py:5-39): encode through the 255-entry float32 threshold table of the
+ * canonical encoder (bit-exact); decode through the 256-entry table. */
+int wn_mulaw_encode_tbl(const float* audio, const float* thresholds, uint8_t* codes, int64_t n, wn_stream_t stream);
+int wn_mulaw_decode_lut(const uint8_t* codes, const float* table, float* audio, int64_t n, wn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,93 @@
+"""ctypes binding of libwavenet_hip.so (the C ABI declared in include/wavenet_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwavenet_hip.so")
+
+F16X3, F16X1, BF16X3, BF16X1 = 0, 1, 2, 3
+MODE_NAMES = {"f16x3": F16X3, "f16x1": F16X1, "bf16x3": BF16X3, "bf16x1": BF16X1}
+CE_NUM_PARTIALS = 1024
+ABI_VERSION = 1
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_int64
+_f = ctypes.c_float
+
+# name -> argtypes  (every function returns int status except wn_last_error)
+SIGNATURES = {
+    "wn_version": [],
+    "wn_pack_weights": [_p, _p, _p, _i, _i, _p],
+    "wn_chan_gemm": [_p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i,
+                     _p, _l, _i, _i, _p,
+                     _p, _l, _i, _i,
+                     _p, _l, _i,
+                     _i, _i, _i, _i, _i, _p],
+    "wn_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i,
+                        _i, _i, _i, _i, _i, _i, _p],
+    "wn_resblock_bwd": [_p, _p, _p, _p, _p, _l, _l, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
+                        _i, _i, _i, _p],
+    "wn_wgrad": [_p, _l, _i, _i, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _i,
+                 _i, _i, _i, _i, _i, _p],
+    "wn_bias_grad": [_p, _l, _i, _i, _i, _i, _i, _i, _p, _p],
+    "wn_chunk_softmax256_fwd": [_p, _p, _l, _p],
+    "wn_chunk_softmax256_bwd": [_p, _p, _p, _l, _p],
+    "wn_chunk_softmax256_ce": [_p, _p, _p, _p, _p, _l, _f, _p],
+    "wn_adam_flat": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p],
+    "wn_gather_grads": [_p, _p, _p, _i, _p],
+    "wn_onehot": [_p, _p, _i, _i, _i, _i, _p],
+    "wn_mulaw_encode_tbl": [_p, _p, _p, _l, _p],
+    "wn_mulaw_decode_lut": [_p, _p, _p, _l, _p],
+}
+
+_lib = None
+
+
+class WavenetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises WavenetHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WavenetHipError(
+            "libwavenet_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C music_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError here = header/library out of sync
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    lib.wn_last_error.argtypes = []
+    lib.wn_last_error.restype = ctypes.c_char_p
+    if lib.wn_version() != ABI_VERSION:
+        raise WavenetHipError("libwavenet_hip.so ABI version %d != expected %d" % (lib.wn_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an entry point; raise on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise WavenetHipError("%s failed (%d): %s" % (name, rc, lib.wn_last_error().decode()))
+
+
+def ptr(t, offset=0):
+    """Device pointer of a torch tensor (+ element offset), or None."""
+    if t is None:
+        return None
+    return t.data_ptr() + offset * t.element_size()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,125 @@
+// C ABI of libwavenet_hip.so (declared in include/wavenet_hip.h): argument marshalling only.
+#include <stdio.h>
+#include <string.h>
+#include "../../include/wavenet_hip.h"
+#include "wn_common.h"
+#include "wn_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+int wn_set_error(hipError_t e, const char* file, int line) {
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
+    return -1;
+}
+int wn_set_error_msg(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+static_assert(WN_F16X3 == WN_MODE_F16X3 && WN_F16X1 == WN_MODE_F16X1 && WN_BF16X3 == WN_MODE_BF16X3 &&
+              WN_BF16X1 == WN_MODE_BF16X1, "mode enums out of sync");
+static_assert(WN_CE_NUM_PARTIALS == WN_CE_PARTIALS, "partials out of sync");
+
+extern "C" {
+
+int wn_version(void) { return WN_ABI_VERSION; }
+const char* wn_last_error(void) { return g_err; }
+
+int wn_pack_weights(const float* flat, const int32_t* idx, uint16_t* out, int n, int mode, wn_stream_t stream) {
+    if (n % 512 != 0) return wn_set_error_msg(-4, "wn_pack_weights: n must be a multiple of 512");
+    return wn_launch_pack(flat, idx, out, n, wn_mode_is_bf16(mode), wn_mode_ns(mode), (hipStream_t)stream);
+}
+
+int wn_chan_gemm(const float* in0, const float* in1, int64_t in_bstride, int in_pitch, int in_lo, int in_hi,
+                 int shift0, int shift1, int ks0, int ks1, const uint16_t* wpack, int mt, int m_valid,
+                 float* out, int64_t out_bstride, int out_pitch, int out_shift, const float* bias,
+                 const float* resid, int64_t resid_bstride, int resid_pitch, int resid_lo,
+                 const float* mask, int64_t mask_bstride, int mask_pitch,
+                 int t_lo, int t_hi, int relu_in, int batch, int mode, wn_stream_t stream) {
+    if (ks0 <= 0 || (ks1 > 0 && !in1) || mt <= 0) return wn_set_error_msg(-4, "wn_chan_gemm: bad shape");
+    WnGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in0 = in0; a.in1 = ks1 > 0 ? in1 : nullptr; a.in_bstride = in_bstride; a.in_pitch = in_pitch; a.in_lo = in_lo; a.in_hi = in_hi;
+    a.shift0 = shift0; a.shift1 = shift1; a.ks0 = ks0; a.ks1 = ks1 > 0 ? ks1 : 0; a.wpack = wpack; a.mt = mt; a.m_valid = m_valid;
+    a.out = out; a.out_bstride = out_bstride; a.out_pitch = out_pitch; a.out_shift = out_shift; a.bias = bias;
+    a.resid = resid; a.resid_bstride = resid_bstride; a.resid_pitch = resid_pitch; a.resid_lo = resid_lo;
+    a.mask = mask; a.mask_bstride = mask_bstride; a.mask_pitch = mask_pitch;
+    a.t_lo = t_lo; a.t_hi = t_hi; a.relu_in = relu_in;
+    return wn_launch_gemm(a, batch, mode, (hipStream_t)stream);
+}
+
+int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bstride, int64_t z_bstride,
+                    int pitch, const uint16_t* wfg, const uint16_t* wd, const float* bias_f,
+                    const float* bias_g, const float* bias_d, int n_f, int n_d, int ch, int d,
+                    int t_lo, int t_hi, int z_lo, int write_x, int batch, int mode, wn_stream_t stream) {
+    if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_fwd: pitch must be a multiple of 4");
+    if (t_lo < d + 1) return wn_set_error_msg(-4, "wn_resblock_fwd: t_lo must be >= d + 1");
+    WnResArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x_in = x_in; a.x_out = x_out; a.z_out = z_out; a.x_bstride = x_bstride; a.z_bstride = z_bstride; a.pitch = pitch;
+    a.wfg = wfg; a.wd = wd; a.bias_f = bias_f; a.bias_g = bias_g; a.bias_d = bias_d; a.n_f = n_f; a.n_d = n_d;
+    a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = z_lo; a.write_x = write_x;
+    return wn_launch_resblock_fwd(a, ch, batch, mode, (hipStream_t)stream);
+}
+
+int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* dfg, float* z,
+                    int64_t x_bstride, int64_t dz_bstride, int64_t dfg_bstride, int64_t z_bstride,
+                    int pitch, const uint16_t* wfg, const uint16_t* wdT, const float* bias_f,
+                    const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
+                    int batch, int mode_fwd, int mode_bwd, wn_stream_t stream) {
+    if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_bwd: pitch must be a multiple of 4");
+    WnResBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x_in = x_in; a.dy = dy; a.dz = dz; a.dfg = dfg; a.z = z;
+    a.x_bstride = x_bstride; a.dz_bstride = dz_bstride; a.dfg_bstride = dfg_bstride; a.z_bstride = z_bstride; a.pitch = pitch;
+    a.wfg = wfg; a.wdT = wdT; a.bias_f = bias_f; a.bias_g = bias_g; a.n_f = n_f;
+    a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = z_lo;
+    return wn_launch_resblock_bwd(a, ch, batch, mode_fwd, mode_bwd, (hipStream_t)stream);
+}
+
+int wn_wgrad(const float* a_, int64_t a_bstride, int a_pitch, int a_shift, int a_cols,
+             const float* b0, const float* b1, int64_t b_bstride, int b_pitch, int b_shift0,
+             int b_shift1, int b_cols, int nt_per_tap, int mt, int relu_b, float* c, int ldc,
+             int t_lo, int t_hi, int chunk, int batch, int mode, wn_stream_t stream) {
+    WnWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.a = a_; a.a_bstride = a_bstride; a.a_pitch = a_pitch; a.a_shift = a_shift; a.a_cols = a_cols;
+    a.b0 = b0; a.b1 = b1; a.b_bstride = b_bstride; a.b_pitch = b_pitch; a.b_shift0 = b_shift0; a.b_shift1 = b_shift1; a.b_cols = b_cols;
+    a.nt_per_tap = nt_per_tap; a.mt = mt; a.relu_b = relu_b; a.c = c; a.ldc = ldc;
+    a.t_lo = t_lo; a.t_hi = t_hi; a.chunk = chunk;
+    return wn_launch_wgrad(a, batch, mode, (hipStream_t)stream);
+}
+
+int wn_bias_grad(const float* a, int64_t a_bstride, int a_pitch, int a_shift, int rows, int t_lo,
+                 int t_hi, int batch, float* out, wn_stream_t stream) {
+    return wn_launch_bias_grad(a, a_bstride, a_pitch, a_shift, rows, t_lo, t_hi, batch, out, (hipStream_t)stream);
+}
+
+int wn_chunk_softmax256_fwd(const float* x, float* y, int64_t nrows, wn_stream_t stream) {
+    return wn_launch_softmax_fwd(x, y, nrows, (hipStream_t)stream);
+}
+int wn_chunk_softmax256_bwd(const float* y, const float* dy, float* dx, int64_t nrows, wn_stream_t stream) {
+    return wn_launch_softmax_bwd(y, dy, dx, nrows, (hipStream_t)stream);
+}
+int wn_chunk_softmax256_ce(const float* x, const int64_t* target, float* probs, float* dx,
+                           float* loss_part, int64_t nrows, float inv_n, wn_stream_t stream) {
+    return wn_launch_softmax_ce(x, target, probs, dx, loss_part, nrows, inv_n, (hipStream_t)stream);
+}
+int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float bias_corr1, float bias_corr2, float gscale, wn_stream_t stream) {
+    return wn_launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, bias_corr1, bias_corr2, gscale, (hipStream_t)stream);
+}
+int wn_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, wn_stream_t stream) {
+    return wn_launch_gather_grads(packed, idx, flat_grad, n, (hipStream_t)stream);
+}
+int wn_onehot(const int32_t* codes, float* out, int batch, int q, int t, int scrambled, wn_stream_t stream) {
+    return wn_launch_onehot(codes, out, batch, q, t, scrambled, (hipStream_t)stream);
+}
+int wn_mulaw_encode_tbl(const float* audio, const float* thresholds, uint8_t* codes, int64_t n, wn_stream_t stream) {
+    return wn_launch_mulaw_encode(audio, thresholds, codes, n, (hipStream_t)stream);
+}
+int wn_mulaw_decode_lut(const uint8_t* codes, const float* table, float* audio, int64_t n, wn_stream_t stream) {
+    return wn_launch_mulaw_decode(codes, table, audio, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// Shared device helpers for the WaveNet HIP kernels (gfx950 / CDNA4 only).
+//
+// Conventions used by every kernel in this directory
+// --------------------------------------------------
+// * Activations are fp32, channels-first, time contiguous, in ABSOLUTE time: element (b, c, t) of
+//   a layer buffer lives at  base + b*bstride + c*pitch + t  where t is the index of the newest
+//   input sample the value depends on.  All layers therefore share one pitch and the "shifted"
+//   read of a dilated tap is just  t - d  in the same coordinate system.  pitch % 4 == 0 and all
+//   bases are 16-byte aligned, so a lane that owns 4 consecutive t (t % 4 == 0) moves float4s.
+// * Every channel-mixing product runs on v_mfma_f32_16x16x32_{f16,bf16} with TIME ON THE LANES:
+//   C[channel][time] = W[channel][k] * X[k][time].  One wave owns 64 time columns as four 16-wide
+//   N-tiles; lane (c = lane&15, q = lane>>4) of N-tile n holds time  t0 + 4c + n, so the four
+//   N-tiles of a lane are 4 consecutive samples (one float4 per channel row).
+//     A fragment: lane holds W[16m + c][kmap(s,q,j)], j = 0..7   (8 x 16-bit = 16 B)
+//     B fragment: lane holds X[kmap(s,q,j)][col c]
+//     C/D       : lane holds C[16m + 4q + i][col c], i = 0..3
+//   kmap is either natural (32s + 8q + j: B built from global rows) or "chained"
+//   (32s + 16(j>>2) + 4q + (j&3): B built from the accumulators of a previous product, no LDS
+//   round trip).  Weights are pre-packed into fragment order by wn_pack_weights.
+// * fp32-grade accuracy comes from a 2-term split of both operands into 16-bit pieces
+//   (x = hi + lo) and three MFMAs per product (hi*hi + lo*hi + hi*lo) accumulated in fp32
+//   ("x3" modes).  The x1 modes use hi*hi only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct __attribute__((packed, aligned(4))) F4U { float v[4]; };   // 16-B load, 4-B aligned
+
+#define WN_WAVE 64
+#define WN_FRAG_HALFS 512          // 64 lanes x 8 halfs: one packed A fragment (1 KB)
+
+// ---- 16-bit operand traits -----------------------------------------------------------------
+struct F16 {
+    typedef f16x8 vec8;
+    typedef _Float16 elem;
+    static __device__ __forceinline__ elem cvt(float x) { return (_Float16)x; }
+    static __device__ __forceinline__ float back(elem h) { return (float)h; }
+    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+struct BF16 {
+    typedef bf16x8 vec8;
+    typedef __bf16 elem;
+    static __device__ __forceinline__ elem cvt(float x) { return (__bf16)x; }
+    static __device__ __forceinline__ float back(elem h) { return (float)h; }
+    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <class T>
+struct Frag {            // one operand fragment, split into hi + lo
+    typename T::vec8 hi, lo;
+};
+
+// acc += A*B with NS products (1: hi*hi ; 3: hi*hi + lo*hi + hi*lo)
+template <class T, int NS>
+__device__ __forceinline__ void mma(f32x4& acc, const Frag<T>& a, const Frag<T>& b) {
+    if (NS == 3) {
+        acc = T::mfma(a.lo, b.hi, acc);
+        acc = T::mfma(a.hi, b.lo, acc);
+    }
+    acc = T::mfma(a.hi, b.hi, acc);
+}
+
+template <class T, int NS>
+__device__ __forceinline__ void split8(Frag<T>& f, const float* v) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        typename T::elem h = T::cvt(v[j]);
+        f.hi[j] = h;
+        if (NS == 3) f.lo[j] = T::cvt(v[j] - T::back(h));
+    }
+}
+
+// Packed A fragment (hi block then lo block, 1 KB each) from global or LDS.
+// layout: [(m*KS + s)][NS==3 ? 2 : 1][64 lanes][8 halfs]
+template <class T, int NS>
+__device__ __forceinline__ void load_a(Frag<T>& f, const uint16_t* pack, int frag_index, int lane) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(pack) +
+                     (size_t)frag_index * (NS == 3 ? 128 : 64) + lane;
+    u32x4 h = p[0];
+    f.hi = __builtin_bit_cast(typename T::vec8, h);
+    if (NS == 3) {
+        u32x4 l = p[64];
+        f.lo = __builtin_bit_cast(typename T::vec8, l);
+    }
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4u(const float* p) {
+    F4U u = *reinterpret_cast<const F4U*>(p);
+    f32x4 r = {u.v[0], u.v[1], u.v[2], u.v[3]};
+    return r;
+}
+// guarded 4-column load: columns outside [lo, hi) read as 0 and are never dereferenced
+__device__ __forceinline__ f32x4 ld4g(const float* p, int col, int lo, int hi) {
+    if (col >= lo && col + 3 < hi) return ld4u(p);
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (col + e >= lo && col + e < hi) r[e] = p[e];
+    return r;
+}
+// store the 4 consecutive samples t..t+3 of one channel row, only those inside [lo, hi)
+__device__ __forceinline__ void st4m(float* p, f32x4 v, int t, int lo, int hi) {
+    if (t >= lo && t + 3 < hi) {
+        *reinterpret_cast<f32x4*>(p) = v;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (t + e >= lo && t + e < hi) p[e] = v[e];
+    }
+}
+
+__device__ __forceinline__ float wn_sigmoid(float g) { return __builtin_amdgcn_rcpf(1.0f + __expf(-g)); }
+// tanh via exp with a small-|x| polynomial so the relative error stays ~1e-7 everywhere
+__device__ __forceinline__ float wn_tanh(float f) {
+    float a = fabsf(f);
+    float e = __expf(-2.0f * a);
+    float big = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    float x2 = f * f;
+    // odd Taylor series to x^9 : |x| < 0.25 -> rel err < 2e-8
+    float small = a * (1.0f + x2 * (-0.33333333f + x2 * (0.13333333f + x2 * (-0.053968254f + x2 * 0.021869489f))));
+    float r = a < 0.25f ? small : big;
+    return copysignf(r, f);
+}
+
+#define WN_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return wn_set_error(e_, __FILE__, __LINE__); } while (0)
+int wn_set_error(hipError_t e, const char* file, int line);
+int wn_set_error_msg(int code, const char* msg);

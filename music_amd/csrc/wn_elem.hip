@@ -1,0 +1,248 @@
+// Memory-bound helpers of the WaveNet path: the reference's 256-wide CHUNK softmax
+// (wavenet/model.py:142-144), the CrossEntropyLoss the training loop applies to those
+// probabilities (wavenet/train.py:146,179), flat Adam, the loader's one-hot layouts
+// (wavenet/faster_audio_data.py:62-83), and mu-law (wavenet/audio_func.py:5-39).
+#include "wn_common.h"
+#include "wn_kernels.h"
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One wave per 256-float row: lane holds 4 consecutive floats (one 1 KB coalesced access per wave).
+__global__ __launch_bounds__(256) void softmax256_fwd_k(const float* __restrict__ x, float* __restrict__ y, long nrows) {
+    const int lane = threadIdx.x & 63;
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * 4;
+    for (; row < nrows; row += stride) {
+        f32x4 v = ld4(x + row * 256 + lane * 4);
+        float m = wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        f32x4 e = {expf(v[0] - m), expf(v[1] - m), expf(v[2] - m), expf(v[3] - m)};
+        float s = wave_sum((e[0] + e[1]) + (e[2] + e[3]));
+        float inv = 1.0f / s;
+        f32x4 r = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
+        *reinterpret_cast<f32x4*>(y + row * 256 + lane * 4) = r;
+    }
+}
+
+// dx = y * (dy - <dy, y>)
+__global__ __launch_bounds__(256) void softmax256_bwd_k(const float* __restrict__ y, const float* __restrict__ dy,
+                                                        float* __restrict__ dx, long nrows) {
+    const int lane = threadIdx.x & 63;
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * 4;
+    for (; row < nrows; row += stride) {
+        f32x4 p = ld4(y + row * 256 + lane * 4);
+        f32x4 g = ld4(dy + row * 256 + lane * 4);
+        float dot = wave_sum((p[0] * g[0] + p[1] * g[1]) + (p[2] * g[2] + p[3] * g[3]));
+        f32x4 r = {p[0] * (g[0] - dot), p[1] * (g[1] - dot), p[2] * (g[2] - dot), p[3] * (g[3] - dot)};
+        *reinterpret_cast<f32x4*>(dx + row * 256 + lane * 4) = r;
+    }
+}
+
+// Fused: p = softmax(x_row); loss_row = logsumexp(p) - p[y]; dp = (softmax(p) - e_y) * inv_n;
+// dx = p * (dp - <dp,p>).  probs / dx may be null.  loss_part[blockIdx.x] = this block's share of
+// mean_r loss_r (the caller sums the WN_CE_PARTIALS partials; no contended atomics).
+__global__ __launch_bounds__(256) void softmax256_ce_k(const float* __restrict__ x, const int64_t* __restrict__ target,
+                                                       float* __restrict__ probs, float* __restrict__ dx,
+                                                       float* __restrict__ loss_part, long nrows, float inv_n) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63;
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * 4;
+    float lacc = 0.f;
+    for (; row < nrows; row += stride) {
+        f32x4 v = ld4(x + row * 256 + lane * 4);
+        float m = wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        f32x4 e = {expf(v[0] - m), expf(v[1] - m), expf(v[2] - m), expf(v[3] - m)};
+        float inv = 1.0f / wave_sum((e[0] + e[1]) + (e[2] + e[3]));
+        f32x4 p = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
+        if (probs) *reinterpret_cast<f32x4*>(probs + row * 256 + lane * 4) = p;
+        // second (log-)softmax over the probabilities: p in [0,1] so no max shift is needed
+        f32x4 e2 = {expf(p[0]), expf(p[1]), expf(p[2]), expf(p[3])};
+        float s2 = wave_sum((e2[0] + e2[1]) + (e2[2] + e2[3]));
+        int y = (int)target[row];
+        int yl = y >> 2, ye = y & 3;
+        float py = __shfl(ye == 0 ? p[0] : ye == 1 ? p[1] : ye == 2 ? p[2] : p[3], yl, 64);
+        lacc += logf(s2) - py;
+        if (dx) {
+            float is2 = inv_n / s2;
+            f32x4 dp = {e2[0] * is2, e2[1] * is2, e2[2] * is2, e2[3] * is2};
+            if (lane == yl) dp[ye] -= inv_n;
+            float dot = wave_sum((p[0] * dp[0] + p[1] * dp[1]) + (p[2] * dp[2] + p[3] * dp[3]));
+            f32x4 r = {p[0] * (dp[0] - dot), p[1] * (dp[1] - dot), p[2] * (dp[2] - dot), p[3] * (dp[3] - dot)};
+            *reinterpret_cast<f32x4*>(dx + row * 256 + lane * 4) = r;
+        }
+    }
+    if (lane == 0) red[threadIdx.x >> 6] = lacc * inv_n;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_part) loss_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+static inline int sm_grid(long nrows) {
+    long g = (nrows + 3) / 4;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+int wn_launch_softmax_fwd(const float* x, float* y, long nrows, hipStream_t st) {
+    if (nrows <= 0) return 0;
+    hipLaunchKernelGGL(softmax256_fwd_k, dim3(sm_grid(nrows)), dim3(256), 0, st, x, y, nrows);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+int wn_launch_softmax_bwd(const float* y, const float* dy, float* dx, long nrows, hipStream_t st) {
+    if (nrows <= 0) return 0;
+    hipLaunchKernelGGL(softmax256_bwd_k, dim3(sm_grid(nrows)), dim3(256), 0, st, y, dy, dx, nrows);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+int wn_launch_softmax_ce(const float* x, const int64_t* target, float* probs, float* dx, float* loss_part,
+                         long nrows, float inv_n, hipStream_t st) {
+    if (nrows <= 0) return 0;
+    // always WN_CE_PARTIALS blocks so that every partial is (re)written each call
+    hipLaunchKernelGGL(softmax256_ce_k, dim3(WN_CE_PARTIALS), dim3(256), 0, st, x, target, probs, dx,
+                       loss_part, nrows, inv_n);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flat Adam (torch.optim.Adam semantics, wavenet/train.py:39-42): g is pre-scaled by gscale
+// (1/world_size after the all-reduce); bc1 = 1 - b1^t, bc2 = 1 - b2^t are supplied by the host.
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1,
+                       float bc2, float gscale) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const float step = lr / bc1, rs = 1.0f / sqrtf(bc2);
+    for (; i < n; i += stride) {
+        float gi = g[i] * gscale;
+        float mi = b1 * m[i] + (1.0f - b1) * gi;
+        float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) * rs + eps);
+    }
+}
+int wn_launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                   float eps, float bc1, float bc2, float gscale, hipStream_t st) {
+    if (n <= 0) return 0;
+    long grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(adam_k, dim3((int)grid), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2, gscale);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
+// flat_grad[i] = packed[idx[i]]  (idx < 0: structural zero).  Maps the dense C matrices written
+// by wgrad into the reference's (out, in, k) state_dict layout.
+__global__ void gather_grads_k(const float* __restrict__ packed, const int32_t* __restrict__ idx,
+                               float* __restrict__ flat, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flat[i] = idx[i] >= 0 ? packed[idx[i]] : 0.f;
+}
+int wn_launch_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gather_grads_k, dim3((n + 255) / 256), dim3(256), 0, st, packed, idx, flat_grad, n);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-hot construction on device from int32 codes (B, T) -> float32 (B, Q, T).
+//   scrambled = 1: faster_audio_data.py:77-81 layout, one for sample s at flat offset s*Q + code
+//   scrambled = 0: textbook layout, out[code][s] = 1  (fast_generate.py:159-160)
+// The output must have been zero-filled (the launcher does it with hipMemsetAsync).
+// ---------------------------------------------------------------------------------------------
+__global__ void onehot_k(const int32_t* __restrict__ idx, float* __restrict__ out, int q, int t, int scrambled, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long b = i / t, s = i % t;
+    int code = idx[i];
+    if (code < 0 || code >= q) return;
+    long pos = scrambled ? (s * q + code) : ((long)code * t + s);
+    out[b * (long)q * t + pos] = 1.0f;
+}
+int wn_launch_onehot(const int32_t* idx, float* out, int batch, int q, int t, int scrambled, hipStream_t st) {
+    long total = (long)batch * t;
+    if (total <= 0) return 0;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)total * q * sizeof(float), st);
+    if (e != hipSuccess) return wn_set_error(e, __FILE__, __LINE__);
+    hipLaunchKernelGGL(onehot_k, dim3((int)((total + 255) / 256)), dim3(256), 0, st, idx, out, q, t, scrambled, total);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mu-law.  encode: code = #{k : thr[k] <= a} over the 255 float32 decision thresholds of
+// audio_func.mu_law_encode (bit-exact by construction); decode: 256-entry table.
+// ---------------------------------------------------------------------------------------------
+__global__ void mulaw_encode_k(const float* __restrict__ audio, const float* __restrict__ thr,
+                               uint8_t* __restrict__ codes, long n) {
+    __shared__ float s_thr[256];
+    if (threadIdx.x < 255) s_thr[threadIdx.x] = thr[threadIdx.x];
+    __syncthreads();
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float a = audio[i];
+        int lo = 0, hi = 255;                 // count of thresholds <= a, by bisection
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (s_thr[mid] <= a) lo = mid + 1; else hi = mid;
+        }
+        codes[i] = (uint8_t)lo;
+    }
+}
+__global__ void mulaw_decode_k(const uint8_t* __restrict__ codes, const float* __restrict__ table,
+                               float* __restrict__ audio, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) audio[i] = table[codes[i]];
+}
+int wn_launch_mulaw_encode(const float* audio, const float* thr, uint8_t* codes, long n, hipStream_t st) {
+    if (n <= 0) return 0;
+    long grid = (n + 255) / 256; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(mulaw_encode_k, dim3((int)grid), dim3(256), 0, st, audio, thr, codes, n);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+int wn_launch_mulaw_decode(const uint8_t* codes, const float* table, float* audio, long n, hipStream_t st) {
+    if (n <= 0) return 0;
+    long grid = (n + 255) / 256; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(mulaw_decode_k, dim3((int)grid), dim3(256), 0, st, codes, table, audio, n);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bias gradient: out[row] = sum_{b, t in [t_lo,t_hi)} a[b][row][t + a_shift]; one WG per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_grad_k(const float* __restrict__ a, long a_bstride, int a_pitch, int a_shift,
+                                                   int t_lo, int t_hi, int batch, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < batch; ++b) {
+        const float* p = a + (size_t)b * a_bstride + (size_t)row * a_pitch + a_shift;
+        for (int t = t_lo + threadIdx.x; t < t_hi; t += 256) s += p[t];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[row] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+int wn_launch_bias_grad(const float* a, long a_bstride, int a_pitch, int a_shift, int rows, int t_lo,
+                        int t_hi, int batch, float* out, hipStream_t st) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(bias_grad_k, dim3(rows), dim3(256), 0, st, a, a_bstride, a_pitch, a_shift, t_lo, t_hi, batch, out);
+    WN_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,79 @@
+// Internal host-side launch interface between the C-ABI layer (wn_api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// arithmetic modes of the channel-mixing products (see wn_common.h)
+enum { WN_MODE_F16X3 = 0, WN_MODE_F16X1 = 1, WN_MODE_BF16X3 = 2, WN_MODE_BF16X1 = 3 };
+static inline int wn_mode_is_bf16(int m) { return m >= 2; }
+static inline int wn_mode_ns(int m) { return (m & 1) ? 1 : 3; }
+static inline size_t wn_frag_halfs(int mode) { return wn_mode_ns(mode) == 3 ? 1024 : 512; }
+
+struct WnGemmArgs {
+    const float* in0; const float* in1;   // tap inputs ([K rows][in_pitch]); in1 may be null
+    long in_bstride; int in_pitch; int in_lo, in_hi;   // input columns outside [in_lo,in_hi) read as 0
+    int shift0, shift1;                    // input column = t + shift
+    int ks0, ks1;                          // 32-channel k-steps per tap
+    const uint16_t* wpack;                 // [mt][ks0+ks1] packed A fragments
+    int mt, m_valid;                       // 16-row tiles / number of real rows
+    float* out; long out_bstride; int out_pitch; int out_shift;   // out column = t + out_shift
+    const float* bias;                     // [m_valid] or null
+    const float* resid; long resid_bstride; int resid_pitch; int resid_lo;   // += resid[row][t] for t >= resid_lo
+    const float* mask; long mask_bstride; int mask_pitch;         // keep where mask[row][t] > 0
+    int t_lo, t_hi, t_base;                // valid output columns [t_lo, t_hi); t_base set by launcher
+    int relu_in;
+};
+int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
+int wn_launch_pack(const float* flat, const int32_t* idx, uint16_t* out, int n, int is_bf16, int ns,
+                   hipStream_t st);
+
+struct WnResArgs {
+    const float* x_in; float* x_out; float* z_out;      // [B][CH][pitch] each (z_out: layer slice)
+    long x_bstride, z_bstride; int pitch;
+    const uint16_t* wfg; const uint16_t* wd;            // packed [2CH/16][2CH/32] and [CH/16][CH/32] (chained k)
+    const float* bias_f; const float* bias_g; const float* bias_d;   // [<=CH] or null
+    int n_f, n_d;                                       // real dilation / residual channel counts
+    int d, t_lo, t_hi, z_lo, t_base;                    // outputs valid on [t_lo,t_hi); z stored for t >= z_lo
+    int write_x;                                        // 0 for the last block (its x is unused)
+};
+int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);
+
+struct WnResBwdArgs {
+    const float* x_in;          // x_i          [B][CH][pitch]
+    const float* dy;            // d x_{i+1}    [B][CH][pitch]   (may be null for the last block)
+    const float* dz;            // d z-crop     [B][CH][pitch] layer slice (valid t >= z_lo)
+    float* dfg;                 // out: [B][2CH][pitch]  rows [0,CH) = d f, [CH,2CH) = d g
+    float* z;                   // out: [B][CH][pitch]   recomputed gated activation
+    long x_bstride, dz_bstride, dfg_bstride, z_bstride; int pitch;
+    const uint16_t* wfg;        // forward fg pack
+    const uint16_t* wdT;        // packed Wd^T [CH/16][CH/32] (natural k), grad mode
+    const float* bias_f; const float* bias_g; int n_f;
+    int d, t_lo, t_hi, z_lo, t_base;
+};
+int wn_launch_resblock_bwd(const WnResBwdArgs& a, int ch, int batch, int mode_fwd, int mode_bwd,
+                           hipStream_t st);
+
+struct WnWgradArgs {
+    const float* a; long a_bstride; int a_pitch; int a_shift; int a_cols;   // A: [M rows][time]
+    const float* b0; const float* b1; long b_bstride; int b_pitch; int b_shift0, b_shift1; int b_cols;
+    int nt_per_tap;             // 16-row tiles of B per tap (C columns = taps * nt_per_tap * 16)
+    int mt;                     // 16-row tiles of A
+    int relu_b;
+    float* c; int ldc;          // C[mt*16][ldc] fp32, accumulated with atomics
+    int t_lo, t_hi, t_base; int chunk;      // time range and per-WG chunk (multiple of 32)
+};
+int wn_launch_wgrad(const WnWgradArgs& a, int batch, int mode, hipStream_t st);
+
+int wn_launch_softmax_fwd(const float* x, float* y, long nrows, hipStream_t st);
+int wn_launch_softmax_bwd(const float* y, const float* dy, float* dx, long nrows, hipStream_t st);
+#define WN_CE_PARTIALS 1024
+int wn_launch_softmax_ce(const float* x, const int64_t* target, float* probs, float* dx,
+                         float* loss_part, long nrows, float inv_n, hipStream_t st);
+int wn_launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                   float eps, float bc1, float bc2, float gscale, hipStream_t st);
+int wn_launch_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, hipStream_t st);
+int wn_launch_onehot(const int32_t* idx, float* out, int batch, int q, int t, int scrambled, hipStream_t st);
+int wn_launch_mulaw_encode(const float* audio, const float* thr, uint8_t* codes, long n, hipStream_t st);
+int wn_launch_mulaw_decode(const uint8_t* codes, const float* table, float* audio, long n, hipStream_t st);
+int wn_launch_bias_grad(const float* a, long a_bstride, int a_pitch, int a_shift, int rows, int t_lo,
+                        int t_hi, int batch, float* out, hipStream_t st);

@@ -1,0 +1,499 @@
+"""Host-side execution plan of the WaveNet hot path on one MI355X.
+
+`WaveNetEngine` owns the flat parameter / gradient buffers, the fragment-packing index maps, the
+per-(batch, length) workspaces, and sequences the C-ABI kernels of libwavenet_hip.so for
+
+    forward   wavenet/model.py:86-145          (probabilities, chunk-softmax semantics)
+    backward  autograd of the above             (SURVEY Appendix B formulas)
+    train_step  wavenet/train.py:171-182        (forward + CE-on-probs + backward [+ all-reduce] + Adam)
+
+PyTorch is used for device memory and streams only.  Nothing here imports oracle/.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+
+SLACK = 64          # floats in front of every activation buffer
+PAD_BACK = 512      # floats behind
+
+
+def _pad(n, m):
+    return (n + m - 1) // m * m
+
+
+def pack_positions(mt, ks, chained):
+    """Logical A-fragment order -> (row, k) of the effective weight matrix.
+    p = ((m*ks + s)*64 + lane)*8 + j ; row = 16m + (lane&15) ; k = kmap(s, lane>>4, j)."""
+    m, s, lane, j = np.indices((mt, ks, 64, 8))
+    row = 16 * m + (lane & 15)
+    q = lane >> 4
+    if chained:
+        k = 32 * s + 16 * (j >> 2) + 4 * q + (j & 3)
+    else:
+        k = 32 * s + 8 * q + j
+    return row.reshape(-1), k.reshape(-1)
+
+
+def pack_index(weff, chained=False):
+    """weff: int32 [Mp, Kp] of flat-parameter offsets (-1 = zero).  Returns idx[p] (int32)."""
+    mp, kp = weff.shape
+    assert mp % 16 == 0 and kp % 32 == 0
+    row, k = pack_positions(mp // 16, kp // 32, chained)
+    return weff[row, k].astype(np.int32)
+
+
+class _Spec:
+    """Offsets of every reference parameter inside the flat buffer (state_dict order)."""
+
+    def __init__(self, named_shapes):
+        self.off, self.shape = {}, {}
+        o = 0
+        for name, shape in named_shapes:
+            self.off[name] = o
+            self.shape[name] = tuple(shape)
+            o += int(np.prod(shape))
+        self.total = o
+
+    def conv(self, name):
+        """int64 array [O, I, k] of flat offsets of a Conv1d weight."""
+        shp = self.shape[name]
+        return self.off[name] + np.arange(int(np.prod(shp)), dtype=np.int64).reshape(shp)
+
+
+class WaveNetEngine:
+    def __init__(self, dilations, residual_channels, dilation_channels, skip_channels,
+                 quantization_channels=256, filter_width=2, use_bias=False,
+                 mode_fwd="f16x3", mode_bwd="bf16x3", device=None):
+        if filter_width != 2:
+            raise NotImplementedError("HIP path implements filter_width == 2 (the reference's only configuration)")
+        if quantization_channels != 256:
+            raise NotImplementedError("HIP path implements quantization_channels == 256 (chunk softmax width)")
+        self.dil = [int(d) for d in dilations]
+        self.N = len(self.dil)
+        self.R, self.D, self.S, self.Q = residual_channels, dilation_channels, skip_channels, quantization_channels
+        self.use_bias = bool(use_bias)
+        self.CH = _pad(max(self.R, self.D), 32)
+        if self.CH not in (32, 64):
+            raise NotImplementedError("HIP path supports residual/dilation channels <= 64")
+        self.SP = _pad(self.S, 32)
+        self.rf = sum(self.dil) + 2
+        self.off = [1]                                   # first valid absolute time of x_i
+        for d in self.dil:
+            self.off.append(self.off[-1] + d)
+        assert self.off[-1] == self.rf - 1
+        self.mode_fwd = _lib.MODE_NAMES[mode_fwd] if isinstance(mode_fwd, str) else mode_fwd
+        self.mode_bwd = _lib.MODE_NAMES[mode_bwd] if isinstance(mode_bwd, str) else mode_bwd
+        self.device = torch.device(device if device is not None else "cuda")
+        _lib.load()
+        self._build_spec()
+        self._build_packs()
+        self._ws = {}
+        self._gen = 0
+        self.adam_state = None
+        self.marks = None            # list of (name, torch.cuda.Event) when profiling is on
+
+    def mark(self, name):
+        """Record a timing event on the current stream (only when self.marks is a list)."""
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((name, ev))
+
+    # ------------------------------------------------------------------ parameters
+    def _build_spec(self):
+        names = [("causal_layer.weight", (self.R, self.Q, 2))]
+        if self.use_bias:
+            names.append(("causal_layer.bias", (self.R,)))
+        for i in range(self.N):
+            for k, shp in enumerate([(self.D, self.R, 2), (self.D, self.R, 2), (self.R, self.D, 1), (self.S, self.D, 1)]):
+                names.append(("dilation_layer_stack.%d.weight" % (4 * i + k), shp))
+                if self.use_bias:
+                    names.append(("dilation_layer_stack.%d.bias" % (4 * i + k), (shp[0],)))
+        names.append(("post_process_1.weight", (self.S, self.S, 1)))
+        if self.use_bias:
+            names.append(("post_process_1.bias", (self.S,)))
+        names.append(("post_process_2.weight", (self.Q, self.S, 1)))
+        if self.use_bias:
+            names.append(("post_process_2.bias", (self.Q,)))
+        self.spec = _Spec(names)
+        self.param_names = [n for n, _ in names]
+        dev = self.device
+        self.flat = torch.zeros(self.spec.total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(self.spec.total, dtype=torch.float32, device=dev)
+
+    def param_view(self, name, grad=False):
+        o, shp = self.spec.off[name], self.spec.shape[name]
+        n = int(np.prod(shp))
+        return (self.flat_grad if grad else self.flat)[o:o + n].view(shp)
+
+    def load_state_dict_tensors(self, sd):
+        with torch.no_grad():
+            for n in self.param_names:
+                self.param_view(n).copy_(sd[n])
+
+    def _bias_ptr(self, name):
+        if not self.use_bias:
+            return None
+        return ptr(self.flat, self.spec.off[name])
+
+    # ------------------------------------------------------------------ packs
+    def _build_packs(self):
+        sp, CH, N, R, D, S, Q, SP = self.spec, self.CH, self.N, self.R, self.D, self.S, self.Q, self.SP
+        fwd, bwd = [], []            # lists of (name, idx array)
+        gp = []                      # gradient C matrices: (name, rows, cols)
+
+        def full(m, k):
+            return np.full((m, k), -1, dtype=np.int64)
+
+        # 1. causal: rows R, K = [tap0 Q | tap1 Q]
+        wc = sp.conv("causal_layer.weight")                 # [R,Q,2]
+        w = full(CH, 2 * Q)
+        w[:R, :Q] = wc[:, :, 0]
+        w[:R, Q:] = wc[:, :, 1]
+        fwd.append(("causal", pack_index(w)))
+        gp.append(("causal", CH, 2 * Q))
+        for i in range(N):
+            wf = sp.conv("dilation_layer_stack.%d.weight" % (4 * i))       # [D,R,2]
+            wg = sp.conv("dilation_layer_stack.%d.weight" % (4 * i + 1))
+            wd = sp.conv("dilation_layer_stack.%d.weight" % (4 * i + 2))   # [R,D,1]
+            # 2. fg: rows [f(D) pad CH | g(D) pad CH], K = [tap0 CH | tap1 CH]
+            w = full(2 * CH, 2 * CH)
+            for h, src in enumerate((wf, wg)):
+                w[h * CH:h * CH + D, 0:R] = src[:, :, 0]
+                w[h * CH:h * CH + D, CH:CH + R] = src[:, :, 1]
+            fwd.append(("fg%d" % i, pack_index(w)))
+            gp.append(("fg%d" % i, 2 * CH, 2 * CH))
+            # 3. dense (chained k order: B fragments come from the z accumulators)
+            w = full(CH, CH)
+            w[:R, :D] = wd[:, :, 0]
+            fwd.append(("d%d" % i, pack_index(w, chained=True)))
+            gp.append(("d%d" % i, CH, CH))
+            # 10. Wd^T (rows D, K = R)
+            bwd.append(("dT%d" % i, pack_index(np.ascontiguousarray(w.T))))
+            # 11. data gradient of fg: rows R, K = [W1^T over (df|dg) | W0^T over (df|dg)]
+            w = full(CH, 4 * CH)
+            for h, src in enumerate((wf, wg)):
+                w[:R, h * CH:h * CH + D] = src[:, :, 1].T
+                w[:R, 2 * CH + h * CH:2 * CH + h * CH + D] = src[:, :, 0].T
+            bwd.append(("fgT%d" % i, pack_index(w)))
+        # 4. skip over the concatenated z-crops: rows S, K = N*CH
+        w = full(SP, N * CH)
+        for i in range(N):
+            ws = sp.conv("dilation_layer_stack.%d.weight" % (4 * i + 3))   # [S,D,1]
+            w[:S, i * CH:i * CH + D] = ws[:, :, 0]
+        fwd.append(("skip", pack_index(w)))
+        gp.append(("skip", SP, N * CH))
+        bwd.append(("skipT", pack_index(np.ascontiguousarray(w.T))))      # rows N*CH, K = SP
+        # 5/6. post-process
+        p1 = sp.conv("post_process_1.weight")[:, :, 0]
+        p2 = sp.conv("post_process_2.weight")[:, :, 0]
+        w = full(SP, SP)
+        w[:S, :S] = p1
+        fwd.append(("p1", pack_index(w)))
+        gp.append(("p1", SP, SP))
+        bwd.append(("p1T", pack_index(np.ascontiguousarray(w.T))))
+        w = full(Q, SP)
+        w[:, :S] = p2
+        fwd.append(("p2", pack_index(w)))
+        gp.append(("p2", Q, SP))
+        bwd.append(("p2T", pack_index(np.ascontiguousarray(w.T))))        # rows SP, K = Q
+
+        dev = self.device
+
+        def finish(lst, mode):
+            halfs_per_frag = 1024 if mode in (_lib.F16X3, _lib.BF16X3) else 512
+            offs, o = {}, 0
+            for name, idx in lst:
+                offs[name] = o * halfs_per_frag // 512          # offset in halfs of the packed buffer
+                o += len(idx)
+            idx_all = torch.from_numpy(np.concatenate([i for _, i in lst]).astype(np.int32)).to(dev)
+            buf = torch.zeros(o * halfs_per_frag // 512, dtype=torch.int16, device=dev)
+            return offs, idx_all, buf
+
+        self.pk_f_off, self.pk_f_idx, self.pk_f = finish(fwd, self.mode_fwd)
+        self.pk_b_off, self.pk_b_idx, self.pk_b = finish(bwd, self.mode_bwd)
+
+        # gradient matrices + gather map (flat parameter element -> offset in gpack)
+        self.gp_off, o = {}, 0
+        for name, r, c in gp:
+            self.gp_off[name] = (o, r, c)
+            o += r * c
+        bias_rows = {}
+        if self.use_bias:
+            for name in self.param_names:
+                if name.endswith(".bias"):
+                    bias_rows[name] = o
+                    o += _pad(self.spec.shape[name][0], 4)
+        self.gp_bias_off = bias_rows
+        self.gpack = torch.zeros(o, dtype=torch.float32, device=dev)
+        gidx = np.full(self.spec.total, -1, dtype=np.int64)
+
+        def put(pname, mat_off):
+            """mat_off: int array with the same shape as the parameter holding gpack offsets."""
+            po = self.spec.off[pname]
+            gidx[po:po + mat_off.size] = mat_off.reshape(-1)
+
+        o0, r, c = self.gp_off["causal"]
+        rows = np.arange(R)[:, None, None]
+        put("causal_layer.weight", o0 + rows * c + (np.arange(2)[None, None, :] * Q + np.arange(Q)[None, :, None]))
+        for i in range(N):
+            o0, r, c = self.gp_off["fg%d" % i]
+            for h in range(2):
+                put("dilation_layer_stack.%d.weight" % (4 * i + h),
+                    o0 + (h * CH + np.arange(D)[:, None, None]) * c +
+                    (np.arange(2)[None, None, :] * CH + np.arange(R)[None, :, None]))
+            o0, r, c = self.gp_off["d%d" % i]
+            put("dilation_layer_stack.%d.weight" % (4 * i + 2),
+                o0 + np.arange(R)[:, None, None] * c + np.arange(D)[None, :, None])
+            o0, r, c = self.gp_off["skip"]
+            put("dilation_layer_stack.%d.weight" % (4 * i + 3),
+                o0 + np.arange(S)[:, None, None] * c + (i * CH + np.arange(D)[None, :, None]))
+        o0, r, c = self.gp_off["p1"]
+        put("post_process_1.weight", o0 + np.arange(S)[:, None, None] * c + np.arange(S)[None, :, None])
+        o0, r, c = self.gp_off["p2"]
+        put("post_process_2.weight", o0 + np.arange(Q)[:, None, None] * c + np.arange(S)[None, :, None])
+        for name, bo in bias_rows.items():
+            put(name, bo + np.arange(self.spec.shape[name][0]))
+        assert (gidx >= 0).all()
+        self.gidx = torch.from_numpy(gidx.astype(np.int32)).to(dev)
+
+    def pack_weights(self):
+        st = _lib.stream()
+        call("wn_pack_weights", ptr(self.flat), ptr(self.pk_f_idx), ptr(self.pk_f), self.pk_f_idx.numel(), self.mode_fwd, st)
+        call("wn_pack_weights", ptr(self.flat), ptr(self.pk_b_idx), ptr(self.pk_b), self.pk_b_idx.numel(), self.mode_bwd, st)
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, B, T):
+        key = (B, T)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        if len(self._ws) >= 4:
+            self._ws.clear()
+        dev = self.device
+        pitch = _pad(T, 256) + 256
+        W = T - self.rf + 1
+
+        def buf(rows):
+            t = torch.zeros(SLACK + B * rows * pitch + PAD_BACK, dtype=torch.float32, device=dev)
+            return t
+
+        ws = dict(B=B, T=T, W=W, pitch=pitch)
+        ws["X"] = torch.zeros(SLACK + (self.N + 1) * B * self.CH * pitch + PAD_BACK, dtype=torch.float32, device=dev)
+        ws["Z"] = buf(self.N * self.CH)
+        ws["U"] = buf(self.SP)
+        ws["H"] = buf(self.SP)
+        ws["O"] = torch.zeros(B * self.Q * W + PAD_BACK, dtype=torch.float32, device=dev)
+        ws["bwd"] = None
+        self._ws[key] = ws
+        return ws
+
+    def _bwd_workspace(self, ws):
+        if ws["bwd"] is not None:
+            return ws["bwd"]
+        B, pitch, W, dev = ws["B"], ws["pitch"], ws["W"], self.device
+
+        def buf(rows):
+            return torch.zeros(SLACK + B * rows * pitch + PAD_BACK, dtype=torch.float32, device=dev)
+
+        bw = dict(dO=torch.zeros(B * self.Q * W + PAD_BACK, dtype=torch.float32, device=dev),
+                  dH=buf(self.SP), dU=buf(self.SP), dZ=buf(self.N * self.CH),
+                  dX=[buf(self.CH), buf(self.CH)], dfg=buf(2 * self.CH), zs=buf(self.CH))
+        ws["bwd"] = bw
+        return bw
+
+    def _x(self, ws, i):
+        return ptr(ws["X"], SLACK + i * ws["B"] * self.CH * ws["pitch"])
+
+    # ------------------------------------------------------------------ forward
+    def forward_logits(self, x, ws=None):
+        """x: (B,Q,T) float32 contiguous on the device.  Runs causal conv, the residual stack, the
+        skip product and both post-process convs; leaves the pre-softmax (B,Q,W) in ws['O']."""
+        B, Q, T = x.shape
+        assert Q == self.Q and x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda
+        W = T - self.rf + 1
+        if W <= 0:
+            raise ValueError("wave sample not long enough")          # wavenet/model.py:100-101
+        ws = ws or self.workspace(B, T)
+        st = _lib.stream()
+        CH, N, SP, pitch, mf = self.CH, self.N, self.SP, ws["pitch"], self.mode_fwd
+        fr = lambda name: ptr(self.pk_f, self.pk_f_off[name])
+        xb = CH * pitch
+        self._gen += 1
+        ws["gen"] = self._gen
+        ws["x_in"] = x
+        # causal conv (wavenet/model.py:104): x0[t] = W0 in[t-1] + W1 in[t], t in [1,T)
+        call("wn_chan_gemm", ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, fr("causal"), CH // 16, self.R,
+             self._x(ws, 0), xb, pitch, 0, self._bias_ptr("causal_layer.bias"),
+             None, 0, 0, 0, None, 0, 0, 1, T, 0, B, mf, st)
+        zb = N * CH * pitch
+        self.mark("causal_fwd")
+        for i, d in enumerate(self.dil):
+            bn = "dilation_layer_stack.%d.bias"
+            call("wn_resblock_fwd", self._x(ws, i), self._x(ws, i + 1), ptr(ws["Z"], SLACK + i * CH * pitch), xb, zb, pitch,
+                 fr("fg%d" % i), fr("d%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),
+                 self._bias_ptr(bn % (4 * i + 2)), self.D, self.R, CH, d, self.off[i + 1], T, self.rf - 1,
+                 1 if i < N - 1 else 0, B, mf, st)
+        self.mark("stack_fwd")
+        lo = self.rf - 1
+        bias_s = None
+        if self.use_bias:
+            bs = sum(self.param_view("dilation_layer_stack.%d.bias" % (4 * i + 3)) for i in range(N))
+            ws["bias_skip"] = bs.contiguous()
+            bias_s = ptr(ws["bias_skip"])
+        call("wn_chan_gemm", ptr(ws["Z"], SLACK), None, zb, pitch, lo, T, 0, 0, N * CH // 32, 0, fr("skip"), SP // 16, self.S,
+             ptr(ws["U"], SLACK), SP * pitch, pitch, 0, bias_s, None, 0, 0, 0, None, 0, 0, lo, T, 0, B, mf, st)
+        call("wn_chan_gemm", ptr(ws["U"], SLACK), None, SP * pitch, pitch, lo, T, 0, 0, SP // 32, 0, fr("p1"), SP // 16, self.S,
+             ptr(ws["H"], SLACK), SP * pitch, pitch, 0, self._bias_ptr("post_process_1.bias"),
+             None, 0, 0, 0, None, 0, 0, lo, T, 1, B, mf, st)
+        call("wn_chan_gemm", ptr(ws["H"], SLACK), None, SP * pitch, pitch, lo, T, 0, 0, SP // 32, 0, fr("p2"), Q // 16, Q,
+             ptr(ws["O"]), Q * W, W, -lo, self._bias_ptr("post_process_2.bias"),
+             None, 0, 0, 0, None, 0, 0, lo, T, 1, B, mf, st)
+        self.mark("epilogue_fwd")
+        return ws
+
+    def forward(self, x):
+        """wavenet/model.py:86-145 -> probabilities (B*W, Q) (fresh tensor)."""
+        self.pack_weights()
+        ws = self.forward_logits(x)
+        B, W = ws["B"], ws["W"]
+        probs = torch.empty(B * W, self.Q, dtype=torch.float32, device=self.device)
+        call("wn_chunk_softmax256_fwd", ptr(ws["O"]), ptr(probs), B * W, _lib.stream())
+        ws["probs"] = probs
+        return probs, ws
+
+    # ------------------------------------------------------------------ backward
+    def backward_from_dlogits(self, ws):
+        """ws['bwd']['dO'] holds d loss / d pre-softmax (B,Q,W).  Fills self.flat_grad."""
+        bw = self._bwd_workspace(ws)
+        st = _lib.stream()
+        B, T, W, pitch = ws["B"], ws["T"], ws["W"], ws["pitch"]
+        CH, N, SP, Q, mb, mf = self.CH, self.N, self.SP, self.Q, self.mode_bwd, self.mode_fwd
+        br = lambda name: ptr(self.pk_b, self.pk_b_off[name])
+        fr = lambda name: ptr(self.pk_f, self.pk_f_off[name])
+        lo = self.rf - 1
+        xb, zb, sb = CH * pitch, N * CH * pitch, SP * pitch
+        self.gpack.zero_()
+        gp = lambda name: ptr(self.gpack, self.gp_off[name][0])
+        chunk = 512
+        dO, dH, dU, dZ = ptr(bw["dO"]), ptr(bw["dH"], SLACK), ptr(bw["dU"], SLACK), ptr(bw["dZ"], SLACK)
+        U, H, Z = ptr(ws["U"], SLACK), ptr(ws["H"], SLACK), ptr(ws["Z"], SLACK)
+        # dH = (P2^T dO) * [H > 0]
+        call("wn_chan_gemm", dO, None, Q * W, W, 0, W, -lo, 0, Q // 32, 0, br("p2T"), SP // 16, self.S,
+             dH, sb, pitch, 0, None, None, 0, 0, 0, H, sb, pitch, lo, T, 0, B, mb, st)
+        # dU = (P1^T dH) * [U > 0]
+        call("wn_chan_gemm", dH, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, br("p1T"), SP // 16, self.S,
+             dU, sb, pitch, 0, None, None, 0, 0, 0, U, sb, pitch, lo, T, 0, B, mb, st)
+        # dZ = Ws^T dU   (all N crops at once)
+        call("wn_chan_gemm", dU, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, br("skipT"), N * CH // 16, N * CH,
+             dZ, zb, pitch, 0, None, None, 0, 0, 0, None, 0, 0, lo, T, 0, B, mb, st)
+        # weight gradients of the epilogue
+        call("wn_wgrad", dO, Q * W, W, -lo, W, H, None, sb, pitch, 0, 0, pitch, SP // 16, Q // 16, 1,
+             gp("p2"), SP, lo, T, chunk, B, mb, st)
+        call("wn_wgrad", dH, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1,
+             gp("p1"), SP, lo, T, chunk, B, mb, st)
+        call("wn_wgrad", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CH // 16, SP // 16, 0,
+             gp("skip"), N * CH, lo, T, chunk, B, mb, st)
+        if self.use_bias:
+            bo = self.gp_bias_off
+            call("wn_bias_grad", dO, Q * W, W, -lo, Q, lo, T, B, ptr(self.gpack, bo["post_process_2.bias"]), st)
+            call("wn_bias_grad", dH, sb, pitch, 0, self.S, lo, T, B, ptr(self.gpack, bo["post_process_1.bias"]), st)
+            for i in range(N):
+                call("wn_bias_grad", dU, sb, pitch, 0, self.S, lo, T, B,
+                     ptr(self.gpack, bo["dilation_layer_stack.%d.bias" % (4 * i + 3)]), st)
+        self.mark("epilogue_bwd")
+        dfg, zs = ptr(bw["dfg"], SLACK), ptr(bw["zs"], SLACK)
+        for i in range(N - 1, -1, -1):
+            d = self.dil[i]
+            t_lo = self.off[i + 1]
+            dy = ptr(bw["dX"][(i + 1) % 2], SLACK) if i < N - 1 else None
+            bn = "dilation_layer_stack.%d.bias"
+            call("wn_resblock_bwd", self._x(ws, i), dy, ptr(bw["dZ"], SLACK + i * CH * pitch), dfg, zs,
+                 xb, zb, 2 * CH * pitch, xb, pitch, fr("fg%d" % i), br("dT%d" % i),
+                 self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)), self.D, CH, d, t_lo, T, lo,
+                 B, mf, mb, st)
+            # dWf/dWg: C[2CH][tap0 CH | tap1 CH] = sum dfg[t] * [x(t-d) | x(t)]
+            call("wn_wgrad", dfg, 2 * CH * pitch, pitch, 0, pitch, self._x(ws, i), self._x(ws, i), xb, pitch, -d, 0, pitch,
+                 CH // 16, 2 * CH // 16, 0, gp("fg%d" % i), 2 * CH, t_lo, T, chunk, B, mb, st)
+            if i < N - 1:
+                # dWd = sum dy z^T
+                call("wn_wgrad", dy, xb, pitch, 0, pitch, zs, None, xb, pitch, 0, 0, pitch, CH // 16, CH // 16, 0,
+                     gp("d%d" % i), CH, t_lo, T, chunk, B, mb, st)
+            if self.use_bias:
+                bo = self.gp_bias_off
+                call("wn_bias_grad", dfg, 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i)]), st)
+                call("wn_bias_grad", ptr(bw["dfg"], SLACK + CH * pitch), 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B,
+                     ptr(self.gpack, bo[bn % (4 * i + 1)]), st)
+                if i < N - 1:
+                    call("wn_bias_grad", dy, xb, pitch, 0, self.R, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i + 2)]), st)
+            # dx_i[t] = W1^T dfg[t] + W0^T dfg[t+d] + dy[t]        on [off_i, T)
+            call("wn_chan_gemm", dfg, dfg, 2 * CH * pitch, pitch, t_lo, T, 0, d, 2 * CH // 32, 2 * CH // 32, br("fgT%d" % i),
+                 CH // 16, self.R, ptr(bw["dX"][i % 2], SLACK), xb, pitch, 0, None,
+                 dy, xb, pitch, t_lo, None, 0, 0, self.off[i], T, 0, B, mb, st)
+        self.mark("stack_bwd")
+        # causal weight gradient: dWc[r][q][tap] = sum dx0[r][t] in[q][t-1+tap]
+        x = ws["x_in"]
+        dx0 = ptr(bw["dX"][0], SLACK)
+        call("wn_wgrad", dx0, xb, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CH // 16, 0,
+             gp("causal"), 2 * Q, 1, T, chunk, B, mb, st)
+        if self.use_bias:
+            call("wn_bias_grad", dx0, xb, pitch, 0, self.R, 1, T, B, ptr(self.gpack, self.gp_bias_off["causal_layer.bias"]), st)
+        call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
+        self.mark("causal_bwd")
+
+    def backward(self, ws, dprobs):
+        """dprobs: (B*W, Q) gradient w.r.t. the probabilities returned by forward()."""
+        bw = self._bwd_workspace(ws)
+        dprobs = dprobs.contiguous()
+        call("wn_chunk_softmax256_bwd", ptr(ws["probs"]), ptr(dprobs), ptr(bw["dO"]), ws["B"] * ws["W"], _lib.stream())
+        self.backward_from_dlogits(ws)
+
+    # ------------------------------------------------------------------ fused training step
+    def loss_and_grad(self, x, target, want_probs=False):
+        """forward + CrossEntropyLoss(probs, target) + backward (wavenet/train.py:178-181).
+        Returns the loss as a 0-d device tensor; gradients land in self.flat_grad."""
+        self.mark("begin")
+        self.pack_weights()
+        self.mark("pack")
+        ws = self.forward_logits(x)
+        bw = self._bwd_workspace(ws)
+        B, W = ws["B"], ws["W"]
+        n = B * W
+        target = target.reshape(-1)
+        assert target.numel() == n and target.dtype == torch.int64 and target.is_cuda
+        if "loss_part" not in ws:
+            ws["loss_part"] = torch.zeros(_lib.CE_NUM_PARTIALS, dtype=torch.float32, device=self.device)
+        probs = None
+        if want_probs:
+            probs = torch.empty(n, self.Q, dtype=torch.float32, device=self.device)
+            ws["probs"] = probs
+        call("wn_chunk_softmax256_ce", ptr(ws["O"]), ptr(target), ptr(probs), ptr(bw["dO"]), ptr(ws["loss_part"]),
+             n, 1.0 / n, _lib.stream())
+        self.mark("softmax_ce")
+        self.backward_from_dlogits(ws)
+        return ws["loss_part"].sum()
+
+    def adam_init(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.adam_state = dict(m=torch.zeros_like(self.flat), v=torch.zeros_like(self.flat), t=0,
+                               lr=lr, b1=betas[0], b2=betas[1], eps=eps)
+
+    def adam_step(self, gscale=1.0):
+        s = self.adam_state
+        s["t"] += 1
+        bc1 = 1.0 - s["b1"] ** s["t"]
+        bc2 = 1.0 - s["b2"] ** s["t"]
+        call("wn_adam_flat", ptr(self.flat), ptr(self.flat_grad), ptr(s["m"]), ptr(s["v"]), self.spec.total,
+             s["lr"], s["b1"], s["b2"], s["eps"], bc1, bc2, gscale, _lib.stream())
+        self.mark("adam")
+
+    def onehot(self, codes, scrambled=True):
+        """int32 (B,T) codes on the device -> float32 (B,Q,T) (faster_audio_data.py:62-83)."""
+        B, T = codes.shape
+        out = torch.empty(B, self.Q, T, dtype=torch.float32, device=self.device)
+        call("wn_onehot", ptr(codes), ptr(out), B, self.Q, T, 1 if scrambled else 0, _lib.stream())
+        self.mark("onehot")
+        return out

@@ -1,0 +1,128 @@
+"""Drop-in counterpart of the reference's ``wavenet/model.py`` backed by the MI355X HIP kernels.
+
+Same constructor kwargs, attributes, registered ``nn.Conv1d`` sub-modules (hence the same
+``state_dict`` keys / shapes and the attribute access ``fast_generate.py`` relies on), same
+``forward`` contract (wavenet/model.py:86-145): input ``(B, Q, T >= receptive_field)`` float ->
+probabilities ``(B*(T-rf+1), Q)`` with the reference's CHUNK softmax semantics, and the same
+``ValueError("wave sample not long enough")``.
+
+The arithmetic runs only through libwavenet_hip.so (music_amd/engine.py).  There is no CPU
+implementation: calling ``forward`` without a ROCm device raises.
+"""
+import torch
+import torch.nn as nn
+
+try:
+    from .engine import WaveNetEngine
+except ImportError:                      # imported as a bare module (`from model import wavenet`)
+    from music_amd.engine import WaveNetEngine
+
+
+class _WaveNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, wave_sample, *params):
+        eng = net._engine_for(wave_sample.device)
+        x = wave_sample.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        probs, ws = eng.forward(x)
+        ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        eng, ws = ctx.eng, ctx.ws
+        if ws.get("gen") != ctx.gen:
+            raise RuntimeError("music_amd.wavenet: the activations of this forward were overwritten by a later "
+                               "forward of the same module before backward() ran")
+        eng.backward(ws, dprobs)
+        g = eng.flat_grad.clone()
+        grads = []
+        for name in eng.param_names:
+            o, shp = eng.spec.off[name], eng.spec.shape[name]
+            n = 1
+            for s in shp:
+                n *= s
+            grads.append(g[o:o + n].view(shp))
+        return (None, None) + tuple(grads)
+
+
+class wavenet(nn.Module):
+
+    def __init__(self, filter_width, dilations, dilation_channels, residual_channels, skip_channels,
+                 quantization_channels, use_bias):
+        super(wavenet, self).__init__()
+        self.filter_width = filter_width
+        self.dilations = dilations
+        self.dilation_channels = dilation_channels
+        self.residual_channels = residual_channels
+        self.skip_channels = skip_channels
+        self.quantization_channels = quantization_channels
+        self.use_bias = use_bias
+        self.receptive_field = self.calc_receptive_field()
+        # construction order (and therefore the default-init RNG stream) follows
+        # wavenet/model.py:38-41: causal, then per dilation filter/gate/dense/skip, then post-process
+        self.causal_layer = nn.Conv1d(quantization_channels, residual_channels, filter_width, bias=use_bias)
+        self.dilation_layer_stack = nn.ModuleList()
+        for d in dilations:
+            self.dilation_layer_stack.extend([
+                nn.Conv1d(residual_channels, dilation_channels, filter_width, dilation=d, bias=use_bias),
+                nn.Conv1d(residual_channels, dilation_channels, filter_width, dilation=d, bias=use_bias),
+                nn.Conv1d(dilation_channels, residual_channels, 1, bias=use_bias),
+                nn.Conv1d(dilation_channels, skip_channels, 1, bias=use_bias)])
+        self.post_process_1 = nn.Conv1d(skip_channels, skip_channels, 1, bias=use_bias)
+        self.post_process_2 = nn.Conv1d(skip_channels, quantization_channels, 1, bias=use_bias)
+        self.softmax = nn.Softmax(dim=1)     # the reference's nn.Softmax() resolves to dim 1 on 2-D input
+        self._engine = None
+        self.precision = ("f16x3", "bf16x3")     # (forward, backward) arithmetic of the MFMA products
+
+    def calc_receptive_field(self):
+        return (self.filter_width - 1) * (sum(self.dilations) + 1) + 1
+
+    # ---- engine plumbing ------------------------------------------------------------------
+    def _named_ref_params(self):
+        """Parameters in the reference's state_dict order."""
+        return list(self.named_parameters())
+
+    def _engine_for(self, device):
+        if device.type != "cuda":
+            raise RuntimeError("music_amd.wavenet runs on an MI355X (ROCm) device only; there is no CPU path. "
+                               "Move the module and its input to 'cuda'.")
+        eng = self._engine
+        named = self._named_ref_params()
+        if eng is not None and eng.device == device and eng.mode_names == tuple(self.precision):
+            # parameters must still alias the flat buffer (e.g. net.cpu().cuda() breaks that)
+            p0 = named[0][1]
+            if p0.data_ptr() == eng.flat.data_ptr() + 4 * eng.spec.off[named[0][0]]:
+                return eng
+        if any(p.device != device for _, p in named):
+            raise RuntimeError("music_amd.wavenet: parameters and input are on different devices")
+        eng = WaveNetEngine(self.dilations, self.residual_channels, self.dilation_channels, self.skip_channels,
+                            self.quantization_channels, self.filter_width, self.use_bias,
+                            mode_fwd=self.precision[0], mode_bwd=self.precision[1], device=device)
+        eng.mode_names = tuple(self.precision)
+        assert [n for n, _ in named] == eng.param_names, "parameter order differs from the reference layout"
+        with torch.no_grad():
+            for name, p in named:
+                view = eng.param_view(name)
+                view.copy_(p.data)
+                p.data = view                     # the module's parameters now ARE the flat buffer
+        self._engine = eng
+        return eng
+
+    def forward(self, wave_sample):
+        batch_size, original_channels, seq_len = wave_sample.size()
+        output_width = seq_len - self.receptive_field + 1
+        if output_width <= 0:
+            raise ValueError("wave sample not long enough")
+        params = [p for _, p in self._named_ref_params()]
+        return _WaveNetFunction.apply(self, wave_sample, *params)
+
+
+def predict_next(model, wave_var, quantization_channels=256):
+    """wavenet/model.py:148-165 — argmax over the last chunk-row of the model output."""
+    raw_out = model(wave_var)
+    out = raw_out.view(-1, quantization_channels)
+    last = out[-1, :].view(-1)
+    _, predict = torch.topk(last, 1)
+    return predict

@@ -1,0 +1,348 @@
+"""GPU unit tests of the individual C-ABI kernels against plain fp64/fp32 math (run with -m gpu)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from music_amd import _lib
+from music_amd._lib import call, ptr
+from music_amd.engine import pack_index, SLACK
+
+DEV = "cuda"
+
+
+def _packed(wmat, mode, chained=False):
+    """wmat: numpy [M,K] float32 (M%16==0, K%32==0) -> (packed int16 tensor, flat tensor)."""
+    m, k = wmat.shape
+    flat = torch.from_numpy(np.ascontiguousarray(wmat, dtype=np.float32).reshape(-1)).to(DEV)
+    weff = np.arange(m * k, dtype=np.int64).reshape(m, k)
+    idx = torch.from_numpy(pack_index(weff, chained)).to(DEV)
+    hp = 1024 if mode in (_lib.F16X3, _lib.BF16X3) else 512
+    out = torch.zeros(idx.numel() // 512 * hp, dtype=torch.int16, device=DEV)
+    call("wn_pack_weights", ptr(flat), ptr(idx), ptr(out), idx.numel(), mode, _lib.stream())
+    return out
+
+
+def _buf(b, rows, pitch, fill=None, seed=0):
+    t = torch.zeros(SLACK + b * rows * pitch + 512, dtype=torch.float32, device=DEV)
+    if fill is not None:
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        v = torch.randn(b, rows, pitch, generator=g) * fill
+        t[SLACK:SLACK + b * rows * pitch] = v.reshape(-1).to(DEV)
+    return t
+
+
+def _view(t, b, rows, pitch):
+    return t[SLACK:SLACK + b * rows * pitch].view(b, rows, pitch)
+
+
+TOL = {_lib.F16X3: 2e-5, _lib.BF16X3: 3e-4, _lib.F16X1: 2e-2, _lib.BF16X1: 1e-1}
+
+
+@pytest.mark.parametrize("mode", [_lib.F16X3, _lib.BF16X3, _lib.F16X1, _lib.BF16X1])
+def test_chan_gemm_single_tap(mode):
+    rng = np.random.default_rng(1)
+    B, M, K, pitch, T = 2, 80, 96, 1024, 700          # M = 5 tiles (partial M-block), K = 3 k-steps
+    w = rng.standard_normal((M, K)).astype(np.float32) * 0.2
+    pk = _packed(w, mode)
+    xin = _buf(B, K, pitch, 1.0, 2)
+    out = _buf(B, M, pitch)
+    t_lo, t_hi = 37, T
+    call("wn_chan_gemm", ptr(xin, SLACK), None, K * pitch, pitch, 0, pitch, 0, 0, K // 32, 0, ptr(pk), M // 16, M - 3,
+         ptr(out, SLACK), M * pitch, pitch, 0, None, None, 0, 0, 0, None, 0, 0, t_lo, t_hi, 0, B, mode, _lib.stream())
+    torch.cuda.synchronize()
+    x = _view(xin, B, K, pitch).cpu().double()
+    ref = torch.einsum("mk,bkt->bmt", torch.from_numpy(w).double(), x)
+    got = _view(out, B, M, pitch).cpu().double()
+    err = (got[:, :M - 3, t_lo:t_hi] - ref[:, :M - 3, t_lo:t_hi]).abs().max().item()
+    scale = ref.abs().max().item()
+    print("mode", mode, "err", err, "scale", scale)
+    assert err <= TOL[mode] * scale
+    # nothing outside the valid window / valid rows was written
+    assert got[:, :, :t_lo].abs().max().item() == 0 and got[:, :, t_hi:].abs().max().item() == 0
+    assert got[:, M - 3:].abs().max().item() == 0
+
+
+def test_chan_gemm_two_taps_epilogues():
+    mode = _lib.F16X3
+    rng = np.random.default_rng(2)
+    B, M, K, pitch, T = 2, 64, 64, 768, 600
+    w = rng.standard_normal((M, 2 * K)).astype(np.float32) * 0.2
+    pk = _packed(w, mode)
+    xin = _buf(B, K, pitch, 1.0, 3)
+    res = _buf(B, M, pitch, 1.0, 4)
+    msk = _buf(B, M, pitch, 1.0, 5)
+    bias = torch.from_numpy(rng.standard_normal(M).astype(np.float32)).to(DEV)
+    W_out = 500
+    out = torch.zeros(B * M * W_out + 512, device=DEV)
+    d, t_lo, t_hi = 7, 50, 550                                  # compact output: col = t - 50
+    in_lo, in_hi = 45, 548                                      # input window narrower than needed
+    call("wn_chan_gemm", ptr(xin, SLACK), ptr(xin, SLACK), K * pitch, pitch, in_lo, in_hi, -d, 0, K // 32, K // 32, ptr(pk),
+         M // 16, M, ptr(out), M * W_out, W_out, -t_lo, ptr(bias), ptr(res, SLACK), M * pitch, pitch, 60,
+         ptr(msk, SLACK), M * pitch, pitch, t_lo, t_hi, 1, B, mode, _lib.stream())
+    torch.cuda.synchronize()
+    x = _view(xin, B, K, pitch).cpu().double().clamp(min=0)
+    win = torch.zeros_like(x)
+    win[:, :, in_lo:in_hi] = x[:, :, in_lo:in_hi]
+    wt = torch.from_numpy(w).double()
+    ts = torch.arange(t_lo, t_hi)
+    ref = torch.einsum("mk,bkt->bmt", wt[:, :K], win[:, :, ts - d]) + torch.einsum("mk,bkt->bmt", wt[:, K:], win[:, :, ts])
+    ref = ref + bias.cpu().double()[None, :, None]
+    r = _view(res, B, M, pitch).cpu().double()[:, :, ts]
+    r[:, :, ts < 60] = 0
+    ref = ref + r
+    ref = torch.where(_view(msk, B, M, pitch).cpu().double()[:, :, ts] > 0, ref, torch.zeros_like(ref))
+    got = out[:B * M * W_out].view(B, M, W_out).cpu().double()
+    err = (got - ref).abs().max().item()
+    print("err", err, "scale", ref.abs().max().item())
+    assert err <= 3e-5 * ref.abs().max().item()
+
+
+def test_chan_gemm_user_tensor_unaligned_pitch():
+    """Causal-conv use: input is a plain contiguous (B,Q,T) tensor with T % 4 != 0."""
+    mode = _lib.F16X3
+    rng = np.random.default_rng(3)
+    B, Q, T, M, pitch = 2, 256, 333, 32, 768
+    w = rng.standard_normal((M, 2 * Q)).astype(np.float32) * 0.1
+    pk = _packed(w, mode)
+    x = torch.from_numpy(rng.standard_normal((B, Q, T)).astype(np.float32)).to(DEV)
+    out = _buf(B, M, pitch)
+    call("wn_chan_gemm", ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, ptr(pk), M // 16, M,
+         ptr(out, SLACK), M * pitch, pitch, 0, None, None, 0, 0, 0, None, 0, 0, 1, T, 0, B, mode, _lib.stream())
+    torch.cuda.synchronize()
+    wt = torch.from_numpy(w).view(M, 2, Q).permute(0, 2, 1).contiguous()       # (M,Q,2) conv weight
+    ref = F.conv1d(x.cpu().double(), wt.double())                              # (B,M,T-1): index t-1
+    got = _view(out, B, M, pitch).cpu().double()[:, :, 1:T]
+    err = (got - ref).abs().max().item()
+    print("err", err, "scale", ref.abs().max().item())
+    assert err <= 3e-5 * ref.abs().max().item()
+
+
+def _res_ref(x, wf, wg, wd, d):
+    f = F.conv1d(x, wf, dilation=d)
+    g = F.conv1d(x, wg, dilation=d)
+    z = torch.tanh(f) * torch.sigmoid(g)
+    y = F.conv1d(z, wd) + x[:, :, d:]
+    return f, g, z, y
+
+
+def _fg_pack(wf, wg, CH, mode):
+    D, R = wf.shape[0], wf.shape[1]
+    w = np.zeros((2 * CH, 2 * CH), np.float32)
+    for h, src in enumerate((wf, wg)):
+        w[h * CH:h * CH + D, :R] = src[:, :, 0]
+        w[h * CH:h * CH + D, CH:CH + R] = src[:, :, 1]
+    return _packed(w, mode), w
+
+
+@pytest.mark.parametrize("CH,R,D,d", [(32, 32, 32, 1), (32, 16, 16, 2), (64, 64, 64, 4), (64, 64, 64, 512), (64, 48, 40, 3)])
+@pytest.mark.parametrize("mode", [_lib.F16X3, _lib.BF16X3])
+def test_resblock_fwd(CH, R, D, d, mode):
+    rng = np.random.default_rng(10 + d)
+    B, T = 2, 1400
+    pitch = 2048
+    wf = (rng.standard_normal((D, R, 2)) * 0.3).astype(np.float32)
+    wg = (rng.standard_normal((D, R, 2)) * 0.3).astype(np.float32)
+    wd = (rng.standard_normal((R, D, 1)) * 0.3).astype(np.float32)
+    pfg, _ = _fg_pack(wf, wg, CH, mode)
+    wdp = np.zeros((CH, CH), np.float32)
+    wdp[:R, :D] = wd[:, :, 0]
+    pd = _packed(wdp, mode, chained=True)
+    xin = _buf(B, CH, pitch, 1.0, 7)
+    _view(xin, B, CH, pitch)[:, R:] = 0                       # padded channels are zero by contract
+    xout, zout = _buf(B, CH, pitch), _buf(B, CH, pitch)
+    off_in = 5
+    t_lo, z_lo = off_in + d, off_in + d + 300
+    call("wn_resblock_fwd", ptr(xin, SLACK), ptr(xout, SLACK), ptr(zout, SLACK), CH * pitch, CH * pitch, pitch,
+         ptr(pfg), ptr(pd), None, None, None, D, R, CH, d, t_lo, T, z_lo, 1, B, mode, _lib.stream())
+    torch.cuda.synchronize()
+    x = _view(xin, B, CH, pitch).cpu()[:, :R, off_in:T].double()
+    f, g, z, y = _res_ref(x, torch.from_numpy(wf).double(), torch.from_numpy(wg).double(), torch.from_numpy(wd).double(), d)
+    goty = _view(xout, B, CH, pitch).cpu().double()
+    gotz = _view(zout, B, CH, pitch).cpu().double()
+    ey = (goty[:, :R, t_lo:T] - y).abs().max().item()
+    ez = (gotz[:, :D, z_lo:T] - z[:, :, z_lo - t_lo:]).abs().max().item()
+    print("CH", CH, "d", d, "mode", mode, "err y", ey, "err z", ez, "scale", y.abs().max().item())
+    tol = 3e-5 if mode == _lib.F16X3 else 5e-4
+    assert ey <= tol * max(1.0, y.abs().max().item()) and ez <= tol
+    assert goty[:, :, :t_lo].abs().max().item() == 0 and gotz[:, :, :z_lo].abs().max().item() == 0
+    assert goty[:, R:].abs().max().item() == 0 and gotz[:, D:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("CH,R,D,d", [(32, 32, 32, 1), (64, 64, 64, 8), (64, 48, 40, 2)])
+def test_resblock_bwd_and_dx(CH, R, D, d):
+    mf, mb = _lib.F16X3, _lib.BF16X3
+    rng = np.random.default_rng(20 + d)
+    B, T, pitch = 2, 900, 1280
+    wf = (rng.standard_normal((D, R, 2)) * 0.3).astype(np.float32)
+    wg = (rng.standard_normal((D, R, 2)) * 0.3).astype(np.float32)
+    wd = (rng.standard_normal((R, D, 1)) * 0.3).astype(np.float32)
+    pfg, _ = _fg_pack(wf, wg, CH, mf)
+    wdT = np.zeros((CH, CH), np.float32)
+    wdT[:D, :R] = wd[:, :, 0].T
+    pdT = _packed(wdT, mb)
+    wx = np.zeros((CH, 4 * CH), np.float32)                    # data-gradient pack [W1^T | W0^T]
+    for h, src in enumerate((wf, wg)):
+        wx[:R, h * CH:h * CH + D] = src[:, :, 1].T
+        wx[:R, 2 * CH + h * CH:2 * CH + h * CH + D] = src[:, :, 0].T
+    pX = _packed(wx, mb)
+    xin = _buf(B, CH, pitch, 1.0, 8)
+    _view(xin, B, CH, pitch)[:, R:] = 0
+    dy = _buf(B, CH, pitch, 1e-3, 9)
+    _view(dy, B, CH, pitch)[:, R:] = 0
+    dz = _buf(B, CH, pitch, 1e-3, 10)
+    _view(dz, B, CH, pitch)[:, D:] = 0
+    dfg, zs, dx = _buf(B, 2 * CH, pitch, 1.0, 11), _buf(B, CH, pitch), _buf(B, CH, pitch)   # dfg pre-filled with junk
+    off_in = 3
+    t_lo, z_lo = off_in + d, off_in + d + 200
+    st = _lib.stream()
+    call("wn_resblock_bwd", ptr(xin, SLACK), ptr(dy, SLACK), ptr(dz, SLACK), ptr(dfg, SLACK), ptr(zs, SLACK),
+         CH * pitch, CH * pitch, 2 * CH * pitch, CH * pitch, pitch, ptr(pfg), ptr(pdT), None, None, D, CH, d,
+         t_lo, T, z_lo, B, mf, mb, st)
+    call("wn_chan_gemm", ptr(dfg, SLACK), ptr(dfg, SLACK), 2 * CH * pitch, pitch, t_lo, T, 0, d, 2 * CH // 32, 2 * CH // 32,
+         ptr(pX), CH // 16, R, ptr(dx, SLACK), CH * pitch, pitch, 0, None, ptr(dy, SLACK), CH * pitch, pitch, t_lo,
+         None, 0, 0, off_in, T, 0, B, mb, st)
+    gW = torch.zeros(2 * CH, 2 * CH, device=DEV)
+    gD = torch.zeros(CH, CH, device=DEV)
+    call("wn_wgrad", ptr(dfg, SLACK), 2 * CH * pitch, pitch, 0, pitch, ptr(xin, SLACK), ptr(xin, SLACK), CH * pitch, pitch,
+         -d, 0, pitch, CH // 16, 2 * CH // 16, 0, ptr(gW), 2 * CH, t_lo, T, 256, B, mb, st)
+    call("wn_wgrad", ptr(dy, SLACK), CH * pitch, pitch, 0, pitch, ptr(zs, SLACK), None, CH * pitch, pitch, 0, 0, pitch,
+         CH // 16, CH // 16, 0, ptr(gD), CH, t_lo, T, 256, B, mb, st)
+    torch.cuda.synchronize()
+    # reference through autograd in fp64
+    x = _view(xin, B, CH, pitch).cpu()[:, :R, off_in:T].double().requires_grad_(True)
+    twf, twg, twd = (torch.from_numpy(a).double().requires_grad_(True) for a in (wf, wg, wd))
+    f, g, z, y = _res_ref(x, twf, twg, twd, d)
+    gy = _view(dy, B, CH, pitch).cpu()[:, :R, t_lo:T].double()
+    gz = torch.zeros_like(z)
+    gz[:, :, z_lo - t_lo:] = _view(dz, B, CH, pitch).cpu()[:, :D, z_lo:T].double()
+    f.retain_grad(); g.retain_grad()
+    (y * gy).sum().backward(retain_graph=True, inputs=[x, twf, twg, twd, f, g])
+    gx1, gwf1, gwg1, gwd1, gf1, gg1 = x.grad.clone(), twf.grad.clone(), twg.grad.clone(), twd.grad.clone(), f.grad.clone(), g.grad.clone()
+    for t in (x, twf, twg, twd, f, g):
+        t.grad = None
+    (z * gz).sum().backward(inputs=[x, twf, twg, f, g])
+    gx, gwf, gwg, gf, gg = gx1 + x.grad, gwf1 + twf.grad, gwg1 + twg.grad, gf1 + f.grad, gg1 + g.grad
+    got_dfg = _view(dfg, B, 2 * CH, pitch).cpu().double()
+    sc = gf.abs().max().item()
+    e1 = (got_dfg[:, :D, t_lo:T] - gf).abs().max().item() / sc
+    e2 = (got_dfg[:, CH:CH + D, t_lo:T] - gg).abs().max().item() / sc
+    ez = (_view(zs, B, CH, pitch).cpu().double()[:, :D, t_lo:T] - z.detach()).abs().max().item()
+    got_dx = _view(dx, B, CH, pitch).cpu().double()[:, :R, off_in:T]
+    e3 = (got_dx - gx).abs().max().item() / gx.abs().max().item()
+    gWc = gW.cpu().double()
+    ref_wf = torch.cat([gwf[:, :, 0], gwf[:, :, 1]], 1)         # [D, 2R] laid out as tap0|tap1
+    got_wf = torch.cat([gWc[:D, :R], gWc[:D, CH:CH + R]], 1)
+    got_wg = torch.cat([gWc[CH:CH + D, :R], gWc[CH:CH + D, CH:CH + R]], 1)
+    ref_wg = torch.cat([gwg[:, :, 0], gwg[:, :, 1]], 1)
+    e4 = (got_wf - ref_wf).abs().max().item() / ref_wf.abs().max().item()
+    e5 = (got_wg - ref_wg).abs().max().item() / ref_wg.abs().max().item()
+    e6 = (gD.cpu().double()[:R, :D] - gwd1[:, :, 0]).abs().max().item() / gwd1.abs().max().item()
+    print("df", e1, "dg", e2, "z", ez, "dx", e3, "dWf", e4, "dWg", e5, "dWd", e6)
+    assert max(e1, e2, e3, e4, e5, e6) < 2e-3 and ez < 3e-5
+
+
+def test_wgrad_compact_relu():
+    mode = _lib.BF16X3
+    rng = np.random.default_rng(5)
+    B, M, N, pitch, T, W = 2, 48, 80, 1024, 900, 640
+    lo = T - W
+    a = torch.from_numpy(rng.standard_normal((B, M, W)).astype(np.float32) * 1e-4).to(DEV)   # compact A
+    a_pad = torch.cat([a.reshape(-1), torch.zeros(512, device=DEV)])
+    b = _buf(B, N, pitch, 1.0, 6)
+    c = torch.zeros(M, N, device=DEV)
+    call("wn_wgrad", ptr(a_pad), M * W, W, -lo, W, ptr(b, SLACK), None, N * pitch, pitch, 0, 0, pitch, N // 16, M // 16, 1,
+         ptr(c), N, lo, T, 128, B, mode, _lib.stream())
+    torch.cuda.synchronize()
+    bb = _view(b, B, N, pitch).cpu().double()[:, :, lo:T].clamp(min=0)
+    ref = torch.einsum("bmt,bnt->mn", a.cpu().double(), bb)
+    err = (c.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    print("wgrad rel err", err)
+    assert err < 1e-3
+
+
+def test_chunk_softmax_fwd_bwd_ce():
+    from tests.helpers import load_npz
+    from tests.tools_cfg import g3_inputs
+    d = load_npz("g3_softmax.npz")
+    for w, x in g3_inputs().items():
+        xt = torch.from_numpy(x).to(DEV)
+        y = torch.empty(w, 256, device=DEV)
+        call("wn_chunk_softmax256_fwd", ptr(xt), ptr(y), w, _lib.stream())
+        np.testing.assert_allclose(y.cpu().numpy(), d["y_w%d" % w], atol=2e-7, rtol=1e-5)
+    rng = np.random.default_rng(9)
+    n = 1037
+    x = torch.from_numpy((3 * rng.standard_normal((n, 256))).astype(np.float32))
+    tgt = torch.from_numpy(rng.integers(0, 256, n).astype(np.int64))
+    xr = x.clone().double().requires_grad_(True)
+    p = torch.softmax(xr, 1)
+    loss = F.cross_entropy(p, tgt)
+    loss.backward()
+    xd, td = x.to(DEV), tgt.to(DEV)
+    probs, dx = torch.empty(n, 256, device=DEV), torch.empty(n, 256, device=DEV)
+    part = torch.zeros(_lib.CE_NUM_PARTIALS, device=DEV)
+    call("wn_chunk_softmax256_ce", ptr(xd), ptr(td), ptr(probs), ptr(dx), ptr(part), n, 1.0 / n, _lib.stream())
+    assert abs(part.sum().item() - loss.item()) < 1e-5
+    assert (probs.cpu().double() - p.detach()).abs().max().item() < 1e-6
+    assert (dx.cpu().double() - xr.grad).abs().max().item() < 1e-9 + 1e-5 * xr.grad.abs().max().item()
+    # separate backward kernel: dx = y*(dy - <dy,y>)
+    dy = torch.from_numpy(rng.standard_normal((n, 256)).astype(np.float32)).to(DEV)
+    dx2 = torch.empty(n, 256, device=DEV)
+    call("wn_chunk_softmax256_bwd", ptr(probs), ptr(dy), ptr(dx2), n, _lib.stream())
+    pr = p.detach()
+    ref = pr * (dy.cpu().double() - (dy.cpu().double() * pr).sum(1, keepdim=True))
+    assert (dx2.cpu().double() - ref).abs().max().item() < 1e-5
+
+
+def test_onehot_and_mulaw():
+    from oracle import intops
+    from tests.helpers import load_npz
+    rng = np.random.default_rng(11)
+    codes = rng.integers(0, 256, size=(3, 1025)).astype(np.int32)
+    cd = torch.from_numpy(codes).to(DEV)
+    for scr in (1, 0):
+        out = torch.empty(3, 256, 1025, device=DEV)
+        call("wn_onehot", ptr(cd), ptr(out), 3, 256, 1025, scr, _lib.stream())
+        ref = np.stack([(intops.one_hot_scrambled if scr else intops.one_hot_proper)(r) for r in codes])
+        assert np.array_equal(out.cpu().numpy(), ref)              # bit-exact
+    g4 = load_npz("g4_data.npz")
+    piece = g4["oh_piece3"]
+    out = torch.empty(1, 256, len(piece), device=DEV)
+    call("wn_onehot", ptr(torch.from_numpy(piece.astype(np.int32)).to(DEV)), ptr(out), 1, 256, len(piece), 1, _lib.stream())
+    assert np.array_equal(np.flatnonzero(out.cpu().numpy().reshape(-1)), g4["oh_flatpos3"])
+    g5 = load_npz("g5_mulaw.npz")
+    x = torch.from_numpy(g5["x"]).to(DEV)
+    thr = torch.from_numpy(g5["thresholds"]).to(DEV)
+    c = torch.empty(x.numel(), dtype=torch.uint8, device=DEV)
+    call("wn_mulaw_encode_tbl", ptr(x), ptr(thr), ptr(c), x.numel(), _lib.stream())
+    assert np.array_equal(c.cpu().numpy(), g5["codes"])             # bit-exact vs the reference encoder
+    tab = torch.from_numpy(g5["decode_table"]).to(DEV)
+    a = torch.empty(x.numel(), device=DEV)
+    call("wn_mulaw_decode_lut", ptr(c), ptr(tab), ptr(a), x.numel(), _lib.stream())
+    assert np.array_equal(a.cpu().numpy(), g5["decode_table"][g5["codes"]])
+    # encode(decode(k)) == k round trip on device
+    ks = torch.arange(256, dtype=torch.uint8, device=DEV)
+    a2 = torch.empty(256, device=DEV)
+    c2 = torch.empty(256, dtype=torch.uint8, device=DEV)
+    call("wn_mulaw_decode_lut", ptr(ks), ptr(tab), ptr(a2), 256, _lib.stream())
+    call("wn_mulaw_encode_tbl", ptr(a2), ptr(thr), ptr(c2), 256, _lib.stream())
+    assert torch.equal(c2, ks)
+
+
+def test_adam_flat_matches_torch():
+    n = 100003
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(n, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=1e-3)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for t in range(1, 6):
+        gr = torch.randn(n, generator=g) * 0.01
+        p_ref.grad = gr.clone()
+        opt.step()
+        call("wn_adam_flat", ptr(p), ptr((gr * 4).to(DEV)), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8,
+             1 - 0.9 ** t, 1 - 0.999 ** t, 0.25, _lib.stream())
+    assert (p.cpu() - p_ref.detach()).abs().max().item() < 2e-6

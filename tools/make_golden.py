@@ -280,6 +280,9 @@ def g5_mulaw(af):
     assert (enc(dec) == np.arange(256)).all()
     np.savez_compressed(os.path.join(OUT, "g5_mulaw.npz"), thresholds=thr, x=xs,
                         codes=ys.astype(np.uint8), decode_table=dec.astype(np.float32))
+    # the two tables are also product data (music_amd/audio_func.py encodes/decodes through them)
+    np.savez(os.path.join(OUT, "..", "..", "music_amd", "mulaw_tables.npz"), thresholds=thr,
+             decode_table=dec.astype(np.float32))
 
 
 def load_fast_predict_next(correct=False):
