@@ -66,7 +66,9 @@ def cpu_baseline(seconds_budget=25.0):
     x = torch.from_numpy(intops.one_hot_scrambled(codes[:T]))[None]
     rf = 3071
     target = torch.from_numpy(codes[rf:rf + T - rf + 1].astype(np.int64))
-    cores = os.cpu_count() or 1
+    # ATen's CPU conv kernels stop scaling (and then collapse) long before a 256-core host is
+    # full: use at most 32 threads and say so in `cores`
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     times = []
     t_start = time.time()

@@ -60,6 +60,9 @@ def load():
         raise WavenetHipError(
             "libwavenet_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C music_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    # torch first: libwavenet_hip.so must bind to the SAME libamdhip64 (HIP runtime, device
+    # context, streams) that PyTorch-ROCm has loaded, not to a second copy from /opt/rocm
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError here = header/library out of sync

@@ -62,7 +62,7 @@ def test_chan_gemm_single_tap(mode):
     assert err <= TOL[mode] * scale
     # nothing outside the valid window / valid rows was written
     assert got[:, :, :t_lo].abs().max().item() == 0 and got[:, :, t_hi:].abs().max().item() == 0
-    assert got[:, M - 3:].abs().max().item() == 0
+    assert got[:, M - 3:].abs().sum().item() == 0
 
 
 def test_chan_gemm_two_taps_epilogues():
@@ -168,7 +168,7 @@ def test_resblock_fwd(CH, R, D, d, mode):
     tol = 3e-5 if mode == _lib.F16X3 else 5e-4
     assert ey <= tol * max(1.0, y.abs().max().item()) and ez <= tol
     assert goty[:, :, :t_lo].abs().max().item() == 0 and gotz[:, :, :z_lo].abs().max().item() == 0
-    assert goty[:, R:].abs().max().item() == 0 and gotz[:, D:].abs().max().item() == 0
+    assert goty[:, R:].abs().sum().item() == 0 and gotz[:, D:].abs().sum().item() == 0
 
 
 @pytest.mark.parametrize("CH,R,D,d", [(32, 32, 32, 1), (64, 64, 64, 8), (64, 48, 40, 2)])

@@ -128,7 +128,7 @@ def test_module_surface():
 
 
 def test_fused_train_step_matches_autograd_path_and_oracle():
-    meta = [m for m in g1_meta() if m["name"] == "tiny_s0_g6_w130"][0]
+    meta = [m for m in g1_meta() if m["name"] == "tiny_s0_g3_w130"][0]
     d = load_npz("g1_%s.npz" % meta["name"])
     params = params_from(d)
     net = build(meta["cfg"], params)

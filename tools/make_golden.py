@@ -65,15 +65,21 @@ def scrambled_batch(fad, idx):
 
 
 def g1_forward(model, fad):
+    # Weight gains: the tolerance of the path is ABSOLUTE (1e-3 on logits/probabilities), so the
+    # fixtures must be (a) non-vacuous - at default init every probability is within 1.1e-4 of
+    # 1/256 - and (b) well enough conditioned that the reference's own float32
+    # rounding noise (|fp32 - fp64|) stays far below 1e-3.  Gain 3 gives pre-softmax |max| ~ 15,
+    # max probability ~ 0.93-0.99 and fp32 noise ~ 1e-5; at gain 6 the reference itself is only
+    # reproducible to 4e-3 (tiny) .. 3e-2 (c1) against fp64, i.e. not testable at 1e-3.
     cases = {}
     meta = []
     specs = [
         # name, cfg, seed, gain, B, extra T over rf-1 (so W = extra), input kind
         ("tiny_s0_g1_w1", TINY, 0, 1.0, 2, 1, "scrambled"),
-        ("tiny_s0_g6_w130", TINY, 0, 6.0, 2, 130, "scrambled"),
-        ("tiny_s1_g6_w257", TINY, 1, 6.0, 1, 257, "scrambled"),
+        ("tiny_s0_g3_w130", TINY, 0, 3.0, 2, 130, "scrambled"),
+        ("tiny_s1_g3_w257", TINY, 1, 3.0, 1, 257, "scrambled"),
         ("tiny_s2_g4_w255_randn", TINY, 2, 4.0, 1, 255, "randn"),
-        ("tinybias_s3_g5_w64", TINY_BIAS, 3, 5.0, 2, 64, "scrambled"),
+        ("tinybias_s3_g3_w64", TINY_BIAS, 3, 3.0, 2, 64, "scrambled"),
     ]
     for name, cfg, seed, gain, b, w, kind in specs:
         torch.manual_seed(seed)
@@ -110,7 +116,7 @@ def g1_forward(model, fad):
         meta.append(dict(name=name, cfg=cfg, seed=seed, gain=gain, B=b, W=w, kind=kind))
     # c1-shaped case: B=1, T=4000 — outputs subsampled to keep the fixture small
     torch.manual_seed(0)
-    net = scaled(model.wavenet(**C1), 6.0)
+    net = scaled(model.wavenet(**C1), 3.0)
     rf = net.receptive_field
     t = 4000
     w = t - rf + 1
@@ -138,8 +144,8 @@ def g1_forward(model, fad):
     for k, p in net.named_parameters():
         d["g:" + k] = p.grad.numpy().copy() if p.grad is not None else np.zeros(p.shape, np.float32)
     d["nograd"] = np.array([k for k, p in net.named_parameters() if p.grad is None])
-    np.savez_compressed(os.path.join(OUT, "g1_c1_s0_g6.npz"), **d)
-    meta.append(dict(name="c1_s0_g6", cfg=C1, seed=0, gain=6.0, B=1, W=int(w), kind="scrambled"))
+    np.savez_compressed(os.path.join(OUT, "g1_c1_s0_g3.npz"), **d)
+    meta.append(dict(name="c1_s0_g3", cfg=C1, seed=0, gain=3.0, B=1, W=int(w), kind="scrambled"))
     with open(os.path.join(OUT, "g1_meta.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
@@ -147,7 +153,7 @@ def g1_forward(model, fad):
 def g2_layers(model, fad):
     """Per-layer residual stream x_i and gated activation z_i of the tiny config (forward hooks)."""
     torch.manual_seed(5)
-    net = scaled(model.wavenet(**TINY), 6.0)
+    net = scaled(model.wavenet(**TINY), 3.0)
     rf = net.receptive_field
     rng = np.random.default_rng(55)
     idx = rng.integers(0, 256, size=(1, rf + 40)).astype(np.int32)
@@ -312,7 +318,7 @@ def load_fast_predict_next(correct=False):
 def g6_fastgen(model):
     cfg = dict(TINY, dilations=[1, 2, 4, 8, 16, 1, 2, 4, 8, 16])
     torch.manual_seed(6)
-    net = scaled(model.wavenet(**cfg), 6.0)
+    net = scaled(model.wavenet(**cfg), 3.0)
     rf = net.receptive_field
     rng = np.random.default_rng(66)
     start = rng.integers(0, 256, size=(rf,))
@@ -365,7 +371,7 @@ def g7_train():
     src = open(os.path.join(REF, "wavenet", "train.py")).read()
     src = src.replace("async=True", "non_blocking=True").replace("loss.data[0]", "loss.item()")
     out = {}
-    for tag, gain in (("plain", None), ("gain", 6.0)):
+    for tag, gain in (("plain", None), ("gain", 3.0)):
         tmp = tempfile.mkdtemp()
         os.makedirs(os.path.join(tmp, "params"))
         rng = np.random.default_rng(77)
@@ -409,7 +415,7 @@ def g7_train():
         out["wavenet_params"], out["dataset_params"], out["train_params"] = wp, dict(dp, audio_path="np_audio.pkl"), tp
         out["data_lens"] = [2400, 1500, 1230]
         out["data_seed"] = 77
-        out["gain"] = 6.0
+        out["gain"] = 3.0
     json.dump(out, open(os.path.join(OUT, "g7_train.json"), "w"), indent=1)
 
 
@@ -428,7 +434,7 @@ def g8_autoencoder():
     d = {}
     # W = 60 -> Le = 6: layers whose length is a multiple of 6 take the stretch branch
     torch.manual_seed(8)
-    net = scaled(model1.wavenet_autoencoder(**cfg), 5.0)
+    net = scaled(model1.wavenet_autoencoder(**cfg), 3.0)
     rf = net.receptive_field
     rng = np.random.default_rng(88)
     for tag, w in (("a", 60), ("b", 47)):

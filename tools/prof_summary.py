@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (kernel trace + PMC passes) into a small markdown table.
+
+usage: python tools/prof_summary.py gpurun_out > profiles/rNN_summary.md
+Looks for */*kernel_stats.csv, */*kernel_trace.csv and */*counter_collection.csv below
+<dir>/prof, <dir>/pmc_fetch, <dir>/pmc_write.
+"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    return sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name[:90]
+
+
+def main():
+    root = sys.argv[1]
+    print("# rocprofv3 summary (%s)\n" % root)
+    stats = find(os.path.join(root, "prof"), "*kernel_stats.csv")
+    if stats:
+        print("## kernel time (rocprofv3 --kernel-trace --stats)\n")
+        print("| kernel | calls | total ms | avg us | % |")
+        print("|---|---|---|---|---|")
+        rows = list(csv.DictReader(open(stats[0])))
+        for r in rows[:25]:
+            print("| %s | %s | %.3f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                  float(r["AverageNs"]) / 1e3, r["Percentage"]))
+        print()
+    for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        files = find(os.path.join(root, tag), "*counter_collection.csv")
+        if not files:
+            continue
+        acc = defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(files[0])):
+            if r.get("Counter_Name") != counter:
+                continue
+            k = short(r["Kernel_Name"])
+            acc[k][0] += 1
+            acc[k][1] += float(r["Counter_Value"])
+        print("## %s per launch (raw counter units = KiB; gfx950: double FETCH_SIZE for wide streaming reads)\n" % counter)
+        print("| kernel | launches | avg %s (KiB) |" % counter)
+        print("|---|---|---|")
+        for k, (n, v) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:20]:
+            print("| %s | %d | %.1f |" % (k, n, v / n))
+        print()
+
+
+if __name__ == "__main__":
+    main()
