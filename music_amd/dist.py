@@ -1,0 +1,80 @@
+"""Data parallelism for the WaveNet path: one process per GPU, RCCL all-reduce over xGMI.
+
+Replaces ``nn.DataParallel`` (wavenet/train.py:116-122): instead of scatter / replicate / gather /
+reduce-to-GPU-0 every step, each rank keeps a persistent replica and its own clips, and the only
+exchange is ONE sum all-reduce of the flat fp32 gradient buffer per step (5.08 MB at the 30-layer
+config), followed by the 1/world scale.  Equal per-rank batches make that the gradient of the mean
+loss over the global batch, which is what DataParallel computes.
+Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* if WORLD_SIZE > 1.
+    Returns (rank, world, local_rank)."""
+    w = int(os.environ.get("WORLD_SIZE", "1"))
+    r = int(os.environ.get("RANK", "0"))
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    if w > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(lr)
+            dist.init_process_group(backend, device_id=torch.device("cuda", lr))
+        else:
+            dist.init_process_group(backend)
+    return r, w, lr
+
+
+def broadcast_parameters(params, src=0):
+    """Make every replica identical to rank `src` (DataParallel replicates from device 0)."""
+    if world() == 1:
+        return
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        dist.broadcast(flat, src)
+        o = 0
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[o:o + n].view_as(p))
+            o += n
+
+
+def allreduce_flat_(flat_grad, average=True):
+    """In-place sum all-reduce of one flat gradient buffer (+ 1/world)."""
+    w = world()
+    if w == 1:
+        return flat_grad
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    if average:
+        flat_grad.mul_(1.0 / w)
+    return flat_grad
+
+
+def allreduce_gradients(params, average=True):
+    """All-reduce the .grad of `params` as ONE flat bucket (parameters without a grad contribute
+    zeros so that every rank issues the same collective)."""
+    w = world()
+    if w == 1:
+        return
+    params = list(params)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    allreduce_flat_(flat, average)
+    o = 0
+    for p in params:
+        n = p.numel()
+        if p.grad is not None:
+            p.grad.copy_(flat[o:o + n].view_as(p))
+        o += n

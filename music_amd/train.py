@@ -1,0 +1,198 @@
+"""Counterpart of the reference's ``wavenet/train.py`` for the MI355X path.
+
+Same function names, JSON schema (./params/{train,wavenet,dataset}_params.json read relative to the
+CWD), step order ``zero_grad -> forward -> CrossEntropyLoss(probs, target.view(-1)) -> backward ->
+step`` (wavenet/train.py:171-182), batch counter and its recovery from the last log line
+(:160-166,186), log-line formats (:189-191,217-218), checkpoint naming / rotation / ``module.``
+stripping (:45-73,198-216).  The reference file itself cannot run on Python >= 3.7
+(``.cuda(async=True)``), so this module is the drop-in.
+
+Differences, all additive:
+  * ``nn.DataParallel`` (one process, GPU-0 bottleneck) is replaced by one process per GPU
+    (``torchrun --nproc-per-node N train.py``) with ONE flat RCCL all-reduce per step
+    (music_amd/dist.py); each rank builds only its own shard of every global batch.
+  * optional keys in train_params.json: ``"seed"`` (int), ``"fused_step"`` (bool: Adam only — the
+    whole step runs as forward+CE+backward+flat-Adam kernels without autograd).
+"""
+from collections import OrderedDict
+from functools import cmp_to_key
+import glob
+import json
+import os
+
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+try:
+    from . import dist as wdist
+    from .faster_audio_data import audio_data_loader
+    from .model import wavenet
+except ImportError:                                  # run as a script / bare modules from the CWD
+    from music_amd import dist as wdist
+    from music_amd.faster_audio_data import audio_data_loader
+    from music_amd.model import wavenet
+
+
+def get_params(json_dir):
+    with open(json_dir, 'r') as f:
+        return json.load(f)
+
+
+def get_arguments():
+    return (get_params('./params/train_params.json'),
+            get_params('./params/wavenet_params.json'),
+            get_params('./params/dataset_params.json'))
+
+
+def get_optimizer(model, optimizer_type, learning_rate, momentum):
+    """wavenet/train.py:28-42 — 'sgd' / 'rmsprop' (with momentum) / 'adam'; anything else -> None."""
+    if optimizer_type == 'sgd':
+        return optim.SGD(model.parameters(), lr=learning_rate, momentum=momentum)
+    if optimizer_type == 'rmsprop':
+        return optim.RMSprop(model.parameters(), lr=learning_rate, momentum=momentum)
+    if optimizer_type == 'adam':
+        return optim.Adam(model.parameters(), lr=learning_rate)
+
+
+def save_model(model, num_iter, path):
+    """``restore_dir + "wavenet{N}.model"`` = bare state_dict pickle (wavenet/train.py:45-50)."""
+    checkpoint_path = path + "wavenet" + str(num_iter) + ".model"
+    print("Storing checkpoint to {} ...".format(path))
+    state = OrderedDict((k, v.detach().cpu().clone()) for k, v in model.state_dict().items())
+    torch.save(state, checkpoint_path)
+    print("Done!")
+
+
+def load_model(model, path, model_name):
+    """Returns the model, or None when the file does not exist (wavenet/train.py:53-73).  Keys
+    saved from a DataParallel wrapper ("module." prefix) are accepted."""
+    checkpoint_path = path + model_name
+    print("Trying to restore saved checkpoint from ", "{}".format(checkpoint_path))
+    if not os.path.exists(checkpoint_path):
+        print("No checkpoint found!")
+        return None
+    print("Checkpoint found, restoring!")
+    state_dict = torch.load(checkpoint_path, map_location="cpu")
+    if list(state_dict.keys())[0][:6] == 'module':
+        state_dict = OrderedDict((k[7:], v) for k, v in state_dict.items())
+    model.load_state_dict(state_dict)
+    return model
+
+
+def _rotate_checkpoints(restore_dir, max_check_points):
+    """Delete the numerically oldest wavenet{N}.model once max_check_points exist (:198-213)."""
+    stored = glob.glob(restore_dir + "*.model")
+    if len(stored) == max_check_points:
+        def number(p):
+            return int(p.split('/')[-1].split('.')[0][7:])
+        stored = sorted(stored, key=cmp_to_key(lambda a, b: number(a) - number(b)))
+        os.remove(stored[0])
+
+
+def _resume_counter(log_dir):
+    """Batches trained so far = third word of the last loss_log line (:160-166)."""
+    with open(log_dir + 'loss_log.log', 'r') as f:
+        lines = f.readlines()
+    return int(lines[-1].split(' ')[2]) if lines else 0
+
+
+def train():
+    cuda_available = torch.cuda.is_available()
+    train_params, wavenet_params, dataset_params = get_arguments()
+    rank, world, local_rank = wdist.init_from_env()
+    if "seed" in train_params and train_params["seed"] is not None:
+        torch.manual_seed(int(train_params["seed"]))
+
+    net = wavenet(**wavenet_params)
+    epoch_trained = 0
+    if train_params["restore_model"]:
+        net = load_model(net, train_params["restore_dir"], train_params["restore_model"])
+        if net is None:
+            print("Initialize network and train from scratch.")
+            net = wavenet(**wavenet_params)
+        else:
+            epoch_trained = int(train_params["restore_model"].split('.')[0][7:])
+
+    if cuda_available is False and train_params["device_ids"] is not None:
+        raise ValueError("Cuda is not avalable,", " can not train model using multi-gpu.")
+    if world > 1:
+        # DataParallel semantics: the JSON batch_size is the GLOBAL batch, split evenly
+        assert dataset_params["batch_size"] % world == 0
+        dataset_params = dict(dataset_params, shard=(rank, world))
+    dataloader = audio_data_loader(**dataset_params)
+    if cuda_available:
+        net = net.cuda()
+    wdist.broadcast_parameters(list(net.parameters()))
+
+    print("Start training.")
+    print("Writing logging information to ", "{}".format(train_params["log_dir"]))
+    print("Models are saved in {}".format(train_params["restore_dir"]))
+
+    optimizer = get_optimizer(net, train_params["optimizer"], train_params["learning_rate"],
+                              train_params["momentum"])
+    loss_func = nn.CrossEntropyLoss()
+    if cuda_available:
+        loss_func = loss_func.cuda()
+    fused = bool(train_params.get("fused_step")) and train_params["optimizer"] == 'adam' and cuda_available
+    is_writer = rank == 0
+    loss_log_file = store_log_file = None
+    if is_writer:
+        os.makedirs(train_params["log_dir"], exist_ok=True)
+        os.makedirs(train_params["restore_dir"], exist_ok=True)
+        loss_log_file = open(train_params["log_dir"] + 'loss_log.log', 'a')
+        store_log_file = open(train_params["log_dir"] + 'store_log.log', 'a')
+    if world > 1:
+        torch.distributed.barrier()
+    num_trained = _resume_counter(train_params["log_dir"])
+
+    device = next(net.parameters()).device
+    total_loss = torch.zeros((), dtype=torch.float64, device=device)     # summed without host syncs
+    engine = None
+    for epoch in range(train_params["num_epochs"]):
+        for i_batch, sampled_batch in enumerate(dataloader):
+            piece = sampled_batch["audio_piece"]
+            target = sampled_batch["audio_target"]
+            if cuda_available:
+                piece = piece.cuda(non_blocking=True)
+                target = target.cuda(non_blocking=True)
+            target = target.view(-1)
+            if fused:
+                if engine is None:
+                    engine = net._engine_for(piece.device)
+                    engine.adam_init(lr=train_params["learning_rate"])
+                loss = engine.loss_and_grad(piece.contiguous(), target)
+                wdist.allreduce_flat_(engine.flat_grad, average=True)
+                engine.adam_step()
+            else:
+                optimizer.zero_grad()
+                logits = net(piece)            # probabilities, named as in the reference (Q1)
+                loss = loss_func(logits, target)
+                loss.backward()
+                wdist.allreduce_gradients(net.parameters(), average=True)
+                optimizer.step()
+            total_loss += loss.detach().double()
+            num_trained += 1
+            if num_trained % train_params["print_every"] == 0:
+                if world > 1:
+                    torch.distributed.all_reduce(total_loss)
+                    total_loss /= world
+                avg_loss = total_loss.item() / train_params["print_every"]
+                if is_writer:
+                    loss_log_file.writelines("Trained over " + str(num_trained) + " pieces," +
+                                             "Average loss is " + str(avg_loss) + "\n")
+                    loss_log_file.flush()
+                total_loss.zero_()
+
+        if (epoch + 1) % train_params["check_point_every"] == 0 and is_writer:
+            _rotate_checkpoints(train_params["restore_dir"], train_params["max_check_points"])
+            save_model(net, epoch_trained + epoch + 1, train_params["restore_dir"])
+            store_log_file.writelines("Epoch " + str(epoch_trained + epoch + 1) + ", model saved!\n")
+            store_log_file.flush()
+    if is_writer:
+        loss_log_file.close()
+        store_log_file.close()
+
+
+if __name__ == '__main__':
+    train()

@@ -1,0 +1,89 @@
+"""world_size-2 data-parallel tests on CPU (gloo): the flat-bucket all-reduce reproduces
+DataParallel's global-batch-mean gradient, and train() under 2 ranks writes the same logs /
+checkpoints as 1 rank with the same global batch."""
+import json
+import os
+import pickle
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+from tests.helpers import ROOT
+
+CFG = dict(filter_width=2, dilations=[1, 2, 4, 8], dilation_channels=16, residual_channels=16,
+           skip_channels=16, quantization_channels=256, use_bias=False)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(nproc, mode, workdir):
+    env = dict(os.environ, OMP_NUM_THREADS="2", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(workdir)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_allreduce_equals_global_batch_gradient(tmp_path):
+    from tests.cpu_model import OracleWavenet, onehot_oracle
+    json.dump(CFG, open(tmp_path / "cfg.json", "w"))
+    rng = np.random.default_rng(0)
+    rf = 17
+    codes = torch.from_numpy(rng.integers(0, 256, size=(4, rf + 39)).astype(np.int64))
+    x = onehot_oracle(codes)
+    y = torch.from_numpy(rng.integers(0, 256, size=(4, 40)).astype(np.int64))
+    torch.save({"x": x, "y": y}, tmp_path / "batch.pt")
+    _launch(2, "grads", tmp_path)
+    torch.manual_seed(0)
+    net = OracleWavenet(**CFG)
+    with torch.no_grad():
+        pass
+    loss = torch.nn.CrossEntropyLoss()(net(x), y.reshape(-1))
+    loss.backward()
+    got = torch.load(tmp_path / "grads_dp.pt")
+    for k, p in net.named_parameters():
+        want = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert (got[k] - want).abs().max().item() <= 1e-6 * max(1e-3, want.abs().max().item()) + 1e-9, k
+
+
+def _write_run(tmp, batch_size):
+    os.makedirs(tmp / "params", exist_ok=True)
+    rng = np.random.default_rng(5)
+    data = [rng.integers(0, 256, size=(l,)).astype(np.int32) for l in (900, 700)]
+    pickle.dump(data, open(tmp / "np_audio.pkl", "wb"))
+    dp = dict(batch_size=batch_size, shuffle=True, num_workers=0, pin_memory=False, audio_path=str(tmp / "np_audio.pkl"),
+              receptive_field=17, window_length=100, cuda_available=False, quantization_channels=256)
+    tp = dict(log_dir="./log/", restore_dir="./restore/", restore_model="", check_point_every=1, print_every=1,
+              num_epochs=2, wavenet_params="", optimizer="adam", max_check_points=10, learning_rate=1e-3,
+              momentum=0.9, device_ids=None, seed=3)
+    for n, p in (("wavenet", CFG), ("dataset", dp), ("train", tp)):
+        json.dump(p, open(tmp / "params" / (n + "_params.json"), "w"))
+
+
+def test_train_two_ranks_equals_one_rank(tmp_path):
+    a, b = tmp_path / "one", tmp_path / "two"
+    os.makedirs(a), os.makedirs(b)
+    _write_run(a, 4)
+    _write_run(b, 4)
+    _launch(1, "train", a)
+    _launch(2, "train", b)
+    la = open(a / "log" / "loss_log.log").read().strip().split("\n")
+    lb = open(b / "log" / "loss_log.log").read().strip().split("\n")
+    assert len(la) == len(lb) and len(la) >= 4
+    for x, y in zip(la, lb):
+        assert x.split("Average")[0] == y.split("Average")[0]
+        assert abs(float(x.split(' ')[-1]) - float(y.split(' ')[-1])) < 2e-6
+    assert open(a / "log" / "store_log.log").read() == open(b / "log" / "store_log.log").read()
+    ca, cb = torch.load(a / "restore" / "wavenet2.model"), torch.load(b / "restore" / "wavenet2.model")
+    for k in ca:
+        assert (ca[k] - cb[k]).abs().max().item() < 1e-5, k

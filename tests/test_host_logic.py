@@ -1,0 +1,113 @@
+"""CPU tests of the host side: dataset chopping vs the golden vectors, the train() loop's files and
+formats vs the text the reference's own train() wrote (G7), checkpoint compatibility."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, load_npz
+
+
+def test_dataset_pieces_match_reference(tmp_path):
+    from music_amd.faster_audio_data import audio_dataset
+    d = load_npz("g4_data.npz")
+    n = 0
+    while "mp%d_lens" % n in d:
+        rf, win = (int(v) for v in d["mp%d_rf_win" % n])
+        flat, data, o = d["mp%d_data" % n], [], 0
+        for l in d["mp%d_lens" % n]:
+            data.append(flat[o:o + l].astype(np.int32))
+            o += l
+        path = tmp_path / ("a%d.pkl" % n)
+        pickle.dump(data, open(path, "wb"))
+        ds = audio_dataset(str(path), rf, win)
+        assert len(ds) == int(d["mp%d_n" % n])
+        assert [len(p["audio_piece"]) for p in ds.data] == list(d["mp%d_piece_len" % n])
+        assert [int(p["audio_piece"].long().sum()) for p in ds.data] == list(d["mp%d_piece_sum" % n])
+        assert [int(p["audio_piece"][0]) for p in ds.data] == list(d["mp%d_piece_first" % n])
+        assert [int(p["audio_target"].sum()) for p in ds.data] == list(d["mp%d_target_sum" % n])
+        assert all(p["audio_target"].dtype == torch.int64 for p in ds.data)
+        n += 1
+    assert n == 3
+    pickle.dump([np.arange(30, dtype=np.int32)], open(tmp_path / "short.pkl", "wb"))
+    with pytest.raises(NameError):
+        audio_dataset(str(tmp_path / "short.pkl"), 20, 30)
+
+
+def _setup_run(tmp_path, g7, monkeypatch, gain):
+    from music_amd import train as T
+    from music_amd import faster_audio_data as fad
+    from tests.cpu_model import OracleWavenet, onehot_oracle
+    os.makedirs(tmp_path / "params")
+    rng = np.random.default_rng(g7["data_seed"])
+    data = [rng.integers(0, 256, size=(l,)).astype(np.int32) for l in g7["data_lens"]]
+    pickle.dump(data, open(tmp_path / "np_audio.pkl", "wb"))
+    dp = dict(g7["dataset_params"], audio_path=str(tmp_path / "np_audio.pkl"))
+    for n, p in (("wavenet", g7["wavenet_params"]), ("dataset", dp), ("train", g7["train_params"])):
+        json.dump(p, open(tmp_path / "params" / (n + "_params.json"), "w"))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(fad, "onehot_device", onehot_oracle)
+
+    def ctor(**kw):
+        net = OracleWavenet(**kw)
+        if gain is not None:
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.mul_(gain)
+        return net
+    monkeypatch.setattr(T, "wavenet", ctor)
+    return T
+
+
+@pytest.mark.parametrize("tag", ["plain", "gain"])
+def test_train_loop_files_match_reference(tmp_path, monkeypatch, tag):
+    g7 = json.load(open(os.path.join(GOLDEN, "g7_train.json")))
+    T = _setup_run(tmp_path, g7, monkeypatch, None if tag == "plain" else g7["gain"])
+    torch.manual_seed(0)
+    T.train()
+    got = open(tmp_path / "log" / "loss_log.log").read()
+    want = g7[tag + "_loss_log"]
+    gl, wl = got.strip().split("\n"), want.strip().split("\n")
+    assert len(gl) == len(wl)
+    for a, b in zip(gl, wl):
+        assert a.split("Average")[0] == b.split("Average")[0]          # "Trained over N pieces,"
+        assert abs(float(a.split(' ')[-1]) - float(b.split(' ')[-1])) < 1e-6
+    assert open(tmp_path / "log" / "store_log.log").read() == g7[tag + "_store_log"]
+    assert sorted(os.listdir(tmp_path / "restore")) == g7[tag + "_files"]
+    ck = torch.load(tmp_path / "restore" / "wavenet2.model")
+    assert list(ck.keys()) == g7[tag + "_ckpt_keys"]
+    assert [list(v.shape) for v in ck.values()] == g7[tag + "_ckpt_shapes"]
+    for v, s in zip(ck.values(), g7[tag + "_ckpt_abs_sum"]):
+        assert abs(float(v.double().abs().sum()) - s) <= 1e-4 * max(1.0, s)
+    # resume: counter continues from the last log line, epoch number from the file name
+    tp = dict(g7["train_params"], restore_model="wavenet2.model", num_epochs=1)
+    json.dump(tp, open(tmp_path / "params" / "train_params.json", "w"))
+    T.train()
+    lines = open(tmp_path / "log" / "loss_log.log").read().strip().split("\n")
+    assert int(lines[-1].split(' ')[2]) > int(wl[-1].split(' ')[2])
+    assert open(tmp_path / "log" / "store_log.log").read().endswith("Epoch 3, model saved!\n")
+    assert "wavenet3.model" in os.listdir(tmp_path / "restore")
+
+
+def test_checkpoint_rotation_and_module_prefix(tmp_path):
+    from music_amd import train as T
+    from music_amd.model import wavenet
+    rd = str(tmp_path) + "/"
+    net = wavenet(2, [1, 2], 16, 16, 16, 256, False)
+    for n in (3, 10, 4):
+        T.save_model(net, n, rd)
+    T._rotate_checkpoints(rd, 3)                      # numeric, not lexicographic: deletes 3
+    assert sorted(os.listdir(rd)) == ["wavenet10.model", "wavenet4.model"]
+    sd = torch.load(rd + "wavenet4.model")
+    torch.save({"module." + k: v for k, v in sd.items()}, rd + "wavenet5.model")
+    net2 = wavenet(2, [1, 2], 16, 16, 16, 256, False)
+    assert T.load_model(net2, rd, "wavenet5.model") is net2
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
+    assert T.load_model(net2, rd, "missing.model") is None
+    assert T.get_optimizer(net, "sgd", 0.1, 0.9).defaults["momentum"] == 0.9
+    assert isinstance(T.get_optimizer(net, "rmsprop", 0.1, 0.9), torch.optim.RMSprop)
+    assert isinstance(T.get_optimizer(net, "adam", 0.1, 0.9), torch.optim.Adam)
+    assert T.get_optimizer(net, "lbfgs", 0.1, 0.9) is None
