@@ -78,14 +78,23 @@ int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* 
                     const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
                     int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
 
-/* Weight gradient: C[m][n] += sum_{b, t in [t_lo,t_hi)} A[b][m][t+a_shift] * B_tap[b][n][t+b_shift_tap]
+/* Weight gradient: C[m][n] = sum_{b, t in [t_lo,t_hi)} A[b][m][t+a_shift] * B_tap[b][n][t+b_shift_tap]
  * C columns [0, 16*nt_per_tap) come from b0, the next 16*nt_per_tap from b1 (if not NULL).
- * C (fp32, leading dimension ldc) is accumulated with atomics: zero it first.
- * Replaces the weight half of autograd's conv backward (wavenet/train.py:181). */
+ * The time axis is cut into chunks; workgroup (clip b, chunk j) writes its partial C (leading
+ * dimension ldc) with plain stores into slab number b*nchunks + j at c + slab*c_slab_stride.
+ * wn_wgrad_slabs() returns the number of slabs a call writes; wn_reduce_slabs() sums them in slab
+ * order (bit-reproducible, no float atomics).  Replaces the weight half of autograd's conv
+ * backward (wavenet/train.py:181). */
 int wn_wgrad(const float* a, int64_t a_bstride, int a_pitch, int a_shift, int a_cols,
              const float* b0, const float* b1, int64_t b_bstride, int b_pitch, int b_shift0,
              int b_shift1, int b_cols, int nt_per_tap, int mt, int relu_b, float* c, int ldc,
-             int t_lo, int t_hi, int chunk, int batch, int mode, wn_stream_t stream);
+             int64_t c_slab_stride, int t_lo, int t_hi, int chunk, int batch, int mode, wn_stream_t stream);
+int wn_wgrad_slabs(int t_lo, int t_hi, int chunk, int batch);
+/* desc[op] = {vec_start, slab_off, n_slabs, stride, out_off, n} (int64, device memory):
+ * out[out_off+e] = sum_s slab[slab_off + s*stride + e] for e < n; work item v covers 4 floats and
+ * belongs to the op with vec_start <= v. */
+int wn_reduce_slabs(const int64_t* desc, int n_ops, int64_t total_vec, const float* slab, float* out,
+                    wn_stream_t stream);
 
 /* out[row] = sum_{b,t} a[b][row][t+a_shift]  (bias gradients, use_bias=true) */
 int wn_bias_grad(const float* a, int64_t a_bstride, int a_pitch, int a_shift, int rows, int t_lo,

@@ -32,7 +32,9 @@ SIGNATURES = {
     "wn_resblock_bwd": [_p, _p, _p, _p, _p, _l, _l, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
                         _i, _i, _i, _p],
     "wn_wgrad": [_p, _l, _i, _i, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _i,
-                 _i, _i, _i, _i, _i, _p],
+                 _l, _i, _i, _i, _i, _i, _p],
+    "wn_wgrad_slabs": [_i, _i, _i, _i],
+    "wn_reduce_slabs": [_p, _i, _l, _p, _p, _p],
     "wn_bias_grad": [_p, _l, _i, _i, _i, _i, _i, _i, _p, _p],
     "wn_chunk_softmax256_fwd": [_p, _p, _l, _p],
     "wn_chunk_softmax256_bwd": [_p, _p, _p, _l, _p],
@@ -74,6 +76,11 @@ def load():
         raise WavenetHipError("libwavenet_hip.so ABI version %d != expected %d" % (lib.wn_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+def wgrad_slabs(t_lo, t_hi, chunk, batch):
+    """Number of slabs one wn_wgrad call writes (plain int return, not a status)."""
+    return load().wn_wgrad_slabs(t_lo, t_hi, chunk, batch)
 
 
 def call(name, *args):

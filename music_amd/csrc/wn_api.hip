@@ -80,14 +80,21 @@ int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* 
 int wn_wgrad(const float* a_, int64_t a_bstride, int a_pitch, int a_shift, int a_cols,
              const float* b0, const float* b1, int64_t b_bstride, int b_pitch, int b_shift0,
              int b_shift1, int b_cols, int nt_per_tap, int mt, int relu_b, float* c, int ldc,
-             int t_lo, int t_hi, int chunk, int batch, int mode, wn_stream_t stream) {
+             int64_t c_slab_stride, int t_lo, int t_hi, int chunk, int batch, int mode, wn_stream_t stream) {
+    if (c_slab_stride < (int64_t)mt * 16 * ldc) return wn_set_error_msg(-4, "wn_wgrad: slab stride smaller than C");
     WnWgradArgs a;
     memset(&a, 0, sizeof(a));
     a.a = a_; a.a_bstride = a_bstride; a.a_pitch = a_pitch; a.a_shift = a_shift; a.a_cols = a_cols;
     a.b0 = b0; a.b1 = b1; a.b_bstride = b_bstride; a.b_pitch = b_pitch; a.b_shift0 = b_shift0; a.b_shift1 = b_shift1; a.b_cols = b_cols;
-    a.nt_per_tap = nt_per_tap; a.mt = mt; a.relu_b = relu_b; a.c = c; a.ldc = ldc;
+    a.nt_per_tap = nt_per_tap; a.mt = mt; a.relu_b = relu_b; a.c = c; a.ldc = ldc; a.c_slab_stride = c_slab_stride;
     a.t_lo = t_lo; a.t_hi = t_hi; a.chunk = chunk;
     return wn_launch_wgrad(a, batch, mode, (hipStream_t)stream);
+}
+
+int wn_wgrad_slabs(int t_lo, int t_hi, int chunk, int batch) { return wn_wgrad_num_slabs(t_lo, t_hi, chunk, batch); }
+
+int wn_reduce_slabs(const int64_t* desc, int n_ops, int64_t total_vec, const float* slab, float* out, wn_stream_t stream) {
+    return wn_launch_reduce_slabs(reinterpret_cast<const long*>(desc), n_ops, total_vec, slab, out, (hipStream_t)stream);
 }
 
 int wn_bias_grad(const float* a, int64_t a_bstride, int a_pitch, int a_shift, int rows, int t_lo,

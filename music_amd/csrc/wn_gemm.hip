@@ -42,23 +42,32 @@ int wn_launch_pack(const float* flat, const int32_t* idx, uint16_t* out, int n, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// chan_gemm: WG = 4 waves; wave w owns columns [tile*256 + 64w, +64) and 4 M-tiles (64 rows) of
-// M-block blockIdx.y; blockIdx.z = clip.
+// chan_gemm: WG = 8 waves arranged WM (row groups) x 8/WM (column groups of 64).  A wave owns
+// MTW 16-row tiles x 64 columns (accumulators MTW x 4 x f32x4):
+//   wide   (MTW 8, WM 2): 256 rows x 256 columns per workgroup - every byte of the activation
+//          tile and of the packed weights is fetched once per workgroup (L1 serves the sharing
+//          waves), which is what bounds the K = 1920 skip product and its transposes;
+//   narrow (MTW 4, WM 1): 64 rows x 512 columns per workgroup (causal conv, per-layer dx).
+// blockIdx.y = row group, blockIdx.z = clip.  Activations stream HBM -> registers two k-steps
+// ahead; weight fragments come from L2 one tile ahead of the MFMAs that use them.
 // ---------------------------------------------------------------------------------------------
-template <class T, int NS>
-__global__ __launch_bounds__(256) void chan_gemm_k(WnGemmArgs a) {
+template <class T, int NS, int MTW, int WM>
+__global__ __launch_bounds__(512) void chan_gemm_k(WnGemmArgs a) {
+    constexpr int WN = 8 / WM;
+    constexpr int PF = MTW > 4 ? 1 : 2;        // k-steps of activations in flight (register budget)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int b = blockIdx.z;
-    const int t0 = a.t_base + blockIdx.x * 256 + wave * 64;      // first column of this wave
+    const int wm = wave / WN, wn = wave % WN;
+    const int t0 = a.t_base + (blockIdx.x * WN + wn) * 64;       // first column of this wave
     const int tl = t0 + 4 * c;                                    // this lane's first column
-    if (t0 >= a.t_hi) return;
-    const int m0 = blockIdx.y * 4;                                // first M-tile
+    const int m0 = (blockIdx.y * WM + wm) * MTW;                  // first M-tile of this wave
+    if (t0 >= a.t_hi || m0 >= a.mt) return;
     const int KS = a.ks0 + a.ks1;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MTW][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MTW; ++m) {
         f32x4 init = {0.f, 0.f, 0.f, 0.f};
         if (a.bias != nullptr) {
 #pragma unroll
@@ -75,8 +84,7 @@ __global__ __launch_bounds__(256) void chan_gemm_k(WnGemmArgs a) {
     const float* in1 = a.in1 ? a.in1 + (size_t)b * a.in_bstride : nullptr;
     const int col0 = tl + a.shift0, col1 = tl + a.shift1;
 
-    f32x4 raw[8];
-    auto issue = [&](int s) {
+    auto issue = [&](f32x4* raw, int s) {
         const float* base; int col; int ch;
         if (s < a.ks0) { base = in0; col = col0; ch = s * 32; }
         else { base = in1; col = col1; ch = (s - a.ks0) * 32; }
@@ -85,8 +93,7 @@ __global__ __launch_bounds__(256) void chan_gemm_k(WnGemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) raw[j] = ld4g(p + (size_t)j * a.in_pitch, col, a.in_lo, a.in_hi);
     };
-    issue(0);
-    for (int s = 0; s < KS; ++s) {
+    auto step = [&](f32x4* raw, int s) {
         Frag<T> bf[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -98,23 +105,38 @@ __global__ __launch_bounds__(256) void chan_gemm_k(WnGemmArgs a) {
             }
             split8<T, NS>(bf[n], v);
         }
-        if (s + 1 < KS) issue(s + 1);
+        if (s + PF < KS) issue(raw, s + PF);
+        Frag<T> af[2];
+        load_a<T, NS>(af[0], a.wpack, m0 * KS + s, lane);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MTW; ++m) {
+            if (m + 1 < MTW && m0 + m + 1 < a.mt) load_a<T, NS>(af[(m + 1) & 1], a.wpack, (m0 + m + 1) * KS + s, lane);
             if (m0 + m < a.mt) {
-                Frag<T> af;
-                load_a<T, NS>(af, a.wpack, (m0 + m) * KS + s, lane);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
+                for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af[m & 1], bf[n]);
             }
         }
+    };
+    if (PF == 2) {
+        f32x4 raw0[8], raw1[8];
+        issue(raw0, 0);
+        if (KS > 1) issue(raw1, 1);
+        for (int s = 0; s < KS; s += 2) {
+            step(raw0, s);
+            if (s + 1 < KS) step(raw1, s + 1);
+        }
+    } else {
+        f32x4 raw0[8];
+        issue(raw0, 0);
+        for (int s = 0; s < KS; ++s) step(raw0, s);
     }
 
     float* out = a.out + (size_t)b * a.out_bstride;
     const float* resid = a.resid ? a.resid + (size_t)b * a.resid_bstride : nullptr;
     const float* mask = a.mask ? a.mask + (size_t)b * a.mask_bstride : nullptr;
+    const bool full = tl >= a.t_lo && tl + 3 < a.t_hi;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MTW; ++m) {
         if (m0 + m >= a.mt) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -123,35 +145,61 @@ __global__ __launch_bounds__(256) void chan_gemm_k(WnGemmArgs a) {
             f32x4 v = {acc[m][0][i], acc[m][1][i], acc[m][2][i], acc[m][3][i]};
             if (resid) {
                 const float* rp = resid + (size_t)row * a.resid_pitch + tl;
+                if (full && tl >= a.resid_lo) {
+                    v += ld4u(rp);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (tl + e >= a.resid_lo && tl + e >= a.t_lo && tl + e < a.t_hi) v[e] += rp[e];
+                    for (int e = 0; e < 4; ++e)
+                        if (tl + e >= a.resid_lo && tl + e >= a.t_lo && tl + e < a.t_hi) v[e] += rp[e];
+                }
             }
             if (mask) {
                 const float* mp = mask + (size_t)row * a.mask_pitch + tl;
+                if (full) {
+                    f32x4 mv = ld4u(mp);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (tl + e >= a.t_lo && tl + e < a.t_hi) v[e] = mp[e] > 0.f ? v[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tl + e >= a.t_lo && tl + e < a.t_hi) v[e] = mp[e] > 0.f ? v[e] : 0.f;
+                }
             }
             float* op = out + (size_t)row * a.out_pitch + tl + a.out_shift;
+            if (full) {
+                F4U u = {{v[0], v[1], v[2], v[3]}};
+                *reinterpret_cast<F4U*>(op) = u;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (tl + e >= a.t_lo && tl + e < a.t_hi) op[e] = v[e];
+                for (int e = 0; e < 4; ++e)
+                    if (tl + e >= a.t_lo && tl + e < a.t_hi) op[e] = v[e];
+            }
         }
     }
+}
+
+template <class T, int NS>
+static int launch_gemm(const WnGemmArgs& k, int batch, hipStream_t st) {
+    const int ncol = k.t_hi - k.t_base;
+    if (k.mt <= 4) {                     // narrow: 64 rows x 512 columns per workgroup
+        dim3 g((ncol + 511) / 512, 1, batch), b(512);
+        hipLaunchKernelGGL((chan_gemm_k<T, NS, 4, 1>), g, b, 0, st, k);
+    } else {                             // wide: 256 rows x 256 columns per workgroup
+        dim3 g((ncol + 255) / 256, (k.mt + 15) / 16, batch), b(512);
+        hipLaunchKernelGGL((chan_gemm_k<T, NS, 8, 2>), g, b, 0, st, k);
+    }
+    return 0;
 }
 
 int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st) {
     if (a.t_hi <= a.t_lo || batch <= 0) return 0;
     WnGemmArgs k = a;
     k.t_base = a.t_lo & ~3;                 // lanes own 4 consecutive, 4-aligned columns
-    int ncol = a.t_hi - k.t_base;
-    dim3 g((ncol + 255) / 256, (a.mt + 3) / 4, batch), b(256);
     switch (mode) {
-        case WN_MODE_F16X3: hipLaunchKernelGGL((chan_gemm_k<F16, 3>), g, b, 0, st, k); break;
-        case WN_MODE_F16X1: hipLaunchKernelGGL((chan_gemm_k<F16, 1>), g, b, 0, st, k); break;
-        case WN_MODE_BF16X3: hipLaunchKernelGGL((chan_gemm_k<BF16, 3>), g, b, 0, st, k); break;
-        case WN_MODE_BF16X1: hipLaunchKernelGGL((chan_gemm_k<BF16, 1>), g, b, 0, st, k); break;
+        case WN_MODE_F16X3: launch_gemm<F16, 3>(k, batch, st); break;
+        case WN_MODE_F16X1: launch_gemm<F16, 1>(k, batch, st); break;
+        case WN_MODE_BF16X3: launch_gemm<BF16, 3>(k, batch, st); break;
+        case WN_MODE_BF16X1: launch_gemm<BF16, 1>(k, batch, st); break;
         default: return wn_set_error_msg(-2, "wn_launch_gemm: bad mode");
     }
     WN_CHECK_LAUNCH();

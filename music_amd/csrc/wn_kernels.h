@@ -59,10 +59,13 @@ struct WnWgradArgs {
     int nt_per_tap;             // 16-row tiles of B per tap (C columns = taps * nt_per_tap * 16)
     int mt;                     // 16-row tiles of A
     int relu_b;
-    float* c; int ldc;          // C[mt*16][ldc] fp32, accumulated with atomics
+    float* c; int ldc;          // slab base: workgroup (b, chunk) writes C[mt*16][ldc] at c + slab*c_slab_stride
+    long c_slab_stride;
     int t_lo, t_hi, t_base; int chunk;      // time range and per-WG chunk (multiple of 32)
 };
 int wn_launch_wgrad(const WnWgradArgs& a, int batch, int mode, hipStream_t st);
+int wn_wgrad_num_slabs(int t_lo, int t_hi, int chunk, int batch);
+int wn_launch_reduce_slabs(const long* desc, int n_ops, long total_vec, const float* slab, float* out, hipStream_t st);
 
 int wn_launch_softmax_fwd(const float* x, float* y, long nrows, hipStream_t st);
 int wn_launch_softmax_bwd(const float* y, const float* dy, float* dx, long nrows, hipStream_t st);

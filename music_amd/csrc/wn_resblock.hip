@@ -12,8 +12,14 @@
 #include "wn_common.h"
 #include "wn_kernels.h"
 
+// One workgroup = 8 waves = 512 time columns.  The packed weights of a block (80 KB in the x3
+// modes) are staged once per workgroup; with 4-wave groups only ONE group fits a CU (2 x 80 KB is
+// exactly the 160 KB of LDS) and the 472 groups of a config-2 layer ran as two rounds.
+#define WN_RES_THREADS 512
+#define WN_RES_COLS 512
+
 template <class T, int NS, int CH>
-__global__ __launch_bounds__(256) void resblock_fwd_k(WnResArgs a) {
+__global__ __launch_bounds__(WN_RES_THREADS) void resblock_fwd_k(WnResArgs a) {
     constexpr int MT = 2 * CH / 16;        // fg row tiles (f rows then g rows)
     constexpr int KS = 2 * CH / 32;        // fg k-steps (tap 0 channels then tap 1 channels)
     constexpr int KT = CH / 32;            // k-steps per tap
@@ -28,17 +34,8 @@ __global__ __launch_bounds__(256) void resblock_fwd_k(WnResArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int b = blockIdx.y;
-    const int t0 = a.t_base + blockIdx.x * 256 + wave * 64;
+    const int t0 = a.t_base + blockIdx.x * WN_RES_COLS + wave * 64;
     const int tl = t0 + 4 * c;
-
-    {   // stage the packed weights (contiguous copies, 16 B per thread per step)
-        const u32x4* s0 = reinterpret_cast<const u32x4*>(a.wfg);
-        u32x4* d0 = reinterpret_cast<u32x4*>(l_fg);
-        for (int i = threadIdx.x; i < NFG * FR / 8; i += 256) d0[i] = s0[i];
-        const u32x4* s1 = reinterpret_cast<const u32x4*>(a.wd);
-        u32x4* d1 = reinterpret_cast<u32x4*>(l_d);
-        for (int i = threadIdx.x; i < ND * FR / 8; i += 256) d1[i] = s1[i];
-    }
 
     const float* xin = a.x_in + (size_t)b * a.x_bstride;
     const bool aligned_d = (a.d & 3) == 0;
@@ -59,7 +56,16 @@ __global__ __launch_bounds__(256) void resblock_fwd_k(WnResArgs a) {
             for (int j = 0; j < 8; ++j) raw[j] = ld4(p + (size_t)j * a.pitch);
         }
     };
-    issue(0);
+    issue(0);      // first activation loads are in flight while the weights are staged
+
+    {   // stage the packed weights (contiguous copies, 16 B per thread per step)
+        const u32x4* s0 = reinterpret_cast<const u32x4*>(a.wfg);
+        u32x4* d0 = reinterpret_cast<u32x4*>(l_fg);
+        for (int i = threadIdx.x; i < NFG * FR / 8; i += WN_RES_THREADS) d0[i] = s0[i];
+        const u32x4* s1 = reinterpret_cast<const u32x4*>(a.wd);
+        u32x4* d1 = reinterpret_cast<u32x4*>(l_d);
+        for (int i = threadIdx.x; i < ND * FR / 8; i += WN_RES_THREADS) d1[i] = s1[i];
+    }
 
     f32x4 acc[MT][4];
 #pragma unroll
@@ -180,7 +186,7 @@ static int launch_fwd(const WnResArgs& a, int ch, int batch, hipStream_t st) {
     WnResArgs k = a;
     k.t_base = a.t_lo & ~3;
     int ncol = a.t_hi - k.t_base;
-    dim3 g((ncol + 255) / 256, batch), b(256);
+    dim3 g((ncol + WN_RES_COLS - 1) / WN_RES_COLS, batch), b(WN_RES_THREADS);
     const size_t fr = (NS == 3 ? 1024 : 512) * sizeof(uint16_t);
     if (ch == 32) {
         size_t sh = (size_t)(4 * 2 + 2 * 1) * fr;
@@ -225,7 +231,7 @@ int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipS
 // TB/NSB = gradient operand type (bf16: gradients need fp32's exponent range).
 // ---------------------------------------------------------------------------------------------
 template <class TF, int NSF, class TB, int NSB, int CH>
-__global__ __launch_bounds__(256) void resblock_bwd_k(WnResBwdArgs a) {
+__global__ __launch_bounds__(WN_RES_THREADS) void resblock_bwd_k(WnResBwdArgs a) {
     constexpr int MT = 2 * CH / 16, KS = 2 * CH / 32, KT = CH / 32, MT2 = CH / 16, KS2 = CH / 32;
     constexpr int FRF = (NSF == 3 ? 1024 : 512), FRB = (NSB == 3 ? 1024 : 512);
     constexpr int NFG = MT * KS, ND = MT2 * KS2;
@@ -236,16 +242,8 @@ __global__ __launch_bounds__(256) void resblock_bwd_k(WnResBwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int b = blockIdx.y;
-    const int t0 = a.t_base + blockIdx.x * 256 + wave * 64;
+    const int t0 = a.t_base + blockIdx.x * WN_RES_COLS + wave * 64;
     const int tl = t0 + 4 * c;
-    {
-        const u32x4* s0 = reinterpret_cast<const u32x4*>(a.wfg);
-        u32x4* d0 = reinterpret_cast<u32x4*>(l_fg);
-        for (int i = threadIdx.x; i < NFG * FRF / 8; i += 256) d0[i] = s0[i];
-        const u32x4* s1 = reinterpret_cast<const u32x4*>(a.wdT);
-        u32x4* d1 = reinterpret_cast<u32x4*>(l_dt);
-        for (int i = threadIdx.x; i < ND * FRB / 8; i += 256) d1[i] = s1[i];
-    }
     const float* xin = a.x_in + (size_t)b * a.x_bstride;
     const bool aligned_d = (a.d & 3) == 0;
     const int colm = tl - a.d;          // see resblock_fwd_k
@@ -262,6 +260,14 @@ __global__ __launch_bounds__(256) void resblock_bwd_k(WnResBwdArgs a) {
         }
     };
     issue(0);
+    {
+        const u32x4* s0 = reinterpret_cast<const u32x4*>(a.wfg);
+        u32x4* d0 = reinterpret_cast<u32x4*>(l_fg);
+        for (int i = threadIdx.x; i < NFG * FRF / 8; i += WN_RES_THREADS) d0[i] = s0[i];
+        const u32x4* s1 = reinterpret_cast<const u32x4*>(a.wdT);
+        u32x4* d1 = reinterpret_cast<u32x4*>(l_dt);
+        for (int i = threadIdx.x; i < ND * FRB / 8; i += WN_RES_THREADS) d1[i] = s1[i];
+    }
     f32x4 acc[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -367,7 +373,7 @@ static int launch_bwd(const WnResBwdArgs& a, int ch, int batch, hipStream_t st) 
     WnResBwdArgs k = a;
     k.t_base = a.t_lo & ~3;
     int ncol = a.t_hi - k.t_base;
-    dim3 g((ncol + 255) / 256, batch), b(256);
+    dim3 g((ncol + WN_RES_COLS - 1) / WN_RES_COLS, batch), b(WN_RES_THREADS);
     const size_t frf = (NSF == 3 ? 1024 : 512) * 2, frb = (NSB == 3 ? 1024 : 512) * 2;
     if (ch == 32) {
         size_t sh = 8 * frf + 2 * frb;

@@ -1,22 +1,32 @@
-// Weight-gradient products: C[m][n] += sum_{b,t} A[m][t + a_shift] * B_tap[n][t + b_shift_tap]
+// Weight-gradient products: C[m][n] = sum_{b,t} A[m][t + a_shift] * B_tap[n][t + b_shift_tap]
 // (dWd = sum dy z^T, dWf0 = sum df x(t-d)^T, dWs = sum du z^T, ...).
 //
 // Both operands are channels-first rows with time contiguous, so TIME is the MFMA k index and
 // every fragment is 8 consecutive samples of one row (two float4 loads, no transposition):
 //   A fragment: lane (c,q) holds A[16m + c][tb + 8q + j]
 //   B fragment: lane (c,q) holds B[16n + c][tb + 8q + j]        (C = A * B^T)
-// One wave owns a 64x64 block of C and walks a chunk of the time axis; partial sums are added
-// into the fp32 result with global float atomics (one 64-B segment per 16 lanes).
+// One wave owns a 64x64 block of C and walks a chunk of the time axis with the next step's loads
+// in flight behind the current step's MFMAs.  A 64x64 problem (one block) is instead split in
+// time over the 4 waves of the workgroup and combined through LDS.
+// Each workgroup writes its partial C into its own SLAB with plain stores (no float atomics: the
+// chip-wide atomic rate, ~1.3 TB/s, would dominate, and the result would depend on arrival
+// order); wn_reduce_slabs sums the slabs in a fixed order, so weight gradients are bit-reproducible.
 // Gradients are split in bf16 (fp32 exponent range); see wn_common.h for the x3 scheme.
 #include "wn_common.h"
 #include "wn_kernels.h"
 
+struct WgRaw { f32x4 u0, u1; };
+
+__device__ __forceinline__ WgRaw wg_load(const float* row, int col, int ncols) {
+    WgRaw r;
+    r.u0 = ld4g(row + col, col, 0, ncols);
+    r.u1 = ld4g(row + col + 4, col + 4, 0, ncols);
+    return r;
+}
+
 template <class T, int NS>
-__device__ __forceinline__ void wg_frag(Frag<T>& f, const float* row, int col, int ncols, int t,
-                                        int t_lo, int t_hi, bool masked, bool relu) {
-    f32x4 u0 = ld4g(row + col, col, 0, ncols);
-    f32x4 u1 = ld4g(row + col + 4, col + 4, 0, ncols);
-    float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+__device__ __forceinline__ void wg_frag(Frag<T>& f, const WgRaw& r, int t, int t_lo, int t_hi, bool masked, bool relu) {
+    float v[8] = {r.u0[0], r.u0[1], r.u0[2], r.u0[3], r.u1[0], r.u1[1], r.u1[2], r.u1[3]};
     if (masked) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -31,18 +41,26 @@ __device__ __forceinline__ void wg_frag(Frag<T>& f, const float* row, int col, i
 
 template <class T, int NS>
 __global__ __launch_bounds__(256) void wgrad_k(WnWgradArgs a) {
+    __shared__ float red[3][64 * 64];              // only used by the split-in-time (single block) form
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int b = blockIdx.z;
     const int nt_total = a.nt_per_tap * (a.b1 ? 2 : 1);
     const int nblk_n = (nt_total + 3) / 4, nblk_m = (a.mt + 3) / 4;
-    const int blk = blockIdx.y * 4 + wave;
-    if (blk >= nblk_n * nblk_m) return;
-    const int mb = blk / nblk_n, nb = blk % nblk_n;
-    const int tc0 = a.t_base + blockIdx.x * a.chunk;
+    const int nblk = nblk_n * nblk_m;
+    const bool split_time = nblk == 1;
+    const int blk = split_time ? 0 : blockIdx.y * 4 + wave;
+    const bool active = blk < nblk;
+    const int mb = active ? blk / nblk_n : 0, nb = active ? blk % nblk_n : 0;
+    int tc0 = a.t_base + blockIdx.x * a.chunk;
     int tc1 = tc0 + a.chunk;
     if (tc1 > a.t_hi) tc1 = a.t_hi;
-    if (tc0 >= a.t_hi) return;
+    if (split_time) {                                   // quarter of the chunk per wave (multiple of 32)
+        const int sub = ((a.chunk / 4) + 31) & ~31;
+        tc0 += wave * sub;
+        int e = tc0 + sub;
+        if (e < tc1) tc1 = e;
+    }
 
     const float* A = a.a + (size_t)b * a.a_bstride;
     const float* arow[4];
@@ -72,22 +90,55 @@ __global__ __launch_bounds__(256) void wgrad_k(WnWgradArgs a) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int tb = tc0; tb < tc1; tb += 32) {
-        const bool masked = (tb < a.t_lo) || (tb + 32 > tc1);
-        const int t = tb + 8 * q;
-        Frag<T> af[4], bf[4];
+    if (active && tc0 < tc1) {
+        WgRaw ra[4], rb[4];
+        auto issue = [&](int tb) {
+            const int t = tb + 8 * q;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            wg_frag<T, NS>(af[m], arow[m], t + a.a_shift, a.a_cols, t, a.t_lo, tc1, masked, false);
+            for (int m = 0; m < 4; ++m) ra[m] = wg_load(arow[m], t + a.a_shift, a.a_cols);
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-            wg_frag<T, NS>(bf[n], brow[n], t + bshift[n], a.b_cols, t, a.t_lo, tc1, masked, a.relu_b != 0);
+            for (int n = 0; n < 4; ++n) rb[n] = wg_load(brow[n], t + bshift[n], a.b_cols);
+        };
+        issue(tc0);
+        for (int tb = tc0; tb < tc1; tb += 32) {
+            const bool masked = (tb < a.t_lo) || (tb + 32 > tc1);
+            const int t = tb + 8 * q;
+            Frag<T> af[4], bf[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m) wg_frag<T, NS>(af[m], ra[m], t, a.t_lo, tc1, masked, false);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af[m], bf[n]);
+            for (int n = 0; n < 4; ++n) wg_frag<T, NS>(bf[n], rb[n], t, a.t_lo, tc1, masked, a.relu_b != 0);
+            if (tb + 32 < tc1) issue(tb + 32);          // next step's loads fly behind the MFMAs
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af[m], bf[n]);
+        }
     }
 
+    if (split_time) {                                   // combine the 4 time quarters through LDS
+        if (wave > 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    *reinterpret_cast<f32x4*>(&red[wave - 1][((m * 4 + n) * 64 + lane) * 4]) = acc[m][n];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    f32x4 o = *reinterpret_cast<const f32x4*>(&red[w][((m * 4 + n) * 64 + lane) * 4]);
+                    acc[m][n] += o;
+                }
+    }
+    if (!active) return;
+    // slab of this workgroup: plain stores, every element of the block is written
+    float* cs = a.c + ((size_t)b * gridDim.x + blockIdx.x) * a.c_slab_stride;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         if (!mval[m]) continue;
@@ -98,18 +149,26 @@ __global__ __launch_bounds__(256) void wgrad_k(WnWgradArgs a) {
             for (int i = 0; i < 4; ++i) {
                 int row = (mb * 4 + m) * 16 + 4 * q + i;
                 int col = (nb * 4 + n) * 16 + c;
-                atomicAdd(a.c + (size_t)row * a.ldc + col, acc[m][n][i]);
+                cs[(size_t)row * a.ldc + col] = acc[m][n][i];
             }
         }
     }
+}
+
+int wn_wgrad_num_slabs(int t_lo, int t_hi, int chunk, int batch) {
+    if (t_hi <= t_lo || batch <= 0) return 0;
+    if (chunk < 128) chunk = 128;
+    chunk = (chunk + 127) & ~127;
+    const int t_base = t_lo & ~31;
+    return ((t_hi - t_base + chunk - 1) / chunk) * batch;
 }
 
 int wn_launch_wgrad(const WnWgradArgs& a, int batch, int mode, hipStream_t st) {
     if (a.t_hi <= a.t_lo || batch <= 0) return 0;
     WnWgradArgs k = a;
     k.t_base = a.t_lo & ~31;
-    if (k.chunk < 32) k.chunk = 32;
-    k.chunk = (k.chunk + 31) & ~31;
+    if (k.chunk < 128) k.chunk = 128;
+    k.chunk = (k.chunk + 127) & ~127;
     const int nt_total = a.nt_per_tap * (a.b1 ? 2 : 1);
     const int nblk = ((nt_total + 3) / 4) * ((a.mt + 3) / 4);
     dim3 g((a.t_hi - k.t_base + k.chunk - 1) / k.chunk, (nblk + 3) / 4, batch), b(256);
@@ -120,6 +179,44 @@ int wn_launch_wgrad(const WnWgradArgs& a, int batch, int mode, hipStream_t st) {
         case WN_MODE_F16X1: hipLaunchKernelGGL((wgrad_k<F16, 1>), g, b, 0, st, k); break;
         default: return wn_set_error_msg(-2, "wgrad: bad mode");
     }
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
+// Batched deterministic slab reduction.  desc[op] = {vec_start, slab_off, n_slabs, stride, out_off, n}
+// (int64 each): out[out_off + e] = sum_{s < n_slabs} slab[slab_off + s*stride + e], e < n, summed in
+// slab order.  Work item v (4 floats) belongs to the op with vec_start <= v < next vec_start.
+__global__ __launch_bounds__(256) void reduce_slabs_k(const long* __restrict__ desc, int n_ops, long total_vec,
+                                                      const float* __restrict__ slab, float* __restrict__ out) {
+    long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= total_vec) return;
+    int lo = 0, hi = n_ops - 1;
+    while (lo < hi) {                                   // last op with vec_start <= v
+        int mid = (lo + hi + 1) >> 1;
+        if (desc[mid * 6] <= v) lo = mid; else hi = mid - 1;
+    }
+    const long* d = desc + lo * 6;
+    const long e = (v - d[0]) * 4, n = d[5], stride = d[3];
+    const int ns = (int)d[2];
+    const float* sp = slab + d[1] + e;
+    float* op = out + d[4] + e;
+    if (e + 3 < n) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < ns; ++i) s += ld4u(sp + (size_t)i * stride);
+        op[0] = s[0]; op[1] = s[1]; op[2] = s[2]; op[3] = s[3];
+    } else {
+        for (long k = 0; e + k < n; ++k) {
+            float s = 0.f;
+            for (int i = 0; i < ns; ++i) s += sp[(size_t)i * stride + k];
+            op[k] = s;
+        }
+    }
+}
+
+int wn_launch_reduce_slabs(const long* desc, int n_ops, long total_vec, const float* slab, float* out, hipStream_t st) {
+    if (total_vec <= 0 || n_ops <= 0) return 0;
+    hipLaunchKernelGGL(reduce_slabs_k, dim3((unsigned)((total_vec + 255) / 256)), dim3(256), 0, st, desc, n_ops,
+                       total_vec, slab, out);
     WN_CHECK_LAUNCH();
     return 0;
 }

@@ -275,7 +275,7 @@ class WaveNetEngine:
         if len(self._ws) >= 4:
             self._ws.clear()
         dev = self.device
-        pitch = _pad(T, 256) + 256
+        pitch = _pad(T, 256) + 512        # tiles of 512 columns may overhang T by < 512
         W = T - self.rf + 1
 
         def buf(rows):
@@ -303,6 +303,27 @@ class WaveNetEngine:
         bw = dict(dO=torch.zeros(B * self.Q * W + PAD_BACK, dtype=torch.float32, device=dev),
                   dH=buf(self.SP), dU=buf(self.SP), dZ=buf(self.N * self.CH),
                   dX=[buf(self.CH), buf(self.CH)], dfg=buf(2 * self.CH), zs=buf(self.CH))
+        # weight-gradient slabs: every wgrad workgroup writes its partial C with plain stores,
+        # one batched kernel then sums the slabs of all ops in a fixed order (deterministic)
+        T, lo = ws["T"], self.rf - 1
+        ops = [("p2", lo, T, 1024), ("p1", lo, T, 1024), ("skip", lo, T, 2048)]
+        for i in range(self.N):
+            ops.append(("fg%d" % i, self.off[i + 1], T, 512))
+            if i < self.N - 1:
+                ops.append(("d%d" % i, self.off[i + 1], T, 512))
+        ops.append(("causal", 1, T, 512))
+        plan, desc, so, vs = {}, [], 0, 0
+        for name, t_lo, t_hi, chunk in ops:
+            go, r, c = self.gp_off[name]
+            n = r * c
+            ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B)
+            plan[name] = (so, n, chunk)
+            desc.append([vs, so, ns, n, go, n])
+            so += ns * n
+            vs += (n + 3) // 4
+        bw["slab"] = torch.empty(so, dtype=torch.float32, device=dev)
+        bw["slab_plan"], bw["slab_vec"], bw["slab_nops"] = plan, vs, len(desc)
+        bw["slab_desc"] = torch.tensor(desc, dtype=torch.int64, device=dev)
         ws["bwd"] = bw
         return bw
 
@@ -377,9 +398,13 @@ class WaveNetEngine:
         fr = lambda name: ptr(self.pk_f, self.pk_f_off[name])
         lo = self.rf - 1
         xb, zb, sb = CH * pitch, N * CH * pitch, SP * pitch
-        self.gpack.zero_()
-        gp = lambda name: ptr(self.gpack, self.gp_off[name][0])
-        chunk = 512
+        plan = bw["slab_plan"]
+
+        def wgrad(name, *args):
+            """args = everything of wn_wgrad up to and including relu_b, then ldc, t_lo, t_hi"""
+            so, n, chunk = plan[name]
+            head, (ldc, t_lo, t_hi) = args[:-3], args[-3:]
+            call("wn_wgrad", *head, ptr(bw["slab"], so), ldc, n, t_lo, t_hi, chunk, B, mb, st)
         dO, dH, dU, dZ = ptr(bw["dO"]), ptr(bw["dH"], SLACK), ptr(bw["dU"], SLACK), ptr(bw["dZ"], SLACK)
         U, H, Z = ptr(ws["U"], SLACK), ptr(ws["H"], SLACK), ptr(ws["Z"], SLACK)
         # dH = (P2^T dO) * [H > 0]
@@ -392,12 +417,9 @@ class WaveNetEngine:
         call("wn_chan_gemm", dU, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, br("skipT"), N * CH // 16, N * CH,
              dZ, zb, pitch, 0, None, None, 0, 0, 0, None, 0, 0, lo, T, 0, B, mb, st)
         # weight gradients of the epilogue
-        call("wn_wgrad", dO, Q * W, W, -lo, W, H, None, sb, pitch, 0, 0, pitch, SP // 16, Q // 16, 1,
-             gp("p2"), SP, lo, T, chunk, B, mb, st)
-        call("wn_wgrad", dH, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1,
-             gp("p1"), SP, lo, T, chunk, B, mb, st)
-        call("wn_wgrad", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CH // 16, SP // 16, 0,
-             gp("skip"), N * CH, lo, T, chunk, B, mb, st)
+        wgrad("p2", dO, Q * W, W, -lo, W, H, None, sb, pitch, 0, 0, pitch, SP // 16, Q // 16, 1, SP, lo, T)
+        wgrad("p1", dH, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
+        wgrad("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CH // 16, SP // 16, 0, N * CH, lo, T)
         if self.use_bias:
             bo = self.gp_bias_off
             call("wn_bias_grad", dO, Q * W, W, -lo, Q, lo, T, B, ptr(self.gpack, bo["post_process_2.bias"]), st)
@@ -417,12 +439,11 @@ class WaveNetEngine:
                  self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)), self.D, CH, d, t_lo, T, lo,
                  B, mf, mb, st)
             # dWf/dWg: C[2CH][tap0 CH | tap1 CH] = sum dfg[t] * [x(t-d) | x(t)]
-            call("wn_wgrad", dfg, 2 * CH * pitch, pitch, 0, pitch, self._x(ws, i), self._x(ws, i), xb, pitch, -d, 0, pitch,
-                 CH // 16, 2 * CH // 16, 0, gp("fg%d" % i), 2 * CH, t_lo, T, chunk, B, mb, st)
+            wgrad("fg%d" % i, dfg, 2 * CH * pitch, pitch, 0, pitch, self._x(ws, i), self._x(ws, i), xb, pitch, -d, 0, pitch,
+                  CH // 16, 2 * CH // 16, 0, 2 * CH, t_lo, T)
             if i < N - 1:
                 # dWd = sum dy z^T
-                call("wn_wgrad", dy, xb, pitch, 0, pitch, zs, None, xb, pitch, 0, 0, pitch, CH // 16, CH // 16, 0,
-                     gp("d%d" % i), CH, t_lo, T, chunk, B, mb, st)
+                wgrad("d%d" % i, dy, xb, pitch, 0, pitch, zs, None, xb, pitch, 0, 0, pitch, CH // 16, CH // 16, 0, CH, t_lo, T)
             if self.use_bias:
                 bo = self.gp_bias_off
                 call("wn_bias_grad", dfg, 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i)]), st)
@@ -438,10 +459,10 @@ class WaveNetEngine:
         # causal weight gradient: dWc[r][q][tap] = sum dx0[r][t] in[q][t-1+tap]
         x = ws["x_in"]
         dx0 = ptr(bw["dX"][0], SLACK)
-        call("wn_wgrad", dx0, xb, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CH // 16, 0,
-             gp("causal"), 2 * Q, 1, T, chunk, B, mb, st)
+        wgrad("causal", dx0, xb, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CH // 16, 0, 2 * Q, 1, T)
         if self.use_bias:
             call("wn_bias_grad", dx0, xb, pitch, 0, self.R, 1, T, B, ptr(self.gpack, self.gp_bias_off["causal_layer.bias"]), st)
+        call("wn_reduce_slabs", ptr(bw["slab_desc"]), bw["slab_nops"], bw["slab_vec"], ptr(bw["slab"]), ptr(self.gpack), st)
         call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
         self.mark("causal_bwd")
 

@@ -120,6 +120,19 @@ def test_chan_gemm_user_tensor_unaligned_pitch():
     assert err <= 3e-5 * ref.abs().max().item()
 
 
+def _wgrad(rows, cols, t_lo, t_hi, chunk, B, mode, *head):
+    """wn_wgrad into slabs + wn_reduce_slabs -> dense [rows, cols] tensor.  head = the wn_wgrad
+    arguments up to and including relu_b."""
+    ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B)
+    n = rows * cols
+    slab = torch.full((ns * n,), float("nan"), device=DEV)          # every element must be overwritten
+    out = torch.full((n + 8,), float("nan"), device=DEV)
+    call("wn_wgrad", *head, ptr(slab), cols, n, t_lo, t_hi, chunk, B, mode, _lib.stream())
+    desc = torch.tensor([[0, 0, ns, n, 4, n]], dtype=torch.int64, device=DEV)
+    call("wn_reduce_slabs", ptr(desc), 1, (n + 3) // 4, ptr(slab), ptr(out), _lib.stream())
+    return out[4:4 + n].view(rows, cols)
+
+
 def _res_ref(x, wf, wg, wd, d):
     f = F.conv1d(x, wf, dilation=d)
     g = F.conv1d(x, wg, dilation=d)
@@ -175,7 +188,7 @@ def test_resblock_fwd(CH, R, D, d, mode):
 def test_resblock_bwd_and_dx(CH, R, D, d):
     mf, mb = _lib.F16X3, _lib.BF16X3
     rng = np.random.default_rng(20 + d)
-    B, T, pitch = 2, 900, 1280
+    B, T, pitch = 2, 900, 1536
     wf = (rng.standard_normal((D, R, 2)) * 0.3).astype(np.float32)
     wg = (rng.standard_normal((D, R, 2)) * 0.3).astype(np.float32)
     wd = (rng.standard_normal((R, D, 1)) * 0.3).astype(np.float32)
@@ -204,12 +217,10 @@ def test_resblock_bwd_and_dx(CH, R, D, d):
     call("wn_chan_gemm", ptr(dfg, SLACK), ptr(dfg, SLACK), 2 * CH * pitch, pitch, t_lo, T, 0, d, 2 * CH // 32, 2 * CH // 32,
          ptr(pX), CH // 16, R, ptr(dx, SLACK), CH * pitch, pitch, 0, None, ptr(dy, SLACK), CH * pitch, pitch, t_lo,
          None, 0, 0, off_in, T, 0, B, mb, st)
-    gW = torch.zeros(2 * CH, 2 * CH, device=DEV)
-    gD = torch.zeros(CH, CH, device=DEV)
-    call("wn_wgrad", ptr(dfg, SLACK), 2 * CH * pitch, pitch, 0, pitch, ptr(xin, SLACK), ptr(xin, SLACK), CH * pitch, pitch,
-         -d, 0, pitch, CH // 16, 2 * CH // 16, 0, ptr(gW), 2 * CH, t_lo, T, 256, B, mb, st)
-    call("wn_wgrad", ptr(dy, SLACK), CH * pitch, pitch, 0, pitch, ptr(zs, SLACK), None, CH * pitch, pitch, 0, 0, pitch,
-         CH // 16, CH // 16, 0, ptr(gD), CH, t_lo, T, 256, B, mb, st)
+    gW = _wgrad(2 * CH, 2 * CH, t_lo, T, 256, B, mb, ptr(dfg, SLACK), 2 * CH * pitch, pitch, 0, pitch, ptr(xin, SLACK),
+                ptr(xin, SLACK), CH * pitch, pitch, -d, 0, pitch, CH // 16, 2 * CH // 16, 0)
+    gD = _wgrad(CH, CH, t_lo, T, 256, B, mb, ptr(dy, SLACK), CH * pitch, pitch, 0, pitch, ptr(zs, SLACK), None,
+                CH * pitch, pitch, 0, 0, pitch, CH // 16, CH // 16, 0)
     torch.cuda.synchronize()
     # reference through autograd in fp64
     x = _view(xin, B, CH, pitch).cpu()[:, :R, off_in:T].double().requires_grad_(True)
@@ -252,9 +263,8 @@ def test_wgrad_compact_relu():
     a = torch.from_numpy(rng.standard_normal((B, M, W)).astype(np.float32) * 1e-4).to(DEV)   # compact A
     a_pad = torch.cat([a.reshape(-1), torch.zeros(512, device=DEV)])
     b = _buf(B, N, pitch, 1.0, 6)
-    c = torch.zeros(M, N, device=DEV)
-    call("wn_wgrad", ptr(a_pad), M * W, W, -lo, W, ptr(b, SLACK), None, N * pitch, pitch, 0, 0, pitch, N // 16, M // 16, 1,
-         ptr(c), N, lo, T, 128, B, mode, _lib.stream())
+    c = _wgrad(M, N, lo, T, 128, B, mode, ptr(a_pad), M * W, W, -lo, W, ptr(b, SLACK), None, N * pitch, pitch, 0, 0, pitch,
+               N // 16, M // 16, 1)
     torch.cuda.synchronize()
     bb = _view(b, B, N, pitch).cpu().double()[:, :, lo:T].clamp(min=0)
     ref = torch.einsum("bmt,bnt->mn", a.cpu().double(), bb)

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single kernels of the hot path at BASELINE config-2 shapes (GPU only).
+
+    python tools/kbench.py [fwd|bwd|all] [--reps N] [--precision f16x3,bf16x3]
+
+Prints per-phase / per-layer kernel times measured with HIP events on the launch stream.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import CFG, B_LOCAL, T  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--precision", default="f16x3,bf16x3")
+    args = ap.parse_args()
+    from music_amd.model import wavenet
+    from music_amd import _lib
+    from music_amd._lib import call, ptr
+    from music_amd.engine import SLACK
+    torch.manual_seed(0)
+    net = wavenet(**CFG)
+    net.precision = tuple(args.precision.split(","))
+    net = net.cuda()
+    eng = net._engine_for(torch.device("cuda", 0))
+    rng = np.random.default_rng(0)
+    codes = torch.from_numpy(rng.integers(0, 256, size=(B_LOCAL, T)).astype(np.int32)).cuda()
+    target = torch.from_numpy(rng.integers(0, 256, size=(B_LOCAL * (T - 3070),)).astype(np.int64)).cuda()
+    x = eng.onehot(codes)
+    for _ in range(2):
+        eng.loss_and_grad(x, target)
+    torch.cuda.synchronize()
+    ws = eng.workspace(B_LOCAL, T)
+    st = _lib.stream()
+    CH, N, pitch = eng.CH, eng.N, ws["pitch"]
+    xb, zb = CH * pitch, N * CH * pitch
+    fr = lambda name: ptr(eng.pk_f, eng.pk_f_off[name])
+    res = {}
+    if args.what in ("fwd", "all"):
+        per_layer = []
+        for i, d in enumerate(eng.dil):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            for _ in range(args.reps):
+                call("wn_resblock_fwd", eng._x(ws, i), eng._x(ws, i + 1), ptr(ws["Z"], SLACK + i * CH * pitch), xb, zb, pitch,
+                     fr("fg%d" % i), fr("d%d" % i), None, None, None, eng.D, eng.R, CH, d, eng.off[i + 1], T, eng.rf - 1,
+                     1, B_LOCAL, eng.mode_fwd, st)
+            ev[1].record()
+            torch.cuda.synchronize()
+            per_layer.append(ev[0].elapsed_time(ev[1]) / args.reps * 1e3)
+        res["resblock_fwd_us_by_layer"] = [round(v, 1) for v in per_layer]
+        res["resblock_fwd_us_total"] = round(sum(per_layer), 1)
+    if args.what in ("bwd", "all"):
+        eng.marks = []
+        for _ in range(args.reps):
+            eng.loss_and_grad(x, target)
+        torch.cuda.synchronize()
+        marks, eng.marks = eng.marks, None
+        ph = {}
+        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            ph[n1] = ph.get(n1, 0.0) + e0.elapsed_time(e1)
+        res["phase_ms"] = {k: round(v / args.reps, 3) for k, v in ph.items() if k != "begin"}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
