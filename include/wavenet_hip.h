@@ -90,6 +90,14 @@ int wn_wgrad(const float* a, int64_t a_bstride, int a_pitch, int a_shift, int a_
              int b_shift1, int b_cols, int nt_per_tap, int mt, int relu_b, float* c, int ldc,
              int64_t c_slab_stride, int t_lo, int t_hi, int chunk, int batch, int mode, wn_stream_t stream);
 int wn_wgrad_slabs(int t_lo, int t_hi, int chunk, int batch);
+/* Both weight-gradient products of one residual block in ONE launch:
+ *   slab_fg: C[2ch][2ch]  = sum_t dfg[t] [x(t-d) | x(t)]^T   (rows df then dg; cols tap0 then tap1)
+ *   slab_d : C[ch][ch]    = sum_t dy[t] z[t]^T               (skipped when dy or slab_d is NULL)
+ * slab strides are 4*ch*ch and ch*ch floats; slab counts as wn_wgrad_slabs(t_lo,t_hi,chunk,batch). */
+int wn_resblock_wgrad(const float* dfg, const float* x_in, const float* dy, const float* z,
+                      int64_t dfg_bstride, int64_t x_bstride, int64_t z_bstride, int pitch, int ch, int d,
+                      int t_lo, int t_hi, float* slab_fg, float* slab_d, int chunk, int batch, int mode,
+                      wn_stream_t stream);
 /* desc[op] = {vec_start, slab_off, n_slabs, stride, out_off, n} (int64, device memory):
  * out[out_off+e] = sum_s slab[slab_off + s*stride + e] for e < n; work item v covers 4 floats and
  * belongs to the op with vec_start <= v. */
@@ -126,6 +134,24 @@ int wn_onehot(const int32_t* codes, float* out, int batch, int q, int t, int scr
  * canonical encoder (bit-exact); decode through the 256-entry table. */
 int wn_mulaw_encode_tbl(const float* audio, const float* thresholds, uint8_t* codes, int64_t n, wn_stream_t stream);
 int wn_mulaw_decode_lut(const uint8_t* codes, const float* table, float* audio, int64_t n, wn_stream_t stream);
+
+/* Cached-queue greedy decode, n_steps samples in one persistent launch
+ * (wavenet/fast_generate.py:66-141 per sample; :166-172 loop).  All weights fp32 in "decode
+ * layout" (music_amd/fast_generate.py builds it): w_causal [R][2Q] (k = tap0 q | tap1 q);
+ * per block at w_layers + i*layer_stride: Wfg [2D][2R] (rows f then g; k = tap1 r | tap0 r),
+ * Wd [R][D], Ws [S][D]; b_layers per block [bf D | bg D | bd R | bs S] or NULL; w_p1 [S][S],
+ * w_p2 [Q][S].  queues: block i's FIFO as a ring [d_i][R] (time-major) at float offset q_off[i];
+ * at global step g the column at slot g % d_i is the oldest, is consumed, then overwritten with
+ * the block OUTPUT (as written in the reference) or its INPUT (push_input != 0).
+ * note0 / prev0: dense [Q] current and previous input columns; forced: teacher-forced next codes
+ * (NULL = feed back the argmax).  codes_out[n_steps] = argmax of the probabilities (first index on
+ * ties); probs_out optional.  dilations_host / q_off_host are HOST arrays. */
+int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
+              float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
+              int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
+              const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
+              float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
+              int n_steps, int push_input, wn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,7 @@ SIGNATURES = {
     "wn_wgrad": [_p, _l, _i, _i, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _i,
                  _l, _i, _i, _i, _i, _i, _p],
     "wn_wgrad_slabs": [_i, _i, _i, _i],
+    "wn_resblock_wgrad": [_p, _p, _p, _p, _l, _l, _l, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p],
     "wn_reduce_slabs": [_p, _i, _l, _p, _p, _p],
     "wn_bias_grad": [_p, _l, _i, _i, _i, _i, _i, _i, _p, _p],
     "wn_chunk_softmax256_fwd": [_p, _p, _l, _p],
@@ -44,6 +45,8 @@ SIGNATURES = {
     "wn_onehot": [_p, _p, _i, _i, _i, _i, _p],
     "wn_mulaw_encode_tbl": [_p, _p, _p, _l, _p],
     "wn_mulaw_decode_lut": [_p, _p, _p, _l, _p],
+    "wn_decode": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l,
+                  _i, _i, _p],
 }
 
 _lib = None

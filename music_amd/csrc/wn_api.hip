@@ -91,6 +91,26 @@ int wn_wgrad(const float* a_, int64_t a_bstride, int a_pitch, int a_shift, int a
     return wn_launch_wgrad(a, batch, mode, (hipStream_t)stream);
 }
 
+int wn_resblock_wgrad(const float* dfg, const float* x_in, const float* dy, const float* z,
+                      int64_t dfg_bstride, int64_t x_bstride, int64_t z_bstride, int pitch, int ch, int d,
+                      int t_lo, int t_hi, float* slab_fg, float* slab_d, int chunk, int batch, int mode,
+                      wn_stream_t stream) {
+    WnWgradArgs f, g;
+    memset(&f, 0, sizeof(f));
+    memset(&g, 0, sizeof(g));
+    // dWf/dWg: C[2ch][tap0 ch | tap1 ch] = sum_t dfg[t] * [x(t-d) | x(t)]^T
+    f.a = dfg; f.a_bstride = dfg_bstride; f.a_pitch = pitch; f.a_shift = 0; f.a_cols = pitch;
+    f.b0 = x_in; f.b1 = x_in; f.b_bstride = x_bstride; f.b_pitch = pitch; f.b_shift0 = -d; f.b_shift1 = 0; f.b_cols = pitch;
+    f.nt_per_tap = ch / 16; f.mt = 2 * ch / 16; f.relu_b = 0; f.c = slab_fg; f.ldc = 2 * ch;
+    f.c_slab_stride = (int64_t)4 * ch * ch; f.t_lo = t_lo; f.t_hi = t_hi; f.chunk = chunk;
+    // dWd: C[ch][ch] = sum_t dy[t] * z[t]^T
+    g.a = dy; g.a_bstride = x_bstride; g.a_pitch = pitch; g.a_shift = 0; g.a_cols = pitch;
+    g.b0 = z; g.b1 = nullptr; g.b_bstride = z_bstride; g.b_pitch = pitch; g.b_cols = pitch;
+    g.nt_per_tap = ch / 16; g.mt = ch / 16; g.c = slab_d; g.ldc = ch; g.c_slab_stride = (int64_t)ch * ch;
+    g.t_lo = t_lo; g.t_hi = t_hi; g.chunk = chunk;
+    return wn_launch_wgrad2(&f, (dy && slab_d) ? &g : nullptr, batch, mode, (hipStream_t)stream);
+}
+
 int wn_wgrad_slabs(int t_lo, int t_hi, int chunk, int batch) { return wn_wgrad_num_slabs(t_lo, t_hi, chunk, batch); }
 
 int wn_reduce_slabs(const int64_t* desc, int n_ops, int64_t total_vec, const float* slab, float* out, wn_stream_t stream) {
@@ -127,6 +147,24 @@ int wn_mulaw_encode_tbl(const float* audio, const float* thresholds, uint8_t* co
 }
 int wn_mulaw_decode_lut(const uint8_t* codes, const float* table, float* audio, int64_t n, wn_stream_t stream) {
     return wn_launch_mulaw_decode(codes, table, audio, n, (hipStream_t)stream);
+}
+
+int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
+              float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
+              int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
+              const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
+              float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
+              int n_steps, int push_input, wn_stream_t stream) {
+    if (n_layers > WN_DEC_MAX_LAYERS || n_layers <= 0) return wn_set_error_msg(-4, "wn_decode: 1..64 layers supported");
+    WnDecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_layers = n_layers; a.R = R; a.D = D; a.S = S; a.Q = Q;
+    for (int i = 0; i < n_layers; ++i) { a.dil[i] = dilations_host[i]; a.q_off[i] = q_off_host[i]; }
+    a.queues = queues; a.w_causal = w_causal; a.b_causal = b_causal; a.w_layers = w_layers; a.layer_stride = layer_stride;
+    a.b_layers = b_layers; a.w_p1 = w_p1; a.b_p1 = b_p1; a.w_p2 = w_p2; a.b_p2 = b_p2;
+    a.note0 = note0; a.prev0 = prev0; a.note_out = note_out; a.prev_out = prev_out; a.forced = forced;
+    a.codes_out = codes_out; a.probs_out = probs_out; a.step0 = step0; a.n_steps = n_steps; a.push_input = push_input;
+    return wn_launch_decode(a, (hipStream_t)stream);
 }
 
 }  // extern "C"

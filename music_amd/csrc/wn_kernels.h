@@ -64,6 +64,7 @@ struct WnWgradArgs {
     int t_lo, t_hi, t_base; int chunk;      // time range and per-WG chunk (multiple of 32)
 };
 int wn_launch_wgrad(const WnWgradArgs& a, int batch, int mode, hipStream_t st);
+int wn_launch_wgrad2(const WnWgradArgs* a1, const WnWgradArgs* a2, int batch, int mode, hipStream_t st);
 int wn_wgrad_num_slabs(int t_lo, int t_hi, int chunk, int batch);
 int wn_launch_reduce_slabs(const long* desc, int n_ops, long total_vec, const float* slab, float* out, hipStream_t st);
 
@@ -80,3 +81,21 @@ int wn_launch_mulaw_encode(const float* audio, const float* thr, uint8_t* codes,
 int wn_launch_mulaw_decode(const uint8_t* codes, const float* table, float* audio, long n, hipStream_t st);
 int wn_launch_bias_grad(const float* a, long a_bstride, int a_pitch, int a_shift, int rows, int t_lo,
                         int t_hi, int batch, float* out, hipStream_t st);
+
+#define WN_DEC_MAX_LAYERS 64
+struct WnDecodeArgs {
+    int n_layers, R, D, S, Q;
+    int dil[WN_DEC_MAX_LAYERS];
+    long q_off[WN_DEC_MAX_LAYERS];       // float offset of each block's ring buffer [d][R] inside `queues`
+    float* queues;
+    const float* w_causal; const float* b_causal;        // [R][2Q] (k = tap0 q | tap1 q), [R]
+    const float* w_layers; long layer_stride;            // per block: Wfg [2D][2R] (k = tap1 r | tap0 r), Wd [R][D], Ws [S][D]
+    const float* b_layers;                               // per block: [bf D | bg D | bd R | bs S] or null
+    const float* w_p1; const float* b_p1; const float* w_p2; const float* b_p2;   // [S][S], [Q][S]
+    const float* note0; const float* prev0;              // [Q] dense: first input column and the one before it
+    float* note_out; float* prev_out;                    // [Q] state handed back
+    const int32_t* forced;                               // [n_steps] teacher-forced next codes, or null (greedy)
+    int32_t* codes_out; float* probs_out;                // [n_steps], [n_steps][Q] or null
+    long step0; int n_steps; int push_input;
+};
+int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st);

@@ -39,9 +39,16 @@ __device__ __forceinline__ void wg_frag(Frag<T>& f, const WgRaw& r, int t, int t
     split8<T, NS>(f, v);
 }
 
+// Two independent problems can share one launch (the per-layer dWfg and dWd products): the
+// workgroups with blockIdx.y >= p.y_split work on p.p[1].
+struct WnWgradPair { WnWgradArgs p[2]; int y_split; };
+
 template <class T, int NS>
-__global__ __launch_bounds__(256) void wgrad_k(WnWgradArgs a) {
+__global__ __launch_bounds__(256) void wgrad_k(WnWgradPair pr) {
     __shared__ float red[3][64 * 64];              // only used by the split-in-time (single block) form
+    const bool second = (int)blockIdx.y >= pr.y_split;
+    const WnWgradArgs& a = pr.p[second ? 1 : 0];
+    const int by = second ? blockIdx.y - pr.y_split : blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int b = blockIdx.z;
@@ -49,12 +56,13 @@ __global__ __launch_bounds__(256) void wgrad_k(WnWgradArgs a) {
     const int nblk_n = (nt_total + 3) / 4, nblk_m = (a.mt + 3) / 4;
     const int nblk = nblk_n * nblk_m;
     const bool split_time = nblk == 1;
-    const int blk = split_time ? 0 : blockIdx.y * 4 + wave;
+    const int blk = split_time ? 0 : by * 4 + wave;
     const bool active = blk < nblk;
     const int mb = active ? blk / nblk_n : 0, nb = active ? blk % nblk_n : 0;
     int tc0 = a.t_base + blockIdx.x * a.chunk;
     int tc1 = tc0 + a.chunk;
     if (tc1 > a.t_hi) tc1 = a.t_hi;
+    const int n_chunks = (a.t_hi - a.t_base + a.chunk - 1) / a.chunk;     // grid.x may be larger (paired launch)
     if (split_time) {                                   // quarter of the chunk per wave (multiple of 32)
         const int sub = ((a.chunk / 4) + 31) & ~31;
         tc0 += wave * sub;
@@ -138,7 +146,8 @@ __global__ __launch_bounds__(256) void wgrad_k(WnWgradArgs a) {
     }
     if (!active) return;
     // slab of this workgroup: plain stores, every element of the block is written
-    float* cs = a.c + ((size_t)b * gridDim.x + blockIdx.x) * a.c_slab_stride;
+    if ((int)blockIdx.x >= n_chunks) return;
+    float* cs = a.c + ((size_t)b * n_chunks + blockIdx.x) * a.c_slab_stride;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         if (!mval[m]) continue;
@@ -163,24 +172,45 @@ int wn_wgrad_num_slabs(int t_lo, int t_hi, int chunk, int batch) {
     return ((t_hi - t_base + chunk - 1) / chunk) * batch;
 }
 
-int wn_launch_wgrad(const WnWgradArgs& a, int batch, int mode, hipStream_t st) {
-    if (a.t_hi <= a.t_lo || batch <= 0) return 0;
-    WnWgradArgs k = a;
-    k.t_base = a.t_lo & ~31;
+static void wg_prepare(WnWgradArgs& k, int& nchunks, int& ygroups) {
+    k.t_base = k.t_lo & ~31;
     if (k.chunk < 128) k.chunk = 128;
     k.chunk = (k.chunk + 127) & ~127;
-    const int nt_total = a.nt_per_tap * (a.b1 ? 2 : 1);
-    const int nblk = ((nt_total + 3) / 4) * ((a.mt + 3) / 4);
-    dim3 g((a.t_hi - k.t_base + k.chunk - 1) / k.chunk, (nblk + 3) / 4, batch), b(256);
+    const int nt_total = k.nt_per_tap * (k.b1 ? 2 : 1);
+    const int nblk = ((nt_total + 3) / 4) * ((k.mt + 3) / 4);
+    nchunks = (k.t_hi - k.t_base + k.chunk - 1) / k.chunk;
+    ygroups = (nblk + 3) / 4;
+}
+
+// a2 may be null.  Both problems share the clip count; each writes its own slabs.
+int wn_launch_wgrad2(const WnWgradArgs* a1, const WnWgradArgs* a2, int batch, int mode, hipStream_t st) {
+    if (batch <= 0) return 0;
+    WnWgradPair pr;
+    int n = 0, nch[2] = {0, 0}, yg[2] = {0, 0};
+    const WnWgradArgs* src[2] = {a1, a2};
+    for (int i = 0; i < 2; ++i) {
+        if (!src[i] || src[i]->t_hi <= src[i]->t_lo) continue;
+        pr.p[n] = *src[i];
+        wg_prepare(pr.p[n], nch[n], yg[n]);
+        ++n;
+    }
+    if (n == 0) return 0;
+    if (n == 1) { pr.p[1] = pr.p[0]; yg[1] = 0; nch[1] = 0; }
+    pr.y_split = yg[0];
+    dim3 g(nch[0] > nch[1] ? nch[0] : nch[1], yg[0] + yg[1], batch), b(256);
     switch (mode) {
-        case WN_MODE_BF16X3: hipLaunchKernelGGL((wgrad_k<BF16, 3>), g, b, 0, st, k); break;
-        case WN_MODE_BF16X1: hipLaunchKernelGGL((wgrad_k<BF16, 1>), g, b, 0, st, k); break;
-        case WN_MODE_F16X3: hipLaunchKernelGGL((wgrad_k<F16, 3>), g, b, 0, st, k); break;
-        case WN_MODE_F16X1: hipLaunchKernelGGL((wgrad_k<F16, 1>), g, b, 0, st, k); break;
+        case WN_MODE_BF16X3: hipLaunchKernelGGL((wgrad_k<BF16, 3>), g, b, 0, st, pr); break;
+        case WN_MODE_BF16X1: hipLaunchKernelGGL((wgrad_k<BF16, 1>), g, b, 0, st, pr); break;
+        case WN_MODE_F16X3: hipLaunchKernelGGL((wgrad_k<F16, 3>), g, b, 0, st, pr); break;
+        case WN_MODE_F16X1: hipLaunchKernelGGL((wgrad_k<F16, 1>), g, b, 0, st, pr); break;
         default: return wn_set_error_msg(-2, "wgrad: bad mode");
     }
     WN_CHECK_LAUNCH();
     return 0;
+}
+
+int wn_launch_wgrad(const WnWgradArgs& a, int batch, int mode, hipStream_t st) {
+    return wn_launch_wgrad2(&a, nullptr, batch, mode, st);
 }
 
 // Batched deterministic slab reduction.  desc[op] = {vec_start, slab_off, n_slabs, stride, out_off, n}

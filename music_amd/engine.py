@@ -438,12 +438,12 @@ class WaveNetEngine:
                  xb, zb, 2 * CH * pitch, xb, pitch, fr("fg%d" % i), br("dT%d" % i),
                  self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)), self.D, CH, d, t_lo, T, lo,
                  B, mf, mb, st)
-            # dWf/dWg: C[2CH][tap0 CH | tap1 CH] = sum dfg[t] * [x(t-d) | x(t)]
-            wgrad("fg%d" % i, dfg, 2 * CH * pitch, pitch, 0, pitch, self._x(ws, i), self._x(ws, i), xb, pitch, -d, 0, pitch,
-                  CH // 16, 2 * CH // 16, 0, 2 * CH, t_lo, T)
-            if i < N - 1:
-                # dWd = sum dy z^T
-                wgrad("d%d" % i, dy, xb, pitch, 0, pitch, zs, None, xb, pitch, 0, 0, pitch, CH // 16, CH // 16, 0, CH, t_lo, T)
+            # dWf/dWg = sum dfg[t] [x(t-d) | x(t)]^T  and  dWd = sum dy z^T, one launch
+            so_fg = plan["fg%d" % i][0]
+            so_d = plan["d%d" % i][0] if i < N - 1 else None
+            call("wn_resblock_wgrad", dfg, self._x(ws, i), dy, zs, 2 * CH * pitch, xb, xb, pitch, CH, d, t_lo, T,
+                 ptr(bw["slab"], so_fg), ptr(bw["slab"], so_d) if so_d is not None else None,
+                 plan["fg%d" % i][2], B, mb, st)
             if self.use_bias:
                 bo = self.gp_bias_off
                 call("wn_bias_grad", dfg, 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i)]), st)

@@ -4,6 +4,8 @@ C ABI) vs the golden vectors from the real reference and vs the CPU oracle.  Run
 Tolerances (BASELINE.json north_star): integers bit-exact; float logits / probabilities within
 1e-3 absolute — checked here on GAIN-SCALED weights (at default init a constant 1/256
 passes).  Gradients: 2e-3 of the tensor's max-abs."""
+from collections import OrderedDict
+
 import numpy as np
 import pytest
 import torch
@@ -203,3 +205,57 @@ def test_full_size_c2_properties():
     print("c2 window probs err %.3e" % err)
     assert err < LOGIT_TOL
     assert p4.shape == (256, 256)
+
+
+@pytest.mark.parametrize("tag,correct", [("asis", False), ("fixed", True)])
+def test_g6_fast_generate(tag, correct):
+    """Cached-queue decode (persistent kernel) vs the reference's fast_generate.predict_next:
+    argmax ids bit-exact, queues within float tolerance; as-written (Q5) and corrected recurrences."""
+    from music_amd import fast_generate as fg
+    from oracle import intops
+    d = load_npz("g6_fastgen.npz")
+    dil = [int(v) for v in d["dilations"]]
+    cfg = dict(TINY, dilations=dil)
+    net = build(cfg, params_from(d))
+
+    def onehot(ix):
+        return torch.from_numpy(intops.one_hot_proper(np.atleast_1d(ix)))[None].cuda()
+
+    forced = d["forced"]
+    # (a) one persistent launch, teacher forced
+    pred, st = fg.predict_next(net, onehot(d["start"]), None)
+    assert pred.dtype == torch.int64 and pred.shape == (1,)
+    preds = [int(pred[0])]
+    assert list(st.keys())[:2] == ["causal_layer", "block_1"] and len(st) == len(dil) + 1
+    np.testing.assert_array_equal(st["causal_layer"].cpu().numpy(), d["%s_init_causal" % tag])
+    for i in range(len(dil)):
+        q = st["block_%d" % (i + 1)]
+        assert tuple(q.shape) == (1, 16, dil[i])
+        np.testing.assert_allclose(q.cpu().numpy(), d["%s_init_block%d" % (tag, i + 1)], atol=2e-5, rtol=0)
+    note0 = onehot(forced[0]).reshape(-1)
+    nxt = torch.from_numpy(np.concatenate([forced[1:], [0]]).astype(np.int32))
+    codes, probs, _ = fg._decode(net, st, note0, len(forced), forced=nxt, want_probs=True, correct_queue=correct)
+    preds += codes.cpu().tolist()
+    assert preds == list(d["%s_preds" % tag])
+    assert abs(probs.sum(1).cpu().numpy() - 1).max() < 1e-5
+    for i in range(len(dil)):
+        np.testing.assert_allclose(st["block_%d" % (i + 1)].cpu().numpy(), d["%s_final_block%d" % (tag, i + 1)],
+                                   atol=1e-4, rtol=0)
+    np.testing.assert_array_equal(st["causal_layer"].cpu().numpy(), d["%s_final_causal" % tag])
+    if correct:
+        assert preds == list(d["naive_preds"])
+    # (b) the per-sample API, 12 steps
+    pred, st = fg.predict_next(net, onehot(d["start"]), None)
+    preds = [int(pred[0])]
+    for s in forced[:12]:
+        pred, st = fg.predict_next(net, onehot(s), st, correct_queue=correct)
+        preds.append(int(pred[0]))
+    assert preds == list(d["%s_preds" % tag][:13])
+    # (c) free-running greedy generation: init + ONE launch
+    free = fg.generate_codes(net, onehot(d["start"]), 49, correct_queue=correct)
+    assert free.cpu().tolist() == list(d["%s_free" % tag])
+    # (d) a reference-style queue dict (plain tensors) is accepted too
+    pred, st = fg.predict_next(net, onehot(d["start"]), None)
+    plain = OrderedDict((k, v.cpu()) for k, v in st.items())
+    p1, _ = fg.predict_next(net, onehot(forced[0]), plain, correct_queue=correct)
+    assert int(p1[0]) == int(d["%s_preds" % tag][1])

@@ -70,6 +70,21 @@ def main():
         for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
             ph[n1] = ph.get(n1, 0.0) + e0.elapsed_time(e1)
         res["phase_ms"] = {k: round(v / args.reps, 3) for k, v in ph.items() if k != "begin"}
+    if args.what in ("decode", "all"):
+        # BASELINE config 5: 30-layer model, class-128 start piece, 1 s of 16 kHz audio, greedy
+        import time
+        from music_amd import fast_generate as fg
+        start = torch.zeros(1, 256, net.receptive_field, device="cuda")
+        start[:, 128, :] = 1.0
+        fg.generate_codes(net, start, 200)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        codes = fg.generate_codes(net, start, 16000)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res["decode_16000_samples_s"] = round(dt, 4)
+        res["decode_samples_per_s"] = round(16000 / dt, 1)
+        res["decode_distinct_codes"] = int(torch.unique(codes).numel())
     print(json.dumps(res))
 
 
