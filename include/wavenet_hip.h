@@ -63,11 +63,17 @@ int wn_chan_gemm(const float* in0, const float* in1, int64_t in_bstride, int in_
 
 /* Fused gated residual block, forward (wavenet/model.py:111-129 for one dilation d):
  *   [f;g] = Wfg [x(t-d); x(t)] ; z = tanh f * sigmoid g ; x_out = Wd z + x(t) on [t_lo,t_hi);
- *   z is stored on [z_lo, t_hi) (the crop the skip product needs).  ch = padded channels (32|64). */
+ *   z is stored on [z_lo, t_hi) (the crop the skip product needs).  ch = padded channels (32|64).
+ * Optional conditioning of the autoencoder's decoder (wavenet_autoencoder/model1.py:175-192,
+ * 227-247): [f;g][row][t] += cond[b][row][idx(t)], cond = [B][2*ch][cond_pitch] (rows f then g),
+ * idx = (t - t_lo) / cond_q when cond_mode == 1 ("stretch"), (t - t_lo) % cond_le when 2 ("tile");
+ * cond == NULL disables it. */
 int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bstride, int64_t z_bstride,
                     int pitch, const uint16_t* wfg, const uint16_t* wd, const float* bias_f,
                     const float* bias_g, const float* bias_d, int n_f, int n_d, int ch, int d,
-                    int t_lo, int t_hi, int z_lo, int write_x, int batch, int mode, wn_stream_t stream);
+                    int t_lo, int t_hi, int z_lo, int write_x, const float* cond, int64_t cond_bstride,
+                    int cond_pitch, int cond_mode, int cond_le, int cond_q, int batch, int mode,
+                    wn_stream_t stream);
 
 /* Fused gated residual block, backward recompute half (autograd of model.py:118-124, SURVEY
  * Appendix B): recomputes f,g,z from x_in; dz = Wd^T dy (+ dz_crop on t >= z_lo);
@@ -124,6 +130,11 @@ int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float 
                  wn_stream_t stream);
 /* flat_grad[i] = packed[idx[i]] (idx<0 -> 0): dense wgrad results -> state_dict (out,in,k) layout. */
 int wn_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, wn_stream_t stream);
+
+/* out[b][c][j] = mean_{k < pool} in[b][c][t0 + j*pool + k], j < n_out  (nn.AvgPool1d,
+ * wavenet_autoencoder/model1.py:154-155). */
+int wn_avgpool(const float* in, int64_t in_bstride, int in_pitch, int t0, int pool, int n_out, int rows,
+               float* out, int64_t out_bstride, int out_pitch, int batch, wn_stream_t stream);
 
 /* One-hot input on device from int32 codes (B,T) -> float32 (B,Q,T).  scrambled=1 reproduces
  * faster_audio_data.one_hot_encode's reshape (wavenet/faster_audio_data.py:77-81);

@@ -51,14 +51,20 @@ int wn_chan_gemm(const float* in0, const float* in1, int64_t in_bstride, int in_
 int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bstride, int64_t z_bstride,
                     int pitch, const uint16_t* wfg, const uint16_t* wd, const float* bias_f,
                     const float* bias_g, const float* bias_d, int n_f, int n_d, int ch, int d,
-                    int t_lo, int t_hi, int z_lo, int write_x, int batch, int mode, wn_stream_t stream) {
+                    int t_lo, int t_hi, int z_lo, int write_x, const float* cond, int64_t cond_bstride,
+                    int cond_pitch, int cond_mode, int cond_le, int cond_q, int batch, int mode,
+                    wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_fwd: pitch must be a multiple of 4");
+    if (cond && (cond_le <= 0 || (cond_mode == 1 && cond_q <= 0) || (cond_mode != 1 && cond_mode != 2)))
+        return wn_set_error_msg(-4, "wn_resblock_fwd: bad conditioning arguments");
     if (t_lo < d + 1) return wn_set_error_msg(-4, "wn_resblock_fwd: t_lo must be >= d + 1");
     WnResArgs a;
     memset(&a, 0, sizeof(a));
     a.x_in = x_in; a.x_out = x_out; a.z_out = z_out; a.x_bstride = x_bstride; a.z_bstride = z_bstride; a.pitch = pitch;
     a.wfg = wfg; a.wd = wd; a.bias_f = bias_f; a.bias_g = bias_g; a.bias_d = bias_d; a.n_f = n_f; a.n_d = n_d;
     a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = z_lo; a.write_x = write_x;
+    a.cond = cond; a.cond_bstride = cond_bstride; a.cond_pitch = cond_pitch; a.cond_mode = cond_mode;
+    a.cond_le = cond_le; a.cond_q = cond_q;
     return wn_launch_resblock_fwd(a, ch, batch, mode, (hipStream_t)stream);
 }
 
@@ -147,6 +153,12 @@ int wn_mulaw_encode_tbl(const float* audio, const float* thresholds, uint8_t* co
 }
 int wn_mulaw_decode_lut(const uint8_t* codes, const float* table, float* audio, int64_t n, wn_stream_t stream) {
     return wn_launch_mulaw_decode(codes, table, audio, n, (hipStream_t)stream);
+}
+
+int wn_avgpool(const float* in, int64_t in_bstride, int in_pitch, int t0, int pool, int n_out, int rows,
+               float* out, int64_t out_bstride, int out_pitch, int batch, wn_stream_t stream) {
+    return wn_launch_avgpool(in, in_bstride, in_pitch, t0, pool, n_out, rows, out, out_bstride, out_pitch, batch,
+                             (hipStream_t)stream);
 }
 
 int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,

@@ -246,3 +246,30 @@ int wn_launch_bias_grad(const float* a, long a_bstride, int a_pitch, int a_shift
     WN_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// AvgPool1d(pool) over the time axis (wavenet_autoencoder/model1.py:154-155): one wave per output.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_k(const float* __restrict__ in, long in_bstride, int in_pitch, int t0,
+                                                 int pool, int n_out, int rows, float* __restrict__ out,
+                                                 long out_bstride, int out_pitch) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (item >= (long)rows * n_out) return;
+    const int row = (int)(item / n_out), j = (int)(item % n_out);
+    const float* p = in + (size_t)b * in_bstride + (size_t)row * in_pitch + t0 + (size_t)j * pool;
+    float s = 0.f;
+    for (int k = lane; k < pool; k += 64) s += p[k];
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)b * out_bstride + (size_t)row * out_pitch + j] = s / (float)pool;
+}
+int wn_launch_avgpool(const float* in, long in_bstride, int in_pitch, int t0, int pool, int n_out, int rows,
+                      float* out, long out_bstride, int out_pitch, int batch, hipStream_t st) {
+    if (rows <= 0 || n_out <= 0 || batch <= 0) return 0;
+    long items = (long)rows * n_out;
+    hipLaunchKernelGGL(avgpool_k, dim3((unsigned)((items + 3) / 4), batch), dim3(256), 0, st, in, in_bstride, in_pitch, t0,
+                       pool, n_out, rows, out, out_bstride, out_pitch);
+    WN_CHECK_LAUNCH();
+    return 0;
+}

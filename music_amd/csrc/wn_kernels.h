@@ -35,6 +35,9 @@ struct WnResArgs {
     int n_f, n_d;                                       // real dilation / residual channel counts
     int d, t_lo, t_hi, z_lo, t_base;                    // outputs valid on [t_lo,t_hi); z stored for t >= z_lo
     int write_x;                                        // 0 for the last block (its x is unused)
+    // optional conditioning (wavenet_autoencoder/model1.py:183,227-247): [f;g] += cond[b][row][idx(t)]
+    const float* cond; long cond_bstride; int cond_pitch;   // [B][2CH][cond_pitch]
+    int cond_mode, cond_le, cond_q;                     // 1: idx = (t-t_lo)/cond_q (stretch); 2: idx = (t-t_lo) % cond_le (tile)
 };
 int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);
 
@@ -81,6 +84,9 @@ int wn_launch_mulaw_encode(const float* audio, const float* thr, uint8_t* codes,
 int wn_launch_mulaw_decode(const uint8_t* codes, const float* table, float* audio, long n, hipStream_t st);
 int wn_launch_bias_grad(const float* a, long a_bstride, int a_pitch, int a_shift, int rows, int t_lo,
                         int t_hi, int batch, float* out, hipStream_t st);
+
+int wn_launch_avgpool(const float* in, long in_bstride, int in_pitch, int t0, int pool, int n_out, int rows,
+                      float* out, long out_bstride, int out_pitch, int batch, hipStream_t st);
 
 #define WN_DEC_MAX_LAYERS 64
 struct WnDecodeArgs {

@@ -104,6 +104,26 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_fwd_k(WnResArgs a) {
         }
     }
 
+    if (a.cond) {       // per-(channel, time-bucket) conditioning bias, gathered from a tiny table
+        const float* cb = a.cond + (size_t)b * a.cond_bstride;
+        int idx[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            int tr = tl + n - a.t_lo;
+            tr = tr < 0 ? 0 : tr;
+            int ix = a.cond_mode == 1 ? tr / a.cond_q : tr % a.cond_le;
+            idx[n] = ix < a.cond_le ? ix : a.cond_le - 1;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* cr = cb + (size_t)(16 * m + 4 * q + i) * a.cond_pitch;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n][i] += cr[idx[n]];
+            }
+    }
+
     // residual rows in C layout (row 16m+4q+i, columns tl..tl+3): issue early, used at the end
     f32x4 res[MT2][4];
     if (a.write_x) {

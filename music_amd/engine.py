@@ -358,7 +358,7 @@ class WaveNetEngine:
             call("wn_resblock_fwd", self._x(ws, i), self._x(ws, i + 1), ptr(ws["Z"], SLACK + i * CH * pitch), xb, zb, pitch,
                  fr("fg%d" % i), fr("d%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),
                  self._bias_ptr(bn % (4 * i + 2)), self.D, self.R, CH, d, self.off[i + 1], T, self.rf - 1,
-                 1 if i < N - 1 else 0, B, mf, st)
+                 1 if i < N - 1 else 0, None, 0, 0, 0, 0, 0, B, mf, st)
         self.mark("stack_fwd")
         lo = self.rf - 1
         bias_s = None

@@ -259,3 +259,35 @@ def test_g6_fast_generate(tag, correct):
     plain = OrderedDict((k, v.cpu()) for k, v in st.items())
     p1, _ = fg.predict_next(net, onehot(forced[0]), plain, correct_queue=correct)
     assert int(p1[0]) == int(d["%s_preds" % tag][1])
+
+
+def test_g8_autoencoder_forward():
+    """wavenet_autoencoder/model1.py forward (encoder, pooled encoding, conditioned decoder with the
+    per-forward random projections, both _conditon branches) vs the reference's own outputs."""
+    import json
+    import os
+    from music_amd.model1 import wavenet_autoencoder
+    from oracle import intops
+    from tests.helpers import GOLDEN
+    d = load_npz("g8_autoencoder.npz")
+    cfg = json.load(open(os.path.join(GOLDEN, "g8_cfg.json")))
+    params = params_from(d)
+    net = wavenet_autoencoder(**cfg)
+    assert list(net.state_dict().keys()) == list(params.keys())
+    net.load_state_dict(params)
+    net = net.cuda()
+    assert net.receptive_field == int(d["rf"])
+    for tag in ("a", "b"):
+        idx = d[tag + "_idx"]
+        x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx])).cuda()
+        torch.manual_seed(int(d[tag + "_fwd_seed"]))
+        probs = net(x)
+        e_enc = np.abs(net.last_encoding.cpu().numpy() - d[tag + "_enc"]).max()
+        e_p = np.abs(probs.cpu().numpy() - d[tag + "_probs"]).max()
+        print("autoencoder", tag, "enc err %.2e probs err %.2e" % (e_enc, e_p))
+        assert e_enc < 1e-4 and e_p < LOGIT_TOL
+        assert probs.shape == d[tag + "_probs"].shape
+        torch.manual_seed(int(d[tag + "_fwd_seed"]) + 1)                  # other projections -> other output
+        assert np.abs(net(x).cpu().numpy() - d[tag + "_probs"]).max() > 1e-6
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 256, net.receptive_field - 1, device="cuda"))
