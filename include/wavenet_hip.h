@@ -84,6 +84,25 @@ int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* 
                     const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
                     int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
 
+/* Fully fused backward of one residual block (autograd of wavenet/model.py:111-129 for one layer,
+ * SURVEY Appendix B) in ONE launch: recompute f,g,z from x_in; dy = dx_{i+1} given as the pair
+ * dP_in[t] (t >= p_lo) + dQ_in[t+dn] (t+dn < t_hi) (NULL for the last block); dz = Wd^T dy + dz;
+ * [df;dg]; the data gradient as the UNSHIFTED pair dP_out[t] = W1^T[df;dg] + dy, dQ_out[t] =
+ * W0^T[df;dg] (so dx_i[t] = dP_out[t] + dQ_out[t+d]; wn_shift_add materialises it); and both
+ * weight-gradient products, one slab per workgroup (512 columns): slab index = clip *
+ * wn_resblock_bwd_fused_tiles(t_lo,t_hi) + tile; slab_fg stride 4*ch*ch, slab_d stride ch*ch.
+ * scratch: (batch * tiles) * 4*ch*512 floats.  wpq = packed [W1^T ; W0^T] ([2ch rows][2ch k]). */
+int wn_resblock_bwd_fused(const float* x_in, const float* dP_in, const float* dQ_in, const float* dz, float* dP_out,
+                          float* dQ_out, float* scratch, int64_t x_bstride, int64_t dz_bstride, int pitch,
+                          const uint16_t* wfg, const uint16_t* wdT, const uint16_t* wpq, const float* bias_f,
+                          const float* bias_g, int n_f, int ch, int d, int dn, int p_lo, int t_lo, int t_hi, int z_lo,
+                          float* slab_fg, float* slab_d, int has_d, int batch, int mode_fwd, int mode_bwd,
+                          wn_stream_t stream);
+int wn_resblock_bwd_fused_tiles(int t_lo, int t_hi);
+/* out[b][r][t] = p[b][r][t] (t >= p_lo) + q[b][r][t+dn] (t+dn < t_hi), t in [t_lo,t_hi) */
+int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,
+                 int t_lo, int t_hi, int batch, wn_stream_t stream);
+
 /* Weight gradient: C[m][n] = sum_{b, t in [t_lo,t_hi)} A[b][m][t+a_shift] * B_tap[b][n][t+b_shift_tap]
  * C columns [0, 16*nt_per_tap) come from b0, the next 16*nt_per_tap from b1 (if not NULL).
  * The time axis is cut into chunks; workgroup (clip b, chunk j) writes its partial C (leading

@@ -85,6 +85,22 @@ int wn_launch_mulaw_decode(const uint8_t* codes, const float* table, float* audi
 int wn_launch_bias_grad(const float* a, long a_bstride, int a_pitch, int a_shift, int rows, int t_lo,
                         int t_hi, int batch, float* out, hipStream_t st);
 
+struct WnResFusedArgs {
+    const float* x_in; long x_bstride; int pitch;          // x_i
+    const float* dP_in; const float* dQ_in; int dn, p_lo;  // dx_{i+1}[t] = P[t](t>=p_lo) + Q[t+dn](t+dn<t_hi); null for the last block
+    const float* dz; long dz_bstride; int z_lo;            // d z-crop (layer slice)
+    float* dP_out; float* dQ_out;                          // dx_i as the pair (P, Q) with shift d
+    float* scratch;                                        // [B * tiles][4*CH][512] floats
+    const uint16_t* wfg; const uint16_t* wdT; const uint16_t* wpq;
+    const float* bias_f; const float* bias_g; int n_f;
+    float* slab_fg; float* slab_d; int has_d;              // one slab per workgroup (clip-major)
+    int d, t_lo, t_hi, t_base;
+};
+int wn_launch_resblock_bwd_fused(const WnResFusedArgs& a, int ch, int batch, int mode_fwd, int mode_bwd, hipStream_t st);
+int wn_resfused_tiles(int t_lo, int t_hi);
+int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride, int pitch, int rows, int dn,
+                        int p_lo, int t_lo, int t_hi, int batch, hipStream_t st);
+
 int wn_launch_avgpool(const float* in, long in_bstride, int in_pitch, int t0, int pool, int n_out, int rows,
                       float* out, long out_bstride, int out_pitch, int batch, hipStream_t st);
 

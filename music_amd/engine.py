@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import call, ptr
 
 SLACK = 64          # floats in front of every activation buffer
-PAD_BACK = 512      # floats behind
+PAD_BACK = 2048     # floats behind
 
 
 def _pad(n, m):
@@ -95,6 +95,10 @@ class WaveNetEngine:
         self._gen = 0
         self.adam_state = None
         self.marks = None            # list of (name, torch.cuda.Event) when profiling is on
+        self.pair_wgrad = False      # both per-layer weight-gradient products in one launch
+        self.overlap_wgrad = False   # per-layer weight gradients on a second HIP stream (no gain measured)
+        self.fused_bwd = not self.use_bias   # one launch per residual block for the whole backward
+        self._side = None
 
     def mark(self, name):
         """Record a timing event on the current stream (only when self.marks is a list)."""
@@ -180,6 +184,13 @@ class WaveNetEngine:
                 w[:R, h * CH:h * CH + D] = src[:, :, 1].T
                 w[:R, 2 * CH + h * CH:2 * CH + h * CH + D] = src[:, :, 0].T
             bwd.append(("fgT%d" % i, pack_index(w)))
+            # 11b. the same weights as two UNSHIFTED row blocks for the fused backward:
+            #      rows [0,CH) = W1^T (-> P), rows [CH,2CH) = W0^T (-> Q), K = (df | dg)
+            w = full(2 * CH, 2 * CH)
+            for h, src in enumerate((wf, wg)):
+                w[:R, h * CH:h * CH + D] = src[:, :, 1].T
+                w[CH:CH + R, h * CH:h * CH + D] = src[:, :, 0].T
+            bwd.append(("pq%d" % i, pack_index(w)))
         # 4. skip over the concatenated z-crops: rows S, K = N*CH
         w = full(SP, N * CH)
         for i in range(N):
@@ -302,21 +313,28 @@ class WaveNetEngine:
 
         bw = dict(dO=torch.zeros(B * self.Q * W + PAD_BACK, dtype=torch.float32, device=dev),
                   dH=buf(self.SP), dU=buf(self.SP), dZ=buf(self.N * self.CH),
-                  dX=[buf(self.CH), buf(self.CH)], dfg=buf(2 * self.CH), zs=buf(self.CH))
+                  dX=[buf(self.CH), buf(self.CH)], dfg=[buf(2 * self.CH), buf(2 * self.CH)],
+                  zs=[buf(self.CH), buf(self.CH)])
         # weight-gradient slabs: every wgrad workgroup writes its partial C with plain stores,
         # one batched kernel then sums the slabs of all ops in a fixed order (deterministic)
         T, lo = ws["T"], self.rf - 1
+        fused = self.fused_bwd
         ops = [("p2", lo, T, 1024), ("p1", lo, T, 1024), ("skip", lo, T, 2048)]
         for i in range(self.N):
-            ops.append(("fg%d" % i, self.off[i + 1], T, 512))
+            ops.append(("fg%d" % i, self.off[i + 1], T, 0 if fused else 512))
             if i < self.N - 1:
-                ops.append(("d%d" % i, self.off[i + 1], T, 512))
+                ops.append(("d%d" % i, self.off[i + 1], T, 0 if fused else 512))
         ops.append(("causal", 1, T, 512))
+        if fused:
+            tiles = max(_lib.fused_tiles(self.off[i + 1], T) for i in range(self.N))
+            bw["PQ"] = [(buf(self.CH), buf(self.CH)), (buf(self.CH), buf(self.CH))]
+            bw["scratch"] = torch.zeros(B * tiles * 4 * self.CH * 512, dtype=torch.float32, device=dev)
         plan, desc, so, vs = {}, [], 0, 0
         for name, t_lo, t_hi, chunk in ops:
             go, r, c = self.gp_off[name]
             n = r * c
-            ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B)
+            # chunk 0: the fused backward writes one slab per 512-column workgroup tile
+            ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B) if chunk else _lib.fused_tiles(t_lo, t_hi) * B
             plan[name] = (so, n, chunk)
             desc.append([vs, so, ns, n, go, n])
             so += ns * n
@@ -407,19 +425,39 @@ class WaveNetEngine:
             call("wn_wgrad", *head, ptr(bw["slab"], so), ldc, n, t_lo, t_hi, chunk, B, mb, st)
         dO, dH, dU, dZ = ptr(bw["dO"]), ptr(bw["dH"], SLACK), ptr(bw["dU"], SLACK), ptr(bw["dZ"], SLACK)
         U, H, Z = ptr(ws["U"], SLACK), ptr(ws["H"], SLACK), ptr(ws["Z"], SLACK)
+        main = torch.cuda.current_stream()
+        overlap = self.overlap_wgrad
+        if overlap and self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side if overlap else main
+
+        def on_side(fn):
+            """Run fn on the side stream after everything enqueued so far on the main stream."""
+            if overlap:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+            with torch.cuda.stream(side):
+                fn(_lib.stream())
+
+        def wgrad_s(name, *args):
+            so, n, chunk = plan[name]
+            head, (ldc, t_lo, t_hi) = args[:-3], args[-3:]
+            on_side(lambda s2: call("wn_wgrad", *head, ptr(bw["slab"], so), ldc, n, t_lo, t_hi, chunk, B, mb, s2))
+
+        # weight gradients of the epilogue run on the side stream as soon as their operands exist
+        wgrad_s("p2", dO, Q * W, W, -lo, W, H, None, sb, pitch, 0, 0, pitch, SP // 16, Q // 16, 1, SP, lo, T)
         # dH = (P2^T dO) * [H > 0]
         call("wn_chan_gemm", dO, None, Q * W, W, 0, W, -lo, 0, Q // 32, 0, br("p2T"), SP // 16, self.S,
              dH, sb, pitch, 0, None, None, 0, 0, 0, H, sb, pitch, lo, T, 0, B, mb, st)
+        wgrad_s("p1", dH, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
         # dU = (P1^T dH) * [U > 0]
         call("wn_chan_gemm", dH, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, br("p1T"), SP // 16, self.S,
              dU, sb, pitch, 0, None, None, 0, 0, 0, U, sb, pitch, lo, T, 0, B, mb, st)
+        wgrad_s("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CH // 16, SP // 16, 0, N * CH, lo, T)
         # dZ = Ws^T dU   (all N crops at once)
         call("wn_chan_gemm", dU, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, br("skipT"), N * CH // 16, N * CH,
              dZ, zb, pitch, 0, None, None, 0, 0, 0, None, 0, 0, lo, T, 0, B, mb, st)
-        # weight gradients of the epilogue
-        wgrad("p2", dO, Q * W, W, -lo, W, H, None, sb, pitch, 0, 0, pitch, SP // 16, Q // 16, 1, SP, lo, T)
-        wgrad("p1", dH, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
-        wgrad("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CH // 16, SP // 16, 0, N * CH, lo, T)
         if self.use_bias:
             bo = self.gp_bias_off
             call("wn_bias_grad", dO, Q * W, W, -lo, Q, lo, T, B, ptr(self.gpack, bo["post_process_2.bias"]), st)
@@ -428,33 +466,69 @@ class WaveNetEngine:
                 call("wn_bias_grad", dU, sb, pitch, 0, self.S, lo, T, B,
                      ptr(self.gpack, bo["dilation_layer_stack.%d.bias" % (4 * i + 3)]), st)
         self.mark("epilogue_bwd")
-        dfg, zs = ptr(bw["dfg"], SLACK), ptr(bw["zs"], SLACK)
+        if self.fused_bwd:
+            self._stack_bwd_fused(ws, bw, plan, st)
+            self.mark("stack_bwd")
+            x = ws["x_in"]
+            dx0 = ptr(bw["dX"][0], SLACK)
+            wgrad("causal", dx0, xb, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CH // 16, 0, 2 * Q, 1, T)
+            call("wn_reduce_slabs", ptr(bw["slab_desc"]), bw["slab_nops"], bw["slab_vec"], ptr(bw["slab"]), ptr(self.gpack), st)
+            call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
+            self.mark("causal_bwd")
+            return
+        # The per-layer weight-gradient products only feed the slab reduction at the very end, so
+        # they run on a second HIP stream next to the data-gradient chain
+        # (resblock_bwd -> dx product -> next block); dfg / z scratch is double-buffered for that.
+        ev_w = [None, None]          # side-stream completion of the wgrads that read scratch buffer k
+        ev_prev = None               # ... of the previous layer's wgrads (they read dX[(i+1)%2])
         for i in range(N - 1, -1, -1):
             d = self.dil[i]
             t_lo = self.off[i + 1]
+            k = i % 2
+            dfg, zs = ptr(bw["dfg"][k], SLACK), ptr(bw["zs"][k], SLACK)
             dy = ptr(bw["dX"][(i + 1) % 2], SLACK) if i < N - 1 else None
             bn = "dilation_layer_stack.%d.bias"
+            if overlap and ev_w[k] is not None:
+                main.wait_event(ev_w[k])
             call("wn_resblock_bwd", self._x(ws, i), dy, ptr(bw["dZ"], SLACK + i * CH * pitch), dfg, zs,
                  xb, zb, 2 * CH * pitch, xb, pitch, fr("fg%d" % i), br("dT%d" % i),
                  self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)), self.D, CH, d, t_lo, T, lo,
                  B, mf, mb, st)
-            # dWf/dWg = sum dfg[t] [x(t-d) | x(t)]^T  and  dWd = sum dy z^T, one launch
-            so_fg = plan["fg%d" % i][0]
-            so_d = plan["d%d" % i][0] if i < N - 1 else None
-            call("wn_resblock_wgrad", dfg, self._x(ws, i), dy, zs, 2 * CH * pitch, xb, xb, pitch, CH, d, t_lo, T,
-                 ptr(bw["slab"], so_fg), ptr(bw["slab"], so_d) if so_d is not None else None,
-                 plan["fg%d" % i][2], B, mb, st)
-            if self.use_bias:
-                bo = self.gp_bias_off
-                call("wn_bias_grad", dfg, 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i)]), st)
-                call("wn_bias_grad", ptr(bw["dfg"], SLACK + CH * pitch), 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B,
-                     ptr(self.gpack, bo[bn % (4 * i + 1)]), st)
+            if overlap:
+                ev_r = torch.cuda.Event()
+                ev_r.record(main)
+                side.wait_event(ev_r)
+            with torch.cuda.stream(side):
+                st2 = _lib.stream()
+                so, n, chunk = plan["fg%d" % i]
+                call("wn_wgrad", dfg, 2 * CH * pitch, pitch, 0, pitch, self._x(ws, i), self._x(ws, i), xb, pitch, -d, 0, pitch,
+                     CH // 16, 2 * CH // 16, 0, ptr(bw["slab"], so), 2 * CH, n, t_lo, T, chunk, B, mb, st2)
                 if i < N - 1:
-                    call("wn_bias_grad", dy, xb, pitch, 0, self.R, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i + 2)]), st)
+                    so, n, chunk = plan["d%d" % i]
+                    call("wn_wgrad", dy, xb, pitch, 0, pitch, zs, None, xb, pitch, 0, 0, pitch, CH // 16, CH // 16, 0,
+                         ptr(bw["slab"], so), CH, n, t_lo, T, chunk, B, mb, st2)
+                if self.use_bias:
+                    bo = self.gp_bias_off
+                    call("wn_bias_grad", dfg, 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i)]), st2)
+                    call("wn_bias_grad", ptr(bw["dfg"][k], SLACK + CH * pitch), 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B,
+                         ptr(self.gpack, bo[bn % (4 * i + 1)]), st2)
+                    if i < N - 1:
+                        call("wn_bias_grad", dy, xb, pitch, 0, self.R, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i + 2)]), st2)
+                if overlap:
+                    ev_w[k] = torch.cuda.Event()
+                    ev_w[k].record(side)
             # dx_i[t] = W1^T dfg[t] + W0^T dfg[t+d] + dy[t]        on [off_i, T)
+            # (writes dX[i%2], which the PREVIOUS layer's weight gradients may still be reading)
+            if overlap and ev_prev is not None:
+                main.wait_event(ev_prev)
             call("wn_chan_gemm", dfg, dfg, 2 * CH * pitch, pitch, t_lo, T, 0, d, 2 * CH // 32, 2 * CH // 32, br("fgT%d" % i),
                  CH // 16, self.R, ptr(bw["dX"][i % 2], SLACK), xb, pitch, 0, None,
                  dy, xb, pitch, t_lo, None, 0, 0, self.off[i], T, 0, B, mb, st)
+            ev_prev = ev_w[k]
+        if overlap:
+            for e in ev_w:
+                if e is not None:
+                    main.wait_event(e)
         self.mark("stack_bwd")
         # causal weight gradient: dWc[r][q][tap] = sum dx0[r][t] in[q][t-1+tap]
         x = ws["x_in"]
@@ -465,6 +539,33 @@ class WaveNetEngine:
         call("wn_reduce_slabs", ptr(bw["slab_desc"]), bw["slab_nops"], bw["slab_vec"], ptr(bw["slab"]), ptr(self.gpack), st)
         call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
         self.mark("causal_bwd")
+
+    def _stack_bwd_fused(self, ws, bw, plan, st):
+        """One wn_resblock_bwd_fused launch per block, top to bottom; dx between blocks travels as
+        the unshifted (P, Q) pair.  Leaves dx_0 in bw['dX'][0] for the causal weight gradient."""
+        B, T, pitch = ws["B"], ws["T"], ws["pitch"]
+        CH, N, lo = self.CH, self.N, self.rf - 1
+        xb, zb = CH * pitch, N * CH * pitch
+        fr = lambda name: ptr(self.pk_f, self.pk_f_off[name])
+        br = lambda name: ptr(self.pk_b, self.pk_b_off[name])
+        for i in range(N - 1, -1, -1):
+            p_out, q_out = bw["PQ"][i % 2]
+            if i < N - 1:
+                p_in, q_in = (ptr(t, SLACK) for t in bw["PQ"][(i + 1) % 2])
+                dn, p_lo = self.dil[i + 1], self.off[i + 2]
+            else:
+                p_in = q_in = None
+                dn = p_lo = 0
+            bn = "dilation_layer_stack.%d.bias"
+            call("wn_resblock_bwd_fused", self._x(ws, i), p_in, q_in, ptr(bw["dZ"], SLACK + i * CH * pitch),
+                 ptr(p_out, SLACK), ptr(q_out, SLACK), ptr(bw["scratch"]), xb, zb, pitch,
+                 fr("fg%d" % i), br("dT%d" % i), br("pq%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),
+                 self.D, CH, self.dil[i], dn, p_lo, self.off[i + 1], T, lo,
+                 ptr(bw["slab"], plan["fg%d" % i][0]), ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None,
+                 1 if i < N - 1 else 0, B, self.mode_fwd, self.mode_bwd, st)
+        p0, q0 = bw["PQ"][0]
+        call("wn_shift_add", ptr(p0, SLACK), ptr(q0, SLACK), ptr(bw["dX"][0], SLACK), xb, pitch, self.R, self.dil[0],
+             self.off[1], 1, T, B, st)
 
     def backward(self, ws, dprobs):
         """dprobs: (B*W, Q) gradient w.r.t. the probabilities returned by forward()."""
