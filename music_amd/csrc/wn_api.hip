@@ -1,5 +1,6 @@
 // C ABI of libwavenet_hip.so (declared in include/wavenet_hip.h): argument marshalling only.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/wavenet_hip.h"
 #include "wn_common.h"
@@ -168,6 +169,9 @@ int wn_resblock_bwd_fused(const float* x_in, const float* dP_in, const float* dQ
     a.dn = dn; a.p_lo = p_lo; a.dz = dz; a.dz_bstride = dz_bstride; a.z_lo = z_lo; a.dP_out = dP_out; a.dQ_out = dQ_out;
     a.scratch = scratch; a.wfg = wfg; a.wdT = wdT; a.wpq = wpq; a.bias_f = bias_f; a.bias_g = bias_g; a.n_f = n_f;
     a.slab_fg = slab_fg; a.slab_d = slab_d; a.has_d = (has_d && dP_in && slab_d) ? 1 : 0; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi;
+    static int dbg = -1;                     // WN_FUSED_SKIP=1|2|3 disables phases for TIMING experiments (wrong results)
+    if (dbg < 0) { const char* e = getenv("WN_FUSED_SKIP"); dbg = e ? atoi(e) : 0; }
+    a.dbg_skip = dbg;
     return wn_launch_resblock_bwd_fused(a, ch, batch, mode_fwd, mode_bwd, (hipStream_t)stream);
 }
 int wn_resblock_bwd_fused_tiles(int t_lo, int t_hi) { return wn_resfused_tiles(t_lo, t_hi); }

@@ -95,6 +95,7 @@ struct WnResFusedArgs {
     const float* bias_f; const float* bias_g; int n_f;
     float* slab_fg; float* slab_d; int has_d;              // one slab per workgroup (clip-major)
     int d, t_lo, t_hi, t_base;
+    int dbg_skip;                                          // timing diagnostics only (WN_FUSED_SKIP): bit0 skip P/Q, bit1 skip wgrad
 };
 int wn_launch_resblock_bwd_fused(const WnResFusedArgs& a, int ch, int batch, int mode_fwd, int mode_bwd, hipStream_t st);
 int wn_resfused_tiles(int t_lo, int t_hi);

@@ -198,16 +198,19 @@ __global__ __launch_bounds__(RF_THREADS) void resblock_bwd_fused_k(WnResFusedArg
     __syncthreads();          // (also drains this wave's stores: the tile is complete in L2)
 
     // ---------------- 3. P = W1^T [df;dg] + dy,  Q = W0^T [df;dg]   (B fragments from the scratch tile)
-    {
+    if (!(a.dbg_skip & 1)) {
         f32x4 pq[PQ_MT][4];
 #pragma unroll
         for (int m = 0; m < PQ_MT; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) pq[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < PQ_KS; ++s) {
+        auto issue3 = [&](int s) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[j] = ld4nt(scr + (size_t)(32 * s + 8 * q + j) * RF_COLS + lc);
+        };
+        issue3(0);
+#pragma unroll
+        for (int s = 0; s < PQ_KS; ++s) {
             Frag<TB> bf[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -216,6 +219,7 @@ __global__ __launch_bounds__(RF_THREADS) void resblock_bwd_fused_k(WnResFusedArg
                 for (int j = 0; j < 8; ++j) v[j] = raw[j][n];
                 split8<TB, NSB>(bf[n], v);
             }
+            if (s + 1 < PQ_KS) issue3(s + 1);
 #pragma unroll
             for (int m = 0; m < PQ_MT; ++m) {
                 Frag<TB> af;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(RF_THREADS) void resblock_bwd_fused_k(WnResFusedArg
     }
 
     // ---------------- 4. weight gradients over the 512 columns of the tile (time on k)
-    {
+    if (!(a.dbg_skip & 2)) {
         constexpr int MW = (2 * CH / 16) / 2;          // dWfg: M-tiles per wave (wave grid 2 x 4)
         constexpr int NW = (2 * CH / 16) / 4;          //       N-tiles per wave
         const int wm = wave >> 2, wn = wave & 3;
@@ -257,47 +261,57 @@ __global__ __launch_bounds__(RF_THREADS) void resblock_bwd_fused_k(WnResFusedArg
 #pragma unroll
         for (int m = 0; m < DMW; ++m) dacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int ks = 0; ks < RF_COLS / 32; ++ks) {
+        // raw operands of one k-step (32 samples); the next step's loads fly behind the MFMAs
+        f32x4 ra[MW][2], rb[NW][2], rz[2], ry[DMW][2];
+        auto issue4 = [&](int ks) {
             const int lt = ks * 32 + 8 * q;            // local time of this lane's 8 samples
             const int gt = c0 + lt;                    // absolute time
-            Frag<TB> af[MW], bfr[NW];
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
                 const float* r = scr + (size_t)((wm * MW + m) * 16 + c) * RF_COLS + lt;
-                f32x4 u0 = ld4nt(r), u1 = ld4nt(r + 4);
-                float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
-                split8<TB, NSB>(af[m], v);
+                ra[m][0] = ld4nt(r); ra[m][1] = ld4nt(r + 4);
             }
 #pragma unroll
             for (int n = 0; n < NW; ++n) {
                 const int nt = wn * NW + n;                        // column tile of [x(t-d) | x(t)]
                 const int tap = nt / (CH / 16), r0 = (nt % (CH / 16)) * 16 + c;
                 const float* r = xin + (size_t)r0 * a.pitch + gt + (tap == 0 ? -a.d : 0);
-                f32x4 u0 = ld4u(r), u1 = ld4u(r + 4);
-                float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
-                split8<TB, NSB>(bfr[n], v);
+                rb[n][0] = ld4u(r); rb[n][1] = ld4u(r + 4);
             }
+            if (d_on) {
+                const float* r = scr + (size_t)(2 * CH + d_n * 16 + c) * RF_COLS + lt;
+                rz[0] = ld4nt(r); rz[1] = ld4nt(r + 4);
+#pragma unroll
+                for (int m = 0; m < DMW; ++m) {
+                    const float* ry_ = scr + (size_t)(3 * CH + (d_m0 + m) * 16 + c) * RF_COLS + lt;
+                    ry[m][0] = ld4nt(ry_); ry[m][1] = ld4nt(ry_ + 4);
+                }
+            }
+        };
+        auto frag = [&](Frag<TB>& f, const f32x4* u) {
+            float v[8] = {u[0][0], u[0][1], u[0][2], u[0][3], u[1][0], u[1][1], u[1][2], u[1][3]};
+            split8<TB, NSB>(f, v);
+        };
+        issue4(0);
+        for (int ks = 0; ks < RF_COLS / 32; ++ks) {
+            Frag<TB> af[MW], bfr[NW], zf, yf[DMW];
+#pragma unroll
+            for (int m = 0; m < MW; ++m) frag(af[m], ra[m]);
+#pragma unroll
+            for (int n = 0; n < NW; ++n) frag(bfr[n], rb[n]);
+            if (d_on) {
+                frag(zf, rz);
+#pragma unroll
+                for (int m = 0; m < DMW; ++m) frag(yf[m], ry[m]);
+            }
+            if (ks + 1 < RF_COLS / 32) issue4(ks + 1);
 #pragma unroll
             for (int m = 0; m < MW; ++m)
 #pragma unroll
                 for (int n = 0; n < NW; ++n) mma<TB, NSB>(wacc[m][n], af[m], bfr[n]);
             if (d_on) {
-                Frag<TB> zf;
-                {
-                    const float* r = scr + (size_t)(2 * CH + d_n * 16 + c) * RF_COLS + lt;
-                    f32x4 u0 = ld4nt(r), u1 = ld4nt(r + 4);
-                    float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
-                    split8<TB, NSB>(zf, v);
-                }
 #pragma unroll
-                for (int m = 0; m < DMW; ++m) {
-                    const float* r = scr + (size_t)(3 * CH + (d_m0 + m) * 16 + c) * RF_COLS + lt;
-                    f32x4 u0 = ld4nt(r), u1 = ld4nt(r + 4);
-                    float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
-                    Frag<TB> yf;
-                    split8<TB, NSB>(yf, v);
-                    mma<TB, NSB>(dacc[m], yf, zf);
-                }
+                for (int m = 0; m < DMW; ++m) mma<TB, NSB>(dacc[m], yf[m], zf);
             }
         }
         const size_t slab = (size_t)b * gridDim.x + blockIdx.x;

@@ -97,7 +97,11 @@ class WaveNetEngine:
         self.marks = None            # list of (name, torch.cuda.Event) when profiling is on
         self.pair_wgrad = False      # both per-layer weight-gradient products in one launch
         self.overlap_wgrad = False   # per-layer weight gradients on a second HIP stream (no gain measured)
-        self.fused_bwd = not self.use_bias   # one launch per residual block for the whole backward
+        # One launch per residual block for the whole backward (wn_resblock_bwd_fused).  Correct and
+        # tested, but SLOWER than the unfused kernels at config 2 (6.0 vs 4.5 ms for the stack): its
+        # 512 KB-per-workgroup scratch tile does not fit the 128 KB-per-CU share of the XCD's L2, so the
+        # re-reads come from the Infinity Cache.  Kept opt-in ("what did not work").
+        self.fused_bwd = False
         self._side = None
 
     def mark(self, name):

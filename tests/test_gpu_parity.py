@@ -315,6 +315,7 @@ def test_grads_64_channels_vs_oracle(fused):
     net(x[:, :, :net.receptive_field].cuda())
     eng = net._engine
     eng.fused_bwd = fused
+    eng._ws.clear()                      # the backward workspace plan depends on the flag
     loss = eng.loss_and_grad(x.cuda(), target.cuda())
     l_ref, p_ref, g_ref = wo.loss_and_grads(params, cfg["dilations"], x, target)
     assert abs(loss.item() - l_ref.item()) < 1e-4
