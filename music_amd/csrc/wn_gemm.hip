@@ -178,6 +178,152 @@ __global__ __launch_bounds__(512) void chan_gemm_k(WnGemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide variant with the packed weights of each k-step staged through LDS: the 16 row tiles of a
+// k-step (32 KB in the x3 modes) are fetched from L2 ONCE per workgroup (cooperatively, one k-step
+// ahead, double-buffered) instead of once per wave, and every wave reads its 8 fragments with
+// ds_read_b128.  256 rows x 256 columns per workgroup, 8 waves = 2 (rows) x 4 (columns).
+// ---------------------------------------------------------------------------------------------
+template <class T, int NS>
+__global__ __launch_bounds__(512) void chan_gemm_wide_lds_k(WnGemmArgs a) {
+    constexpr int MTW = 8, WM = 2, WN = 4;
+    constexpr int FR = (NS == 3 ? 1024 : 512);               // halfs per fragment
+    constexpr int STEP_VEC = 16 * FR / 8;                     // u32x4 per k-step (16 row tiles)
+    __shared__ __attribute__((aligned(16))) uint16_t l_a[2][16 * FR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.z;
+    const int wm = wave / WN, wn = wave % WN;
+    const int t0 = a.t_base + (blockIdx.x * WN + wn) * 64;
+    const int tl = t0 + 4 * c;
+    const int mg0 = blockIdx.y * 16;                           // first M-tile of the workgroup
+    const int m0 = mg0 + wm * MTW;                             // first M-tile of this wave
+    const int KS = a.ks0 + a.ks1;
+
+    f32x4 acc[MTW][4];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        f32x4 init = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = (m0 + m) * 16 + 4 * q + i;
+                init[i] = row < a.m_valid ? a.bias[row] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = init;
+    }
+    const float* in0 = a.in0 + (size_t)b * a.in_bstride;
+    const float* in1 = a.in1 ? a.in1 + (size_t)b * a.in_bstride : nullptr;
+    const int col0 = tl + a.shift0, col1 = tl + a.shift1;
+    f32x4 raw[8];
+    auto issue = [&](int s) {
+        const float* base; int col; int ch;
+        if (s < a.ks0) { base = in0; col = col0; ch = s * 32; }
+        else { base = in1; col = col1; ch = (s - a.ks0) * 32; }
+        const float* p = base + (size_t)(ch + 8 * q) * a.in_pitch + col;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[j] = ld4g(p + (size_t)j * a.in_pitch, col, a.in_lo, a.in_hi);
+    };
+    // weight staging: tile (mg0 + mt) of k-step s lives at fragment index (mg0 + mt) * KS + s
+    constexpr int PER_THREAD = (STEP_VEC + 511) / 512;
+    u32x4 wreg[PER_THREAD];
+    auto wload = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            int v = threadIdx.x + i * 512;                     // u32x4 index inside the k-step image
+            int mt = v / (FR / 8), r = v % (FR / 8);
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if (v < STEP_VEC && mg0 + mt < a.mt)
+                z = reinterpret_cast<const u32x4*>(a.wpack)[((size_t)(mg0 + mt) * KS + s) * (FR / 8) + r];
+            wreg[i] = z;
+        }
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            int v = threadIdx.x + i * 512;
+            if (v < STEP_VEC) reinterpret_cast<u32x4*>(l_a[buf])[v] = wreg[i];
+        }
+    };
+    issue(0);
+    wload(0);
+    wstore(0);
+    __syncthreads();
+    for (int s = 0; s < KS; ++s) {
+        Frag<T> bf[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = raw[j][n];
+                v[j] = a.relu_in ? fmaxf(x, 0.f) : x;
+            }
+            split8<T, NS>(bf[n], v);
+        }
+        if (s + 1 < KS) { issue(s + 1); wload(s + 1); }
+        const uint16_t* la = l_a[s & 1];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            Frag<T> af;
+            load_a<T, NS>(af, la, wm * MTW + m, lane);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
+        }
+        if (s + 1 < KS) wstore((s + 1) & 1);
+        __syncthreads();
+    }
+    if (t0 >= a.t_hi || m0 >= a.mt) return;
+
+    float* out = a.out + (size_t)b * a.out_bstride;
+    const float* resid = a.resid ? a.resid + (size_t)b * a.resid_bstride : nullptr;
+    const float* mask = a.mask ? a.mask + (size_t)b * a.mask_bstride : nullptr;
+    const bool full = tl >= a.t_lo && tl + 3 < a.t_hi;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        if (m0 + m >= a.mt) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = (m0 + m) * 16 + 4 * q + i;
+            if (row >= a.m_valid) continue;
+            f32x4 v = {acc[m][0][i], acc[m][1][i], acc[m][2][i], acc[m][3][i]};
+            if (resid) {
+                const float* rp = resid + (size_t)row * a.resid_pitch + tl;
+                if (full && tl >= a.resid_lo) {
+                    v += ld4u(rp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tl + e >= a.resid_lo && tl + e >= a.t_lo && tl + e < a.t_hi) v[e] += rp[e];
+                }
+            }
+            if (mask) {
+                const float* mp = mask + (size_t)row * a.mask_pitch + tl;
+                if (full) {
+                    f32x4 mv = ld4u(mp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tl + e >= a.t_lo && tl + e < a.t_hi) v[e] = mp[e] > 0.f ? v[e] : 0.f;
+                }
+            }
+            float* op = out + (size_t)row * a.out_pitch + tl + a.out_shift;
+            if (full) {
+                F4U u = {{v[0], v[1], v[2], v[3]}};
+                *reinterpret_cast<F4U*>(op) = u;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (tl + e >= a.t_lo && tl + e < a.t_hi) op[e] = v[e];
+            }
+        }
+    }
+}
+
 template <class T, int NS>
 static int launch_gemm(const WnGemmArgs& k, int batch, hipStream_t st) {
     const int ncol = k.t_hi - k.t_base;
@@ -186,7 +332,7 @@ static int launch_gemm(const WnGemmArgs& k, int batch, hipStream_t st) {
         hipLaunchKernelGGL((chan_gemm_k<T, NS, 4, 1>), g, b, 0, st, k);
     } else {                             // wide: 256 rows x 256 columns per workgroup
         dim3 g((ncol + 255) / 256, (k.mt + 15) / 16, batch), b(512);
-        hipLaunchKernelGGL((chan_gemm_k<T, NS, 8, 2>), g, b, 0, st, k);
+        hipLaunchKernelGGL((chan_gemm_wide_lds_k<T, NS>), g, b, 0, st, k);
     }
     return 0;
 }

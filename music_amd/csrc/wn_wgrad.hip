@@ -172,6 +172,118 @@ int wn_wgrad_num_slabs(int t_lo, int t_hi, int chunk, int batch) {
     return ((t_hi - t_base + chunk - 1) / chunk) * batch;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large outputs (>= 256 x 256: dP1, dP2, dWskip): one workgroup of 8 waves owns a 256 x 256 block
+// of C.  Per 32-sample k-step every wave loads + splits only 4 of the 32 operand tiles and parks
+// the 16-bit fragments in LDS (double-buffered, 2 x 64 KB in the x3 modes); all waves then read
+// the 8 A and 4 B fragments of their 128 x 64 sub-block with ds_read_b128.  This removes the
+// 8-30x redundant fp32 -> hi/lo splitting that bounds wgrad_k on these shapes.
+// ---------------------------------------------------------------------------------------------
+template <class T, int NS>
+__global__ __launch_bounds__(512) void wgrad_big_k(WnWgradArgs a) {
+    constexpr int FR = (NS == 3 ? 1024 : 512);
+    extern __shared__ __attribute__((aligned(16))) uint16_t l_f[];      // [2][32][FR]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.z;
+    const int nt_total = a.nt_per_tap * (a.b1 ? 2 : 1);
+    const int n_ng = (nt_total + 15) / 16;
+    const int mg = blockIdx.y / n_ng, ng = blockIdx.y % n_ng;
+    const int tc0 = a.t_base + blockIdx.x * a.chunk;
+    int tc1 = tc0 + a.chunk;
+    if (tc1 > a.t_hi) tc1 = a.t_hi;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // the 4 tiles this wave loads: A tiles 2w, 2w+1 and B tiles 2w, 2w+1 of the block
+    const float* lrow[4];
+    int lshift[4], lcols[4];
+    bool lval[4], lrelu[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int tile = 2 * wave + (k & 1);
+        if (k < 2) {
+            const int mt = mg * 16 + tile;
+            lval[k] = mt < a.mt;
+            lrow[k] = a.a + (size_t)b * a.a_bstride + (size_t)((lval[k] ? mt : 0) * 16 + c) * a.a_pitch;
+            lshift[k] = a.a_shift; lcols[k] = a.a_cols; lrelu[k] = false;
+        } else {
+            int nt = ng * 16 + tile;
+            lval[k] = nt < nt_total;
+            if (!lval[k]) nt = 0;
+            const int tap = nt / a.nt_per_tap, r = (nt % a.nt_per_tap) * 16 + c;
+            lrow[k] = (tap == 0 ? a.b0 : a.b1) + (size_t)b * a.b_bstride + (size_t)r * a.b_pitch;
+            lshift[k] = tap == 0 ? a.b_shift0 : a.b_shift1; lcols[k] = a.b_cols; lrelu[k] = a.relu_b != 0;
+        }
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    WgRaw raw[4];
+    auto issue = [&](int tb) {
+        const int t = tb + 8 * q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) raw[k] = wg_load(lrow[k], t + lshift[k], lcols[k]);
+    };
+    auto park = [&](int buf, int tb) {
+        const bool masked = (tb < a.t_lo) || (tb + 32 > tc1);
+        const int t = tb + 8 * q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            Frag<T> f;
+            wg_frag<T, NS>(f, raw[k], t, a.t_lo, tc1, masked || !lval[k], lrelu[k]);
+            if (!lval[k]) {                                  // tile outside the matrix: zeros
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { f.hi[j] = T::cvt(0.f); f.lo[j] = T::cvt(0.f); }
+            }
+            const int slot = (k < 2 ? 0 : 16) + 2 * wave + (k & 1);
+            u32x4* dst = reinterpret_cast<u32x4*>(l_f + ((size_t)buf * 32 + slot) * FR);
+            dst[lane] = __builtin_bit_cast(u32x4, f.hi);
+            if (NS == 3) dst[64 + lane] = __builtin_bit_cast(u32x4, f.lo);
+        }
+    };
+    if (tc0 < tc1) {
+        issue(tc0);
+        park(0, tc0);
+    }
+    __syncthreads();
+    int it = 0;
+    for (int tb = tc0; tb < tc1; tb += 32, ++it) {
+        const bool more = tb + 32 < tc1;
+        if (more) issue(tb + 32);
+        const uint16_t* base = l_f + (size_t)(it & 1) * 32 * FR;
+        Frag<T> bf[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) load_a<T, NS>(bf[n], base, 16 + wn * 4 + n, lane);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            Frag<T> af;
+            load_a<T, NS>(af, base, wm * 8 + m, lane);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
+        }
+        if (more) park((it + 1) & 1, tb + 32);
+        __syncthreads();
+    }
+    const int n_chunks = (a.t_hi - a.t_base + a.chunk - 1) / a.chunk;
+    float* cs = a.c + ((size_t)b * n_chunks + blockIdx.x) * a.c_slab_stride;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int mt = mg * 16 + wm * 8 + m;
+        if (mt >= a.mt) continue;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int nt = ng * 16 + wn * 4 + n;
+            if (nt >= nt_total) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                cs[(size_t)(mt * 16 + 4 * q + i) * a.ldc + nt * 16 + c] = acc[m][n][i];
+        }
+    }
+}
+
 static void wg_prepare(WnWgradArgs& k, int& nchunks, int& ygroups) {
     k.t_base = k.t_lo & ~31;
     if (k.chunk < 128) k.chunk = 128;
@@ -195,7 +307,35 @@ int wn_launch_wgrad2(const WnWgradArgs* a1, const WnWgradArgs* a2, int batch, in
         ++n;
     }
     if (n == 0) return 0;
-    if (n == 1) { pr.p[1] = pr.p[0]; yg[1] = 0; nch[1] = 0; }
+    if (n == 1) {
+        const WnWgradArgs& k = pr.p[0];
+        const int nt_total = k.nt_per_tap * (k.b1 ? 2 : 1);
+        if (k.mt >= 16 && nt_total >= 16) {
+            const int ns = wn_mode_ns(mode);
+            const size_t sh = (size_t)2 * 32 * (ns == 3 ? 1024 : 512) * sizeof(uint16_t);
+            dim3 g(nch[0], ((k.mt + 15) / 16) * ((nt_total + 15) / 16), batch), b(512);
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            static unsigned long long done[4] = {0, 0, 0, 0};
+#define WN_BIG(TT, NN, slot) do { \
+                if (!((done[slot] >> dev) & 1ull)) { \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_k<TT, NN>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+                    done[slot] |= 1ull << dev; } \
+                hipLaunchKernelGGL((wgrad_big_k<TT, NN>), g, b, sh, st, k); } while (0)
+            switch (mode) {
+                case WN_MODE_BF16X3: WN_BIG(BF16, 3, 0); break;
+                case WN_MODE_BF16X1: WN_BIG(BF16, 1, 1); break;
+                case WN_MODE_F16X3: WN_BIG(F16, 3, 2); break;
+                case WN_MODE_F16X1: WN_BIG(F16, 1, 3); break;
+                default: return wn_set_error_msg(-2, "wgrad: bad mode");
+            }
+#undef WN_BIG
+            WN_CHECK_LAUNCH();
+            return 0;
+        }
+        pr.p[1] = pr.p[0]; yg[1] = 0; nch[1] = 0;
+    }
     pr.y_split = yg[0];
     dim3 g(nch[0] > nch[1] ? nch[0] : nch[1], yg[0] + yg[1], batch), b(256);
     switch (mode) {

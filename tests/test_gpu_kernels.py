@@ -356,3 +356,26 @@ def test_adam_flat_matches_torch():
         call("wn_adam_flat", ptr(p), ptr((gr * 4).to(DEV)), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8,
              1 - 0.9 ** t, 1 - 0.999 ** t, 0.25, _lib.stream())
     assert (p.cpu() - p_ref.detach()).abs().max().item() < 2e-6
+
+
+def test_wgrad_big_lds_path():
+    """Outputs >= 256 x 256 take the LDS-shared workgroup kernel (wgrad_big_k): 256 x 304 with a
+    ragged last column group, two taps, relu on B, masked chunk ends."""
+    mode = _lib.BF16X3
+    rng = np.random.default_rng(15)
+    B, M, NB, pitch, T = 2, 256, 160, 2304, 1900          # C = [256][2 taps * 160 = 320]... use 152 -> 19 tiles
+    NB = 152
+    a = _buf(B, M, pitch, 1e-3, 21)
+    bsrc = _buf(B, NB + 8, pitch, 1.0, 22)
+    t_lo, d = 700, 5
+    c = _wgrad(M, 2 * NB + 16, t_lo, T, 512, B, mode, ptr(a, SLACK), M * pitch, pitch, 0, pitch, ptr(bsrc, SLACK),
+               ptr(bsrc, SLACK), (NB + 8) * pitch, pitch, -d, 0, pitch, (NB + 8) // 16, M // 16, 1)
+    torch.cuda.synchronize()
+    aa = _view(a, B, M, pitch).cpu().double()[:, :, t_lo:T]
+    bb = _view(bsrc, B, NB + 8, pitch).cpu().double().clamp(min=0)
+    ref0 = torch.einsum("bmt,bnt->mn", aa, bb[:, :, t_lo - d:T - d])
+    ref1 = torch.einsum("bmt,bnt->mn", aa, bb[:, :, t_lo:T])
+    ref = torch.cat([ref0, ref1], 1)
+    err = (c.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    print("wgrad big rel err", err)
+    assert err < 1e-4
