@@ -162,8 +162,22 @@ def main():
 
     fwd_b, bwd_b = stack_bytes(CFG["dilations"], 64, 64, B_LOCAL, T)
     n_layers = len(CFG["dilations"])
-    stack_fwd_s = phase.get("stack_fwd", float("nan")) * 1e-3
-    achieved = fwd_b / stack_fwd_s / 1e9 if stack_fwd_s == stack_fwd_s and stack_fwd_s > 0 else None
+    nan = float("nan")
+    fwd_ms, bwd_ms = phase.get("stack_fwd", nan), phase.get("stack_bwd", nan)
+
+    def gbs(nbytes, ms):
+        return nbytes / (ms * 1e-3) / 1e9 if ms == ms and ms > 0 else None
+
+    # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes (tools/gpu_check.sh
+    # prof; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), if a summary is committed
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_resblock_fwd.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    ach = gbs(fwd_b, fwd_ms)
     out = {
         "metric": "audio samples/sec trained (whole node), 30-layer WaveNet @16kHz",
         "value": world * B_LOCAL * T * args.steps / dt,
@@ -178,13 +192,21 @@ def main():
                                "batch 8x16000 per GPU, full train step (one-hot + fwd + CE + bwd + all-reduce + Adam)",
                    "global_batch": world * B_LOCAL, "seq_len": T, "parallelism": "dp%d" % world,
                    "precision": args.precision, "final_loss": float(loss.item())},
-        "roofline": {"bound": "hbm", "kernel": "resblock_fwd_k (30 launches/step)",
-                     "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": (achieved * 1e9 / HBM_PEAK) if achieved else None, "traffic": None,
+        # dominant kernel family = the dilated-conv stack: forward kernel, one launch per block
+        "roofline": {"bound": "hbm", "kernel": "resblock_fwd_k (dilated-conv stack forward, %d launches/step)" % n_layers,
+                     "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": (ach * 1e9 / HBM_PEAK) if ach else None, "traffic": traffic,
                      "algorithmic_bytes_per_launch": fwd_b / n_layers,
-                     "avg_launch_ms": phase.get("stack_fwd", float("nan")) / n_layers,
-                     "stack_fwd_bwd_frac": ((fwd_b + bwd_b) / ((phase.get("stack_fwd", 0) + phase.get("stack_bwd", 0)) * 1e-3) / HBM_PEAK)
-                     if phase.get("stack_bwd") else None},
+                     "avg_launch_ms": fwd_ms / n_layers},
+        # the same stack, backward (resblock_bwd_k + 2 wgrad_k + chan_gemm_k per block) and forward+backward
+        "roofline_stack_bwd": {"bound": "hbm", "achieved": gbs(bwd_b, bwd_ms), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": (gbs(bwd_b, bwd_ms) * 1e9 / HBM_PEAK) if gbs(bwd_b, bwd_ms) else None,
+                               "algorithmic_bytes_per_step": bwd_b},
+        "roofline_stack_fwd_bwd": {"bound": "hbm", "achieved": gbs(fwd_b + bwd_b, fwd_ms + bwd_ms), "peak": HBM_PEAK / 1e9,
+                                   "unit": "GB/s",
+                                   "frac": (gbs(fwd_b + bwd_b, fwd_ms + bwd_ms) * 1e9 / HBM_PEAK)
+                                   if gbs(fwd_b + bwd_b, fwd_ms + bwd_ms) else None,
+                                   "algorithmic_bytes_per_step": fwd_b + bwd_b},
         "phase_ms_per_step": {k: round(v, 4) for k, v in phase.items()},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
