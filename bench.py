@@ -193,7 +193,7 @@ def main():
                    "global_batch": world * B_LOCAL, "seq_len": T, "parallelism": "dp%d" % world,
                    "precision": args.precision, "final_loss": float(loss.item())},
         # dominant kernel family = the dilated-conv stack: forward kernel, one launch per block
-        "roofline": {"bound": "hbm", "kernel": "resblock_fwd_k (dilated-conv stack forward, %d launches/step)" % n_layers,
+        "roofline": {"bound": "hbm", "kernel": "resblock_fwd_nt_k (dilated-conv stack forward, %d launches/step)" % n_layers,
                      "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": (ach * 1e9 / HBM_PEAK) if ach else None, "traffic": traffic,
                      "algorithmic_bytes_per_launch": fwd_b / n_layers,

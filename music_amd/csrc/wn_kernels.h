@@ -40,6 +40,7 @@ struct WnResArgs {
     int cond_mode, cond_le, cond_q;                     // 1: idx = (t-t_lo)/cond_q (stretch); 2: idx = (t-t_lo) % cond_le (tile)
 };
 int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);
+int wn_launch_resblock_fwd_nt(const WnResArgs& a, int ch, int batch, int mode, int nt, hipStream_t st);
 
 struct WnResBwdArgs {
     const float* x_in;          // x_i          [B][CH][pitch]

@@ -9,6 +9,7 @@
 //   z is stored only on the crop t >= z_lo that the skip product needs.
 // The packed weights (hi/lo fragments) of the block are staged once per workgroup in LDS; the
 // activations stream HBM -> registers as float4 (time on the lanes, see wn_common.h).
+#include <stdlib.h>
 #include "wn_common.h"
 #include "wn_kernels.h"
 
@@ -231,6 +232,11 @@ static int launch_fwd(const WnResArgs& a, int ch, int batch, hipStream_t st) {
 
 int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st) {
     if (a.t_hi <= a.t_lo || batch <= 0) return 0;
+    // default: the NT-templated kernel of wn_resblock2.hip with 4 N-tiles per wave (26.6 us per
+    // config-2 layer vs 29.2 for resblock_fwd_k below; NT = 2 measured 33 us).  WN_FWD_NT=0|2|4 overrides.
+    static int nt = -1;
+    if (nt < 0) { const char* e = getenv("WN_FWD_NT"); nt = e ? atoi(e) : 4; }
+    if (nt == 2 || nt == 4) return wn_launch_resblock_fwd_nt(a, ch, batch, mode, nt, st);
     switch (mode) {
         case WN_MODE_F16X3: return launch_fwd<F16, 3>(a, ch, batch, st);
         case WN_MODE_F16X1: return launch_fwd<F16, 1>(a, ch, batch, st);

@@ -1,0 +1,288 @@
+// Fused gated residual block, forward — variant templated on the number NT of 16-column N-tiles a
+// wave owns (see wn_resblock.hip for the algorithm).  NT = 4: 8 waves x 64 columns (float4 per
+// lane); NT = 2: 16 waves x 32 columns (float2 per lane, <= 128 VGPRs, 4 waves per SIMD) - more
+// waves in different phases hide the load -> MFMA -> transcendental -> MFMA -> store chain of a
+// tile better.  Both cover 512 columns per workgroup and share one copy of the packed weights.
+#include "wn_common.h"
+#include "wn_kernels.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) F2U { float v[2]; };
+template <int NT> struct VecN;
+template <> struct VecN<4> {
+    typedef f32x4 t;
+    static __device__ __forceinline__ t ld(const float* p) { return ld4(p); }
+    static __device__ __forceinline__ t ldu(const float* p) { return ld4u(p); }
+    static __device__ __forceinline__ void stm(float* p, t v, int tt, int lo, int hi) { st4m(p, v, tt, lo, hi); }
+};
+template <> struct VecN<2> {
+    typedef f32x2 t;
+    static __device__ __forceinline__ t ld(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+    static __device__ __forceinline__ t ldu(const float* p) {
+        F2U u = *reinterpret_cast<const F2U*>(p);
+        t r = {u.v[0], u.v[1]};
+        return r;
+    }
+    static __device__ __forceinline__ void stm(float* p, t v, int tt, int lo, int hi) {
+        if (tt >= lo && tt + 1 < hi) *reinterpret_cast<f32x2*>(p) = v;
+        else {
+            if (tt >= lo && tt < hi) p[0] = v[0];
+            if (tt + 1 >= lo && tt + 1 < hi) p[1] = v[1];
+        }
+    }
+};
+
+// z = tanh(f) * sigmoid(g) with ONE reciprocal: (1 - e1) / ((1 + e1)(1 + e2)), e1 = exp(-2f), e2 = exp(-g).
+// Absolute error ~1e-7 (the cancellation in 1 - e1 only costs RELATIVE accuracy near f = 0).
+__device__ __forceinline__ float wn_gate(float f, float g) {
+    f = fminf(fmaxf(f, -15.f), 15.f);
+    const float e1 = __expf(-2.0f * f), e2 = __expf(-g);
+    return (1.0f - e1) * __builtin_amdgcn_rcpf((1.0f + e1) * (1.0f + e2));
+}
+
+template <int NT> struct NtCfg { static constexpr int WAVES = NT == 4 ? 8 : 16; };     // 512 columns per workgroup either way
+
+template <class T, int NS, int CH, int NT>
+__global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnResArgs a) {
+    typedef typename VecN<NT>::t fvec;
+    constexpr int THREADS = 64 * NtCfg<NT>::WAVES;
+    constexpr int COLS = NtCfg<NT>::WAVES * 16 * NT;
+    constexpr int MT = 2 * CH / 16;        // fg row tiles (f rows then g rows)
+    constexpr int KS = 2 * CH / 32;        // fg k-steps (tap 0 channels then tap 1 channels)
+    constexpr int KT = CH / 32;            // k-steps per tap
+    constexpr int MT2 = CH / 16;           // dense row tiles
+    constexpr int KS2 = CH / 32;           // dense k-steps
+    constexpr int FR = (NS == 3 ? 1024 : 512);          // halfs per packed fragment
+    constexpr int NFG = MT * KS, ND = MT2 * KS2;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t* l_fg = lds;
+    uint16_t* l_d = lds + (size_t)NFG * FR;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.y;
+    const int t0 = a.t_base + blockIdx.x * COLS + wave * (16 * NT);
+    const int tl = t0 + NT * c;
+
+    const float* xin = a.x_in + (size_t)b * a.x_bstride;
+    const bool aligned_d = (a.d & (NT - 1)) == 0;
+    // tap-0 column.  Lanes that own at least one valid output have tl - d >= -2 (t_lo >= d + 1);
+    // every activation buffer is allocated with >= 64 floats of slack in front and >= 256 behind,
+    // so the (masked-out) garbage columns are still addressable.
+    const int colm = tl - a.d;
+
+    fvec raw[8];
+    auto issue = [&](int s) {
+        const int tap = s / KT, ch = (s % KT) * 32 + 8 * q;
+        const float* p = xin + (size_t)ch * a.pitch + (tap == 0 ? colm : tl);
+        if (tap == 0 && !aligned_d) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[j] = VecN<NT>::ldu(p + (size_t)j * a.pitch);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[j] = VecN<NT>::ld(p + (size_t)j * a.pitch);
+        }
+    };
+    issue(0);      // first activation loads are in flight while the weights are staged
+
+    {   // stage the packed weights (contiguous copies, 16 B per thread per step)
+        const u32x4* s0 = reinterpret_cast<const u32x4*>(a.wfg);
+        u32x4* d0 = reinterpret_cast<u32x4*>(l_fg);
+        for (int i = threadIdx.x; i < NFG * FR / 8; i += THREADS) d0[i] = s0[i];
+        const u32x4* s1 = reinterpret_cast<const u32x4*>(a.wd);
+        u32x4* d1 = reinterpret_cast<u32x4*>(l_d);
+        for (int i = threadIdx.x; i < ND * FR / 8; i += THREADS) d1[i] = s1[i];
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        f32x4 init = {0.f, 0.f, 0.f, 0.f};
+        const float* bp = m < MT2 ? a.bias_f : a.bias_g;
+        if (bp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = (m % MT2) * 16 + 4 * q + i;
+                init[i] = row < a.n_f ? bp[row] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = init;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        Frag<T> bf[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = raw[j][n];
+            split8<T, NS>(bf[n], v);
+        }
+        if (s + 1 < KS) issue(s + 1);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            Frag<T> af;
+            load_a<T, NS>(af, l_fg, m * KS + s, lane);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
+        }
+    }
+
+    if (a.cond) {       // per-(channel, time-bucket) conditioning bias, gathered from a tiny table
+        const float* cb = a.cond + (size_t)b * a.cond_bstride;
+        int idx[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            int tr = tl + n - a.t_lo;
+            tr = tr < 0 ? 0 : tr;
+            int ix = a.cond_mode == 1 ? tr / a.cond_q : tr % a.cond_le;
+            idx[n] = ix < a.cond_le ? ix : a.cond_le - 1;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* cr = cb + (size_t)(16 * m + 4 * q + i) * a.cond_pitch;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n][i] += cr[idx[n]];
+            }
+    }
+
+    // residual rows in C layout (row 16m+4q+i, columns tl..tl+3): issue early, used at the end
+    fvec res[MT2][4];
+    if (a.write_x && NT == 4) {
+#pragma unroll
+        for (int m = 0; m < MT2; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                res[m][i] = VecN<NT>::ld(xin + (size_t)(16 * m + 4 * q + i) * a.pitch + tl);
+    }
+
+    // gate: z tile m = tanh(f tile m) * sigmoid(g tile m)
+    f32x4 z[MT2][NT];
+#pragma unroll
+    for (int m = 0; m < MT2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                z[m][n][i] = wn_gate(acc[m][n][i], acc[m + MT2][n][i]);
+
+    // z-crop store (rows 16m+4q+i; the lane's 4 N-tiles are 4 consecutive samples)
+    {
+        float* zo = a.z_out + (size_t)b * a.z_bstride;
+#pragma unroll
+        for (int m = 0; m < MT2; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fvec v;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) v[n] = z[m][n][i];
+                VecN<NT>::stm(zo + (size_t)(16 * m + 4 * q + i) * a.pitch + tl, v, tl, a.z_lo, a.t_hi);
+            }
+    }
+    if (!a.write_x) return;
+
+    // dense: x' = Wd z + x   (B fragments straight from the z accumulators, chained k order)
+    f32x4 acc2[MT2][NT];
+#pragma unroll
+    for (int m = 0; m < MT2; ++m) {
+        f32x4 init = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias_d) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = m * 16 + 4 * q + i;
+                init[i] = row < a.n_d ? a.bias_d[row] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc2[m][n] = init;
+    }
+#pragma unroll
+    for (int s = 0; s < KS2; ++s) {
+        Frag<T> bf[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = z[2 * s][n][i]; v[4 + i] = z[2 * s + 1][n][i]; }
+            split8<T, NS>(bf[n], v);
+        }
+#pragma unroll
+        for (int m = 0; m < MT2; ++m) {
+            Frag<T> af;
+            load_a<T, NS>(af, l_d, m * KS2 + s, lane);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) mma<T, NS>(acc2[m][n], af, bf[n]);
+        }
+    }
+    if (NT != 4) {                        // 128-VGPR budget: fetch the residual rows only now
+#pragma unroll
+        for (int m = 0; m < MT2; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                res[m][i] = VecN<NT>::ld(xin + (size_t)(16 * m + 4 * q + i) * a.pitch + tl);
+    }
+    float* xo = a.x_out + (size_t)b * a.x_bstride;
+#pragma unroll
+    for (int m = 0; m < MT2; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fvec v;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) v[n] = acc2[m][n][i] + res[m][i][n];
+            VecN<NT>::stm(xo + (size_t)(16 * m + 4 * q + i) * a.pitch + tl, v, tl, a.t_lo, a.t_hi);
+        }
+}
+
+
+template <class T, int NS, int NT>
+static int launch_fwd_nt(const WnResArgs& a, int ch, int batch, hipStream_t st) {
+    WnResArgs k = a;
+    k.t_base = a.t_lo & ~3;
+    const int ncol = a.t_hi - k.t_base;
+    constexpr int COLS = NtCfg<NT>::WAVES * 16 * NT;
+    dim3 g((ncol + COLS - 1) / COLS, batch), b(64 * NtCfg<NT>::WAVES);
+    const size_t fr = (NS == 3 ? 1024 : 512) * sizeof(uint16_t);
+    if (ch == 32) {
+        hipLaunchKernelGGL((resblock_fwd_nt_k<T, NS, 32, NT>), g, b, (size_t)(4 * 2 + 2 * 1) * fr, st, k);
+    } else if (ch == 64) {
+        const size_t sh = (size_t)(8 * 4 + 4 * 2) * fr;
+        static unsigned long long done = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!((done >> dev) & 1ull)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_fwd_nt_k<T, NS, 64, NT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            done |= 1ull << dev;
+        }
+        hipLaunchKernelGGL((resblock_fwd_nt_k<T, NS, 64, NT>), g, b, sh, st, k);
+    } else {
+        return wn_set_error_msg(-3, "resblock: padded channel count must be 32 or 64");
+    }
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
+int wn_launch_resblock_fwd_nt(const WnResArgs& a, int ch, int batch, int mode, int nt, hipStream_t st) {
+    if (a.t_hi <= a.t_lo || batch <= 0) return 0;
+    if (nt == 2) {
+        switch (mode) {
+            case WN_MODE_F16X3: return launch_fwd_nt<F16, 3, 2>(a, ch, batch, st);
+            case WN_MODE_F16X1: return launch_fwd_nt<F16, 1, 2>(a, ch, batch, st);
+            case WN_MODE_BF16X3: return launch_fwd_nt<BF16, 3, 2>(a, ch, batch, st);
+            case WN_MODE_BF16X1: return launch_fwd_nt<BF16, 1, 2>(a, ch, batch, st);
+        }
+    } else {
+        switch (mode) {
+            case WN_MODE_F16X3: return launch_fwd_nt<F16, 3, 4>(a, ch, batch, st);
+            case WN_MODE_F16X1: return launch_fwd_nt<F16, 1, 4>(a, ch, batch, st);
+            case WN_MODE_BF16X3: return launch_fwd_nt<BF16, 3, 4>(a, ch, batch, st);
+            case WN_MODE_BF16X1: return launch_fwd_nt<BF16, 1, 4>(a, ch, batch, st);
+        }
+    }
+    return wn_set_error_msg(-2, "resblock_fwd: bad mode");
+}
