@@ -201,6 +201,7 @@ int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations
     a.b_layers = b_layers; a.w_p1 = w_p1; a.b_p1 = b_p1; a.w_p2 = w_p2; a.b_p2 = b_p2;
     a.note0 = note0; a.prev0 = prev0; a.note_out = note_out; a.prev_out = prev_out; a.forced = forced;
     a.codes_out = codes_out; a.probs_out = probs_out; a.step0 = step0; a.n_steps = n_steps; a.push_input = push_input;
+    { const char* e = getenv("WN_DEC_DBG"); a.dbg = e ? atoi(e) : 0; }
     return wn_launch_decode(a, (hipStream_t)stream);
 }
 

@@ -131,11 +131,214 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_k(WnDecodeArgs a) {
     for (int i = tid; i < a.Q; i += DEC_THREADS) { a.prev_out[i] = prev[i]; a.note_out[i] = note[i]; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// decode_v4_k: same recurrence, built for the real bottleneck of a one-CU sequential kernel, the
+// INSTRUCTION count per multiply-add: every thread owns a CONTIGUOUS k-slice of one output row,
+// reads its weights as float4 (prefetched one block ahead, they do not depend on data) and its
+// slice of the input vector as float4 from LDS, and `parts` adjacent lanes combine with shuffles.
+// The residual stream ping-pongs between two LDS buffers, queue columns are written by the lanes
+// that own the outputs, ring positions live in LDS (no 64-bit modulo per block).
+// Requires (else decode_k): no biases, one pass per product, weights per thread = 16 / 4 / 16 for
+// the f/g, dense and skip products and multiples of 4 for causal / post-process.
+// ---------------------------------------------------------------------------------------------
+struct DecMap { int parts, p, o, nw; };
+__device__ __forceinline__ DecMap dec_map(int M, int K) {
+    int parts = DEC_THREADS / M;
+    if (parts < 1) parts = 1;
+    if (parts > 64) parts = 64;
+    while (parts & (parts - 1)) parts &= parts - 1;
+    DecMap m;
+    m.parts = parts; m.p = threadIdx.x % parts; m.o = threadIdx.x / parts; m.nw = K / parts;
+    return m;
+}
+template <int NV>      // NV float4 of weights: W[o][p*nw .. p*nw + 4*NV)
+__device__ __forceinline__ void dec_loadw4(f32x4 (&w)[NV], const DecMap& m, const float* __restrict__ W, int ldw, int M) {
+    const float* r = W + (size_t)(m.o < M ? m.o : 0) * ldw + m.p * m.nw;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) w[j] = ld4(r + 4 * j);
+}
+template <int NV>
+__device__ __forceinline__ float dec_dot4(const f32x4 (&w)[NV], const DecMap& m, const float* x) {
+    const float* xs = x + m.p * m.nw;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + 4 * j);
+        s = fmaf(w[j][0], xv[0], s); s = fmaf(w[j][1], xv[1], s);
+        s = fmaf(w[j][2], xv[2], s); s = fmaf(w[j][3], xv[3], s);
+    }
+    for (int off = m.parts >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+// long rows (causal, post-process): weights streamed at use, 4 float4 in flight
+__device__ __forceinline__ float dec_dot_stream(const DecMap& m, const float* __restrict__ W, int ldw, int M, const float* x) {
+    const float* r = W + (size_t)(m.o < M ? m.o : 0) * ldw + m.p * m.nw;
+    const float* xs = x + m.p * m.nw;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int k = 0; k < m.nw; k += 16) {
+        f32x4 w0 = ld4(r + k), w1 = ld4(r + k + 4), w2 = ld4(r + k + 8), w3 = ld4(r + k + 12);
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + k), x1 = *reinterpret_cast<const f32x4*>(xs + k + 4);
+        const f32x4 x2 = *reinterpret_cast<const f32x4*>(xs + k + 8), x3 = *reinterpret_cast<const f32x4*>(xs + k + 12);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s0 = fmaf(w0[e], x0[e], s0); s1 = fmaf(w1[e], x1[e], s1);
+            s2 = fmaf(w2[e], x2[e], s2); s3 = fmaf(w3[e], x3[e], s3);
+        }
+    }
+    float s = (s0 + s1) + (s2 + s3);
+    for (int off = m.parts >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+
+// Workgroup barrier that only drains LDS traffic.  __syncthreads() also waits for every outstanding
+// global access (vmcnt(0), because of the queue-column stores), which would expose the L2 latency
+// of the weight prefetches at each of the ~90 barriers of a sample.
+__device__ __forceinline__ void dec_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(DEC_THREADS) void decode_v4_k(WnDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* prev = sm;                       // [Q]
+    float* note = prev + a.Q;               // [Q]   ([prev|note] contiguous)
+    float* cur0 = note + a.Q;               // [2R]  cur (R) followed by old (R), buffer 0
+    float* cur1 = cur0 + 2 * a.R;           // [2R]  buffer 1
+    float* fg = cur1 + 2 * a.R;             // [2D]
+    float* zz = fg + 2 * a.D;               // [D]
+    float* skip = zz + a.D;                 // [S]
+    float* h1 = skip + a.S;                 // [S]
+    float* logit = h1 + a.S;                // [Q]
+    __shared__ int s_arg;
+    __shared__ int slots[WN_DEC_MAX_LAYERS];          // ring position of every block
+    const int tid = threadIdx.x;
+    const int R = a.R, D = a.D, S = a.S, Q = a.Q;
+    const DecMap mc = dec_map(R, 2 * Q), mfg = dec_map(2 * D, 2 * R), md = dec_map(R, D), ms = dec_map(S, D);
+    const DecMap mp1 = dec_map(S, S), mp2 = dec_map(Q, S);
+    const size_t lstride = (size_t)a.layer_stride;
+    const size_t o_d = (size_t)2 * D * 2 * R, o_s = o_d + (size_t)R * D;
+
+    for (int i = tid; i < Q; i += DEC_THREADS) { note[i] = a.note0[i]; prev[i] = a.prev0[i]; }
+    if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
+    dec_sync();
+
+    f32x4 wfg[4], wd[1], ws[4];
+    for (int step = 0; step < a.n_steps; ++step) {
+        // block-0 weights and queue column are fetched while the causal layer runs
+        dec_loadw4(wfg, mfg, a.w_layers, 2 * R, 2 * D);
+        dec_loadw4(wd, md, a.w_layers + o_d, D, R);
+        dec_loadw4(ws, ms, a.w_layers + o_s, D, S);
+        float oldv = 0.f;
+        if (tid < R) oldv = a.queues[a.q_off[0] + (size_t)slots[0] * R + tid];
+        if (!(a.dbg & 8)) {
+            const float s = dec_dot_stream(mc, a.w_causal, 2 * Q, R, prev);
+            if (mc.o < R && mc.p == 0) cur0[mc.o] = s;
+        }
+        for (int i = tid; i < S; i += DEC_THREADS) skip[i] = 0.f;
+        if (tid < R) cur0[R + tid] = oldv;
+        dec_sync();
+        float* cur = cur0;
+        float* nxt = cur1;
+        for (int l = 0; l < ((a.dbg & 16) ? 1 : a.n_layers); ++l) {
+            // ---- [f;g] = Wfg [cur | old]
+            const float s = dec_dot4(wfg, mfg, cur);
+            if (mfg.o < 2 * D && mfg.p == 0) fg[mfg.o] = s;
+            const int ln = l + 1;
+            const float* wn = a.w_layers + (size_t)ln * lstride;
+            float oldn = 0.f;
+            if (ln < a.n_layers) {
+                dec_loadw4(wfg, mfg, wn, 2 * R, 2 * D);
+                if (tid < R && !(a.dbg & 2)) oldn = a.queues[a.q_off[ln] + (size_t)slots[ln] * R + tid];
+            }
+            dec_sync();
+            if (tid < D) zz[tid] = (a.dbg & 1) ? wn_tanh(fg[tid]) * wn_sigmoid(fg[D + tid])
+                                               : tanhf(fg[tid]) * (1.0f / (1.0f + expf(-fg[D + tid])));
+            dec_sync();
+            // ---- dense (+ residual) and skip products
+            const float sd = dec_dot4(wd, md, zz);
+            const float ss = dec_dot4(ws, ms, zz);
+            if (md.o < R && md.p == 0) {
+                const float v = sd + cur[md.o];
+                nxt[md.o] = v;
+                if (!(a.dbg & 2)) a.queues[a.q_off[l] + (size_t)slots[l] * R + md.o] = a.push_input ? cur[md.o] : v;   // Q5: output by default
+            }
+            if (ms.o < S && ms.p == 0) skip[ms.o] += ss;
+            if (ln < a.n_layers) {
+                dec_loadw4(wd, md, wn + o_d, D, R);
+                dec_loadw4(ws, ms, wn + o_s, D, S);
+                if (tid < R) nxt[R + tid] = oldn;
+            }
+            dec_sync();
+            float* t = cur; cur = nxt; nxt = t;
+        }
+        // ---- post-processing: relu -> P1 -> relu -> P2 -> softmax -> argmax
+        for (int i = tid; i < S; i += DEC_THREADS) skip[i] = fmaxf(skip[i], 0.f);
+        dec_sync();
+        if (!(a.dbg & 4)) {
+            const float s = dec_dot_stream(mp1, a.w_p1, S, S, skip);
+            if (mp1.o < S && mp1.p == 0) h1[mp1.o] = fmaxf(s, 0.f);
+        }
+        dec_sync();
+        if (!(a.dbg & 4)) {
+            const float s = dec_dot_stream(mp2, a.w_p2, S, Q, h1);
+            if (mp2.o < Q && mp2.p == 0) logit[mp2.o] = s;
+        }
+        dec_sync();
+        if (tid < 64) {
+            float v[4], m = -INFINITY;
+            for (int e = 0; e < 4; ++e) { v[e] = logit[tid * 4 + e]; m = fmaxf(m, v[e]); }
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            float s = 0.f;
+            for (int e = 0; e < 4; ++e) { v[e] = expf(v[e] - m); s += v[e]; }
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            const float inv = 1.0f / s;
+            float best = -1.f; int bi = 0;
+            for (int e = 0; e < 4; ++e) {
+                v[e] *= inv;
+                if (a.probs_out) a.probs_out[(size_t)step * Q + tid * 4 + e] = v[e];
+                if (v[e] > best) { best = v[e]; bi = tid * 4 + e; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                float ob = __shfl_xor(best, off, 64);
+                int oi = __shfl_xor(bi, off, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (tid == 0) { s_arg = bi; a.codes_out[step] = bi; }
+        }
+        dec_sync();
+        const int nextc = a.forced ? a.forced[step] : s_arg;
+        for (int i = tid; i < Q; i += DEC_THREADS) prev[i] = note[i];
+        if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
+        dec_sync();
+        for (int i = tid; i < Q; i += DEC_THREADS) note[i] = (i == nextc) ? 1.0f : 0.0f;
+        dec_sync();
+    }
+    for (int i = tid; i < Q; i += DEC_THREADS) { a.prev_out[i] = prev[i]; a.note_out[i] = note[i]; }
+}
+
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
     if (a.n_steps <= 0) return 0;
     if (a.n_layers > WN_DEC_MAX_LAYERS) return wn_set_error_msg(-4, "decode: too many layers");
-    size_t sh = sizeof(float) * (size_t)(3 * a.Q + 3 * a.R + 3 * a.D + 2 * a.S + 64);
-    hipLaunchKernelGGL(decode_k, dim3(1), dim3(DEC_THREADS), sh, st, a);
+    // the float4 kernel needs: no biases, one pass per product, exactly 16 / 4 / 16 weights per thread for
+    // the per-block products and a multiple of 16 for the streamed ones
+    auto nw = [](int M, int K) {
+        int parts = DEC_THREADS / M; if (parts < 1) parts = 1; if (parts > 64) parts = 64;
+        while (parts & (parts - 1)) parts &= parts - 1;
+        return (K % parts) ? -1 : K / parts;
+    };
+    const bool v4 = !a.b_layers && !a.b_causal && !a.b_p1 && !a.b_p2 &&
+                    2 * a.D <= DEC_THREADS && a.S <= DEC_THREADS && a.Q <= DEC_THREADS && a.R <= DEC_THREADS &&
+                    nw(2 * a.D, 2 * a.R) == 16 && nw(a.R, a.D) == 4 && nw(a.S, a.D) == 16 &&
+                    nw(a.R, 2 * a.Q) > 0 && nw(a.R, 2 * a.Q) % 16 == 0 && nw(a.S, a.S) > 0 && nw(a.S, a.S) % 16 == 0 &&
+                    nw(a.Q, a.S) > 0 && nw(a.Q, a.S) % 16 == 0 && (a.layer_stride % 4) == 0;
+    if (v4) {
+        size_t sh = sizeof(float) * (size_t)(3 * a.Q + 4 * a.R + 3 * a.D + 2 * a.S);
+        hipLaunchKernelGGL(decode_v4_k, dim3(1), dim3(DEC_THREADS), sh, st, a);
+    } else {
+        size_t sh = sizeof(float) * (size_t)(3 * a.Q + 3 * a.R + 3 * a.D + 2 * a.S + 64);
+        hipLaunchKernelGGL(decode_k, dim3(1), dim3(DEC_THREADS), sh, st, a);
+    }
     WN_CHECK_LAUNCH();
     return 0;
 }

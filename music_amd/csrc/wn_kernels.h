@@ -115,11 +115,13 @@ struct WnDecodeArgs {
     const float* w_causal; const float* b_causal;        // [R][2Q] (k = tap0 q | tap1 q), [R]
     const float* w_layers; long layer_stride;            // per block: Wfg [2D][2R] (k = tap1 r | tap0 r), Wd [R][D], Ws [S][D]
     const float* b_layers;                               // per block: [bf D | bg D | bd R | bs S] or null
+    const float* b_skip_sum;                             // unused (reserved)
     const float* w_p1; const float* b_p1; const float* w_p2; const float* b_p2;   // [S][S], [Q][S]
     const float* note0; const float* prev0;              // [Q] dense: first input column and the one before it
     float* note_out; float* prev_out;                    // [Q] state handed back
     const int32_t* forced;                               // [n_steps] teacher-forced next codes, or null (greedy)
     int32_t* codes_out; float* probs_out;                // [n_steps], [n_steps][Q] or null
     long step0; int n_steps; int push_input;
+    int dbg;                                             // WN_DEC_DBG timing diagnostics (wrong results)
 };
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st);

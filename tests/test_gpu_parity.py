@@ -330,3 +330,46 @@ def test_grads_64_channels_vs_oracle(fused):
     g1 = eng.flat_grad.clone()
     eng.loss_and_grad(x.cuda(), target.cuda())
     assert torch.equal(g1, eng.flat_grad)
+
+
+def test_decode_config5_vs_oracle():
+    """BASELINE config 5 shape (30 blocks, 64/64/256): the float4 persistent decode kernel vs the
+    oracle's cached-queue recurrence - argmax ids exact, probabilities within 1e-4."""
+    from music_amd import fast_generate as fg
+    from music_amd.model import wavenet
+    from oracle import intops
+    cfg = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 3, dilation_channels=64,
+               residual_channels=64, skip_channels=256, quantization_channels=256, use_bias=False)
+    torch.manual_seed(21)
+    net = wavenet(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.2)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    rng = np.random.default_rng(22)
+    start = rng.integers(0, 256, size=(net.receptive_field,))
+    forced = rng.integers(0, 256, size=(20,))
+
+    def onehot(ix):
+        return torch.from_numpy(intops.one_hot_proper(np.atleast_1d(ix)))[None]
+
+    torch.set_num_threads(8)
+    for correct in (False, True):
+        pred_o, q_o, p0 = wo.fast_predict_next(params, cfg["dilations"], onehot(start), None, return_probs=True)
+        want, want_p = [int(pred_o[0])], []
+        for s in forced:
+            pred_o, q_o, pr = wo.fast_predict_next(params, cfg["dilations"], onehot(s), q_o, correct_queue=correct,
+                                                  return_probs=True)
+            want.append(int(pred_o[0]))
+            want_p.append(pr.numpy())
+        pred, st = fg.predict_next(net, onehot(start).cuda(), None)
+        got = [int(pred[0])]
+        nxt = torch.from_numpy(np.concatenate([forced[1:], [0]]).astype(np.int32))
+        codes, probs, _ = fg._decode(net, st, onehot(forced[0]).reshape(-1).cuda(), len(forced), forced=nxt,
+                                     want_probs=True, correct_queue=correct)
+        got += codes.cpu().tolist()
+        err = np.abs(probs.cpu().numpy() - np.stack(want_p)).max()
+        print("config-5 decode (correct_queue=%s): probs err %.2e" % (correct, err))
+        assert got == want and err < 1e-4
+        np.testing.assert_allclose(st["block_30"].cpu().numpy(), q_o["block_30"].numpy(), atol=1e-4, rtol=0)
