@@ -47,7 +47,7 @@ int wn_pack_weights(const float* flat, const int32_t* idx, uint16_t* out, int n,
                     wn_stream_t stream);
 
 /* Generic channel-mixing product over time:
- *   out[b][m][t+out_shift] = mask( bias[m] + resid[b][m][t] (t >= resid_lo)
+ *   out[b][m][t+out_shift] = resid[b][m][t] (t >= resid_lo) + mask( bias[m]
  *        + sum_k W[m][k]      * pre(in0[b][k][t+shift0])            (k <  32*ks0)
  *        + sum_k W[m][K0 + k] * pre(in1[b][k][t+shift1]) )          (k <  32*ks1)
  * for t in [t_lo, t_hi); pre = relu if relu_in; mask keeps values where mask[b][m][t] > 0.
@@ -77,11 +77,13 @@ int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bst
 
 /* Fused gated residual block, backward recompute half (autograd of model.py:118-124, SURVEY
  * Appendix B): recomputes f,g,z from x_in; dz = Wd^T dy (+ dz_crop on t >= z_lo);
- * writes dfg = [df; dg] (2*ch rows) and z (ch rows) on [t_lo,t_hi).  dy may be NULL. */
+ * writes dfg = [df; dg] (2*ch rows) and z (ch rows) on [t_lo,t_hi).  dy may be NULL.
+ * cond*: the conditioning table of wn_resblock_fwd (the recompute adds it as well); NULL = none. */
 int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* dfg, float* z,
                     int64_t x_bstride, int64_t dz_bstride, int64_t dfg_bstride, int64_t z_bstride,
                     int pitch, const uint16_t* wfg, const uint16_t* wdT, const float* bias_f,
                     const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
+                    const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode, int cond_le, int cond_q,
                     int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
 
 /* Fully fused backward of one residual block (autograd of wavenet/model.py:111-129 for one layer,
@@ -149,6 +151,15 @@ int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float 
                  wn_stream_t stream);
 /* flat_grad[i] = packed[idx[i]] (idx<0 -> 0): dense wgrad results -> state_dict (out,in,k) layout. */
 int wn_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, wn_stream_t stream);
+
+/* Gradient of the conditioning table: out[b][row][j] = sum over t in [t_lo,t_hi) with idx(t) == j of
+ * in[b][row][t]; idx as in wn_resblock_fwd (mode 1 stretch by q, mode 2 tile modulo le)
+ * (autograd of wavenet_autoencoder/model1.py:227-247). */
+int wn_cond_grad(const float* in, int64_t in_bstride, int in_pitch, int rows, int t_lo, int t_hi, int mode, int le,
+                 int q, float* out, int64_t out_bstride, int out_pitch, int batch, wn_stream_t stream);
+/* Backward of AvgPool1d: out[b][c][t0 + j*pool + k] = denc[b][c][j] / pool (j < n_out), 0 up to t_hi. */
+int wn_avgpool_bwd(const float* denc, int64_t denc_bstride, int denc_pitch, int t0, int pool, int n_out, int rows,
+                   float* out, int64_t out_bstride, int out_pitch, int t_hi, int batch, wn_stream_t stream);
 
 /* out[b][c][j] = mean_{k < pool} in[b][c][t0 + j*pool + k], j < n_out  (nn.AvgPool1d,
  * wavenet_autoencoder/model1.py:154-155). */

@@ -73,6 +73,7 @@ int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* 
                     int64_t x_bstride, int64_t dz_bstride, int64_t dfg_bstride, int64_t z_bstride,
                     int pitch, const uint16_t* wfg, const uint16_t* wdT, const float* bias_f,
                     const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
+                    const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode, int cond_le, int cond_q,
                     int batch, int mode_fwd, int mode_bwd, wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_bwd: pitch must be a multiple of 4");
     WnResBwdArgs a;
@@ -81,6 +82,8 @@ int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* 
     a.x_bstride = x_bstride; a.dz_bstride = dz_bstride; a.dfg_bstride = dfg_bstride; a.z_bstride = z_bstride; a.pitch = pitch;
     a.wfg = wfg; a.wdT = wdT; a.bias_f = bias_f; a.bias_g = bias_g; a.n_f = n_f;
     a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = z_lo;
+    a.cond = cond; a.cond_bstride = cond_bstride; a.cond_pitch = cond_pitch; a.cond_mode = cond_mode;
+    a.cond_le = cond_le; a.cond_q = cond_q;
     return wn_launch_resblock_bwd(a, ch, batch, mode_fwd, mode_bwd, (hipStream_t)stream);
 }
 
@@ -178,6 +181,17 @@ int wn_resblock_bwd_fused_tiles(int t_lo, int t_hi) { return wn_resfused_tiles(t
 int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,
                  int t_lo, int t_hi, int batch, wn_stream_t stream) {
     return wn_launch_shift_add(p, q, out, bstride, pitch, rows, dn, p_lo, t_lo, t_hi, batch, (hipStream_t)stream);
+}
+
+int wn_cond_grad(const float* in, int64_t in_bstride, int in_pitch, int rows, int t_lo, int t_hi, int mode, int le,
+                 int q, float* out, int64_t out_bstride, int out_pitch, int batch, wn_stream_t stream) {
+    return wn_launch_cond_grad(in, in_bstride, in_pitch, rows, t_lo, t_hi, mode, le, q, out, out_bstride, out_pitch, batch,
+                               (hipStream_t)stream);
+}
+int wn_avgpool_bwd(const float* denc, int64_t denc_bstride, int denc_pitch, int t0, int pool, int n_out, int rows,
+                   float* out, int64_t out_bstride, int out_pitch, int t_hi, int batch, wn_stream_t stream) {
+    return wn_launch_avgpool_bwd(denc, denc_bstride, denc_pitch, t0, pool, n_out, rows, out, out_bstride, out_pitch, t_hi,
+                                 batch, (hipStream_t)stream);
 }
 
 int wn_avgpool(const float* in, int64_t in_bstride, int in_pitch, int t0, int pool, int n_out, int rows,

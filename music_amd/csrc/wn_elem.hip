@@ -294,3 +294,53 @@ int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride
     WN_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Gradient w.r.t. the autoencoder's conditioning table (model1.py:227-247): bucket sums of a row
+// over time.  One workgroup per (row, clip); LDS float atomics into <= 1024 buckets.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cond_grad_k(const float* __restrict__ in, long in_bstride, int in_pitch, int t_lo,
+                                                   int t_hi, int mode, int le, int q, float* __restrict__ out,
+                                                   long out_bstride, int out_pitch) {
+    __shared__ float bucket[1024];
+    const int row = blockIdx.x, b = blockIdx.y;
+    for (int j = threadIdx.x; j < le; j += 256) bucket[j] = 0.f;
+    __syncthreads();
+    const float* p = in + (size_t)b * in_bstride + (size_t)row * in_pitch;
+    for (int t = t_lo + threadIdx.x; t < t_hi; t += 256) {
+        const int tr = t - t_lo;
+        int ix = mode == 1 ? tr / q : tr % le;
+        ix = ix < le ? ix : le - 1;
+        atomicAdd(&bucket[ix], p[t]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < le; j += 256) out[(size_t)b * out_bstride + (size_t)row * out_pitch + j] = bucket[j];
+}
+int wn_launch_cond_grad(const float* in, long in_bstride, int in_pitch, int rows, int t_lo, int t_hi, int mode, int le,
+                        int q, float* out, long out_bstride, int out_pitch, int batch, hipStream_t st) {
+    if (rows <= 0 || batch <= 0 || le <= 0) return 0;
+    if (le > 1024) return wn_set_error_msg(-4, "cond_grad: more than 1024 buckets");
+    hipLaunchKernelGGL(cond_grad_k, dim3(rows, batch), dim3(256), 0, st, in, in_bstride, in_pitch, t_lo, t_hi, mode, le,
+                       q, out, out_bstride, out_pitch);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void avgpool_bwd_k(const float* __restrict__ denc, long denc_bstride, int denc_pitch, int t0, int pool,
+                              int n_out, float* __restrict__ out, long out_bstride, int out_pitch, int t_hi) {
+    const int t = t0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y, b = blockIdx.z;
+    if (t >= t_hi) return;
+    const int j = (t - t0) / pool;
+    float v = 0.f;
+    if (j < n_out) v = denc[(size_t)b * denc_bstride + (size_t)row * denc_pitch + j] / (float)pool;
+    out[(size_t)b * out_bstride + (size_t)row * out_pitch + t] = v;
+}
+int wn_launch_avgpool_bwd(const float* denc, long denc_bstride, int denc_pitch, int t0, int pool, int n_out, int rows,
+                          float* out, long out_bstride, int out_pitch, int t_hi, int batch, hipStream_t st) {
+    if (rows <= 0 || batch <= 0 || t_hi <= t0) return 0;
+    hipLaunchKernelGGL(avgpool_bwd_k, dim3((t_hi - t0 + 255) / 256, rows, batch), dim3(256), 0, st, denc, denc_bstride,
+                       denc_pitch, t0, pool, n_out, out, out_bstride, out_pitch, t_hi);
+    WN_CHECK_LAUNCH();
+    return 0;
+}

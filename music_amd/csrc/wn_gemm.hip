@@ -1,6 +1,6 @@
 // Generic channel-mixing GEMM over the time axis (time on the MFMA lanes) and the weight packer.
 //
-//   out[m][t + out_shift] = epi( bias[m] + sum_tap sum_k W[m][tap,k] * pre(in_tap[k][t + shift_tap]) )
+//   out[m][t + out_shift] = resid[m][t] + mask( bias[m] + sum_tap sum_k W[m][tap,k] * pre(in_tap[k][t + shift_tap]) )
 //
 // Used for: causal conv (wavenet/model.py:104, two taps of K=Q), the skip product over the
 // concatenated z-crops and post_process_1/2 (model.py:128-138), and every "weights transposed"
@@ -143,16 +143,6 @@ __global__ __launch_bounds__(512) void chan_gemm_k(WnGemmArgs a) {
             int row = (m0 + m) * 16 + 4 * q + i;
             if (row >= a.m_valid) continue;
             f32x4 v = {acc[m][0][i], acc[m][1][i], acc[m][2][i], acc[m][3][i]};
-            if (resid) {
-                const float* rp = resid + (size_t)row * a.resid_pitch + tl;
-                if (full && tl >= a.resid_lo) {
-                    v += ld4u(rp);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (tl + e >= a.resid_lo && tl + e >= a.t_lo && tl + e < a.t_hi) v[e] += rp[e];
-                }
-            }
             if (mask) {
                 const float* mp = mask + (size_t)row * a.mask_pitch + tl;
                 if (full) {
@@ -163,6 +153,16 @@ __global__ __launch_bounds__(512) void chan_gemm_k(WnGemmArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (tl + e >= a.t_lo && tl + e < a.t_hi) v[e] = mp[e] > 0.f ? v[e] : 0.f;
+                }
+            }
+            if (resid) {
+                const float* rp = resid + (size_t)row * a.resid_pitch + tl;
+                if (full && tl >= a.resid_lo) {
+                    v += ld4u(rp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tl + e >= a.resid_lo && tl + e >= a.t_lo && tl + e < a.t_hi) v[e] += rp[e];
                 }
             }
             float* op = out + (size_t)row * a.out_pitch + tl + a.out_shift;
@@ -289,16 +289,6 @@ __global__ __launch_bounds__(512) void chan_gemm_wide_lds_k(WnGemmArgs a) {
             int row = (m0 + m) * 16 + 4 * q + i;
             if (row >= a.m_valid) continue;
             f32x4 v = {acc[m][0][i], acc[m][1][i], acc[m][2][i], acc[m][3][i]};
-            if (resid) {
-                const float* rp = resid + (size_t)row * a.resid_pitch + tl;
-                if (full && tl >= a.resid_lo) {
-                    v += ld4u(rp);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (tl + e >= a.resid_lo && tl + e >= a.t_lo && tl + e < a.t_hi) v[e] += rp[e];
-                }
-            }
             if (mask) {
                 const float* mp = mask + (size_t)row * a.mask_pitch + tl;
                 if (full) {
@@ -309,6 +299,16 @@ __global__ __launch_bounds__(512) void chan_gemm_wide_lds_k(WnGemmArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (tl + e >= a.t_lo && tl + e < a.t_hi) v[e] = mp[e] > 0.f ? v[e] : 0.f;
+                }
+            }
+            if (resid) {
+                const float* rp = resid + (size_t)row * a.resid_pitch + tl;
+                if (full && tl >= a.resid_lo) {
+                    v += ld4u(rp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tl + e >= a.resid_lo && tl + e >= a.t_lo && tl + e < a.t_hi) v[e] += rp[e];
                 }
             }
             float* op = out + (size_t)row * a.out_pitch + tl + a.out_shift;

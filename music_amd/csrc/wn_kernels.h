@@ -53,6 +53,8 @@ struct WnResBwdArgs {
     const uint16_t* wdT;        // packed Wd^T [CH/16][CH/32] (natural k), grad mode
     const float* bias_f; const float* bias_g; int n_f;
     int d, t_lo, t_hi, z_lo, t_base;
+    const float* cond; long cond_bstride; int cond_pitch;   // as in WnResArgs (the recompute adds it too)
+    int cond_mode, cond_le, cond_q;
 };
 int wn_launch_resblock_bwd(const WnResBwdArgs& a, int ch, int batch, int mode_fwd, int mode_bwd,
                            hipStream_t st);
@@ -103,6 +105,10 @@ int wn_resfused_tiles(int t_lo, int t_hi);
 int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride, int pitch, int rows, int dn,
                         int p_lo, int t_lo, int t_hi, int batch, hipStream_t st);
 
+int wn_launch_cond_grad(const float* in, long in_bstride, int in_pitch, int rows, int t_lo, int t_hi, int mode, int le,
+                        int q, float* out, long out_bstride, int out_pitch, int batch, hipStream_t st);
+int wn_launch_avgpool_bwd(const float* denc, long denc_bstride, int denc_pitch, int t0, int pool, int n_out, int rows,
+                          float* out, long out_bstride, int out_pitch, int t_hi, int batch, hipStream_t st);
 int wn_launch_avgpool(const float* in, long in_bstride, int in_pitch, int t0, int pool, int n_out, int rows,
                       float* out, long out_bstride, int out_pitch, int batch, hipStream_t st);
 

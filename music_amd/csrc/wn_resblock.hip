@@ -330,6 +330,25 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_bwd_k(WnResBwdArgs a)
         }
     }
 
+    if (a.cond) {       // same conditioning bias as the forward (wavenet_autoencoder/model1.py:183)
+        const float* cb = a.cond + (size_t)b * a.cond_bstride;
+        int idx[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            int tr = tl + n - a.t_lo;
+            tr = tr < 0 ? 0 : tr;
+            int ix = a.cond_mode == 1 ? tr / a.cond_q : tr % a.cond_le;
+            idx[n] = ix < a.cond_le ? ix : a.cond_le - 1;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* cr = cb + (size_t)(16 * m + 4 * q + i) * a.cond_pitch;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n][i] += cr[idx[n]];
+            }
+    }
     // dz = Wd^T dy : M = CH (dilation channels), K = CH (residual channels), B = dy rows (natural k)
     f32x4 dz[MT2][4];
 #pragma unroll

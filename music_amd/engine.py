@@ -497,7 +497,7 @@ class WaveNetEngine:
             call("wn_resblock_bwd", self._x(ws, i), dy, ptr(bw["dZ"], SLACK + i * CH * pitch), dfg, zs,
                  xb, zb, 2 * CH * pitch, xb, pitch, fr("fg%d" % i), br("dT%d" % i),
                  self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)), self.D, CH, d, t_lo, T, lo,
-                 B, mf, mb, st)
+                 None, 0, 0, 0, 0, 0, B, mf, mb, st)
             if overlap:
                 ev_r = torch.cuda.Event()
                 ev_r.record(main)

@@ -14,8 +14,9 @@ Reference behaviours that are reproduced on purpose:
   * ``_conditon`` (sic) stretches the encoding when ``len(x) % len(enc) == 0`` and tiles it
     otherwise (model1.py:227-247; SURVEY Q9);
   * gate = FIRST half of the filter_gate channels, filter = second half (model1.py:188-190).
-The arithmetic runs through libwavenet_hip.so only (no CPU path).  The backward pass of this model
-is not implemented yet (the reference trains the encoder only through those random projections).
+The arithmetic runs through libwavenet_hip.so only (no CPU path).  ``forward`` is differentiable
+(``loss.backward()`` fills every parameter's gradient, the encoder's through the random projections
+exactly as in the reference); the backward is implemented for ``use_bias=False``.
 """
 import numpy as np
 import torch
@@ -33,9 +34,13 @@ except ImportError:
 
 
 class _AutoencoderEngine:
-    def __init__(self, net, device, mode="f16x3"):
+    """Host-side plan of the autoencoder on one MI355X: flat parameters, packed-weight index maps,
+    workspaces, forward (model1.py:256-268) and backward (autograd of it)."""
+
+    def __init__(self, net, device, mode="f16x3", mode_bwd="bf16x3"):
         self.net, self.device = net, device
         self.mode = _lib.MODE_NAMES[mode]
+        self.mode_b = _lib.MODE_NAMES[mode_bwd]
         self.dil = [int(d) for d in net.dilations]
         self.N = len(self.dil)
         self.Q = net.quantization_channel
@@ -54,8 +59,10 @@ class _AutoencoderEngine:
             self.off.append(self.off[-1] + d)
         self.use_bias = bool(net.use_bias)
         named = list(net.named_parameters())
+        self.param_names = [n for n, _ in named]
         self.spec = _Spec([(n, tuple(p.shape)) for n, p in named])
         self.flat = torch.zeros(self.spec.total, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(self.spec.total, dtype=torch.float32, device=device)
         with torch.no_grad():
             for n, p in named:
                 o = self.spec.off[n]
@@ -64,6 +71,7 @@ class _AutoencoderEngine:
                 p.data = view
         self._build_packs()
         self._ws = {}
+        self._gen = 0
 
     def _bias(self, name):
         return ptr(self.flat, self.spec.off[name + ".bias"]) if self.use_bias else None
@@ -72,53 +80,87 @@ class _AutoencoderEngine:
         sp, Q, N = self.spec, self.Q, self.N
         CHe, CHd, SP, BwP = self.CHe, self.CHd, self.SP, self.BwP
         Re, De, Rd, Dd, Sd, Bw = self.Re, self.De, self.Rd, self.Dd, self.Sd, self.Bw
-        packs = []
+        fwd, bwd, gp = [], [], []
+        gidx = np.full(self.spec.total, -1, dtype=np.int64)
+        gsize = [0]
 
         def full(m, k):
             return np.full((m, k), -1, dtype=np.int64)
+
+        def add(name, w, chained=False, grad=True):
+            """forward pack of the effective matrix w (entries = flat parameter offsets) + its
+            gradient matrix (same shape) + the gather map back to the parameters"""
+            fwd.append((name, pack_index(w, chained)))
+            if grad:
+                o = gsize[0]
+                gp.append((name, o, w.shape[0], w.shape[1]))
+                r, c = np.nonzero(w >= 0)
+                gidx[w[r, c]] = o + r * w.shape[1] + c
+                gsize[0] += w.size
 
         for name, ch, r in (("en_causal", CHe, Re), ("de_causal", CHd, Rd)):
             wc = sp.conv(name + "_layer.weight")
             w = full(ch, 2 * Q)
             w[:r, :Q], w[:r, Q:] = wc[:, :, 0], wc[:, :, 1]
-            packs.append((name, pack_index(w)))
+            add(name, w)
         for i in range(N):
             wd = sp.conv("en_dilation_layer_stack.%d.weight" % i)              # [De,Re,2]
             w = full(CHe, 2 * CHe)
             w[:De, :Re], w[:De, CHe:CHe + Re] = wd[:, :, 0], wd[:, :, 1]
-            packs.append(("en_dil%d" % i, pack_index(w)))
+            add("en_dil%d" % i, w)
+            wt = full(CHe, 2 * CHe)                                            # dx: rows Re, K = [tap1^T | tap0^T] over De
+            wt[:Re, :De], wt[:Re, CHe:CHe + De] = wd[:, :, 1].T, wd[:, :, 0].T
+            bwd.append(("en_dilT%d" % i, pack_index(wt)))
             w = full(CHe, CHe)
             w[:Re, :De] = sp.conv("en_dense_layer_stack.%d.weight" % i)[:, :, 0]
-            packs.append(("en_dense%d" % i, pack_index(w)))
+            add("en_dense%d" % i, w)
+            bwd.append(("en_denseT%d" % i, pack_index(np.ascontiguousarray(w.T))))
             wfg = sp.conv("de_dilation_layer_stack.%d.weight" % (3 * i))       # [2Dd,Rd,2], gate rows first
             w = full(2 * CHd, 2 * CHd)
+            wx = full(CHd, 4 * CHd)
             for h, rows in enumerate((slice(Dd, 2 * Dd), slice(0, Dd))):        # my rows: filter then gate
                 w[h * CHd:h * CHd + Dd, :Rd] = wfg[rows, :, 0]
                 w[h * CHd:h * CHd + Dd, CHd:CHd + Rd] = wfg[rows, :, 1]
-            packs.append(("de_fg%d" % i, pack_index(w)))
+                wx[:Rd, h * CHd:h * CHd + Dd] = wfg[rows, :, 1].T
+                wx[:Rd, 2 * CHd + h * CHd:2 * CHd + h * CHd + Dd] = wfg[rows, :, 0].T
+            add("de_fg%d" % i, w)
+            bwd.append(("de_fgT%d" % i, pack_index(wx)))
             w = full(CHd, CHd)
             w[:Rd, :Dd] = sp.conv("de_dilation_layer_stack.%d.weight" % (3 * i + 1))[:, :, 0]
-            packs.append(("de_d%d" % i, pack_index(w, chained=True)))
+            add("de_d%d" % i, w, chained=True)
+            bwd.append(("de_dT%d" % i, pack_index(np.ascontiguousarray(w.T))))
         w = full(BwP, CHe)
         w[:Bw, :Re] = sp.conv("bottleneck_layer.weight")[:, :, 0]
-        packs.append(("bottleneck", pack_index(w)))
+        add("bottleneck", w)
+        bwd.append(("bottleneckT", pack_index(np.ascontiguousarray(w.T))))
         w = full(SP, N * CHd)
         for i in range(N):
             w[:Sd, i * CHd:i * CHd + Dd] = sp.conv("de_dilation_layer_stack.%d.weight" % (3 * i + 2))[:, :, 0]
-        packs.append(("skip", pack_index(w)))
+        add("skip", w)
+        bwd.append(("skipT", pack_index(np.ascontiguousarray(w.T))))
         w = full(SP, SP)
         w[:Sd, :Sd] = sp.conv("connection_1.weight")[:, :, 0]
-        packs.append(("c1", pack_index(w)))
+        add("c1", w)
+        bwd.append(("c1T", pack_index(np.ascontiguousarray(w.T))))
         w = full(Q, SP)
         w[:, :Sd] = sp.conv("connection_2.weight")[:, :, 0]
-        packs.append(("c2", pack_index(w)))
-        hp = 1024 if self.mode in (_lib.F16X3, _lib.BF16X3) else 512
-        self.pk_off, o = {}, 0
-        for name, idx in packs:
-            self.pk_off[name] = o * hp // 512
-            o += len(idx)
-        self.pk_idx = torch.from_numpy(np.concatenate([i for _, i in packs]).astype(np.int32)).to(self.device)
-        self.pk = torch.zeros(o * hp // 512, dtype=torch.int16, device=self.device)
+        add("c2", w)
+        bwd.append(("c2T", pack_index(np.ascontiguousarray(w.T))))
+
+        def finish(lst, mode):
+            hp = 1024 if mode in (_lib.F16X3, _lib.BF16X3) else 512
+            offs, o = {}, 0
+            for name, idx in lst:
+                offs[name] = o * hp // 512
+                o += len(idx)
+            idx_all = torch.from_numpy(np.concatenate([i for _, i in lst]).astype(np.int32)).to(self.device)
+            return offs, idx_all, torch.zeros(o * hp // 512, dtype=torch.int16, device=self.device)
+
+        self.pk_off, self.pk_idx, self.pk = finish(fwd, self.mode)
+        self.pkb_off, self.pkb_idx, self.pkb = finish(bwd, self.mode_b)
+        self.gp_off = {name: (o, r, c) for name, o, r, c in gp}
+        self.gpack = torch.zeros(gsize[0], dtype=torch.float32, device=self.device)
+        self.gidx = torch.from_numpy(gidx.astype(np.int32)).to(self.device)   # -1 (biases) -> zero gradient
 
     def workspace(self, B, T):
         ws = self._ws.get((B, T))
@@ -128,15 +170,26 @@ class _AutoencoderEngine:
         dev = self.device
         pitch = _pad(T, 256) + 512
         W = T - self.rf + 1
+        N = self.N
 
         def buf(rows):
             return torch.zeros(SLACK + B * rows * pitch + PAD_BACK, dtype=torch.float32, device=dev)
 
-        ws = dict(B=B, T=T, W=W, pitch=pitch, Xe=[buf(self.CHe), buf(self.CHe)], He=buf(self.CHe), E=buf(self.BwP),
-                  Xd=[buf(self.CHd), buf(self.CHd)], Z=buf(self.N * self.CHd), U=buf(self.SP), R1=buf(self.SP),
-                  C1=buf(self.SP), O=torch.zeros(B * self.Q * W + PAD_BACK, dtype=torch.float32, device=dev))
+        ws = dict(B=B, T=T, W=W, pitch=pitch, Xe=buf((N + 1) * self.CHe), He=buf(N * self.CHe), E=buf(self.BwP),
+                  Xd=buf((N + 1) * self.CHd), Z=buf(N * self.CHd), U=buf(self.SP), R1=buf(self.SP),
+                  C1=buf(self.SP), O=torch.zeros(B * self.Q * W + PAD_BACK, dtype=torch.float32, device=dev), bwd=None)
         self._ws[(B, T)] = ws
         return ws
+
+    # layer i of a stacked [(N+1) or N][B][CH][pitch] buffer
+    def _lay(self, t, i, ch, ws):
+        return ptr(t, SLACK + i * ws["B"] * ch * ws["pitch"])
+
+    def _gemm(self, st, B, mode, pack_ptr, in0, in1, in_bs, in_pitch, in_lo, in_hi, s0, s1, ks0, ks1, mt, mvalid, out, out_bs,
+              out_pitch, out_shift, bias, resid, mask, t_lo, t_hi, relu_in):
+        call("wn_chan_gemm", in0, in1, in_bs, in_pitch, in_lo, in_hi, s0, s1, ks0, ks1, pack_ptr, mt, mvalid,
+             out, out_bs, out_pitch, out_shift, bias, resid[0], resid[1], resid[2], resid[3] if len(resid) > 3 else 0,
+             mask[0], mask[1], mask[2], t_lo, t_hi, relu_in, B, mode, st)
 
     def forward(self, x, cond):
         """cond: list of N+1 (weight (C,Bw,1), bias (C,)) CPU tensors (see wavenet_autoencoder.forward)."""
@@ -146,34 +199,31 @@ class _AutoencoderEngine:
         if Le < 1:
             raise RuntimeError("Output size is too small: %d samples of encoding cannot be pooled by %d" % (W, self.pool))
         ws = self.workspace(B, T)
+        self._gen += 1
+        ws["gen"], ws["x_in"], ws["Le"] = self._gen, x, Le
         st = _lib.stream()
         m, pitch, N, CHe, CHd, SP, BwP = self.mode, ws["pitch"], self.N, self.CHe, self.CHd, self.SP, self.BwP
         call("wn_pack_weights", ptr(self.flat), ptr(self.pk_idx), ptr(self.pk), self.pk_idx.numel(), m, st)
         fr = lambda name: ptr(self.pk, self.pk_off[name])
         lo = self.rf - 1
         NONE3 = (None, 0, 0)
+        gemm = lambda pack, *a: self._gemm(st, B, m, fr(pack), *a)
 
-        def gemm(in0, in1, in_bs, in_pitch, in_lo, in_hi, s0, s1, ks0, ks1, pack, mt, mvalid, out, out_bs, out_pitch, out_shift,
-                 bias, resid, mask, t_lo, t_hi, relu_in):
-            call("wn_chan_gemm", in0, in1, in_bs, in_pitch, in_lo, in_hi, s0, s1, ks0, ks1, fr(pack), mt, mvalid,
-                 out, out_bs, out_pitch, out_shift, bias, resid[0], resid[1], resid[2], resid[3] if len(resid) > 3 else 0,
-                 mask[0], mask[1], mask[2], t_lo, t_hi, relu_in, B, m, st)
-
-        # ---------------- encoder (model1.py:137-156)
-        xe = [ptr(b_, SLACK) for b_ in ws["Xe"]]
-        He, E = ptr(ws["He"], SLACK), ptr(ws["E"], SLACK)
+        # ---------------- encoder (model1.py:137-156); every x_i and h_i is kept for the backward
+        xe = lambda i: self._lay(ws["Xe"], i, CHe, ws)
+        he = lambda i: self._lay(ws["He"], i, CHe, ws)
+        E = ptr(ws["E"], SLACK)
         eb = CHe * pitch
-        gemm(ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, "en_causal", CHe // 16, self.Re,
-             xe[0], eb, pitch, 0, self._bias("en_causal_layer"), NONE3, NONE3, 1, T, 0)
+        gemm("en_causal", ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, CHe // 16, self.Re,
+             xe(0), eb, pitch, 0, self._bias("en_causal_layer"), NONE3, NONE3, 1, T, 0)
         for i, d in enumerate(self.dil):
-            src, dst = xe[i % 2], xe[(i + 1) % 2]
             t_lo = self.off[i + 1]
             # h = dilated_conv(relu(x));   x' = dense(relu(h)) + x[tail]
-            gemm(src, src, eb, pitch, self.off[i], T, -d, 0, CHe // 32, CHe // 32, "en_dil%d" % i, CHe // 16, self.De,
-                 He, eb, pitch, 0, self._bias("en_dilation_layer_stack.%d" % i), NONE3, NONE3, t_lo, T, 1)
-            gemm(He, None, eb, pitch, t_lo, T, 0, 0, CHe // 32, 0, "en_dense%d" % i, CHe // 16, self.Re,
-                 dst, eb, pitch, 0, self._bias("en_dense_layer_stack.%d" % i), (src, eb, pitch, t_lo), NONE3, t_lo, T, 1)
-        gemm(xe[N % 2], None, eb, pitch, lo, T, 0, 0, CHe // 32, 0, "bottleneck", BwP // 16, self.Bw,
+            gemm("en_dil%d" % i, xe(i), xe(i), eb, pitch, self.off[i], T, -d, 0, CHe // 32, CHe // 32, CHe // 16, self.De,
+                 he(i), eb, pitch, 0, self._bias("en_dilation_layer_stack.%d" % i), NONE3, NONE3, t_lo, T, 1)
+            gemm("en_dense%d" % i, he(i), None, eb, pitch, t_lo, T, 0, 0, CHe // 32, 0, CHe // 16, self.Re,
+                 xe(i + 1), eb, pitch, 0, self._bias("en_dense_layer_stack.%d" % i), (xe(i), eb, pitch, t_lo), NONE3, t_lo, T, 1)
+        gemm("bottleneck", xe(N), None, eb, pitch, lo, T, 0, 0, CHe // 32, 0, BwP // 16, self.Bw,
              E, BwP * pitch, pitch, 0, self._bias("bottleneck_layer"), NONE3, NONE3, lo, T, 0)
         enc = torch.empty(B, self.Bw, Le, dtype=torch.float32, device=self.device)
         call("wn_avgpool", E, BwP * pitch, pitch, lo, self.pool, Le, self.Bw, ptr(enc), self.Bw * Le, Le, B, st)
@@ -186,24 +236,28 @@ class _AutoencoderEngine:
         tab = torch.zeros(N, B, 2 * CHd, Le, dtype=torch.float32, device=self.device)
         tab[:, :, :Dd] = en[:, :, Dd:]                                                 # my rows: filter first
         tab[:, :, CHd:CHd + Dd] = en[:, :, :Dd]
-        enf = F.conv1d(enc, cond[N][0].to(self.device), cond[N][1].to(self.device))    # (B, Sd, Le)
+        cfw, cfb = cond[N][0].to(self.device), cond[N][1].to(self.device)
+        enf = F.conv1d(enc, cfw, cfb)                                                  # (B, Sd, Le)
+        ws.update(enc=enc, tab=tab, cw=cw, cfw=cfw)
 
         # ---------------- decoder (model1.py:158-225)
-        xd = [ptr(b_, SLACK) for b_ in ws["Xd"]]
+        xd = lambda i: self._lay(ws["Xd"], i, CHd, ws)
         db, zb = CHd * pitch, N * CHd * pitch
-        gemm(ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, "de_causal", CHd // 16, self.Rd,
-             xd[0], db, pitch, 0, self._bias("de_causal_layer"), NONE3, NONE3, 1, T, 0)
+        gemm("de_causal", ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, CHd // 16, self.Rd,
+             xd(0), db, pitch, 0, self._bias("de_causal_layer"), NONE3, NONE3, 1, T, 0)
+        bn = "de_dilation_layer_stack.%d"
+        cmodes = []
         for i, d in enumerate(self.dil):
             t_lo = self.off[i + 1]
             L = T - t_lo
             mode_c, q = (1, L // Le) if L % Le == 0 else (2, 0)
-            bn = "de_dilation_layer_stack.%d"
+            cmodes.append((mode_c, q))
             bias_fg = self._bias(bn % (3 * i))
-            # filter_gate bias: gate rows first in the reference tensor
-            bf = bias_fg + 4 * Dd if bias_fg is not None else None
-            call("wn_resblock_fwd", xd[i % 2], xd[(i + 1) % 2], ptr(ws["Z"], SLACK + i * CHd * pitch), db, zb, pitch,
+            bf = bias_fg + 4 * Dd if bias_fg is not None else None      # filter_gate bias: gate rows first
+            call("wn_resblock_fwd", xd(i), xd(i + 1), ptr(ws["Z"], SLACK + i * CHd * pitch), db, zb, pitch,
                  fr("de_fg%d" % i), fr("de_d%d" % i), bf, bias_fg, self._bias(bn % (3 * i + 1)), Dd, self.Rd, CHd, d,
                  t_lo, T, lo, 1 if i < N - 1 else 0, ptr(tab[i]), 2 * CHd * Le, Le, mode_c, Le, q, B, m, st)
+        ws["cmodes"] = cmodes
         U, R1, C1 = ptr(ws["U"], SLACK), ptr(ws["R1"], SLACK), ptr(ws["C1"], SLACK)
         sb = SP * pitch
         bias_s = None
@@ -212,19 +266,174 @@ class _AutoencoderEngine:
             bsum = sum(self.flat[o[bn % (3 * i + 2) + ".bias"]:o[bn % (3 * i + 2) + ".bias"] + Sd] for i in range(N)).contiguous()
             ws["bias_skip"] = bsum
             bias_s = ptr(bsum)
-        gemm(ptr(ws["Z"], SLACK), None, zb, pitch, lo, T, 0, 0, N * CHd // 32, 0, "skip", SP // 16, Sd,
+        gemm("skip", ptr(ws["Z"], SLACK), None, zb, pitch, lo, T, 0, 0, N * CHd // 32, 0, SP // 16, Sd,
              U, sb, pitch, 0, bias_s, NONE3, NONE3, lo, T, 0)
         # final conditioning expanded over time (stretch / tile rule on the length-W sequence)
         tr = torch.arange(W, device=self.device)
+        ws["cf_mode"] = (1, W // Le) if W % Le == 0 else (2, 0)
         idx = tr // (W // Le) if W % Le == 0 else tr % Le
         ws["C1"][SLACK:SLACK + B * SP * pitch].view(B, SP, pitch)[:, :Sd, lo:T] = enf[:, :, idx]
-        gemm(U, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, "c1", SP // 16, Sd,
+        gemm("c1", U, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, SP // 16, Sd,
              R1, sb, pitch, 0, self._bias("connection_1"), (C1, sb, pitch, lo), NONE3, lo, T, 1)
-        gemm(R1, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, "c2", Q // 16, Q,
+        gemm("c2", R1, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, Q // 16, Q,
              ptr(ws["O"]), Q * W, W, -lo, self._bias("connection_2"), NONE3, NONE3, lo, T, 1)
         probs = torch.empty(B * W, Q, dtype=torch.float32, device=self.device)
         call("wn_chunk_softmax256_fwd", ptr(ws["O"]), ptr(probs), B * W, st)
-        return probs, enc
+        ws["probs"] = probs
+        return probs, enc, ws
+
+    # ------------------------------------------------------------------ backward
+    def _bwd_workspace(self, ws):
+        if ws["bwd"] is not None:
+            return ws["bwd"]
+        B, T, W, pitch, dev, N = ws["B"], ws["T"], ws["W"], ws["pitch"], self.device, self.N
+
+        def buf(rows):
+            return torch.zeros(SLACK + B * rows * pitch + PAD_BACK, dtype=torch.float32, device=dev)
+
+        bw = dict(dO=torch.zeros(B * self.Q * W + PAD_BACK, dtype=torch.float32, device=dev),
+                  dR1=buf(self.SP), dU=buf(self.SP), dZ=buf(N * self.CHd), dXd=[buf(self.CHd), buf(self.CHd)],
+                  dfg=buf(2 * self.CHd), zs=buf(self.CHd), dE=buf(self.BwP), dXe=[buf(self.CHe), buf(self.CHe)],
+                  dHe=buf(self.CHe))
+        lo = self.rf - 1
+        ops = [("c2", lo, T, 1024), ("c1", lo, T, 1024), ("skip", lo, T, 2048), ("bottleneck", lo, T, 512),
+               ("de_causal", 1, T, 512), ("en_causal", 1, T, 512)]
+        for i in range(N):
+            ops += [("de_fg%d" % i, self.off[i + 1], T, 512), ("en_dil%d" % i, self.off[i + 1], T, 512),
+                    ("en_dense%d" % i, self.off[i + 1], T, 512)]
+            if i < N - 1:
+                ops.append(("de_d%d" % i, self.off[i + 1], T, 512))
+        plan, desc, so, vs = {}, [], 0, 0
+        for name, t_lo, t_hi, chunk in ops:
+            go, r, c = self.gp_off[name]
+            n = r * c
+            ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B)
+            plan[name] = (so, n, chunk)
+            desc.append([vs, so, ns, n, go, n])
+            so += ns * n
+            vs += (n + 3) // 4
+        bw["slab"] = torch.empty(so, dtype=torch.float32, device=dev)
+        bw["plan"], bw["vec"], bw["nops"] = plan, vs, len(desc)
+        bw["desc"] = torch.tensor(desc, dtype=torch.int64, device=dev)
+        ws["bwd"] = bw
+        return bw
+
+    def backward(self, ws, dprobs):
+        """Fills self.flat_grad from d loss / d probabilities (B*W, Q)."""
+        if self.use_bias:
+            raise NotImplementedError("autoencoder backward with use_bias=True is not implemented")
+        bw = self._bwd_workspace(ws)
+        st = _lib.stream()
+        B, T, W, pitch, Le = ws["B"], ws["T"], ws["W"], ws["pitch"], ws["Le"]
+        N, CHe, CHd, SP, BwP, Q = self.N, self.CHe, self.CHd, self.SP, self.BwP, self.Q
+        Dd, Sd, Rd, Re, De, Bw = self.Dd, self.Sd, self.Rd, self.Re, self.De, self.Bw
+        mf, mb = self.mode, self.mode_b
+        lo = self.rf - 1
+        call("wn_pack_weights", ptr(self.flat), ptr(self.pkb_idx), ptr(self.pkb), self.pkb_idx.numel(), mb, st)
+        br = lambda name: ptr(self.pkb, self.pkb_off[name])
+        fr = lambda name: ptr(self.pk, self.pk_off[name])
+        NONE3 = (None, 0, 0)
+        gemm = lambda pack, *a: self._gemm(st, B, mb, br(pack), *a)
+        plan = bw["plan"]
+
+        def wgrad(name, *args):
+            so, n, chunk = plan[name]
+            head, (ldc, t_lo, t_hi) = args[:-3], args[-3:]
+            call("wn_wgrad", *head, ptr(bw["slab"], so), ldc, n, t_lo, t_hi, chunk, B, mb, st)
+
+        dprobs = dprobs.contiguous()
+        call("wn_chunk_softmax256_bwd", ptr(ws["probs"]), ptr(dprobs), ptr(bw["dO"]), B * W, st)
+        dO, dR1, dU, dZ = ptr(bw["dO"]), ptr(bw["dR1"], SLACK), ptr(bw["dU"], SLACK), ptr(bw["dZ"], SLACK)
+        U, R1, Z = ptr(ws["U"], SLACK), ptr(ws["R1"], SLACK), ptr(ws["Z"], SLACK)
+        sb, db, zb, eb = SP * pitch, CHd * pitch, N * CHd * pitch, CHe * pitch
+        # ---- decoder epilogue: o = c2(relu(r)), r = c1(relu(u)) + cond_f, u = skip(z)
+        wgrad("c2", dO, Q * W, W, -lo, W, R1, None, sb, pitch, 0, 0, pitch, SP // 16, Q // 16, 1, SP, lo, T)
+        gemm("c2T", dO, None, Q * W, W, 0, W, -lo, 0, Q // 32, 0, SP // 16, Sd, dR1, sb, pitch, 0, None, NONE3,
+             (R1, sb, pitch), lo, T, 0)
+        cmode, cq = ws["cf_mode"]
+        d_enf = torch.zeros(B, Sd, Le, dtype=torch.float32, device=self.device)
+        call("wn_cond_grad", dR1, sb, pitch, Sd, lo, T, cmode, Le, max(cq, 1), ptr(d_enf), Sd * Le, Le, B, st)
+        wgrad("c1", dR1, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
+        gemm("c1T", dR1, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, SP // 16, Sd, dU, sb, pitch, 0, None, NONE3,
+             (U, sb, pitch), lo, T, 0)
+        wgrad("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CHd // 16, SP // 16, 0, N * CHd, lo, T)
+        gemm("skipT", dU, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, N * CHd // 16, N * CHd, dZ, zb, pitch, 0, None, NONE3,
+             NONE3, lo, T, 0)
+        # ---- decoder stack
+        xd = lambda i: self._lay(ws["Xd"], i, CHd, ws)
+        dfg, zs = ptr(bw["dfg"], SLACK), ptr(bw["zs"], SLACK)
+        d_tab = torch.zeros(N, B, 2 * CHd, Le, dtype=torch.float32, device=self.device)
+        for i in range(N - 1, -1, -1):
+            d, t_lo = self.dil[i], self.off[i + 1]
+            dy = ptr(bw["dXd"][(i + 1) % 2], SLACK) if i < N - 1 else None
+            mode_c, q = ws["cmodes"][i]
+            call("wn_resblock_bwd", xd(i), dy, ptr(bw["dZ"], SLACK + i * CHd * pitch), dfg, zs,
+                 db, zb, 2 * CHd * pitch, db, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), None, None, Dd, CHd, d, t_lo, T, lo,
+                 ptr(ws["tab"][i]), 2 * CHd * Le, Le, mode_c, Le, max(q, 1), B, mf, mb, st)
+            call("wn_cond_grad", dfg, 2 * CHd * pitch, pitch, 2 * CHd, t_lo, T, mode_c, Le, max(q, 1),
+                 ptr(d_tab[i]), 2 * CHd * Le, Le, B, st)
+            wgrad("de_fg%d" % i, dfg, 2 * CHd * pitch, pitch, 0, pitch, xd(i), xd(i), db, pitch, -d, 0, pitch,
+                  CHd // 16, 2 * CHd // 16, 0, 2 * CHd, t_lo, T)
+            if i < N - 1:
+                wgrad("de_d%d" % i, dy, db, pitch, 0, pitch, zs, None, db, pitch, 0, 0, pitch, CHd // 16, CHd // 16, 0, CHd, t_lo, T)
+            gemm("de_fgT%d" % i, dfg, dfg, 2 * CHd * pitch, pitch, t_lo, T, 0, d, 2 * CHd // 32, 2 * CHd // 32, CHd // 16, Rd,
+                 ptr(bw["dXd"][i % 2], SLACK), db, pitch, 0, None, (dy, db, pitch, t_lo) if dy else NONE3, NONE3, self.off[i], T, 0)
+        x = ws["x_in"]
+        wgrad("de_causal", ptr(bw["dXd"][0], SLACK), db, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CHd // 16, 0,
+              2 * Q, 1, T)
+        # ---- conditioning: en_i = cw_i enc + b (rows in the reference order: gate first), enf = cfw enc + b
+        d_en = torch.cat([d_tab[:, :, CHd:CHd + Dd], d_tab[:, :, :Dd]], 2)            # (N,B,2Dd,Le) reference row order
+        d_enc = torch.einsum("nck,nbcl->bkl", ws["cw"], d_en) + torch.einsum("ck,bcl->bkl", ws["cfw"][:, :, 0], d_enf)
+        d_enc = d_enc.contiguous()
+        # ---- encoder: avgpool -> bottleneck -> N blocks -> causal
+        dE = ptr(bw["dE"], SLACK)
+        call("wn_avgpool_bwd", ptr(d_enc), Bw * Le, Le, lo, self.pool, Le, Bw, dE, BwP * pitch, pitch, T, B, st)
+        xe = lambda i: self._lay(ws["Xe"], i, CHe, ws)
+        he = lambda i: self._lay(ws["He"], i, CHe, ws)
+        wgrad("bottleneck", dE, BwP * pitch, pitch, 0, pitch, xe(N), None, eb, pitch, 0, 0, pitch, CHe // 16, BwP // 16, 0, CHe, lo, T)
+        dxe = [ptr(t, SLACK) for t in bw["dXe"]]
+        dHe = ptr(bw["dHe"], SLACK)
+        gemm("bottleneckT", dE, None, BwP * pitch, pitch, lo, T, 0, 0, BwP // 32, 0, CHe // 16, Re, dxe[N % 2], eb, pitch, 0, None,
+             NONE3, NONE3, lo, T, 0)
+        for i in range(N - 1, -1, -1):
+            d, t_lo = self.dil[i], self.off[i + 1]
+            y_lo = lo if i == N - 1 else t_lo                     # the top gradient only exists on the crop
+            dy = dxe[(i + 1) % 2]
+            # dh = (W1^T dy) * [h > 0];  dW1 = sum dy relu(h)^T
+            wgrad("en_dense%d" % i, dy, eb, pitch, 0, pitch, he(i), None, eb, pitch, 0, 0, pitch, CHe // 16, CHe // 16, 1, CHe, y_lo, T)
+            gemm("en_denseT%d" % i, dy, None, eb, pitch, y_lo, T, 0, 0, CHe // 32, 0, CHe // 16, De, dHe, eb, pitch, 0, None, NONE3,
+                 (he(i), eb, pitch), t_lo, T, 0)
+            # dWdil = sum dh [relu(x)(t-d) | relu(x)(t)]^T
+            wgrad("en_dil%d" % i, dHe, eb, pitch, 0, pitch, xe(i), xe(i), eb, pitch, -d, 0, pitch, CHe // 16, CHe // 16, 1, 2 * CHe, t_lo, T)
+            # dx_i[t] = [x_i > 0] (Wdil1^T dh[t] + Wdil0^T dh[t+d]) + dy[t]
+            gemm("en_dilT%d" % i, dHe, dHe, eb, pitch, t_lo, T, 0, d, CHe // 32, CHe // 32, CHe // 16, Re, dxe[i % 2], eb, pitch, 0,
+                 None, (dy, eb, pitch, y_lo), (xe(i), eb, pitch), self.off[i], T, 0)
+        wgrad("en_causal", dxe[0], eb, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CHe // 16, 0, 2 * Q, 1, T)
+        call("wn_reduce_slabs", ptr(bw["desc"]), bw["nops"], bw["vec"], ptr(bw["slab"]), ptr(self.gpack), st)
+        call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
+
+
+class _AutoencoderFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, wave_sample, cond, *params):
+        eng = net._engine_for(wave_sample.device)
+        probs, enc, ws = eng.forward(wave_sample.detach().float().contiguous(), cond)
+        net.last_encoding = enc
+        ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        eng, ws = ctx.eng, ctx.ws
+        if ws.get("gen") != ctx.gen:
+            raise RuntimeError("music_amd.wavenet_autoencoder: activations were overwritten by a later forward")
+        eng.backward(ws, dprobs)
+        g = eng.flat_grad.clone()
+        grads = []
+        for name in eng.param_names:
+            o, shp = eng.spec.off[name], eng.spec.shape[name]
+            grads.append(g[o:o + int(np.prod(shp))].view(shp))
+        return (None, None, None) + tuple(grads)
 
 
 class wavenet_autoencoder(nn.Module):
@@ -298,9 +507,6 @@ class wavenet_autoencoder(nn.Module):
         output_width = seq_len - self.receptive_field + 1
         if output_width <= 0:
             raise ValueError("wave sample not long enough")
-        eng = self._engine_for(wave_sample.device)
+        self._engine_for(wave_sample.device)
         cond = self._draw_conditioning()
-        with torch.no_grad():
-            probs, enc = eng.forward(wave_sample.detach().float().contiguous(), cond)
-        self.last_encoding = enc
-        return probs
+        return _AutoencoderFunction.apply(self, wave_sample, cond, *list(self.parameters()))

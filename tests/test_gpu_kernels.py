@@ -90,10 +90,10 @@ def test_chan_gemm_two_taps_epilogues():
     ts = torch.arange(t_lo, t_hi)
     ref = torch.einsum("mk,bkt->bmt", wt[:, :K], win[:, :, ts - d]) + torch.einsum("mk,bkt->bmt", wt[:, K:], win[:, :, ts])
     ref = ref + bias.cpu().double()[None, :, None]
+    ref = torch.where(_view(msk, B, M, pitch).cpu().double()[:, :, ts] > 0, ref, torch.zeros_like(ref))
     r = _view(res, B, M, pitch).cpu().double()[:, :, ts]
     r[:, :, ts < 60] = 0
-    ref = ref + r
-    ref = torch.where(_view(msk, B, M, pitch).cpu().double()[:, :, ts] > 0, ref, torch.zeros_like(ref))
+    ref = ref + r                                              # the residual is added AFTER the mask
     got = out[:B * M * W_out].view(B, M, W_out).cpu().double()
     err = (got - ref).abs().max().item()
     print("err", err, "scale", ref.abs().max().item())
@@ -213,7 +213,7 @@ def test_resblock_bwd_and_dx(CH, R, D, d):
     st = _lib.stream()
     call("wn_resblock_bwd", ptr(xin, SLACK), ptr(dy, SLACK), ptr(dz, SLACK), ptr(dfg, SLACK), ptr(zs, SLACK),
          CH * pitch, CH * pitch, 2 * CH * pitch, CH * pitch, pitch, ptr(pfg), ptr(pdT), None, None, D, CH, d,
-         t_lo, T, z_lo, B, mf, mb, st)
+         t_lo, T, z_lo, None, 0, 0, 0, 0, 0, B, mf, mb, st)
     call("wn_chan_gemm", ptr(dfg, SLACK), ptr(dfg, SLACK), 2 * CH * pitch, pitch, t_lo, T, 0, d, 2 * CH // 32, 2 * CH // 32,
          ptr(pX), CH // 16, R, ptr(dx, SLACK), CH * pitch, pitch, 0, None, ptr(dy, SLACK), CH * pitch, pitch, t_lo,
          None, 0, 0, off_in, T, 0, B, mb, st)

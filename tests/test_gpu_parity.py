@@ -373,3 +373,46 @@ def test_decode_config5_vs_oracle():
         print("config-5 decode (correct_queue=%s): probs err %.2e" % (correct, err))
         assert got == want and err < 1e-4
         np.testing.assert_allclose(st["block_30"].cpu().numpy(), q_o["block_30"].numpy(), atol=1e-4, rtol=0)
+
+
+def test_autoencoder_backward_vs_oracle():
+    """loss.backward() through the autoencoder (decoder with conditioning, epilogue conditioning,
+    pooled encoding, encoder blocks) vs autograd on the CPU oracle, same per-forward projections."""
+    import json
+    import os
+    from music_amd.model1 import wavenet_autoencoder
+    from oracle import intops
+    from tests.helpers import GOLDEN
+    d = load_npz("g8_autoencoder.npz")
+    cfg = json.load(open(os.path.join(GOLDEN, "g8_cfg.json")))
+    params = params_from(d)
+    net = wavenet_autoencoder(**cfg)
+    net.load_state_dict(params)
+    net = net.cuda()
+    rng = np.random.default_rng(31)
+    for tag in ("a", "b"):                       # "a": some layers stretch, "b": all tile
+        idx = d[tag + "_idx"]
+        x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx]))
+        W = idx.shape[1] - net.receptive_field + 1
+        target = torch.from_numpy(rng.integers(0, 256, size=(idx.shape[0] * W,)).astype(np.int64))
+        torch.manual_seed(77)
+        net.zero_grad()
+        probs = net(x.cuda())
+        loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
+        loss.backward()
+        # oracle with the same projections
+        torch.manual_seed(77)
+        cond = wo.draw_conditioning(len(cfg["dilations"]), cfg["en_bottleneck_width"], cfg["de_dilation_channel"],
+                                    cfg["de_skip_channel"])
+        leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        p_ref, _ = wo.autoencoder_forward(leaf, cfg["dilations"], x, cfg["en_pool_kernel_size"], cond)
+        l_ref = torch.nn.functional.cross_entropy(p_ref, target)
+        g_ref = torch.autograd.grad(l_ref, list(leaf.values()), allow_unused=True)
+        assert abs(loss.item() - l_ref.item()) < 1e-4
+        worst = 0.0
+        for (name, p), g in zip(net.named_parameters(), g_ref):
+            g = torch.zeros_like(leaf[name]) if g is None else g
+            err = (p.grad.cpu() - g).abs().max().item() / max(g.abs().max().item(), 1e-12)
+            worst = max(worst, err)
+            assert err <= GRAD_RTOL, (tag, name, err)
+        print("autoencoder", tag, "worst relative grad err %.2e" % worst)
