@@ -1,0 +1,143 @@
+"""Counterpart of the reference's ``wavenet_autoencoder/train.py`` (training harness of the
+autoencoder) for the MI355X path.
+
+The reference file is a tab-indented copy of ``wavenet/train.py`` that cannot run as shipped: it
+imports ``faster_audio_data`` and reads ``./params/train_params.json`` / ``dataset_params.json`` that
+only exist in ``wavenet/``, its ``model_params.json`` is invalid JSON, ``optim.sgd`` is a
+typo (:28), ``sorted(keys=...)`` raises (:159) and ``int(name[7:])`` raises for its own checkpoint
+names (:77-78).  This module keeps its surface and file formats and fixes only what cannot work:
+
+    get_optimizer(model, optimizer_type in {'sgd','RMSprop','Adam','lbfgs'}, learning_rate, momentum1)
+    save_model(model, num_epoch, path)   -> path + "wavenet_autoencoder{N}.model"
+    load_model(model, path, model_name)
+    train()      reads ./params/train_params.json, ./params/model_params.json, ./params/dataset_params.json
+"""
+import glob
+import os
+
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+try:
+    from . import dist as wdist
+    from .faster_audio_data import audio_data_loader
+    from .model1 import wavenet_autoencoder
+    from .train import get_params, load_model, _resume_counter
+except ImportError:
+    from music_amd import dist as wdist
+    from music_amd.faster_audio_data import audio_data_loader
+    from music_amd.model1 import wavenet_autoencoder
+    from music_amd.train import get_params, load_model, _resume_counter
+
+PREFIX = "wavenet_autoencoder"
+
+
+def get_arguments():
+    return (get_params('./params/train_params.json'), get_params('./params/model_params.json'),
+            get_params('./params/dataset_params.json'))
+
+
+def get_optimizer(model, optimizer_type, learning_rate, momentum1=False):
+    """wavenet_autoencoder/train.py:26-34 (with ``optim.sgd`` spelled ``optim.SGD``)."""
+    if optimizer_type == 'sgd':
+        return optim.SGD(model.parameters(), lr=learning_rate, momentum=momentum1 or 0)
+    if optimizer_type == 'RMSprop':
+        return optim.RMSprop(model.parameters(), lr=learning_rate, momentum=momentum1 or 0)
+    if optimizer_type == 'Adam':
+        return optim.Adam(model.parameters(), lr=learning_rate)
+    if optimizer_type == 'lbfgs':
+        return optim.LBFGS(model.parameters(), lr=learning_rate)
+
+
+def save_model(model, num_epoch, path):
+    checkpoint_path = path + PREFIX + str(num_epoch) + '.model'
+    print('Storing checkpoint to {}...'.format(path))
+    torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, checkpoint_path)
+    print('done')
+
+
+def _epoch_of(name):
+    return int(os.path.basename(name).split('.')[0][len(PREFIX):])
+
+
+def train():
+    cuda_available = torch.cuda.is_available()
+    train_params, model_params, dataset_params = get_arguments()
+    rank, world, _ = wdist.init_from_env()
+    if train_params.get("seed") is not None:
+        torch.manual_seed(int(train_params["seed"]))
+    net = wavenet_autoencoder(**model_params)
+    epoch_trained = 0
+    if train_params["restore_model"]:
+        restored = load_model(net, train_params["restore_dir"], train_params["restore_model"])
+        if restored is None:
+            print("Initialize network and train from scratch.")
+        else:
+            epoch_trained = _epoch_of(train_params["restore_model"])
+    if cuda_available is False and train_params["device_ids"] is not None:
+        raise ValueError("Cuda is not avalable,", " can not train model using multi-gpu.")
+    if world > 1:
+        assert dataset_params["batch_size"] % world == 0
+        dataset_params = dict(dataset_params, shard=(rank, world))
+    dataloader = audio_data_loader(**dataset_params)
+    if cuda_available:
+        net = net.cuda()
+    wdist.broadcast_parameters(list(net.parameters()))
+    optimizer = get_optimizer(net, train_params.get("optimizer_type", train_params.get("optimizer", "Adam")),
+                              train_params["learning_rate"], train_params.get("momentum", False))
+    loss_func = nn.CrossEntropyLoss()
+    is_writer = rank == 0
+    loss_log_file = store_log_file = None
+    if is_writer:
+        os.makedirs(train_params["log_dir"], exist_ok=True)
+        os.makedirs(train_params["restore_dir"], exist_ok=True)
+        loss_log_file = open(train_params["log_dir"] + 'loss_log.log', 'a')
+        store_log_file = open(train_params["log_dir"] + 'store_log.log', 'a')
+    if world > 1:
+        torch.distributed.barrier()
+    num_trained = _resume_counter(train_params["log_dir"])
+    device = next(net.parameters()).device
+    total_loss = torch.zeros((), dtype=torch.float64, device=device)
+    step_seed = int(train_params.get("seed") or 0)
+    for epoch in range(train_params["num_epochs"]):
+        for i_batch, sampled_batch in enumerate(dataloader):
+            piece, target = sampled_batch["audio_piece"], sampled_batch["audio_target"].view(-1)
+            if world > 1:
+                # every replica must draw the SAME per-forward conditioning projections
+                torch.manual_seed(step_seed + num_trained)
+
+            def closure():
+                optimizer.zero_grad()
+                loss = loss_func(net(piece), target)
+                loss.backward()
+                wdist.allreduce_gradients(net.parameters(), average=True)
+                return loss
+            loss = optimizer.step(closure) if isinstance(optimizer, optim.LBFGS) else closure()
+            if not isinstance(optimizer, optim.LBFGS):
+                optimizer.step()
+            total_loss += loss.detach().double()
+            num_trained += 1
+            if num_trained % train_params["print_every"] == 0:
+                if world > 1:
+                    torch.distributed.all_reduce(total_loss)
+                    total_loss /= world
+                if is_writer:
+                    loss_log_file.writelines("Trained over " + str(num_trained) + " pieces," + "Average loss is " +
+                                             str(total_loss.item() / train_params["print_every"]) + "\n")
+                    loss_log_file.flush()
+                total_loss.zero_()
+        if (epoch + 1) % train_params["check_point_every"] == 0 and is_writer:
+            stored = glob.glob(train_params["restore_dir"] + "*.model")
+            if len(stored) == train_params["max_check_points"]:
+                os.remove(sorted(stored, key=_epoch_of)[0])
+            save_model(net, epoch_trained + epoch + 1, train_params["restore_dir"])
+            store_log_file.writelines("Epoch " + str(epoch_trained + epoch + 1) + ", model saved!\n")
+            store_log_file.flush()
+    if is_writer:
+        loss_log_file.close()
+        store_log_file.close()
+
+
+if __name__ == '__main__':
+    train()

@@ -111,3 +111,25 @@ def test_checkpoint_rotation_and_module_prefix(tmp_path):
     assert isinstance(T.get_optimizer(net, "rmsprop", 0.1, 0.9), torch.optim.RMSprop)
     assert isinstance(T.get_optimizer(net, "adam", 0.1, 0.9), torch.optim.Adam)
     assert T.get_optimizer(net, "lbfgs", 0.1, 0.9) is None
+
+
+def test_autoencoder_harness_surface(tmp_path):
+    """ae_train: optimizer names, checkpoint prefix / epoch parsing (the reference's own [7:] slice
+    raises on its file names), module import without side effects."""
+    from music_amd import ae_train as A
+    from music_amd.model1 import wavenet_autoencoder
+    cfg = json.load(open(os.path.join(GOLDEN, "g8_cfg.json")))
+    net = wavenet_autoencoder(**cfg)
+    d = load_npz("g8_autoencoder.npz")
+    assert list(net.state_dict().keys()) == [k[2:] for k in d if k.startswith("w:")]
+    rd = str(tmp_path) + "/"
+    A.save_model(net, 12, rd)
+    assert os.listdir(rd) == ["wavenet_autoencoder12.model"]
+    assert A._epoch_of(rd + "wavenet_autoencoder12.model") == 12
+    net2 = wavenet_autoencoder(**cfg)
+    assert A.load_model(net2, rd, "wavenet_autoencoder12.model") is net2
+    assert isinstance(A.get_optimizer(net, "Adam", 1e-3), torch.optim.Adam)
+    assert isinstance(A.get_optimizer(net, "RMSprop", 1e-3, 0.5), torch.optim.RMSprop)
+    assert isinstance(A.get_optimizer(net, "sgd", 1e-3, 0.5), torch.optim.SGD)
+    assert isinstance(A.get_optimizer(net, "lbfgs", 1e-3), torch.optim.LBFGS)
+    import music_amd.ae_generate  # noqa: F401  (no import-time generation)
