@@ -186,13 +186,16 @@ int wn_mulaw_decode_lut(const uint8_t* codes, const float* table, float* audio, 
  * the block OUTPUT (as written in the reference) or its INPUT (push_input != 0).
  * note0 / prev0: dense [Q] current and previous input columns; forced: teacher-forced next codes
  * (NULL = feed back the argmax).  codes_out[n_steps] = argmax of the probabilities (first index on
- * ties); probs_out optional.  dilations_host / q_off_host are HOST arrays. */
+ * ties); probs_out optional.  dilations_host / q_off_host are HOST arrays.
+ * sync: optional device scratch of (n_layers*D + 2) uint64; when given (and the shape qualifies) the
+ * work is split over two workgroups that hand z / the predicted code over through tagged 8-byte
+ * granules; the last word is an error flag (non-zero = a bounded spin timed out). */
 int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
               float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
               int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
               const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
               float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
-              int n_steps, int push_input, wn_stream_t stream);
+              int n_steps, int push_input, uint64_t* sync, wn_stream_t stream);
 
 #ifdef __cplusplus
 }

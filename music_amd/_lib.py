@@ -53,7 +53,7 @@ SIGNATURES = {
     "wn_mulaw_encode_tbl": [_p, _p, _p, _l, _p],
     "wn_mulaw_decode_lut": [_p, _p, _p, _l, _p],
     "wn_decode": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l,
-                  _i, _i, _p],
+                  _i, _i, _p, _p],
 }
 
 _lib = None

@@ -205,7 +205,7 @@ int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations
               int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
               const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
               float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
-              int n_steps, int push_input, wn_stream_t stream) {
+              int n_steps, int push_input, uint64_t* sync, wn_stream_t stream) {
     if (n_layers > WN_DEC_MAX_LAYERS || n_layers <= 0) return wn_set_error_msg(-4, "wn_decode: 1..64 layers supported");
     WnDecodeArgs a;
     memset(&a, 0, sizeof(a));
@@ -216,6 +216,7 @@ int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations
     a.note0 = note0; a.prev0 = prev0; a.note_out = note_out; a.prev_out = prev_out; a.forced = forced;
     a.codes_out = codes_out; a.probs_out = probs_out; a.step0 = step0; a.n_steps = n_steps; a.push_input = push_input;
     { const char* e = getenv("WN_DEC_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.sync = reinterpret_cast<unsigned long long*>(sync);
     return wn_launch_decode(a, (hipStream_t)stream);
 }
 

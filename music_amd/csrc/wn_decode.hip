@@ -317,6 +317,209 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_v4_k(WnDecodeArgs a) {
     for (int i = tid; i < Q; i += DEC_THREADS) { a.prev_out[i] = prev[i]; a.note_out[i] = note[i]; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// decode_duo_k: the recurrence split over TWO workgroups on (normally) two XCDs, because one CU can
+// only stream ~35 GB/s from beyond its XCD's 4 MB L2 and the 5 MB of fp32 weights do not fit it:
+//   block 0 "chain": causal layer, per block f/g product, gate, dense product, queue update
+//                    (2.6 MB of weights -> resident in ITS L2);
+//   block 1 "skip" : per block the skip product Ws z_l (1.97 MB), then relu/P1/relu/P2/softmax/argmax
+//                    (0.5 MB) -> resident in ITS L2.
+// z_l travels as 8-byte {value, tag} granules written with one agent-scope relaxed 64-bit store
+// and polled with agent-scope relaxed loads (tag = sample number; no fences, no flags: the
+// placement-independent hand-off of MI355X_MICROARCH.md "R2 granule"); the predicted code travels
+// back the same way.  Every spin is bounded; a timeout sets sync[err] and both blocks run out.
+// Measured (config 5): 8.1-8.4 k samples/s vs 5.1 k for one workgroup.  What bounds the chain now is
+// the ~64 KB of f/g weights a block needs per sample through ONE CU's memory pipe (~1.7 us per
+// block even from L2; bisected with the WN_DEC_DBG switches: without the f/g product the chain
+// runs 17.7 k samples/s); the next step is a block-pipelined chain over ~15 CUs with the weights
+// resident in LDS.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long dec_pack(float v, unsigned tag) {
+    return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+__device__ __forceinline__ bool dec_poll(const unsigned long long* p, unsigned tag, float& v, unsigned long long* err) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(g >> 32) == tag) { v = __uint_as_float((unsigned)g); return true; }
+        if ((spin & 255) == 255 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = 0.f;
+    return false;
+}
+
+__global__ __launch_bounds__(DEC_THREADS) void decode_duo_k(WnDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ int s_arg;
+    __shared__ int slots[WN_DEC_MAX_LAYERS];
+    const int tid = threadIdx.x;
+    const int R = a.R, D = a.D, S = a.S, Q = a.Q;
+    unsigned long long* zg = a.sync;                         // [n_layers][D] z granules
+    unsigned long long* cg = a.sync + (size_t)a.n_layers * D;    // code granule
+    unsigned long long* err = cg + 1;
+    const size_t lstride = (size_t)a.layer_stride;
+    const size_t o_d = (size_t)2 * D * 2 * R, o_s = o_d + (size_t)R * D;
+
+    if (blockIdx.x == 0) {
+        // ------------------------------------------------------------------ chain
+        float* prev = sm;
+        float* note = prev + Q;
+        float* cur0 = note + Q;
+        float* cur1 = cur0 + 2 * R;
+        float* fg = cur1 + 2 * R;
+        float* zz = fg + 2 * D;
+        float* oldb = zz + D;                    // [n_layers][R] oldest queue columns of this sample
+        float* pushb = oldb + a.n_layers * R;    // [n_layers][R] columns pushed by this sample
+        const DecMap mc = dec_map(R, 2 * Q), mfg = dec_map(2 * D, 2 * R), md = dec_map(R, D);
+        for (int i = tid; i < Q; i += DEC_THREADS) { note[i] = a.note0[i]; prev[i] = a.prev0[i]; }
+        if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
+        dec_sync();
+        f32x4 wfg[4], wd[1];
+        for (int step = 0; step < a.n_steps; ++step) {
+            const unsigned tag = (unsigned)step + 1u;
+            // all queue traffic of a sample happens here (oldest columns in, L1-bypassing loads) and after
+            // the last block (pushed columns out): global stores inside the block loop would sit in the
+            // in-order vmcnt queue (~2 us each) in front of every wait for prefetched weights
+            for (int i = tid; i < a.n_layers * R; i += DEC_THREADS) {
+                const int l = i / R, r = i - l * R;
+                oldb[i] = __hip_atomic_load(a.queues + a.q_off[l] + (size_t)slots[l] * R + r, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+            }
+            dec_loadw4(wfg, mfg, a.w_layers, 2 * R, 2 * D);
+            dec_loadw4(wd, md, a.w_layers + o_d, D, R);
+            {
+                const float s = dec_dot_stream(mc, a.w_causal, 2 * Q, R, prev);
+                if (mc.o < R && mc.p == 0) cur0[mc.o] = s;
+            }
+            dec_sync();
+            if (tid < R) cur0[R + tid] = oldb[tid];
+            dec_sync();
+            float* cur = cur0;
+            float* nxt = cur1;
+            for (int l = 0; l < a.n_layers; ++l) {
+                const float s = (a.dbg & 1024) ? cur[tid & 63] : dec_dot4(wfg, mfg, cur);
+                if (mfg.o < 2 * D && mfg.p == 0) fg[mfg.o] = s;
+                const int ln = l + 1;
+                const float* wn = a.w_layers + (size_t)ln * lstride;
+                if (ln < a.n_layers && !(a.dbg & 256)) dec_loadw4(wfg, mfg, wn, 2 * R, 2 * D);
+                dec_sync();
+                if (tid < D) {
+                    const float z = (a.dbg & 64) ? wn_tanh(fg[tid]) * wn_sigmoid(fg[D + tid])
+                                                 : tanhf(fg[tid]) * (1.0f / (1.0f + expf(-fg[D + tid])));
+                    zz[tid] = z;
+                    if (!(a.dbg & 128))
+                        __hip_atomic_store(zg + (size_t)l * D + tid, dec_pack(z, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!(a.dbg & 2048)) dec_sync();
+                const float sd = (a.dbg & 4096) ? zz[tid & 63] : dec_dot4(wd, md, zz);
+                if (md.o < R && md.p == 0) {
+                    const float v = sd + cur[md.o];
+                    nxt[md.o] = v;
+                    pushb[l * R + md.o] = a.push_input ? cur[md.o] : v;          // Q5: output by default
+                }
+                if (ln < a.n_layers) {
+                    if (!(a.dbg & 256)) dec_loadw4(wd, md, wn + o_d, D, R);
+                    if (tid < R) nxt[R + tid] = oldb[ln * R + tid];
+                }
+                dec_sync();
+                float* t = cur; cur = nxt; nxt = t;
+            }
+            for (int i = tid; i < a.n_layers * R; i += DEC_THREADS) {            // queue columns out
+                const int l = i / R, r = i - l * R;
+                a.queues[a.q_off[l] + (size_t)slots[l] * R + r] = pushb[i];
+            }
+            // the prediction comes back from the skip block
+            if (tid == 0) {
+                float cv = 0.f;
+                if (!(a.dbg & 32)) dec_poll(cg, tag, cv, err);
+                s_arg = (int)cv;
+            }
+            __syncthreads();                       // full fence: the queue stores are complete before the next sample reads
+            const int nextc = a.forced ? a.forced[step] : s_arg;
+            for (int i = tid; i < Q; i += DEC_THREADS) prev[i] = note[i];
+            if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
+            dec_sync();
+            for (int i = tid; i < Q; i += DEC_THREADS) note[i] = (i == nextc) ? 1.0f : 0.0f;
+            dec_sync();
+        }
+        for (int i = tid; i < Q; i += DEC_THREADS) { a.prev_out[i] = prev[i]; a.note_out[i] = note[i]; }
+    } else {
+        // ------------------------------------------------------------------ skip + post-processing
+        float* zz0 = sm;                       // [2][D]
+        float* skip = zz0 + 2 * D;             // [S]
+        float* h1 = skip + S;                  // [S]
+        float* logit = h1 + S;                 // [Q]
+        const DecMap ms = dec_map(S, D), mp1 = dec_map(S, S), mp2 = dec_map(Q, S);
+        f32x4 ws[4];
+        for (int step = 0; step < ((a.dbg & 32) ? 0 : a.n_steps); ++step) {
+            const unsigned tag = (unsigned)step + 1u;
+            float part = 0.f;                                    // this thread's slice of its skip row, all blocks
+            dec_loadw4(ws, ms, a.w_layers + o_s, D, S);
+            for (int l = 0; l < a.n_layers; ++l) {
+                float* zz = zz0 + (l & 1) * D;
+                if (tid < D) {
+                    float z;
+                    dec_poll(zg + (size_t)l * D + tid, tag, z, err);
+                    zz[tid] = z;
+                }
+                dec_sync();
+                f32x4 wsn[4];
+                if (l + 1 < a.n_layers) dec_loadw4(wsn, ms, a.w_layers + (size_t)(l + 1) * lstride + o_s, D, S);
+                const float* xs = zz + ms.p * ms.nw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + 4 * j);
+                    part = fmaf(ws[j][0], xv[0], part); part = fmaf(ws[j][1], xv[1], part);
+                    part = fmaf(ws[j][2], xv[2], part); part = fmaf(ws[j][3], xv[3], part);
+                }
+                if (l + 1 < a.n_layers) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ws[j] = wsn[j];
+                }
+            }
+            for (int off = ms.parts >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (ms.o < S && ms.p == 0) skip[ms.o] = fmaxf(part, 0.f);
+            dec_sync();
+            {
+                const float s = dec_dot_stream(mp1, a.w_p1, S, S, skip);
+                if (mp1.o < S && mp1.p == 0) h1[mp1.o] = fmaxf(s, 0.f);
+            }
+            dec_sync();
+            {
+                const float s = dec_dot_stream(mp2, a.w_p2, S, Q, h1);
+                if (mp2.o < Q && mp2.p == 0) logit[mp2.o] = s;
+            }
+            dec_sync();
+            if (tid < 64) {
+                float v[4], m = -INFINITY;
+                for (int e = 0; e < 4; ++e) { v[e] = logit[tid * 4 + e]; m = fmaxf(m, v[e]); }
+                for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                float s = 0.f;
+                for (int e = 0; e < 4; ++e) { v[e] = expf(v[e] - m); s += v[e]; }
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                const float inv = 1.0f / s;
+                float best = -1.f; int bi = 0;
+                for (int e = 0; e < 4; ++e) {
+                    v[e] *= inv;
+                    if (a.probs_out) a.probs_out[(size_t)step * Q + tid * 4 + e] = v[e];
+                    if (v[e] > best) { best = v[e]; bi = tid * 4 + e; }
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    float ob = __shfl_xor(best, off, 64);
+                    int oi = __shfl_xor(bi, off, 64);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                if (tid == 0) {
+                    a.codes_out[step] = bi;
+                    __hip_atomic_store(cg, dec_pack((float)bi, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            dec_sync();
+        }
+    }
+}
+
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
     if (a.n_steps <= 0) return 0;
     if (a.n_layers > WN_DEC_MAX_LAYERS) return wn_set_error_msg(-4, "decode: too many layers");
@@ -332,7 +535,14 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
                     nw(2 * a.D, 2 * a.R) == 16 && nw(a.R, a.D) == 4 && nw(a.S, a.D) == 16 &&
                     nw(a.R, 2 * a.Q) > 0 && nw(a.R, 2 * a.Q) % 16 == 0 && nw(a.S, a.S) > 0 && nw(a.S, a.S) % 16 == 0 &&
                     nw(a.Q, a.S) > 0 && nw(a.Q, a.S) % 16 == 0 && (a.layer_stride % 4) == 0;
-    if (v4) {
+    if (v4 && a.sync && a.n_steps >= 4 && !(a.dbg & 31)) {
+        const size_t nsync = ((size_t)a.n_layers * a.D + 2) * sizeof(unsigned long long);
+        hipError_t e = hipMemsetAsync(a.sync, 0, nsync, st);              // tags start at 1
+        if (e != hipSuccess) return wn_set_error(e, __FILE__, __LINE__);
+        size_t sh0 = sizeof(float) * (size_t)(2 * a.Q + 4 * a.R + 3 * a.D + 2 * a.n_layers * a.R);
+        size_t sh1 = sizeof(float) * (size_t)(2 * a.D + 2 * a.S + a.Q);
+        hipLaunchKernelGGL(decode_duo_k, dim3(2), dim3(DEC_THREADS), sh0 > sh1 ? sh0 : sh1, st, a);
+    } else if (v4) {
         size_t sh = sizeof(float) * (size_t)(3 * a.Q + 4 * a.R + 3 * a.D + 2 * a.S);
         hipLaunchKernelGGL(decode_v4_k, dim3(1), dim3(DEC_THREADS), sh, st, a);
     } else {

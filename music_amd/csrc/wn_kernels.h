@@ -129,5 +129,6 @@ struct WnDecodeArgs {
     int32_t* codes_out; float* probs_out;                // [n_steps], [n_steps][Q] or null
     long step0; int n_steps; int push_input;
     int dbg;                                             // WN_DEC_DBG timing diagnostics (wrong results)
+    unsigned long long* sync;                            // (n_layers*D + 2) x 8 B hand-off area for the 2-workgroup kernel, or null
 };
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st);

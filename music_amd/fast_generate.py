@@ -141,13 +141,18 @@ def _decode(net, state, note0, n_steps, forced=None, want_probs=False, correct_q
     dil = (ctypes.c_int32 * eng.N)(*eng.dil)
     qoff = (ctypes.c_int64 * eng.N)(*[int(v) for v in state.q_off])
     forced_t = forced.to(device=dev, dtype=torch.int32).contiguous() if forced is not None else None
+    sync = getattr(net, "_decode_sync", None)
+    if sync is None or sync.device != dev or sync.numel() < eng.N * eng.D + 2:
+        sync = net._decode_sync = torch.zeros(eng.N * eng.D + 2, dtype=torch.int64, device=dev)
     bias = pack.o_bias is not None
     call("wn_decode", eng.N, eng.R, eng.D, eng.S, eng.Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
          ptr(state.rings), pack.p(pack.o_causal), pack.p(pack.ob_causal) if bias else None,
          pack.p(pack.o_layers), pack.layer_stride, pack.p(pack.ob_layers) if bias else None,
          pack.p(pack.o_p1), pack.p(pack.ob_p1) if bias else None, pack.p(pack.o_p2), pack.p(pack.ob_p2) if bias else None,
          ptr(note0), ptr(state.prev), ptr(note_out), ptr(prev_out), ptr(forced_t), ptr(codes), ptr(probs),
-         state.steps, n_steps, 1 if correct_queue else 0, _lib.stream())
+         state.steps, n_steps, 1 if correct_queue else 0, ptr(sync), _lib.stream())
+    if n_steps >= 4 and int(sync[-1].item()) != 0:
+        raise _lib.WavenetHipError("wn_decode: a hand-off between the two decode workgroups timed out")
     state.prev = prev_out
     state.steps += n_steps
     return codes, probs, note_out

@@ -91,6 +91,35 @@ def main():
         res["decode_16000_samples_s"] = round(dt, 4)
         res["decode_samples_per_s"] = round(16000 / dt, 1)
         res["decode_distinct_codes"] = int(torch.unique(codes).numel())
+    if args.what in ("ae", "all"):
+        # BASELINE config 4: autoencoder, 30+30 blocks, 64 ch, skip 256, bottleneck 64, pool 512, batch 8 x 16000:
+        # forward + CE + backward (fresh conditioning projections every forward, as in the reference)
+        import time
+        from music_amd.model1 import wavenet_autoencoder
+        torch.manual_seed(0)
+        ae = wavenet_autoencoder(filter_width=2, quantization_channel=256, dilations=CFG["dilations"], en_residual_channel=64,
+                                 en_dilation_channel=64, en_bottleneck_width=64, en_pool_kernel_size=512,
+                                 de_residual_channel=64, de_dilation_channel=64, de_skip_channel=256, use_bias=False).cuda()
+        opt = torch.optim.Adam(ae.parameters(), lr=1e-4)
+        lossf = torch.nn.CrossEntropyLoss()
+
+        def ae_step():
+            opt.zero_grad()
+            loss = lossf(ae(x), target)
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(2):
+            ae_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            loss = ae_step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.reps
+        res["autoencoder_step_ms"] = round(dt * 1e3, 2)
+        res["autoencoder_samples_per_s"] = round(B_LOCAL * T / dt, 1)
+        res["autoencoder_loss"] = round(float(loss.item()), 5)
     print(json.dumps(res))
 
 
