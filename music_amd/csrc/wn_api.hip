@@ -12,6 +12,12 @@ int wn_set_error(hipError_t e, const char* file, int line) {
     snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
     return -1;
 }
+int wn_xcd_swizzle_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("WN_XCD"); on = e ? atoi(e) : 1; }
+    return on;
+}
+
 int wn_set_error_msg(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
     return code;

@@ -129,6 +129,36 @@ __device__ __forceinline__ float wn_tanh(float f) {
     return (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// XCD-aware work mapping.  Workgroups are observed to be dealt round-robin over the 8 XCDs in
+// dispatch order (x fastest), so blocks with equal (linear id % 8) share one 4 MB L2.  The remap gives
+// each XCD one CONTIGUOUS run of the (x, y, z) work items: neighbouring time tiles of one clip then sit
+// behind the same L2, where the dilated tap (t - d), the shifted gradient tap (t + d) and a second
+// launch over the same columns find the rows their neighbour fetched.  Bijective for any grid size;
+// speed only, nothing depends on the placement.
+struct WnBlock { int x, y, z; };
+template <bool YFAST = false>      // YFAST: y is the fastest-varying work index (row groups that share columns)
+__device__ __forceinline__ WnBlock wn_block(int swz) {
+    WnBlock o;
+    if (!swz) { o.x = blockIdx.x; o.y = blockIdx.y; o.z = blockIdx.z; return o; }
+    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+    const int id = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+    const int qn = nwg >> 3, rn = nwg & 7, xcd = id & 7;
+    const int w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (id >> 3);
+    if (YFAST) {
+        o.y = w % gy;
+        const int t = w / gy;
+        o.x = t % gx;
+        o.z = t / gx;
+    } else {
+        o.x = w % gx;
+        const int t = w / gx;
+        o.y = t % gy;
+        o.z = t / gy;
+    }
+    return o;
+}
+int wn_xcd_swizzle_enabled();      // host: env WN_XCD (default 1)
+
 #define WN_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return wn_set_error(e_, __FILE__, __LINE__); } while (0)
 int wn_set_error(hipError_t e, const char* file, int line);
 int wn_set_error_msg(int code, const char* msg);

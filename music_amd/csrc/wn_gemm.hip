@@ -57,11 +57,12 @@ __global__ __launch_bounds__(512) void chan_gemm_k(WnGemmArgs a) {
     constexpr int PF = MTW > 4 ? 1 : 2;        // k-steps of activations in flight (register budget)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.z;
+    const WnBlock blk = wn_block(a.swz);
+    const int b = blk.z;
     const int wm = wave / WN, wn = wave % WN;
-    const int t0 = a.t_base + (blockIdx.x * WN + wn) * 64;       // first column of this wave
+    const int t0 = a.t_base + (blk.x * WN + wn) * 64;            // first column of this wave
     const int tl = t0 + 4 * c;                                    // this lane's first column
-    const int m0 = (blockIdx.y * WM + wm) * MTW;                  // first M-tile of this wave
+    const int m0 = (blk.y * WM + wm) * MTW;                       // first M-tile of this wave
     if (t0 >= a.t_hi || m0 >= a.mt) return;
     const int KS = a.ks0 + a.ks1;
 
@@ -84,14 +85,22 @@ __global__ __launch_bounds__(512) void chan_gemm_k(WnGemmArgs a) {
     const float* in1 = a.in1 ? a.in1 + (size_t)b * a.in_bstride : nullptr;
     const int col0 = tl + a.shift0, col1 = tl + a.shift1;
 
+    // wave-uniform: all 64 columns of a tap lie inside [in_lo, in_hi) -> plain 16-B loads
+    const int t0u = __builtin_amdgcn_readfirstlane(t0);
+    const bool inner0 = t0u + a.shift0 >= a.in_lo && t0u + 64 + a.shift0 <= a.in_hi;
+    const bool inner1 = t0u + a.shift1 >= a.in_lo && t0u + 64 + a.shift1 <= a.in_hi;
     auto issue = [&](f32x4* raw, int s) {
-        const float* base; int col; int ch;
-        if (s < a.ks0) { base = in0; col = col0; ch = s * 32; }
-        else { base = in1; col = col1; ch = (s - a.ks0) * 32; }
+        const float* base; int col; int ch; bool inner;
+        if (s < a.ks0) { base = in0; col = col0; ch = s * 32; inner = inner0; }
+        else { base = in1; col = col1; ch = (s - a.ks0) * 32; inner = inner1; }
         const float* p = base + (size_t)(ch + 8 * q) * a.in_pitch + col;
-        // input columns outside [in_lo, in_hi) read as 0 and are never dereferenced
+        if (inner) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = ld4g(p + (size_t)j * a.in_pitch, col, a.in_lo, a.in_hi);
+            for (int j = 0; j < 8; ++j) raw[j] = ld4u(p + (size_t)j * a.in_pitch);
+        } else {     // input columns outside [in_lo, in_hi) read as 0 and are never dereferenced
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[j] = ld4g(p + (size_t)j * a.in_pitch, col, a.in_lo, a.in_hi);
+        }
     };
     auto step = [&](f32x4* raw, int s) {
         Frag<T> bf[4];
@@ -192,11 +201,13 @@ __global__ __launch_bounds__(512) void chan_gemm_wide_lds_k(WnGemmArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t l_a[2][16 * FR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.z;
+    // row groups that read the same 256 columns run next to each other on one XCD
+    const WnBlock blk = wn_block<true>(a.swz);
+    const int b = blk.z;
     const int wm = wave / WN, wn = wave % WN;
-    const int t0 = a.t_base + (blockIdx.x * WN + wn) * 64;
+    const int t0 = a.t_base + (blk.x * WN + wn) * 64;
     const int tl = t0 + 4 * c;
-    const int mg0 = blockIdx.y * 16;                           // first M-tile of the workgroup
+    const int mg0 = blk.y * 16;                                // first M-tile of the workgroup
     const int m0 = mg0 + wm * MTW;                             // first M-tile of this wave
     const int KS = a.ks0 + a.ks1;
 
@@ -324,6 +335,198 @@ __global__ __launch_bounds__(512) void chan_gemm_wide_lds_k(WnGemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide variant 2: BOTH operands of a k-step are shared through LDS as ready-to-use 16-bit hi/lo
+// fragments.  Each activation element is fetched from HBM and split ONCE per workgroup (every wave
+// converts 1/8 of the 32 x 256 k-step slab: 4 float4 per lane) instead of once per row-half wave,
+// which leaves registers for a second k-step of activations in flight per wave (the kernel is a
+// streaming one: 0.8 GB of z-crops against 0.3 TFLOP for the skip product, so bytes in flight are
+// what sets its speed).  LDS: 2 stages x (16 A + 16 B fragments) = 128 KB in the x3 modes.
+// 256 rows x 256 columns per workgroup, 8 waves = 2 (rows) x 4 (column groups of 64).
+// ---------------------------------------------------------------------------------------------
+template <class T, int NS>
+__global__ __launch_bounds__(512) void chan_gemm_wide2_k(WnGemmArgs a) {
+    constexpr int MTW = 8, WN = 4;
+    constexpr int FR = (NS == 3 ? 1024 : 512);               // halfs per fragment
+    constexpr int FRV = FR / 8;                               // u32x4 per fragment
+    constexpr int STAGE = 32 * FR;                            // halfs per stage: 16 A then 16 B fragments
+    constexpr int PER_A = 16 * FRV / 512;                     // u32x4 of the A image per thread
+    extern __shared__ __attribute__((aligned(16))) uint16_t l_s[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const WnBlock blk = wn_block<true>(a.swz);
+    const int b = blk.z;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile0 = a.t_base + blk.x * 256;
+    const int t0 = tile0 + wn * 64;
+    const int tl = t0 + 4 * c;
+    const int mg0 = blk.y * 16;
+    const int m0 = mg0 + wm * MTW;
+    const int KS = a.ks0 + a.ks1;
+
+    f32x4 acc[MTW][4];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        f32x4 init = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = (m0 + m) * 16 + 4 * q + i;
+                init[i] = row < a.m_valid ? a.bias[row] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = init;
+    }
+    // loader role of this wave for the activations: column group lg, row half lh of every k-step
+    const int lg = wave & 3, lh = wave >> 2;
+    const int ltl = tile0 + lg * 64 + 4 * c;
+    const float* in0 = a.in0 + (size_t)b * a.in_bstride;
+    const float* in1 = a.in1 ? a.in1 + (size_t)b * a.in_bstride : nullptr;
+    const int tg0 = tile0 + lg * 64;
+    const bool inner0 = tg0 + a.shift0 >= a.in_lo && tg0 + 64 + a.shift0 <= a.in_hi;
+    const bool inner1 = tg0 + a.shift1 >= a.in_lo && tg0 + 64 + a.shift1 <= a.in_hi;
+    auto load_b = [&](f32x4* raw, int s) {
+        const float* base; int col; int ch; bool inner;
+        if (s < a.ks0) { base = in0; col = ltl + a.shift0; ch = s * 32; inner = inner0; }
+        else { base = in1; col = ltl + a.shift1; ch = (s - a.ks0) * 32; inner = inner1; }
+        const float* p = base + (size_t)(ch + 8 * q + 4 * lh) * a.in_pitch + col;
+        if (inner) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw[j] = ld4u(p + (size_t)j * a.in_pitch);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw[j] = ld4g(p + (size_t)j * a.in_pitch, col, a.in_lo, a.in_hi);
+        }
+    };
+    // split 4 rows x 4 columns and write the 8-byte hi / lo pieces of the 4 B fragments of group lg
+    auto store_b = [&](const f32x4* raw, int st) {
+        uint16_t* bb = l_s + (size_t)st * STAGE + (size_t)(16 + lg * 4) * FR + lane * 8 + lh * 4;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            typedef typename T::elem elem;
+            elem h[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = raw[j][n];
+                if (a.relu_in) x = fmaxf(x, 0.f);
+                h[j] = T::cvt(x);
+                if (NS == 3) l[j] = T::cvt(x - T::back(h[j]));
+            }
+            uint2 hv = {(uint32_t)__builtin_bit_cast(uint16_t, h[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[1]) << 16),
+                        (uint32_t)__builtin_bit_cast(uint16_t, h[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[3]) << 16)};
+            *reinterpret_cast<uint2*>(bb + (size_t)n * FR) = hv;
+            if (NS == 3) {
+                uint2 lv = {(uint32_t)__builtin_bit_cast(uint16_t, l[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, l[1]) << 16),
+                            (uint32_t)__builtin_bit_cast(uint16_t, l[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, l[3]) << 16)};
+                *reinterpret_cast<uint2*>(bb + (size_t)n * FR + 512) = lv;
+            }
+        }
+    };
+    u32x4 wreg[PER_A];
+    auto load_w = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < PER_A; ++i) {
+            int v = threadIdx.x + i * 512;
+            int mt = v / FRV, r = v % FRV;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if (mg0 + mt < a.mt) z = reinterpret_cast<const u32x4*>(a.wpack)[((size_t)(mg0 + mt) * KS + s) * FRV + r];
+            wreg[i] = z;
+        }
+    };
+    auto store_w = [&](int st) {
+        u32x4* d = reinterpret_cast<u32x4*>(l_s + (size_t)st * STAGE);
+#pragma unroll
+        for (int i = 0; i < PER_A; ++i) d[threadIdx.x + i * 512] = wreg[i];
+    };
+    f32x4 raw0[4], raw1[4];
+    load_w(0);
+    load_b(raw0, 0);
+    if (KS > 1) load_b(raw1, 1);
+    store_w(0);
+    store_b(raw0, 0);
+    if (KS > 1) load_w(1);
+    if (KS > 2) load_b(raw0, 2);
+    __syncthreads();
+    // one k-step: MFMAs on stage s & 1, meanwhile the next stage is filled from the registers whose
+    // loads were issued two k-steps ago, and those registers are re-armed two (A: one) k-steps ahead.
+    // (Tidier forms of this loop - branch-free k-steps, the fill spread over the row tiles, a
+    // duplicated loop for edge waves - all measured SLOWER: 405-418 us against 355 us for the skip
+    // product)
+    auto step = [&](int s, f32x4* rnext) {
+        const uint16_t* la = l_s + (size_t)(s & 1) * STAGE;
+        const uint16_t* lb = la + (size_t)(16 + wn * 4) * FR;
+        Frag<T> bf[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) load_a<T, NS>(bf[n], lb, n, lane);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            Frag<T> af;
+            load_a<T, NS>(af, la, wm * MTW + m, lane);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
+            if (m == 3 && s + 1 < KS) {
+                store_b(rnext, (s + 1) & 1);
+                store_w((s + 1) & 1);
+                if (s + 3 < KS) load_b(rnext, s + 3);
+                if (s + 2 < KS) load_w(s + 2);
+            }
+        }
+        __syncthreads();
+    };
+    for (int s = 0; s < KS; s += 2) {
+        step(s, raw1);
+        if (s + 1 < KS) step(s + 1, raw0);
+    }
+    if (t0 >= a.t_hi || m0 >= a.mt) return;
+
+    float* out = a.out + (size_t)b * a.out_bstride;
+    const float* resid = a.resid ? a.resid + (size_t)b * a.resid_bstride : nullptr;
+    const float* mask = a.mask ? a.mask + (size_t)b * a.mask_bstride : nullptr;
+    const bool full = tl >= a.t_lo && tl + 3 < a.t_hi;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        if (m0 + m >= a.mt) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = (m0 + m) * 16 + 4 * q + i;
+            if (row >= a.m_valid) continue;
+            f32x4 v = {acc[m][0][i], acc[m][1][i], acc[m][2][i], acc[m][3][i]};
+            if (mask) {
+                const float* mp = mask + (size_t)row * a.mask_pitch + tl;
+                if (full) {
+                    f32x4 mv = ld4u(mp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tl + e >= a.t_lo && tl + e < a.t_hi) v[e] = mp[e] > 0.f ? v[e] : 0.f;
+                }
+            }
+            if (resid) {
+                const float* rp = resid + (size_t)row * a.resid_pitch + tl;
+                if (full && tl >= a.resid_lo) {
+                    v += ld4u(rp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tl + e >= a.resid_lo && tl + e >= a.t_lo && tl + e < a.t_hi) v[e] += rp[e];
+                }
+            }
+            float* op = out + (size_t)row * a.out_pitch + tl + a.out_shift;
+            if (full) {
+                F4U u = {{v[0], v[1], v[2], v[3]}};
+                *reinterpret_cast<F4U*>(op) = u;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (tl + e >= a.t_lo && tl + e < a.t_hi) op[e] = v[e];
+            }
+        }
+    }
+}
+
 template <class T, int NS>
 static int launch_gemm(const WnGemmArgs& k, int batch, hipStream_t st) {
     const int ncol = k.t_hi - k.t_base;
@@ -332,7 +535,22 @@ static int launch_gemm(const WnGemmArgs& k, int batch, hipStream_t st) {
         hipLaunchKernelGGL((chan_gemm_k<T, NS, 4, 1>), g, b, 0, st, k);
     } else {                             // wide: 256 rows x 256 columns per workgroup
         dim3 g((ncol + 255) / 256, (k.mt + 15) / 16, batch), b(512);
-        hipLaunchKernelGGL((chan_gemm_wide_lds_k<T, NS>), g, b, 0, st, k);
+        static int ver = -1;
+        if (ver < 0) { const char* e = getenv("WN_GEMM_WIDE"); ver = e ? atoi(e) : 2; }
+        if (ver == 2) {
+            const size_t sh = (size_t)2 * 32 * (NS == 3 ? 1024 : 512) * sizeof(uint16_t);
+            static unsigned long long done = 0;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (!((done >> dev) & 1ull)) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_gemm_wide2_k<T, NS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+                done |= 1ull << dev;
+            }
+            hipLaunchKernelGGL((chan_gemm_wide2_k<T, NS>), g, b, sh, st, k);
+        } else {
+            hipLaunchKernelGGL((chan_gemm_wide_lds_k<T, NS>), g, b, 0, st, k);
+        }
     }
     return 0;
 }
@@ -341,6 +559,7 @@ int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st) {
     if (a.t_hi <= a.t_lo || batch <= 0) return 0;
     WnGemmArgs k = a;
     k.t_base = a.t_lo & ~3;                 // lanes own 4 consecutive, 4-aligned columns
+    k.swz = wn_xcd_swizzle_enabled();
     switch (mode) {
         case WN_MODE_F16X3: launch_gemm<F16, 3>(k, batch, st); break;
         case WN_MODE_F16X1: launch_gemm<F16, 1>(k, batch, st); break;

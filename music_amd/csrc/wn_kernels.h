@@ -22,6 +22,7 @@ struct WnGemmArgs {
     const float* mask; long mask_bstride; int mask_pitch;         // keep where mask[row][t] > 0
     int t_lo, t_hi, t_base;                // valid output columns [t_lo, t_hi); t_base set by launcher
     int relu_in;
+    int swz;                               // XCD-aware block remap (set by the launcher)
 };
 int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 int wn_launch_pack(const float* flat, const int32_t* idx, uint16_t* out, int n, int is_bf16, int ns,
@@ -38,6 +39,7 @@ struct WnResArgs {
     // optional conditioning (wavenet_autoencoder/model1.py:183,227-247): [f;g] += cond[b][row][idx(t)]
     const float* cond; long cond_bstride; int cond_pitch;   // [B][2CH][cond_pitch]
     int cond_mode, cond_le, cond_q;                     // 1: idx = (t-t_lo)/cond_q (stretch); 2: idx = (t-t_lo) % cond_le (tile)
+    int swz;
 };
 int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);
 int wn_launch_resblock_fwd_nt(const WnResArgs& a, int ch, int batch, int mode, int nt, hipStream_t st);
@@ -55,6 +57,7 @@ struct WnResBwdArgs {
     int d, t_lo, t_hi, z_lo, t_base;
     const float* cond; long cond_bstride; int cond_pitch;   // as in WnResArgs (the recompute adds it too)
     int cond_mode, cond_le, cond_q;
+    int swz;
 };
 int wn_launch_resblock_bwd(const WnResBwdArgs& a, int ch, int batch, int mode_fwd, int mode_bwd,
                            hipStream_t st);
@@ -68,6 +71,7 @@ struct WnWgradArgs {
     float* c; int ldc;          // slab base: workgroup (b, chunk) writes C[mt*16][ldc] at c + slab*c_slab_stride
     long c_slab_stride;
     int t_lo, t_hi, t_base; int chunk;      // time range and per-WG chunk (multiple of 32)
+    int swz;
 };
 int wn_launch_wgrad(const WnWgradArgs& a, int batch, int mode, hipStream_t st);
 int wn_launch_wgrad2(const WnWgradArgs* a1, const WnWgradArgs* a2, int batch, int mode, hipStream_t st);

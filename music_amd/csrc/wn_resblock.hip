@@ -34,8 +34,9 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_fwd_k(WnResArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.y;
-    const int t0 = a.t_base + blockIdx.x * WN_RES_COLS + wave * 64;
+    const WnBlock blk = wn_block(a.swz);
+    const int b = blk.y;
+    const int t0 = a.t_base + blk.x * WN_RES_COLS + wave * 64;
     const int tl = t0 + 4 * c;
 
     const float* xin = a.x_in + (size_t)b * a.x_bstride;
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_fwd_k(WnResArgs a) {
 template <class T, int NS>
 static int launch_fwd(const WnResArgs& a, int ch, int batch, hipStream_t st) {
     WnResArgs k = a;
+    k.swz = wn_xcd_swizzle_enabled();
     k.t_base = a.t_lo & ~3;
     int ncol = a.t_hi - k.t_base;
     dim3 g((ncol + WN_RES_COLS - 1) / WN_RES_COLS, batch), b(WN_RES_THREADS);
@@ -267,8 +269,9 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_bwd_k(WnResBwdArgs a)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.y;
-    const int t0 = a.t_base + blockIdx.x * WN_RES_COLS + wave * 64;
+    const WnBlock blk = wn_block(a.swz);
+    const int b = blk.y;
+    const int t0 = a.t_base + blk.x * WN_RES_COLS + wave * 64;
     const int tl = t0 + 4 * c;
     const float* xin = a.x_in + (size_t)b * a.x_bstride;
     const bool aligned_d = (a.d & 3) == 0;
@@ -416,6 +419,7 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_bwd_k(WnResBwdArgs a)
 template <class TF, int NSF, class TB, int NSB>
 static int launch_bwd(const WnResBwdArgs& a, int ch, int batch, hipStream_t st) {
     WnResBwdArgs k = a;
+    k.swz = wn_xcd_swizzle_enabled();
     k.t_base = a.t_lo & ~3;
     int ncol = a.t_hi - k.t_base;
     dim3 g((ncol + WN_RES_COLS - 1) / WN_RES_COLS, batch), b(WN_RES_THREADS);

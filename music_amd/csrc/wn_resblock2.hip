@@ -60,8 +60,9 @@ __global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnRes
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.y;
-    const int t0 = a.t_base + blockIdx.x * COLS + wave * (16 * NT);
+    const WnBlock blk = wn_block(a.swz);
+    const int b = blk.y;
+    const int t0 = a.t_base + blk.x * COLS + wave * (16 * NT);
     const int tl = t0 + NT * c;
 
     const float* xin = a.x_in + (size_t)b * a.x_bstride;
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnRes
 template <class T, int NS, int NT>
 static int launch_fwd_nt(const WnResArgs& a, int ch, int batch, hipStream_t st) {
     WnResArgs k = a;
+    k.swz = wn_xcd_swizzle_enabled();
     k.t_base = a.t_lo & ~3;
     const int ncol = a.t_hi - k.t_base;
     constexpr int COLS = NtCfg<NT>::WAVES * 16 * NT;

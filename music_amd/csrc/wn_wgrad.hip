@@ -12,6 +12,7 @@
 // chip-wide atomic rate, ~1.3 TB/s, would dominate, and the result would depend on arrival
 // order); wn_reduce_slabs sums the slabs in a fixed order, so weight gradients are bit-reproducible.
 // Gradients are split in bf16 (fp32 exponent range); see wn_common.h for the x3 scheme.
+#include <type_traits>
 #include "wn_common.h"
 #include "wn_kernels.h"
 
@@ -46,12 +47,13 @@ struct WnWgradPair { WnWgradArgs p[2]; int y_split; };
 template <class T, int NS>
 __global__ __launch_bounds__(256) void wgrad_k(WnWgradPair pr) {
     __shared__ float red[3][64 * 64];              // only used by the split-in-time (single block) form
-    const bool second = (int)blockIdx.y >= pr.y_split;
+    const WnBlock wb = wn_block(pr.p[0].swz);
+    const bool second = wb.y >= pr.y_split;
     const WnWgradArgs& a = pr.p[second ? 1 : 0];
-    const int by = second ? blockIdx.y - pr.y_split : blockIdx.y;
+    const int by = second ? wb.y - pr.y_split : wb.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.z;
+    const int b = wb.z;
     const int nt_total = a.nt_per_tap * (a.b1 ? 2 : 1);
     const int nblk_n = (nt_total + 3) / 4, nblk_m = (a.mt + 3) / 4;
     const int nblk = nblk_n * nblk_m;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void wgrad_k(WnWgradPair pr) {
     const int blk = split_time ? 0 : by * 4 + wave;
     const bool active = blk < nblk;
     const int mb = active ? blk / nblk_n : 0, nb = active ? blk % nblk_n : 0;
-    int tc0 = a.t_base + blockIdx.x * a.chunk;
+    int tc0 = a.t_base + wb.x * a.chunk;
     int tc1 = tc0 + a.chunk;
     if (tc1 > a.t_hi) tc1 = a.t_hi;
     const int n_chunks = (a.t_hi - a.t_base + a.chunk - 1) / a.chunk;     // grid.x may be larger (paired launch)
@@ -100,12 +102,32 @@ __global__ __launch_bounds__(256) void wgrad_k(WnWgradPair pr) {
 
     if (active && tc0 < tc1) {
         WgRaw ra[4], rb[4];
+        // [tb_lo, tb_hi]: k-steps whose 32 samples are addressable in every operand row
+        const int bs1 = a.b1 ? a.b_shift1 : a.b_shift0;
+        const int tb_lo = -min(a.a_shift, min(a.b_shift0, bs1));
+        const int tb_hi = min(a.a_cols - a.a_shift, a.b_cols - max(a.b_shift0, bs1)) - 32;
         auto issue = [&](int tb) {
             const int t = tb + 8 * q;
+            const int tbu = __builtin_amdgcn_readfirstlane(tb);
+            if (tbu >= tb_lo && tbu <= tb_hi) {         // wave-uniform: plain 16-B loads
 #pragma unroll
-            for (int m = 0; m < 4; ++m) ra[m] = wg_load(arow[m], t + a.a_shift, a.a_cols);
+                for (int m = 0; m < 4; ++m) {
+                    const float* p = arow[m] + t + a.a_shift;
+                    ra[m].u0 = ld4u(p);
+                    ra[m].u1 = ld4u(p + 4);
+                }
 #pragma unroll
-            for (int n = 0; n < 4; ++n) rb[n] = wg_load(brow[n], t + bshift[n], a.b_cols);
+                for (int n = 0; n < 4; ++n) {
+                    const float* p = brow[n] + t + bshift[n];
+                    rb[n].u0 = ld4u(p);
+                    rb[n].u1 = ld4u(p + 4);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) ra[m] = wg_load(arow[m], t + a.a_shift, a.a_cols);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) rb[n] = wg_load(brow[n], t + bshift[n], a.b_cols);
+            }
         };
         issue(tc0);
         for (int tb = tc0; tb < tc1; tb += 32) {
@@ -146,8 +168,8 @@ __global__ __launch_bounds__(256) void wgrad_k(WnWgradPair pr) {
     }
     if (!active) return;
     // slab of this workgroup: plain stores, every element of the block is written
-    if ((int)blockIdx.x >= n_chunks) return;
-    float* cs = a.c + ((size_t)b * n_chunks + blockIdx.x) * a.c_slab_stride;
+    if (wb.x >= n_chunks) return;
+    float* cs = a.c + ((size_t)b * n_chunks + wb.x) * a.c_slab_stride;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         if (!mval[m]) continue;
@@ -185,11 +207,12 @@ __global__ __launch_bounds__(512) void wgrad_big_k(WnWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t l_f[];      // [2][32][FR]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.z;
+    const WnBlock wb = wn_block<true>(a.swz);       // output blocks over the same time chunk share an XCD
+    const int b = wb.z;
     const int nt_total = a.nt_per_tap * (a.b1 ? 2 : 1);
     const int n_ng = (nt_total + 15) / 16;
-    const int mg = blockIdx.y / n_ng, ng = blockIdx.y % n_ng;
-    const int tc0 = a.t_base + blockIdx.x * a.chunk;
+    const int mg = wb.y / n_ng, ng = wb.y % n_ng;
+    const int tc0 = a.t_base + wb.x * a.chunk;
     int tc1 = tc0 + a.chunk;
     if (tc1 > a.t_hi) tc1 = a.t_hi;
     const int wm = wave >> 2, wn = wave & 3;
@@ -222,11 +245,11 @@ __global__ __launch_bounds__(512) void wgrad_big_k(WnWgradArgs a) {
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     WgRaw raw[4];
-    auto issue = [&](int tb) {
-        const int t = tb + 8 * q;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) raw[k] = wg_load(lrow[k], t + lshift[k], lcols[k]);
-    };
+    // [tb_lo, tb_hi]: k-steps whose 32 samples are addressable in every operand row; the time loop
+    // exists twice (plain / guarded loads), chosen per workgroup chunk (see wgrad_k)
+    const int bs1 = a.b1 ? a.b_shift1 : a.b_shift0;
+    const int tb_lo = -min(a.a_shift, min(a.b_shift0, bs1));
+    const int tb_hi = min(a.a_cols - a.a_shift, a.b_cols - max(a.b_shift0, bs1)) - 32;
     auto park = [&](int buf, int tb) {
         const bool masked = (tb < a.t_lo) || (tb + 32 > tc1);
         const int t = tb + 8 * q;
@@ -244,31 +267,53 @@ __global__ __launch_bounds__(512) void wgrad_big_k(WnWgradArgs a) {
             if (NS == 3) dst[64 + lane] = __builtin_bit_cast(u32x4, f.lo);
         }
     };
-    if (tc0 < tc1) {
-        issue(tc0);
-        park(0, tc0);
-    }
-    __syncthreads();
-    int it = 0;
-    for (int tb = tc0; tb < tc1; tb += 32, ++it) {
-        const bool more = tb + 32 < tc1;
-        if (more) issue(tb + 32);
-        const uint16_t* base = l_f + (size_t)(it & 1) * 32 * FR;
-        Frag<T> bf[4];
+    auto run = [&](auto guarded) {
+        auto issue = [&](int tb) {
+            const int t = tb + 8 * q;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) load_a<T, NS>(bf[n], base, 16 + wn * 4 + n, lane);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            Frag<T> af;
-            load_a<T, NS>(af, base, wm * 8 + m, lane);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
+            for (int k = 0; k < 4; ++k) {
+                if (decltype(guarded)::value) {
+                    raw[k] = wg_load(lrow[k], t + lshift[k], lcols[k]);
+                } else {
+                    const float* p = lrow[k] + t + lshift[k];
+                    raw[k].u0 = ld4u(p);
+                    raw[k].u1 = ld4u(p + 4);
+                }
+            }
+        };
+        if (tc0 < tc1) {
+            issue(tc0);
+            park(0, tc0);
         }
-        if (more) park((it + 1) & 1, tb + 32);
         __syncthreads();
+        int it = 0;
+        const int tb_last = tc0 + ((tc1 - 1 - tc0) & ~31);
+        for (int tb = tc0; tb < tc1; tb += 32, ++it) {
+            const bool more = tb + 32 < tc1;
+            issue(more ? tb + 32 : tb_last);        // unconditional: see wgrad_k
+            __builtin_amdgcn_sched_barrier(0);      // keep the loads AHEAD of the MFMAs
+            const uint16_t* base = l_f + (size_t)(it & 1) * 32 * FR;
+            Frag<T> bf[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) load_a<T, NS>(bf[n], base, 16 + wn * 4 + n, lane);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                Frag<T> af;
+                load_a<T, NS>(af, base, wm * 8 + m, lane);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
+            }
+            park((it + 1) & 1, more ? tb + 32 : tb_last);      // (the last fill is never read)
+            __syncthreads();
+        }
+    };
+    {
+        const int last_tb = tc0 + ((tc1 - 1 - tc0) & ~31);
+        if (tc0 >= tb_lo && last_tb <= tb_hi) run(std::false_type{});
+        else run(std::true_type{});
     }
     const int n_chunks = (a.t_hi - a.t_base + a.chunk - 1) / a.chunk;
-    float* cs = a.c + ((size_t)b * n_chunks + blockIdx.x) * a.c_slab_stride;
+    float* cs = a.c + ((size_t)b * n_chunks + wb.x) * a.c_slab_stride;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int mt = mg * 16 + wm * 8 + m;
@@ -286,6 +331,7 @@ __global__ __launch_bounds__(512) void wgrad_big_k(WnWgradArgs a) {
 
 static void wg_prepare(WnWgradArgs& k, int& nchunks, int& ygroups) {
     k.t_base = k.t_lo & ~31;
+    k.swz = wn_xcd_swizzle_enabled();
     if (k.chunk < 128) k.chunk = 128;
     k.chunk = (k.chunk + 127) & ~127;
     const int nt_total = k.nt_per_tap * (k.b1 ? 2 : 1);

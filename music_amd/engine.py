@@ -103,6 +103,7 @@ class WaveNetEngine:
         # re-reads come from the Infinity Cache.  Kept opt-in ("what did not work").
         self.fused_bwd = False
         self._side = None
+        self.fine_marks = False
 
     def mark(self, name):
         """Record a timing event on the current stream (only when self.marks is a list)."""
@@ -110,6 +111,11 @@ class WaveNetEngine:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.marks.append((name, ev))
+
+    def fmark(self, name):
+        """Per-kernel timing marks of the epilogue (tools/kbench.py epi); off unless self.fine_marks."""
+        if self.fine_marks:
+            self.mark(name)
 
     # ------------------------------------------------------------------ parameters
     def _build_spec(self):
@@ -390,9 +396,11 @@ class WaveNetEngine:
             bias_s = ptr(ws["bias_skip"])
         call("wn_chan_gemm", ptr(ws["Z"], SLACK), None, zb, pitch, lo, T, 0, 0, N * CH // 32, 0, fr("skip"), SP // 16, self.S,
              ptr(ws["U"], SLACK), SP * pitch, pitch, 0, bias_s, None, 0, 0, 0, None, 0, 0, lo, T, 0, B, mf, st)
+        self.fmark("f_skip")
         call("wn_chan_gemm", ptr(ws["U"], SLACK), None, SP * pitch, pitch, lo, T, 0, 0, SP // 32, 0, fr("p1"), SP // 16, self.S,
              ptr(ws["H"], SLACK), SP * pitch, pitch, 0, self._bias_ptr("post_process_1.bias"),
              None, 0, 0, 0, None, 0, 0, lo, T, 1, B, mf, st)
+        self.fmark("f_p1")
         call("wn_chan_gemm", ptr(ws["H"], SLACK), None, SP * pitch, pitch, lo, T, 0, 0, SP // 32, 0, fr("p2"), Q // 16, Q,
              ptr(ws["O"]), Q * W, W, -lo, self._bias_ptr("post_process_2.bias"),
              None, 0, 0, 0, None, 0, 0, lo, T, 1, B, mf, st)
@@ -451,14 +459,19 @@ class WaveNetEngine:
 
         # weight gradients of the epilogue run on the side stream as soon as their operands exist
         wgrad_s("p2", dO, Q * W, W, -lo, W, H, None, sb, pitch, 0, 0, pitch, SP // 16, Q // 16, 1, SP, lo, T)
+        self.fmark("b_wgrad_p2")
         # dH = (P2^T dO) * [H > 0]
         call("wn_chan_gemm", dO, None, Q * W, W, 0, W, -lo, 0, Q // 32, 0, br("p2T"), SP // 16, self.S,
              dH, sb, pitch, 0, None, None, 0, 0, 0, H, sb, pitch, lo, T, 0, B, mb, st)
+        self.fmark("b_p2T")
         wgrad_s("p1", dH, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
+        self.fmark("b_wgrad_p1")
         # dU = (P1^T dH) * [U > 0]
         call("wn_chan_gemm", dH, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, br("p1T"), SP // 16, self.S,
              dU, sb, pitch, 0, None, None, 0, 0, 0, U, sb, pitch, lo, T, 0, B, mb, st)
+        self.fmark("b_p1T")
         wgrad_s("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CH // 16, SP // 16, 0, N * CH, lo, T)
+        self.fmark("b_wgrad_skip")
         # dZ = Ws^T dU   (all N crops at once)
         call("wn_chan_gemm", dU, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, br("skipT"), N * CH // 16, N * CH,
              dZ, zb, pitch, 0, None, None, 0, 0, 0, None, 0, 0, lo, T, 0, B, mb, st)

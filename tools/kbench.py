@@ -66,7 +66,8 @@ def main():
             per_layer.append(ev[0].elapsed_time(ev[1]) / args.reps * 1e3)
         res["resblock_fwd_us_by_layer"] = [round(v, 1) for v in per_layer]
         res["resblock_fwd_us_total"] = round(sum(per_layer), 1)
-    if args.what in ("bwd", "all"):
+    if args.what in ("bwd", "all", "epi"):
+        eng.fine_marks = args.what == "epi"
         eng.marks = []
         for _ in range(args.reps):
             eng.loss_and_grad(x, target)
