@@ -45,29 +45,34 @@ __device__ __forceinline__ void wg_frag(Frag<T>& f, const WgRaw& r, int t, int t
 struct WnWgradPair { WnWgradArgs p[2]; int y_split; };
 
 template <class T, int NS>
-__global__ __launch_bounds__(256) void wgrad_k(WnWgradPair pr) {
-    __shared__ float red[3][64 * 64];              // only used by the split-in-time (single block) form
+__global__ __launch_bounds__(512) void wgrad_k(WnWgradPair pr) {
+    // 8 waves: waves w and w + 4 own the same 64x64 block and split the chunk in time (a single-block
+    // problem is split 8 ways); the partial blocks are combined through LDS at the end.  A layer's
+    // launch has <= 256 workgroups, so the second set of waves is what fills each SIMD's issue slots
+    // while the first waits on its loads.
+    __shared__ float red[4][64 * 64];
     const WnBlock wb = wn_block(pr.p[0].swz);
     const bool second = wb.y >= pr.y_split;
     const WnWgradArgs& a = pr.p[second ? 1 : 0];
     const int by = second ? wb.y - pr.y_split : wb.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, q = lane >> 4;
     const int b = wb.z;
     const int nt_total = a.nt_per_tap * (a.b1 ? 2 : 1);
     const int nblk_n = (nt_total + 3) / 4, nblk_m = (a.mt + 3) / 4;
     const int nblk = nblk_n * nblk_m;
     const bool split_time = nblk == 1;
-    const int blk = split_time ? 0 : by * 4 + wave;
+    const int blk = split_time ? 0 : by * 4 + (wave & 3);
     const bool active = blk < nblk;
     const int mb = active ? blk / nblk_n : 0, nb = active ? blk % nblk_n : 0;
     int tc0 = a.t_base + wb.x * a.chunk;
     int tc1 = tc0 + a.chunk;
     if (tc1 > a.t_hi) tc1 = a.t_hi;
     const int n_chunks = (a.t_hi - a.t_base + a.chunk - 1) / a.chunk;     // grid.x may be larger (paired launch)
-    if (split_time) {                                   // quarter of the chunk per wave (multiple of 32)
-        const int sub = ((a.chunk / 4) + 31) & ~31;
-        tc0 += wave * sub;
+    {                                                   // this wave's share of the chunk (multiple of 32)
+        const int ts = split_time ? 8 : 2, part = split_time ? wave : (wave >> 2);
+        const int sub = ((a.chunk / ts) + 31) & ~31;
+        tc0 += part * sub;
         int e = tc0 + sub;
         if (e < tc1) tc1 = e;
     }
@@ -146,26 +151,31 @@ __global__ __launch_bounds__(256) void wgrad_k(WnWgradPair pr) {
         }
     }
 
-    if (split_time) {                                   // combine the 4 time quarters through LDS
-        if (wave > 0) {
+    // combine the time shares through LDS: waves 4..7 -> waves 0..3, then (single block) 1..3 -> 0
+    auto park = [&](int slot) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    *reinterpret_cast<f32x4*>(&red[wave - 1][((m * 4 + n) * 64 + lane) * 4]) = acc[m][n];
-        }
+            for (int n = 0; n < 4; ++n)
+                *reinterpret_cast<f32x4*>(&red[slot][((m * 4 + n) * 64 + lane) * 4]) = acc[m][n];
+    };
+    auto take = [&](int slot) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[m][n] += *reinterpret_cast<const f32x4*>(&red[slot][((m * 4 + n) * 64 + lane) * 4]);
+    };
+    if (wave >= 4) park(wave - 4);
+    __syncthreads();
+    if (wave < 4) take(wave);
+    if (split_time) {                  // (uniform over the workgroup) shares 1..3 -> wave 0
+        if (wave >= 1 && wave < 4) park(wave);          // slot w was read by wave w only: no hazard
         __syncthreads();
-        if (wave > 0) return;
-#pragma unroll
-        for (int w = 0; w < 3; ++w)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    f32x4 o = *reinterpret_cast<const f32x4*>(&red[w][((m * 4 + n) * 64 + lane) * 4]);
-                    acc[m][n] += o;
-                }
+        if (wave == 0) { take(1); take(2); take(3); }
+        if (wave != 0) return;
     }
+    if (wave >= 4) return;
     if (!active) return;
     // slab of this workgroup: plain stores, every element of the block is written
     if (wb.x >= n_chunks) return;
@@ -383,7 +393,7 @@ int wn_launch_wgrad2(const WnWgradArgs* a1, const WnWgradArgs* a2, int batch, in
         pr.p[1] = pr.p[0]; yg[1] = 0; nch[1] = 0;
     }
     pr.y_split = yg[0];
-    dim3 g(nch[0] > nch[1] ? nch[0] : nch[1], yg[0] + yg[1], batch), b(256);
+    dim3 g(nch[0] > nch[1] ? nch[0] : nch[1], yg[0] + yg[1], batch), b(512);
     switch (mode) {
         case WN_MODE_BF16X3: hipLaunchKernelGGL((wgrad_k<BF16, 3>), g, b, 0, st, pr); break;
         case WN_MODE_BF16X1: hipLaunchKernelGGL((wgrad_k<BF16, 1>), g, b, 0, st, pr); break;
