@@ -77,7 +77,8 @@ int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bst
 
 /* Fused gated residual block, backward recompute half (autograd of model.py:118-124, SURVEY
  * Appendix B): recomputes f,g,z from x_in; dz = Wd^T dy (+ dz_crop on t >= z_lo);
- * writes dfg = [df; dg] (2*ch rows) and z (ch rows) on [t_lo,t_hi).  dy may be NULL.
+ * writes dfg = [df; dg] (2*ch rows) and z (ch rows) on [t_lo,t_hi).  dy may be NULL; z may be NULL
+ * (the caller kept the forward's z, stored with z_lo = t_lo).
  * cond*: the conditioning table of wn_resblock_fwd (the recompute adds it as well); NULL = none. */
 int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* dfg, float* z,
                     int64_t x_bstride, int64_t dz_bstride, int64_t dfg_bstride, int64_t z_bstride,

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_bwd_k(WnResBwdArgs a)
     }
     const float* dzc = a.dz + (size_t)b * a.dz_bstride;
     float* dfg = a.dfg + (size_t)b * a.dfg_bstride;
-    float* zo = a.z + (size_t)b * a.z_bstride;
+    float* zo = a.z ? a.z + (size_t)b * a.z_bstride : nullptr;   // null: the caller keeps the forward's z
 #pragma unroll
     for (int m = 0; m < MT2; ++m)
 #pragma unroll
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_bwd_k(WnResBwdArgs a)
             }
             st4m(dfg + (size_t)row * a.pitch + tl, df, tl, a.t_lo, a.t_hi);
             st4m(dfg + (size_t)(CH + row) * a.pitch + tl, dg, tl, a.t_lo, a.t_hi);
-            st4m(zo + (size_t)row * a.pitch + tl, zz, tl, a.t_lo, a.t_hi);
+            if (a.z) st4m(zo + (size_t)row * a.pitch + tl, zz, tl, a.t_lo, a.t_hi);
         }
 }
 

@@ -104,6 +104,8 @@ class WaveNetEngine:
         self.fused_bwd = False
         self._side = None
         self.fine_marks = False
+        # the unfused backward reads the forward's z (stored on the full valid range) for dWd
+        self.z_from_fwd = True
 
     def mark(self, name):
         """Record a timing event on the current stream (only when self.marks is a list)."""
@@ -381,11 +383,14 @@ class WaveNetEngine:
              None, 0, 0, 0, None, 0, 0, 1, T, 0, B, mf, st)
         zb = N * CH * pitch
         self.mark("causal_fwd")
+        # z is stored on the block's WHOLE valid range [off_{i+1}, T), not only on the skip crop
+        # [rf-1, T): the backward's dWd product reads it from here instead of having the recompute
+        # kernel write a second copy (-1 activation-sized write per block and step, +19 % of z here)
         for i, d in enumerate(self.dil):
             bn = "dilation_layer_stack.%d.bias"
             call("wn_resblock_fwd", self._x(ws, i), self._x(ws, i + 1), ptr(ws["Z"], SLACK + i * CH * pitch), xb, zb, pitch,
                  fr("fg%d" % i), fr("d%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),
-                 self._bias_ptr(bn % (4 * i + 2)), self.D, self.R, CH, d, self.off[i + 1], T, self.rf - 1,
+                 self._bias_ptr(bn % (4 * i + 2)), self.D, self.R, CH, d, self.off[i + 1], T, self.off[i + 1],
                  1 if i < N - 1 else 0, None, 0, 0, 0, 0, 0, B, mf, st)
         self.mark("stack_fwd")
         lo = self.rf - 1
@@ -507,6 +512,7 @@ class WaveNetEngine:
             bn = "dilation_layer_stack.%d.bias"
             if overlap and ev_w[k] is not None:
                 main.wait_event(ev_w[k])
+            zs = None if self.z_from_fwd else zs
             call("wn_resblock_bwd", self._x(ws, i), dy, ptr(bw["dZ"], SLACK + i * CH * pitch), dfg, zs,
                  xb, zb, 2 * CH * pitch, xb, pitch, fr("fg%d" % i), br("dT%d" % i),
                  self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)), self.D, CH, d, t_lo, T, lo,
@@ -522,7 +528,8 @@ class WaveNetEngine:
                      CH // 16, 2 * CH // 16, 0, ptr(bw["slab"], so), 2 * CH, n, t_lo, T, chunk, B, mb, st2)
                 if i < N - 1:
                     so, n, chunk = plan["d%d" % i]
-                    call("wn_wgrad", dy, xb, pitch, 0, pitch, zs, None, xb, pitch, 0, 0, pitch, CH // 16, CH // 16, 0,
+                    zsrc, zstr = (ptr(ws["Z"], SLACK + i * CH * pitch), zb) if self.z_from_fwd else (zs, xb)
+                    call("wn_wgrad", dy, xb, pitch, 0, pitch, zsrc, None, zstr, pitch, 0, 0, pitch, CH // 16, CH // 16, 0,
                          ptr(bw["slab"], so), CH, n, t_lo, T, chunk, B, mb, st2)
                 if self.use_bias:
                     bo = self.gp_bias_off
