@@ -256,7 +256,7 @@ class _AutoencoderEngine:
             bf = bias_fg + 4 * Dd if bias_fg is not None else None      # filter_gate bias: gate rows first
             call("wn_resblock_fwd", xd(i), xd(i + 1), ptr(ws["Z"], SLACK + i * CHd * pitch), db, zb, pitch,
                  fr("de_fg%d" % i), fr("de_d%d" % i), bf, bias_fg, self._bias(bn % (3 * i + 1)), Dd, self.Rd, CHd, d,
-                 t_lo, T, lo, 1 if i < N - 1 else 0, ptr(tab[i]), 2 * CHd * Le, Le, mode_c, Le, q, B, m, st)
+                 t_lo, T, t_lo, 1 if i < N - 1 else 0, ptr(tab[i]), 2 * CHd * Le, Le, mode_c, Le, q, B, m, st)   # z on the whole valid range: the backward's dWd reads it
         ws["cmodes"] = cmodes
         U, R1, C1 = ptr(ws["U"], SLACK), ptr(ws["R1"], SLACK), ptr(ws["C1"], SLACK)
         sb = SP * pitch
@@ -293,7 +293,7 @@ class _AutoencoderEngine:
 
         bw = dict(dO=torch.zeros(B * self.Q * W + PAD_BACK, dtype=torch.float32, device=dev),
                   dR1=buf(self.SP), dU=buf(self.SP), dZ=buf(N * self.CHd), dXd=[buf(self.CHd), buf(self.CHd)],
-                  dfg=buf(2 * self.CHd), zs=buf(self.CHd), dE=buf(self.BwP), dXe=[buf(self.CHe), buf(self.CHe)],
+                  dfg=buf(2 * self.CHd), dE=buf(self.BwP), dXe=[buf(self.CHe), buf(self.CHe)],
                   dHe=buf(self.CHe))
         lo = self.rf - 1
         ops = [("c2", lo, T, 1024), ("c1", lo, T, 1024), ("skip", lo, T, 2048), ("bottleneck", lo, T, 512),
@@ -361,13 +361,13 @@ class _AutoencoderEngine:
              NONE3, lo, T, 0)
         # ---- decoder stack
         xd = lambda i: self._lay(ws["Xd"], i, CHd, ws)
-        dfg, zs = ptr(bw["dfg"], SLACK), ptr(bw["zs"], SLACK)
+        dfg = ptr(bw["dfg"], SLACK)
         d_tab = torch.zeros(N, B, 2 * CHd, Le, dtype=torch.float32, device=self.device)
         for i in range(N - 1, -1, -1):
             d, t_lo = self.dil[i], self.off[i + 1]
             dy = ptr(bw["dXd"][(i + 1) % 2], SLACK) if i < N - 1 else None
             mode_c, q = ws["cmodes"][i]
-            call("wn_resblock_bwd", xd(i), dy, ptr(bw["dZ"], SLACK + i * CHd * pitch), dfg, zs,
+            call("wn_resblock_bwd", xd(i), dy, ptr(bw["dZ"], SLACK + i * CHd * pitch), dfg, None,
                  db, zb, 2 * CHd * pitch, db, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), None, None, Dd, CHd, d, t_lo, T, lo,
                  ptr(ws["tab"][i]), 2 * CHd * Le, Le, mode_c, Le, max(q, 1), B, mf, mb, st)
             call("wn_cond_grad", dfg, 2 * CHd * pitch, pitch, 2 * CHd, t_lo, T, mode_c, Le, max(q, 1),
@@ -375,7 +375,8 @@ class _AutoencoderEngine:
             wgrad("de_fg%d" % i, dfg, 2 * CHd * pitch, pitch, 0, pitch, xd(i), xd(i), db, pitch, -d, 0, pitch,
                   CHd // 16, 2 * CHd // 16, 0, 2 * CHd, t_lo, T)
             if i < N - 1:
-                wgrad("de_d%d" % i, dy, db, pitch, 0, pitch, zs, None, db, pitch, 0, 0, pitch, CHd // 16, CHd // 16, 0, CHd, t_lo, T)
+                wgrad("de_d%d" % i, dy, db, pitch, 0, pitch, ptr(ws["Z"], SLACK + i * CHd * pitch), None, zb, pitch, 0, 0, pitch,
+                      CHd // 16, CHd // 16, 0, CHd, t_lo, T)
             gemm("de_fgT%d" % i, dfg, dfg, 2 * CHd * pitch, pitch, t_lo, T, 0, d, 2 * CHd // 32, 2 * CHd // 32, CHd // 16, Rd,
                  ptr(bw["dXd"][i % 2], SLACK), db, pitch, 0, None, (dy, db, pitch, t_lo) if dy else NONE3, NONE3, self.off[i], T, 0)
         x = ws["x_in"]
