@@ -40,6 +40,8 @@ SIGNATURES = {
     "wn_resblock_bwd_fused": [_p, _p, _p, _p, _p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i,
                               _p, _p, _i, _i, _i, _i, _p],
     "wn_resblock_bwd_fused_tiles": [_i, _i],
+    "wn_resblock_bwd_ms": [_p, _p, _p, _p, _l, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p],
+    "wn_resblock_bwd_ms_slabs": [_i, _i, _i],
     "wn_shift_add": [_p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_wgrad": [_p, _p, _p, _p, _l, _l, _l, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p],
     "wn_reduce_slabs": [_p, _i, _l, _p, _p, _p],
@@ -95,6 +97,11 @@ def wgrad_slabs(t_lo, t_hi, chunk, batch):
 
 def fused_tiles(t_lo, t_hi):
     return load().wn_resblock_bwd_fused_tiles(t_lo, t_hi)
+
+
+def ms_slabs(t_lo, t_hi, batch):
+    """Number of slabs one wn_resblock_bwd_ms call writes (plain int return, not a status)."""
+    return load().wn_resblock_bwd_ms_slabs(t_lo, t_hi, batch)
 
 
 def call(name, *args):

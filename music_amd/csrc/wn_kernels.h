@@ -62,6 +62,21 @@ struct WnResBwdArgs {
 int wn_launch_resblock_bwd(const WnResBwdArgs& a, int ch, int batch, int mode_fwd, int mode_bwd,
                            hipStream_t st);
 
+// channel-split backward of one block with both weight gradients in the launch (wn_resms.hip)
+struct WnResMsArgs {
+    const float* x_in; const float* dy; const float* dz;   // x_i, d x_{i+1} (null for the last block), d z-crop slice
+    float* dfg;                                            // out: [B][2CH][pitch]
+    long x_bstride, dz_bstride, dfg_bstride; int pitch;
+    const uint16_t* wfg; const uint16_t* wdT;              // forward fg pack (f16x3), Wd^T pack (bf16x3)
+    const float* bias_f; const float* bias_g; int n_f;
+    float* slab_fg; float* slab_d;                         // one slab per workgroup: [2CH][2CH] and [CH][CH]
+    int d, t_lo, t_hi, z_lo, t_base;
+    int steps_per_clip, items_per_wg, batch;               // set by the launcher
+    int swz;
+};
+int wn_launch_resblock_bwd_ms(const WnResMsArgs& a, int ch, int batch, int mode_fwd, int mode_bwd, hipStream_t st);
+int wn_resms_slabs(int t_lo, int t_hi, int batch);
+
 struct WnWgradArgs {
     const float* a; long a_bstride; int a_pitch; int a_shift; int a_cols;   // A: [M rows][time]
     const float* b0; const float* b1; long b_bstride; int b_pitch; int b_shift0, b_shift1; int b_cols;

@@ -10,6 +10,7 @@ per-(batch, length) workspaces, and sequences the C-ABI kernels of libwavenet_hi
 PyTorch is used for device memory and streams only.  Nothing here imports oracle/.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -102,6 +103,9 @@ class WaveNetEngine:
         # 512 KB-per-workgroup scratch tile does not fit the 128 KB-per-CU share of the XCD's L2, so the
         # re-reads come from the Infinity Cache.  Kept opt-in ("what did not work").
         self.fused_bwd = False
+        # Channel-split backward block with both weight gradients in the launch (wn_resblock_bwd_ms):
+        # 64 padded channels, (f16x3, bf16x3) only; None = decided by _use_ms()
+        self.ms_bwd = None
         self._side = None
         self.fine_marks = False
         # the unfused backward reads the forward's z (stored on the full valid range) for dWd
@@ -331,11 +335,13 @@ class WaveNetEngine:
         # one batched kernel then sums the slabs of all ops in a fixed order (deterministic)
         T, lo = ws["T"], self.rf - 1
         fused = self.fused_bwd
+        ms = self._use_ms() and not fused
+        bw["ms"] = ms
         ops = [("p2", lo, T, 1024), ("p1", lo, T, 1024), ("skip", lo, T, 2048)]
         for i in range(self.N):
-            ops.append(("fg%d" % i, self.off[i + 1], T, 0 if fused else 512))
+            ops.append(("fg%d" % i, self.off[i + 1], T, 0 if fused else (-1 if ms else 512)))
             if i < self.N - 1:
-                ops.append(("d%d" % i, self.off[i + 1], T, 0 if fused else 512))
+                ops.append(("d%d" % i, self.off[i + 1], T, 0 if fused else (-1 if ms else 512)))
         ops.append(("causal", 1, T, 512))
         if fused:
             tiles = max(_lib.fused_tiles(self.off[i + 1], T) for i in range(self.N))
@@ -346,7 +352,12 @@ class WaveNetEngine:
             go, r, c = self.gp_off[name]
             n = r * c
             # chunk 0: the fused backward writes one slab per 512-column workgroup tile
-            ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B) if chunk else _lib.fused_tiles(t_lo, t_hi) * B
+            if chunk > 0:
+                ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B)
+            elif chunk < 0:                                   # channel-split block: one slab per workgroup
+                ns = _lib.ms_slabs(t_lo, t_hi, B)
+            else:
+                ns = _lib.fused_tiles(t_lo, t_hi) * B
             plan[name] = (so, n, chunk)
             desc.append([vs, so, ns, n, go, n])
             so += ns * n
@@ -356,6 +367,14 @@ class WaveNetEngine:
         bw["slab_desc"] = torch.tensor(desc, dtype=torch.int64, device=dev)
         ws["bwd"] = bw
         return bw
+
+    def _use_ms(self):
+        ok = self.CH == 64 and self.mode_fwd == _lib.F16X3 and self.mode_bwd == _lib.BF16X3
+        if self.ms_bwd is None:
+            return ok and os.environ.get("WN_MS_BWD", "0") == "1"
+        if self.ms_bwd and not ok:
+            raise NotImplementedError("ms_bwd needs 64 padded channels and precision (f16x3, bf16x3)")
+        return bool(self.ms_bwd)
 
     def _x(self, ws, i):
         return ptr(ws["X"], SLACK + i * ws["B"] * self.CH * ws["pitch"])
@@ -512,6 +531,22 @@ class WaveNetEngine:
             bn = "dilation_layer_stack.%d.bias"
             if overlap and ev_w[k] is not None:
                 main.wait_event(ev_w[k])
+            if bw["ms"]:
+                call("wn_resblock_bwd_ms", self._x(ws, i), dy, ptr(bw["dZ"], SLACK + i * CH * pitch), dfg, xb, zb, 2 * CH * pitch,
+                     pitch, fr("fg%d" % i), br("dT%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),
+                     self.D, CH, d, t_lo, T, lo, ptr(bw["slab"], plan["fg%d" % i][0]),
+                     ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None, B, mf, mb, st)
+                if self.use_bias:
+                    bo = self.gp_bias_off
+                    call("wn_bias_grad", dfg, 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i)]), st)
+                    call("wn_bias_grad", ptr(bw["dfg"][k], SLACK + CH * pitch), 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B,
+                         ptr(self.gpack, bo[bn % (4 * i + 1)]), st)
+                    if i < N - 1:
+                        call("wn_bias_grad", dy, xb, pitch, 0, self.R, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i + 2)]), st)
+                call("wn_chan_gemm", dfg, dfg, 2 * CH * pitch, pitch, t_lo, T, 0, d, 2 * CH // 32, 2 * CH // 32, br("fgT%d" % i),
+                     CH // 16, self.R, ptr(bw["dX"][i % 2], SLACK), xb, pitch, 0, None,
+                     dy, xb, pitch, t_lo, None, 0, 0, self.off[i], T, 0, B, mb, st)
+                continue
             zs = None if self.z_from_fwd else zs
             call("wn_resblock_bwd", self._x(ws, i), dy, ptr(bw["dZ"], SLACK + i * CH * pitch), dfg, zs,
                  xb, zb, 2 * CH * pitch, xb, pitch, fr("fg%d" % i), br("dT%d" % i),

@@ -333,6 +333,46 @@ def test_grads_64_channels_vs_oracle(fused):
     assert torch.equal(g1, eng.flat_grad)
 
 
+@pytest.mark.parametrize("bias", [False, True])
+def test_grads_64_channels_channel_split_block(bias):
+    """The channel-split backward block (wn_resblock_bwd_ms: both weight gradients inside the block
+    launch, df/dg/z transposed on the matrix core): loss and every gradient vs the oracle, on tiles
+    that straddle the 64-column steps and the workgroups' item runs, with a dilation that is not a
+    multiple of 4 (unaligned shifted tap) and ragged real channel counts inside the 64 padded ones."""
+    from music_amd.model import wavenet
+    cfg = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 512, 3], dilation_channels=56 if bias else 64,
+               residual_channels=64 if bias else 60, skip_channels=96, quantization_channels=256, use_bias=bias)
+    torch.manual_seed(21)
+    net = wavenet(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.5)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    rng = np.random.default_rng(22)
+    T = net.receptive_field + 1100
+    x = scrambled_input(rng.integers(0, 256, size=(3, T)))
+    target = torch.from_numpy(rng.integers(0, 256, size=(3 * 1101,)).astype(np.int64))
+    net(x[:, :, :net.receptive_field].cuda())
+    eng = net._engine
+    eng.ms_bwd = True
+    eng._ws.clear()                      # the backward workspace plan depends on the flag
+    loss = eng.loss_and_grad(x.cuda(), target.cuda())
+    l_ref, p_ref, g_ref = wo.loss_and_grads(params, cfg["dilations"], x, target)
+    assert abs(loss.item() - l_ref.item()) < 1e-4
+    floor = 1e-3 * max(g.abs().max().item() for g in g_ref.values())
+    worst = 0.0
+    for name in eng.param_names:
+        g = g_ref[name]
+        err = (eng.param_view(name, grad=True).cpu() - g).abs().max().item() / max(g.abs().max().item(), floor)
+        worst = max(worst, err)
+        assert err <= GRAD_RTOL, (name, err)
+    print("channel-split block (bias=%s): worst relative grad err %.2e" % (bias, worst))
+    g1 = eng.flat_grad.clone()
+    eng.loss_and_grad(x.cuda(), target.cuda())
+    assert torch.equal(g1, eng.flat_grad)            # still bit-reproducible
+
+
 def test_decode_config5_vs_oracle():
     """BASELINE config 5 shape (30 blocks, 64/64/256): the float4 persistent decode kernel vs the
     oracle's cached-queue recurrence - argmax ids exact, probabilities within 1e-4."""
