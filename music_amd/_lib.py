@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwavenet_hip.so")
+# WAVENET_HIP_LIB: developer override (kernel experiments built next to the product library)
+LIB_PATH = os.environ.get("WAVENET_HIP_LIB") or os.path.join(_HERE, "libwavenet_hip.so")
 
 F16X3, F16X1, BF16X3, BF16X1 = 0, 1, 2, 3
 MODE_NAMES = {"f16x3": F16X3, "f16x1": F16X1, "bf16x3": BF16X3, "bf16x1": BF16X1}

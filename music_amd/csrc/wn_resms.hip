@@ -37,6 +37,7 @@ __device__ __forceinline__ void ms_store_frag(uint16_t* base, int idx, int lane,
     p[64] = __builtin_bit_cast(u32x4, f.lo);
 }
 
+template <bool HAS_DY>
 __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
     constexpr int CH = MS_CH;
     constexpr int FR = 1024;                                   // halfs per x3 fragment
@@ -48,8 +49,8 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
 
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, q = lane >> 4;
-    const bool has_dy = a.dy != nullptr;
-    const bool has_d = has_dy && a.slab_d != nullptr;
+    constexpr bool has_dy = HAS_DY;                            // false: last block (no dz product, no dWd)
+    constexpr bool has_d = HAS_DY;
 
     // ---- stationary weights of this wave's 16 dilation channels
     Frag<F16> wf[4], wg[4];
@@ -59,8 +60,10 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
         load_a<F16, 3>(wf[s], a.wfg, g * 4 + s, lane);
         load_a<F16, 3>(wg[s], a.wfg, (4 + g) * 4 + s, lane);
     }
+    if (has_dy) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) load_a<BF16, 3>(wd[s], a.wdT, g * 2 + s, lane);
+        for (int s = 0; s < 2; ++s) load_a<BF16, 3>(wd[s], a.wdT, g * 2 + s, lane);
+    }
     // selection matrices of the in-register transposition (B operands): S0 picks k-slot (q = n>>2, j = n&3),
     // S1 picks (q = n>>2, j = 4 + (n&3)), n = lane & 15
     BF16::vec8 s0, s1;
@@ -104,14 +107,22 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
     const float* dy_or_x = has_dy ? a.dy : a.x_in;      // loads stay unconditional (see above)
     struct RawXD { f32x4 x[8]; f32x4 dy[4]; };
     struct RawWO { f32x4 v[3][4]; };
-    auto item_pos = [&](int it, int& b, int& t0) {
+    struct Pos { int b, t0; };
+    auto pos_of = [&](int it) {
         it = it < item_end ? it : item_end - 1;
-        b = it / a.steps_per_clip;
-        t0 = a.t_base + 64 * (it - b * a.steps_per_clip);
+        Pos p;
+        p.b = it / a.steps_per_clip;
+        p.t0 = a.t_base + 64 * (it - p.b * a.steps_per_clip);
+        return p;
     };
-    auto load_xd = [&](RawXD& r, int it) {
-        int b, t0;
-        item_pos(it, b, t0);
+    auto next_pos = [&](Pos p, int it_next) {                 // position of item it_next = (item of p) + 1, clamped
+        if (it_next >= item_end) return p;
+        p.t0 += 64;
+        if (p.t0 >= a.t_base + 64 * a.steps_per_clip) { p.t0 = a.t_base; p.b += 1; }
+        return p;
+    };
+    auto load_xd = [&](RawXD& r, Pos ps) {
+        const int b = ps.b, t0 = ps.t0;
         const int tl = t0 + 4 * c;
         const float* xin = a.x_in + (size_t)b * a.x_bstride;
         const int tap = g >> 1;                 // wave g converts k-step g = (tap g>>1, channel half g&1)
@@ -129,11 +140,10 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
             for (int j = 0; j < 4; ++j) r.dy[j] = ld4(pd + (size_t)j * a.pitch);
         }
     };
-    auto fill_xd = [&](const RawXD& r, int it) {
-        int b, t0;
-        item_pos(it, b, t0);
+    auto fill_xd = [&](const RawXD& r, Pos ps, int stage) {
+        const int t0 = ps.t0;
         const int tl = t0 + 4 * c;
-        uint16_t* xf = l_xf + (size_t)(it & 1) * 24 * FR;
+        uint16_t* xf = l_xf + (size_t)stage * 24 * FR;
         uint16_t* dyf = xf + 16 * FR;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -164,11 +174,10 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
         }
     };
     // "time on k" operands: row tile g of x(t-d), x(t) and dy; lane (row c, group q) owns samples t0+16q..+15
-    auto load_wo = [&](RawWO& r, int it) {
-        int b, t0;
-        item_pos(it, b, t0);
+    auto load_wo = [&](RawWO& r, Pos ps) {
+        const int b = ps.b, t0 = ps.t0;
 #pragma unroll
-        for (int kind = 0; kind < 3; ++kind) {
+        for (int kind = 0; kind < (has_d ? 3 : 2); ++kind) {
             const float* base = (kind == 2 ? dy_or_x : a.x_in) + (size_t)b * a.x_bstride;
             const float* p = base + (size_t)(16 * g + c) * a.pitch + t0 + 16 * q + (kind == 0 ? -a.d : 0);
             if (kind == 0 && !aligned_d) {
@@ -180,12 +189,10 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
             }
         }
     };
-    auto fill_wo = [&](const RawWO& r, int it) {
-        int b, t0;
-        item_pos(it, b, t0);
+    auto fill_wo = [&](const RawWO& r, Pos ps) {
+        const int t0 = ps.t0;
 #pragma unroll
-        for (int kind = 0; kind < 3; ++kind) {
-            if (kind == 2 && !has_d) continue;
+        for (int kind = 0; kind < (has_d ? 3 : 2); ++kind) {
             // k order of the transposed operands: slot j of k-step ks <-> sample 16q + 4(j&3) + 2ks + (j>>2)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -209,14 +216,16 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
     if (item0 < item_end) {
         RawXD rx;
         RawWO rw;
-        load_xd(rx, item0);
-        load_wo(rw, item0);
-        fill_xd(rx, item0);
-        load_xd(rx, item0 + 1);
+        Pos p_cur = pos_of(item0);
+        Pos p_n1 = next_pos(p_cur, item0 + 1);
+        load_xd(rx, p_cur);
+        load_wo(rw, p_cur);
+        fill_xd(rx, p_cur, item0 & 1);
+        load_xd(rx, p_n1);
         __syncthreads();
         for (int item = item0; item < item_end; ++item) {
-            int b, t0;
-            item_pos(item, b, t0);
+            const Pos p_n2 = next_pos(p_n1, item + 2);
+            const int b = p_cur.b, t0 = p_cur.t0;
             const int tl = t0 + 4 * c;
             // d z-crop rows of this item (used after the recompute MFMAs)
             const float* dzc = a.dz + (size_t)b * a.dz_bstride;
@@ -224,8 +233,8 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) cr[i] = ld4(dzc + (size_t)(16 * g + 4 * q + i) * a.pitch + tl);
             // stage of the NEXT item; then re-arm the registers two items ahead
-            fill_xd(rx, item + 1);
-            load_xd(rx, item + 2);
+            fill_xd(rx, p_n1, (item + 1) & 1);
+            load_xd(rx, p_n2);
 
             // ================= recompute f, g of channels 16g.. ; dz ; gate =================
             const uint16_t* xf = l_xf + (size_t)(item & 1) * 24 * FR;
@@ -281,8 +290,8 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
                 st4m(dfg + (size_t)(CH + row) * a.pitch + tl, sdg, tl, a.t_lo, a.t_hi);
             }
             __syncthreads();                    // A: every wave is past the products of the previous item
-            fill_wo(rw, item);
-            load_wo(rw, item + 1);
+            fill_wo(rw, p_cur);
+            load_wo(rw, p_n1);
             __syncthreads();                    // B: "time on k" operands of this item (and the next recompute stage) are in LDS
 
             // ================= transpose df, dg, z on the matrix core; weight-gradient products =================
@@ -300,11 +309,13 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
                     tdg[u][0] = BF16::mfma(a2.hi, s1, zero);
                     tdf[u][1] = BF16::mfma(a2.lo, s0, zero);
                     tdg[u][1] = BF16::mfma(a2.lo, s1, zero);
-                    float vz[8] = {zz[n][0], zz[n][1], zz[n][2], zz[n][3], 0.f, 0.f, 0.f, 0.f};
-                    Frag<BF16> a3;
-                    split8<BF16, 3>(a3, vz);
-                    tz[u][0] = BF16::mfma(a3.hi, s0, zero);
-                    tz[u][1] = BF16::mfma(a3.lo, s0, zero);
+                    if (has_d) {
+                        float vz[8] = {zz[n][0], zz[n][1], zz[n][2], zz[n][3], 0.f, 0.f, 0.f, 0.f};
+                        Frag<BF16> a3;
+                        split8<BF16, 3>(a3, vz);
+                        tz[u][0] = BF16::mfma(a3.hi, s0, zero);
+                        tz[u][1] = BF16::mfma(a3.lo, s0, zero);
+                    }
                 }
                 Frag<BF16> adf, adg, az;
 #pragma unroll
@@ -332,6 +343,8 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
                     }
                 }
             }
+            p_cur = p_n1;
+            p_n1 = p_n2;
         }
     }
 
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 sfg[(size_t)(h * CH + 16 * g + 4 * q + i) * (2 * CH) + nt * 16 + c] = cfg[h][nt][i];
-    if (has_d) {
+    if (has_d && a.slab_d) {
         float* sd = a.slab_d + (size_t)wgid * (CH * CH);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -386,11 +399,14 @@ int wn_launch_resblock_bwd_ms(const WnResMsArgs& a, int ch, int batch, int mode_
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((done >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_ms_k),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_ms_k<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_ms_k<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         done |= 1ull << dev;
     }
-    hipLaunchKernelGGL(resblock_bwd_ms_k, dim3(nwg), dim3(MS_THREADS), sh, st, k);
+    if (k.dy && k.slab_d) hipLaunchKernelGGL(resblock_bwd_ms_k<true>, dim3(nwg), dim3(MS_THREADS), sh, st, k);
+    else hipLaunchKernelGGL(resblock_bwd_ms_k<false>, dim3(nwg), dim3(MS_THREADS), sh, st, k);
     WN_CHECK_LAUNCH();
     return 0;
 }

@@ -104,7 +104,7 @@ class WaveNetEngine:
         # re-reads come from the Infinity Cache.  Kept opt-in ("what did not work").
         self.fused_bwd = False
         # Channel-split backward block with both weight gradients in the launch (wn_resblock_bwd_ms):
-        # 64 padded channels, (f16x3, bf16x3) only; None = decided by _use_ms()
+        # 64 padded channels, (f16x3, bf16x3) only; None = whenever it applies (WN_MS_BWD=0 turns it off)
         self.ms_bwd = None
         self._side = None
         self.fine_marks = False
@@ -371,7 +371,7 @@ class WaveNetEngine:
     def _use_ms(self):
         ok = self.CH == 64 and self.mode_fwd == _lib.F16X3 and self.mode_bwd == _lib.BF16X3
         if self.ms_bwd is None:
-            return ok and os.environ.get("WN_MS_BWD", "0") == "1"
+            return ok and os.environ.get("WN_MS_BWD", "1") == "1"
         if self.ms_bwd and not ok:
             raise NotImplementedError("ms_bwd needs 64 padded channels and precision (f16x3, bf16x3)")
         return bool(self.ms_bwd)
