@@ -89,7 +89,13 @@ __global__ __launch_bounds__(512) void chan_gemm_k(WnGemmArgs a) {
     const int t0u = __builtin_amdgcn_readfirstlane(t0);
     const bool inner0 = t0u + a.shift0 >= a.in_lo && t0u + 64 + a.shift0 <= a.in_hi;
     const bool inner1 = t0u + a.shift1 >= a.in_lo && t0u + 64 + a.shift1 <= a.in_hi;
-    auto issue = [&](f32x4* raw, int s) {
+    // Two taps of equal length are walked INTERLEAVED (tap 0 block j, tap 1 block j, ...): the two
+    // reads of one channel block (columns t + shift0 and t + shift1) are then back to back, so for
+    // small shift differences the second one finds its lines in L1/L2 instead of HBM.
+    const bool weave = a.ks1 == a.ks0;
+    auto kmap = [&](int s) { return weave ? ((s & 1) ? a.ks0 + (s >> 1) : (s >> 1)) : s; };
+    auto issue = [&](f32x4* raw, int s0) {
+        const int s = kmap(s0);
         const float* base; int col; int ch; bool inner;
         if (s < a.ks0) { base = in0; col = col0; ch = s * 32; inner = inner0; }
         else { base = in1; col = col1; ch = (s - a.ks0) * 32; inner = inner1; }
@@ -102,7 +108,8 @@ __global__ __launch_bounds__(512) void chan_gemm_k(WnGemmArgs a) {
             for (int j = 0; j < 8; ++j) raw[j] = ld4g(p + (size_t)j * a.in_pitch, col, a.in_lo, a.in_hi);
         }
     };
-    auto step = [&](f32x4* raw, int s) {
+    auto step = [&](f32x4* raw, int s0) {
+        const int s = kmap(s0);
         Frag<T> bf[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(512) void chan_gemm_k(WnGemmArgs a) {
             }
             split8<T, NS>(bf[n], v);
         }
-        if (s + PF < KS) issue(raw, s + PF);
+        if (s0 + PF < KS) issue(raw, s0 + PF);
         Frag<T> af[2];
         load_a<T, NS>(af[0], a.wpack, m0 * KS + s, lane);
 #pragma unroll
