@@ -40,7 +40,6 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_fwd_k(WnResArgs a) {
     const int tl = t0 + 4 * c;
 
     const float* xin = a.x_in + (size_t)b * a.x_bstride;
-    const bool aligned_d = (a.d & 3) == 0;
     // tap-0 column.  Lanes that own at least one valid output have tl - d >= -2 (t_lo >= d + 1);
     // every activation buffer is allocated with >= 64 floats of slack in front and >= 256 behind,
     // so the (masked-out) garbage columns are still addressable.
@@ -50,7 +49,7 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_fwd_k(WnResArgs a) {
     auto issue = [&](int s) {
         const int tap = s / KT, ch = (s % KT) * 32 + 8 * q;
         const float* p = xin + (size_t)ch * a.pitch + (tap == 0 ? colm : tl);
-        if (tap == 0 && !aligned_d) {
+        if (tap == 0) {        // always the alignment-free form for the shifted tap (no run-time merge of loaded registers)
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[j] = ld4u(p + (size_t)j * a.pitch);
         } else {
@@ -274,13 +273,12 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_bwd_k(WnResBwdArgs a)
     const int t0 = a.t_base + blk.x * WN_RES_COLS + wave * 64;
     const int tl = t0 + 4 * c;
     const float* xin = a.x_in + (size_t)b * a.x_bstride;
-    const bool aligned_d = (a.d & 3) == 0;
     const int colm = tl - a.d;          // see resblock_fwd_k
     f32x4 raw[8];
     auto issue = [&](int s) {
         const int tap = s / KT, ch = (s % KT) * 32 + 8 * q;
         const float* p = xin + (size_t)ch * a.pitch + (tap == 0 ? colm : tl);
-        if (tap == 0 && !aligned_d) {
+        if (tap == 0) {        // always the alignment-free form for the shifted tap (no run-time merge of loaded registers)
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[j] = ld4u(p + (size_t)j * a.pitch);
         } else {

@@ -66,7 +66,6 @@ __global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnRes
     const int tl = t0 + NT * c;
 
     const float* xin = a.x_in + (size_t)b * a.x_bstride;
-    const bool aligned_d = (a.d & (NT - 1)) == 0;
     // tap-0 column.  Lanes that own at least one valid output have tl - d >= -2 (t_lo >= d + 1);
     // every activation buffer is allocated with >= 64 floats of slack in front and >= 256 behind,
     // so the (masked-out) garbage columns are still addressable.
@@ -76,7 +75,10 @@ __global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnRes
     auto issue = [&](int s) {
         const int tap = s / KT, ch = (s % KT) * 32 + 8 * q;
         const float* p = xin + (size_t)ch * a.pitch + (tap == 0 ? colm : tl);
-        if (tap == 0 && !aligned_d) {
+        // the shifted tap is always loaded with the alignment-free form: choosing between the two forms
+        // at run time would merge the loaded registers across a branch, which the compiler implements as
+        // load -> wait -> copy, i.e. no prefetch at all
+        if (tap == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[j] = VecN<NT>::ldu(p + (size_t)j * a.pitch);
         } else {

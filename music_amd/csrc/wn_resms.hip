@@ -95,7 +95,6 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
     const int item0 = wgid * a.items_per_wg;
     int item_end = item0 + a.items_per_wg;
     if (item_end > total) item_end = total;
-    const bool aligned_d = (a.d & 3) == 0;
 
     // Software pipeline over the items (all loads unconditional on a clamped item index, so that no
     // loaded value is merged with an old register across a branch):
@@ -127,13 +126,8 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
         const float* xin = a.x_in + (size_t)b * a.x_bstride;
         const int tap = g >> 1;                 // wave g converts k-step g = (tap g>>1, channel half g&1)
         const float* p = xin + (size_t)(32 * (g & 1) + 8 * q) * a.pitch + (tap == 0 ? tl - a.d : tl);
-        if (tap == 0 && !aligned_d) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r.x[j] = ld4u(p + (size_t)j * a.pitch);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r.x[j] = ld4(p + (size_t)j * a.pitch);
-        }
+        for (int j = 0; j < 8; ++j) r.x[j] = ld4u(p + (size_t)j * a.pitch);      // alignment-free form, branch-free (see above)
         {                                       // dy rows 4(g&1).. of k-step g>>1 (last block: dummy rows of x, unused)
             const float* pd = dy_or_x + (size_t)b * a.x_bstride + (size_t)(32 * (g >> 1) + 8 * q + 4 * (g & 1)) * a.pitch + tl;
 #pragma unroll
@@ -180,13 +174,8 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
         for (int kind = 0; kind < (has_d ? 3 : 2); ++kind) {
             const float* base = (kind == 2 ? dy_or_x : a.x_in) + (size_t)b * a.x_bstride;
             const float* p = base + (size_t)(16 * g + c) * a.pitch + t0 + 16 * q + (kind == 0 ? -a.d : 0);
-            if (kind == 0 && !aligned_d) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r.v[kind][e] = ld4u(p + 4 * e);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) r.v[kind][e] = ld4(p + 4 * e);
-            }
+            for (int e = 0; e < 4; ++e) r.v[kind][e] = ld4u(p + 4 * e);
         }
     };
     auto fill_wo = [&](const RawWO& r, Pos ps) {
@@ -246,24 +235,35 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
                 ag[n] = f32x4{bias_g[0], bias_g[1], bias_g[2], bias_g[3]};
                 dz[n] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            {   // the next fragment is on its way from LDS while the matrix core works on this one
+                Frag<F16> bx[2];
+                load_a<F16, 3>(bx[0], xf, 0, lane);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    Frag<F16> bx;
-                    load_a<F16, 3>(bx, xf, s * 4 + n, lane);
-                    mma<F16, 3>(af[n], wf[s], bx);
-                    mma<F16, 3>(ag[n], wg[s], bx);
+                for (int idx = 0; idx < 16; ++idx) {
+                    if (idx + 1 < 16) load_a<F16, 3>(bx[(idx + 1) & 1], xf, idx + 1, lane);
+                    mma<F16, 3>(af[idx & 3], wf[idx >> 2], bx[idx & 1]);
+                    mma<F16, 3>(ag[idx & 3], wg[idx >> 2], bx[idx & 1]);
                 }
+#ifndef MS_NO_SGB
+                // pin the order "read fragment i+1 (2 x ds_read_b128), then the 6 MFMAs of fragment i": left to
+                // itself the scheduler puts each read right in front of its MFMAs and the LDS latency shows
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int idx = 0; idx < 15; ++idx) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#endif
+            }
             if (has_dy) {
+                Frag<BF16> by[2];
+                load_a<BF16, 3>(by[0], dyf, 0, lane);
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        Frag<BF16> by;
-                        load_a<BF16, 3>(by, dyf, s * 4 + n, lane);
-                        mma<BF16, 3>(dz[n], wd[s], by);
-                    }
+                for (int idx = 0; idx < 8; ++idx) {
+                    if (idx + 1 < 8) load_a<BF16, 3>(by[(idx + 1) & 1], dyf, idx + 1, lane);
+                    mma<BF16, 3>(dz[idx & 3], wd[idx >> 2], by[idx & 1]);
+                }
             }
             float* dfg = a.dfg + (size_t)b * a.dfg_bstride;
             float df[4][4], dg[4][4], zz[4][4];                      // [n][i]
@@ -327,19 +327,19 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
                     az.hi[j] = BF16::cvt(tz[j >> 2][0][j & 3]);
                     az.lo[j] = BF16::cvt(tz[j >> 2][1][j & 3]);
                 }
+                {
+                    constexpr int NTILES = has_d ? 12 : 8;
+                    Frag<BF16> bo[2];
+                    load_a<BF16, 3>(bo[0], l_wo, ks, lane);
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    Frag<BF16> bo;
-                    load_a<BF16, 3>(bo, l_wo, nt * 2 + ks, lane);
-                    mma<BF16, 3>(cfg[0][nt], adf, bo);
-                    mma<BF16, 3>(cfg[1][nt], adg, bo);
-                }
-                if (has_d) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        Frag<BF16> bo;
-                        load_a<BF16, 3>(bo, l_wo, (8 + r) * 2 + ks, lane);
-                        mma<BF16, 3>(cd[r], az, bo);
+                    for (int nt = 0; nt < NTILES; ++nt) {
+                        if (nt + 1 < NTILES) load_a<BF16, 3>(bo[(nt + 1) & 1], l_wo, (nt + 1) * 2 + ks, lane);
+                        if (nt < 8) {
+                            mma<BF16, 3>(cfg[0][nt], adf, bo[nt & 1]);
+                            mma<BF16, 3>(cfg[1][nt], adg, bo[nt & 1]);
+                        } else {
+                            mma<BF16, 3>(cd[nt - 8], az, bo[nt & 1]);
+                        }
                     }
                 }
             }
