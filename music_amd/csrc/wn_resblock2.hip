@@ -125,12 +125,26 @@ __global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnRes
             split8<T, NS>(bf[n], v);
         }
         if (s + 1 < KS) issue(s + 1);
+        {   // weight fragment m+1 is on its way from LDS while the matrix core works on fragment m
+            Frag<T> af[2];
+            load_a<T, NS>(af[0], l_fg, s, lane);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            Frag<T> af;
-            load_a<T, NS>(af, l_fg, m * KS + s, lane);
+            for (int m = 0; m < MT; ++m) {
+                if (m + 1 < MT) load_a<T, NS>(af[(m + 1) & 1], l_fg, (m + 1) * KS + s, lane);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
+                for (int n = 0; n < NT; ++n) mma<T, NS>(acc[m][n], af[m & 1], bf[n]);
+            }
+#ifndef WN_NO_SGB
+            // pin that order (the scheduler would put each LDS read right in front of its MFMAs)
+            constexpr int RD = NS == 3 ? 2 : 1, MM = NT * NS;
+            __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+            for (int m = 0; m < MT - 1; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
+#endif
         }
     }
 

@@ -543,7 +543,11 @@ class WaveNetEngine:
                          ptr(self.gpack, bo[bn % (4 * i + 1)]), st)
                     if i < N - 1:
                         call("wn_bias_grad", dy, xb, pitch, 0, self.R, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i + 2)]), st)
-                call("wn_chan_gemm", dfg, dfg, 2 * CH * pitch, pitch, t_lo, T, 0, d, 2 * CH // 32, 2 * CH // 32, br("fgT%d" % i),
+                # input range [t_lo, pitch): the [df;dg] scratch holds zeros beyond T (never written: every store is
+                # masked to t < T, and pitch >= T + 512 >= T + d), so the waves at the end of a clip need not take
+                # the guarded-load path for the shifted tap.  (Below t_lo the guard IS needed: dx exists on
+                # [t_lo - d, T) and the unshifted tap must read zeros there, not another layer's stale rows.)
+                call("wn_chan_gemm", dfg, dfg, 2 * CH * pitch, pitch, t_lo, pitch, 0, d, 2 * CH // 32, 2 * CH // 32, br("fgT%d" % i),
                      CH // 16, self.R, ptr(bw["dX"][i % 2], SLACK), xb, pitch, 0, None,
                      dy, xb, pitch, t_lo, None, 0, 0, self.off[i], T, 0, B, mb, st)
                 continue
@@ -580,7 +584,7 @@ class WaveNetEngine:
             # (writes dX[i%2], which the PREVIOUS layer's weight gradients may still be reading)
             if overlap and ev_prev is not None:
                 main.wait_event(ev_prev)
-            call("wn_chan_gemm", dfg, dfg, 2 * CH * pitch, pitch, t_lo, T, 0, d, 2 * CH // 32, 2 * CH // 32, br("fgT%d" % i),
+            call("wn_chan_gemm", dfg, dfg, 2 * CH * pitch, pitch, t_lo, pitch, 0, d, 2 * CH // 32, 2 * CH // 32, br("fgT%d" % i),
                  CH // 16, self.R, ptr(bw["dX"][i % 2], SLACK), xb, pitch, 0, None,
                  dy, xb, pitch, t_lo, None, 0, 0, self.off[i], T, 0, B, mb, st)
             ev_prev = ev_w[k]
