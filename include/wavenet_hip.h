@@ -109,11 +109,14 @@ int wn_resblock_bwd_fused_tiles(int t_lo, int t_hi);
  * dilated convs, which wn_chan_gemm forms from dfg).  Writes dfg = [df; dg] on [t_lo,t_hi) and one
  * slab per workgroup: slab_fg[w] = partial dWfg (2ch x 2ch, columns = tap0 ch | tap1 ch), slab_d[w] =
  * partial dWd (ch x ch); wn_resblock_bwd_ms_slabs gives the number of slabs (sum them with
- * wn_reduce_slabs).  dy NULL (last block): no dz product, no dWd.  z is not written at all. */
+ * wn_reduce_slabs).  dy NULL (last block): no dz product, no dWd.  z is not written at all.
+ * cond*: the conditioning table of wn_resblock_fwd (the recompute adds it as well); NULL = none. */
 int wn_resblock_bwd_ms(const float* x_in, const float* dy, const float* dz, float* dfg, int64_t x_bstride,
                        int64_t dz_bstride, int64_t dfg_bstride, int pitch, const uint16_t* wfg, const uint16_t* wdT,
                        const float* bias_f, const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
-                       float* slab_fg, float* slab_d, int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
+                       float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch,
+                       int cond_mode, int cond_le, int cond_q, int batch, int mode_fwd, int mode_bwd,
+                       wn_stream_t stream);
 int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch);
 /* out[b][r][t] = p[b][r][t] (t >= p_lo) + q[b][r][t+dn] (t+dn < t_hi), t in [t_lo,t_hi) */
 int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,

@@ -41,7 +41,8 @@ SIGNATURES = {
     "wn_resblock_bwd_fused": [_p, _p, _p, _p, _p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i,
                               _p, _p, _i, _i, _i, _i, _p],
     "wn_resblock_bwd_fused_tiles": [_i, _i],
-    "wn_resblock_bwd_ms": [_p, _p, _p, _p, _l, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p],
+    "wn_resblock_bwd_ms": [_p, _p, _p, _p, _l, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p,
+                           _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_bwd_ms_slabs": [_i, _i, _i],
     "wn_shift_add": [_p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_wgrad": [_p, _p, _p, _p, _l, _l, _l, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p],

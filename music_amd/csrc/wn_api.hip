@@ -188,14 +188,20 @@ int wn_resblock_bwd_fused_tiles(int t_lo, int t_hi) { return wn_resfused_tiles(t
 int wn_resblock_bwd_ms(const float* x_in, const float* dy, const float* dz, float* dfg, int64_t x_bstride,
                        int64_t dz_bstride, int64_t dfg_bstride, int pitch, const uint16_t* wfg, const uint16_t* wdT,
                        const float* bias_f, const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
-                       float* slab_fg, float* slab_d, int batch, int mode_fwd, int mode_bwd, wn_stream_t stream) {
+                       float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch,
+                       int cond_mode, int cond_le, int cond_q, int batch, int mode_fwd, int mode_bwd,
+                       wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_bwd_ms: pitch must be a multiple of 4");
+    if (cond && (cond_le <= 0 || (cond_mode == 1 && cond_q <= 0) || (cond_mode != 1 && cond_mode != 2)))
+        return wn_set_error_msg(-4, "wn_resblock_bwd_ms: bad conditioning arguments");
     if (!slab_fg) return wn_set_error_msg(-4, "wn_resblock_bwd_ms: slab_fg is required");
     WnResMsArgs a;
     memset(&a, 0, sizeof(a));
     a.x_in = x_in; a.dy = dy; a.dz = dz; a.dfg = dfg; a.x_bstride = x_bstride; a.dz_bstride = dz_bstride;
     a.dfg_bstride = dfg_bstride; a.pitch = pitch; a.wfg = wfg; a.wdT = wdT; a.bias_f = bias_f; a.bias_g = bias_g; a.n_f = n_f;
     a.slab_fg = slab_fg; a.slab_d = dy ? slab_d : nullptr; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = z_lo;
+    a.cond = cond; a.cond_bstride = cond_bstride; a.cond_pitch = cond_pitch; a.cond_mode = cond_mode;
+    a.cond_le = cond_le; a.cond_q = cond_q;
     return wn_launch_resblock_bwd_ms(a, ch, batch, mode_fwd, mode_bwd, (hipStream_t)stream);
 }
 int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch) { return wn_resms_slabs(t_lo, t_hi, batch); }

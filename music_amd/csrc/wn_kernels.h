@@ -73,6 +73,8 @@ struct WnResMsArgs {
     int d, t_lo, t_hi, z_lo, t_base;
     int steps_per_clip, items_per_wg, batch;               // set by the launcher
     int swz;
+    const float* cond; long cond_bstride; int cond_pitch;  // conditioning table as in WnResArgs (null: none)
+    int cond_mode, cond_le, cond_q;
 };
 int wn_launch_resblock_bwd_ms(const WnResMsArgs& a, int ch, int batch, int mode_fwd, int mode_bwd, hipStream_t st);
 int wn_resms_slabs(int t_lo, int t_hi, int batch);

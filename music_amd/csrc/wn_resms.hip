@@ -265,6 +265,24 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
                     mma<BF16, 3>(dz[idx & 3], wd[idx >> 2], by[idx & 1]);
                 }
             }
+            if (a.cond) {       // same conditioning bias as the forward (wavenet_autoencoder/model1.py:183)
+                const float* cb = a.cond + (size_t)b * a.cond_bstride;
+                int idx[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    int tr = tl + n - a.t_lo;
+                    tr = tr < 0 ? 0 : tr;
+                    const int ix = a.cond_mode == 1 ? tr / a.cond_q : tr % a.cond_le;
+                    idx[n] = ix < a.cond_le ? ix : a.cond_le - 1;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* rf = cb + (size_t)(16 * g + 4 * q + i) * a.cond_pitch;
+                    const float* rg = cb + (size_t)(CH + 16 * g + 4 * q + i) * a.cond_pitch;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) { af[n][i] += rf[idx[n]]; ag[n][i] += rg[idx[n]]; }
+                }
+            }
             float* dfg = a.dfg + (size_t)b * a.dfg_bstride;
             float df[4][4], dg[4][4], zz[4][4];                      // [n][i]
 #pragma unroll

@@ -535,7 +535,7 @@ class WaveNetEngine:
                 call("wn_resblock_bwd_ms", self._x(ws, i), dy, ptr(bw["dZ"], SLACK + i * CH * pitch), dfg, xb, zb, 2 * CH * pitch,
                      pitch, fr("fg%d" % i), br("dT%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),
                      self.D, CH, d, t_lo, T, lo, ptr(bw["slab"], plan["fg%d" % i][0]),
-                     ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None, B, mf, mb, st)
+                     ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None, None, 0, 0, 0, 0, 0, B, mf, mb, st)
                 if self.use_bias:
                     bo = self.gp_bias_off
                     call("wn_bias_grad", dfg, 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i)]), st)

@@ -18,6 +18,8 @@ The arithmetic runs through libwavenet_hip.so only (no CPU path).  ``forward`` i
 (``loss.backward()`` fills every parameter's gradient, the encoder's through the random projections
 exactly as in the reference); the backward is implemented for ``use_bias=False``.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -298,16 +300,21 @@ class _AutoencoderEngine:
         lo = self.rf - 1
         ops = [("c2", lo, T, 1024), ("c1", lo, T, 1024), ("skip", lo, T, 2048), ("bottleneck", lo, T, 512),
                ("de_causal", 1, T, 512), ("en_causal", 1, T, 512)]
+        # decoder blocks: the channel-split block kernel (both weight gradients inside the block launch)
+        # where it applies, else resblock_bwd + two wgrad launches
+        ms = (self.CHd == 64 and self.mode == _lib.F16X3 and self.mode_b == _lib.BF16X3
+              and os.environ.get("WN_MS_BWD", "1") == "1")
+        bw["ms"] = ms
         for i in range(N):
-            ops += [("de_fg%d" % i, self.off[i + 1], T, 512), ("en_dil%d" % i, self.off[i + 1], T, 512),
+            ops += [("de_fg%d" % i, self.off[i + 1], T, -1 if ms else 512), ("en_dil%d" % i, self.off[i + 1], T, 512),
                     ("en_dense%d" % i, self.off[i + 1], T, 512)]
             if i < N - 1:
-                ops.append(("de_d%d" % i, self.off[i + 1], T, 512))
+                ops.append(("de_d%d" % i, self.off[i + 1], T, -1 if ms else 512))
         plan, desc, so, vs = {}, [], 0, 0
         for name, t_lo, t_hi, chunk in ops:
             go, r, c = self.gp_off[name]
             n = r * c
-            ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B)
+            ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B) if chunk > 0 else _lib.ms_slabs(t_lo, t_hi, B)
             plan[name] = (so, n, chunk)
             desc.append([vs, so, ns, n, go, n])
             so += ns * n
@@ -367,6 +374,16 @@ class _AutoencoderEngine:
             d, t_lo = self.dil[i], self.off[i + 1]
             dy = ptr(bw["dXd"][(i + 1) % 2], SLACK) if i < N - 1 else None
             mode_c, q = ws["cmodes"][i]
+            if bw["ms"]:
+                call("wn_resblock_bwd_ms", xd(i), dy, ptr(bw["dZ"], SLACK + i * CHd * pitch), dfg, db, zb, 2 * CHd * pitch, pitch,
+                     fr("de_fg%d" % i), br("de_dT%d" % i), None, None, Dd, CHd, d, t_lo, T, lo,
+                     ptr(bw["slab"], plan["de_fg%d" % i][0]), ptr(bw["slab"], plan["de_d%d" % i][0]) if i < N - 1 else None,
+                     ptr(ws["tab"][i]), 2 * CHd * Le, Le, mode_c, Le, max(q, 1), B, mf, mb, st)
+                call("wn_cond_grad", dfg, 2 * CHd * pitch, pitch, 2 * CHd, t_lo, T, mode_c, Le, max(q, 1),
+                     ptr(d_tab[i]), 2 * CHd * Le, Le, B, st)
+                gemm("de_fgT%d" % i, dfg, dfg, 2 * CHd * pitch, pitch, t_lo, T, 0, d, 2 * CHd // 32, 2 * CHd // 32, CHd // 16, Rd,
+                     ptr(bw["dXd"][i % 2], SLACK), db, pitch, 0, None, (dy, db, pitch, t_lo) if dy else NONE3, NONE3, self.off[i], T, 0)
+                continue
             call("wn_resblock_bwd", xd(i), dy, ptr(bw["dZ"], SLACK + i * CHd * pitch), dfg, None,
                  db, zb, 2 * CHd * pitch, db, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), None, None, Dd, CHd, d, t_lo, T, lo,
                  ptr(ws["tab"][i]), 2 * CHd * Le, Le, mode_c, Le, max(q, 1), B, mf, mb, st)

@@ -459,6 +459,52 @@ def test_autoencoder_backward_vs_oracle():
         print("autoencoder", tag, "worst relative grad err %.2e" % worst)
 
 
+def test_autoencoder_backward_64_channels_vs_oracle():
+    """The autoencoder at 64 decoder channels (BASELINE config-4 width): its decoder blocks run the
+    channel-split backward kernel WITH the conditioning table (stretch and tile layers): loss and every
+    gradient vs autograd on the CPU oracle with the same per-forward projections."""
+    from music_amd.model1 import wavenet_autoencoder
+    from oracle import intops
+    cfg = dict(filter_width=2, quantization_channel=256, dilations=[1, 2, 4, 8, 3, 16], en_residual_channel=48,
+               en_dilation_channel=40, en_bottleneck_width=12, en_pool_kernel_size=50, de_residual_channel=64,
+               de_dilation_channel=64, de_skip_channel=80, use_bias=False)
+    torch.manual_seed(41)
+    net = wavenet_autoencoder(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    rng = np.random.default_rng(42)
+    rf = net.receptive_field
+    for B, W in ((2, 400), (1, 733)):            # 400 = 8 pooled frames (some layers stretch), 733: ragged
+        idx = rng.integers(0, 256, size=(B, rf + W - 1))
+        x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx]))
+        target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64))
+        torch.manual_seed(78)
+        net.zero_grad()
+        probs = net(x.cuda())
+        loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
+        loss.backward()
+        torch.manual_seed(78)
+        cond = wo.draw_conditioning(len(cfg["dilations"]), cfg["en_bottleneck_width"], cfg["de_dilation_channel"],
+                                    cfg["de_skip_channel"])
+        leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        p_ref, _ = wo.autoencoder_forward(leaf, cfg["dilations"], x, cfg["en_pool_kernel_size"], cond)
+        l_ref = torch.nn.functional.cross_entropy(p_ref, target)
+        g_ref = torch.autograd.grad(l_ref, list(leaf.values()), allow_unused=True)
+        assert (probs.detach().cpu() - p_ref.detach()).abs().max().item() <= LOGIT_TOL
+        assert abs(loss.item() - l_ref.item()) < 1e-4
+        gs = [torch.zeros_like(leaf[n]) if g is None else g for (n, _), g in zip(net.named_parameters(), g_ref)]
+        floor = 1e-3 * max(g.abs().max().item() for g in gs)
+        worst = 0.0
+        for (name, p), g in zip(net.named_parameters(), gs):
+            err = (p.grad.cpu() - g).abs().max().item() / max(g.abs().max().item(), floor)
+            worst = max(worst, err)
+            assert err <= GRAD_RTOL, (B, W, name, err)
+        print("autoencoder 64 ch (B=%d, W=%d): worst relative grad err %.2e" % (B, W, worst))
+
+
 def _g7_run(tmp_path, monkeypatch, tag, extra=None):
     import json
     import os
