@@ -66,6 +66,35 @@ def main():
             per_layer.append(ev[0].elapsed_time(ev[1]) / args.reps * 1e3)
         res["resblock_fwd_us_by_layer"] = [round(v, 1) for v in per_layer]
         res["resblock_fwd_us_total"] = round(sum(per_layer), 1)
+    if args.what == "dx":
+        # the per-layer data-gradient product in isolation, and cut-down forms of it (timing only)
+        eng.loss_and_grad(x, target)
+        bw = ws["bwd"]
+        i = 12
+        d, t_lo = eng.dil[i], eng.off[i + 1]
+        dfg = ptr(bw["dfg"][0], SLACK)
+        dy = ptr(bw["dX"][1], SLACK)
+        out = ptr(bw["dX"][0], SLACK)
+        br = lambda name: ptr(eng.pk_b, eng.pk_b_off[name])
+
+        def run(ks0, ks1, resid, label, shift=d, in_hi=pitch):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            torch.cuda.synchronize()
+            ev[0].record()
+            for _ in range(args.reps):
+                call("wn_chan_gemm", dfg, dfg if ks1 else None, 2 * CH * pitch, pitch, t_lo, in_hi, 0, shift, ks0, ks1, br("fgT%d" % i),
+                     CH // 16, eng.R, out, xb, pitch, 0, None, dy if resid else None, xb, pitch, t_lo, None, 0, 0, eng.off[i], T, 0,
+                     B_LOCAL, eng.mode_bwd, st)
+            ev[1].record()
+            torch.cuda.synchronize()
+            res[label] = round(ev[0].elapsed_time(ev[1]) / args.reps * 1e3, 1)
+        run(4, 4, True, "dx_full_us")
+        run(4, 4, False, "dx_noresid_us")
+        run(4, 0, True, "dx_one_tap_us")
+        run(2, 0, True, "dx_half_tap_us")
+        run(1, 0, False, "dx_one_kstep_noresid_us")
+        run(4, 4, True, "dx_shift0_us", shift=0)
+        res["layer"] = dict(i=i, d=d, t_lo=t_lo)
     if args.what in ("bwd", "all", "epi"):
         eng.fine_marks = args.what == "epi"
         eng.marks = []
