@@ -95,6 +95,23 @@ def main():
         run(1, 0, False, "dx_one_kstep_noresid_us")
         run(4, 4, True, "dx_shift0_us", shift=0)
         res["layer"] = dict(i=i, d=d, t_lo=t_lo)
+    if args.what == "skip":
+        # the skip product (wide GEMM, K = 1920) in isolation with shortened K (timing only)
+        eng.loss_and_grad(x, target)
+        lo, SP = eng.rf - 1, eng.SP
+
+        def run(ks, label):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            torch.cuda.synchronize()
+            ev[0].record()
+            for _ in range(args.reps):
+                call("wn_chan_gemm", ptr(ws["Z"], SLACK), None, zb, pitch, lo, T, 0, 0, ks, 0, fr("skip"), SP // 16, eng.S,
+                     ptr(ws["U"], SLACK), SP * pitch, pitch, 0, None, None, 0, 0, 0, None, 0, 0, lo, T, 0, B_LOCAL, eng.mode_fwd, st)
+            ev[1].record()
+            torch.cuda.synchronize()
+            res[label] = round(ev[0].elapsed_time(ev[1]) / args.reps * 1e3, 1)
+        for ks in (60, 30, 15, 8, 2):
+            run(ks, "skip_ks%d_us" % ks)
     if args.what in ("bwd", "all", "epi"):
         eng.fine_marks = args.what == "epi"
         eng.marks = []
