@@ -43,6 +43,7 @@ struct WnResArgs {
 };
 int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);
 int wn_launch_resblock_fwd_nt(const WnResArgs& a, int ch, int batch, int mode, int nt, hipStream_t st);
+int wn_launch_resblock_fwd_cs(const WnResArgs& a, int batch, hipStream_t st);      // channel-split form: 64 channels, f16x3
 
 struct WnResBwdArgs {
     const float* x_in;          // x_i          [B][CH][pitch]

@@ -235,6 +235,13 @@ int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipS
     if (a.t_hi <= a.t_lo || batch <= 0) return 0;
     // default: the NT-templated kernel of wn_resblock2.hip with 4 N-tiles per wave (26.6 us per
     // config-2 layer vs 29.2 for resblock_fwd_k below; NT = 2 measured 33 us).  WN_FWD_NT=0|2|4 overrides.
+    // WN_FWD_CS=1: the channel-split form (wn_resblock3.hip; 64 padded channels at f16x3).  Correct (the
+    // whole GPU suite passes with it) but 8-10 % SLOWER than the kernel below at config 2 (28.8 vs
+    // 26.2 us per block): the forward is bound by its HBM share (390 KB per CU and launch), not by the
+    // length of a wave's dependency chain, so shortening the chain buys nothing.  Off by default.
+    static int cs = -1;
+    if (cs < 0) { const char* e = getenv("WN_FWD_CS"); cs = e ? atoi(e) : 0; }
+    if (cs && ch == 64 && mode == WN_MODE_F16X3) return wn_launch_resblock_fwd_cs(a, batch, st);
     static int nt = -1;
     if (nt < 0) { const char* e = getenv("WN_FWD_NT"); nt = e ? atoi(e) : 4; }
     if (nt == 2 || nt == 4) return wn_launch_resblock_fwd_nt(a, ch, batch, mode, nt, st);
