@@ -97,7 +97,10 @@ class WaveNetEngine:
         self.adam_state = None
         self.marks = None            # list of (name, torch.cuda.Event) when profiling is on
         self.pair_wgrad = False      # both per-layer weight-gradient products in one launch
-        self.overlap_wgrad = False   # per-layer weight gradients on a second HIP stream (no gain measured)
+        # weight-gradient launches that only feed the final slab reduction run on a second HIP stream: the
+        # epilogue's three (2 rounds of workgroups at 80 % fill each) then pack into the data-gradient GEMMs'
+        # idle CUs (epilogue backward 1.25 -> 1.00 ms)
+        self.overlap_wgrad = True
         # One launch per residual block for the whole backward (wn_resblock_bwd_fused).  Correct and
         # tested, but SLOWER than the unfused kernels at config 2 (6.0 vs 4.5 ms for the stack): its
         # 512 KB-per-workgroup scratch tile does not fit the 128 KB-per-CU share of the XCD's L2, so the
@@ -592,6 +595,9 @@ class WaveNetEngine:
             for e in ev_w:
                 if e is not None:
                     main.wait_event(e)
+            ev_join = torch.cuda.Event()          # everything on the side stream (epilogue weight gradients)
+            ev_join.record(side)
+            main.wait_event(ev_join)
         self.mark("stack_bwd")
         # causal weight gradient: dWc[r][q][tap] = sum dx0[r][t] in[q][t-1+tap]
         x = ws["x_in"]
