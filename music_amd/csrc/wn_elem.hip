@@ -297,24 +297,62 @@ int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride
 
 // ---------------------------------------------------------------------------------------------
 // Gradient w.r.t. the autoencoder's conditioning table (model1.py:227-247): bucket sums of a row
-// over time.  One workgroup per (row, clip); LDS float atomics into <= 1024 buckets.
+// over time.  One workgroup (4 waves) per (row, clip).  No float atomics: every partial sum has a
+// fixed owner and the partials are combined in a fixed order, so the result is bit-reproducible.
+//   mode 1 (stretch, bucket = (t - t_lo) / q, clamped to le-1): bucket j is the contiguous segment
+//          [j q, (j+1) q) (the last one runs to the end); wave w sums buckets w, w+4, ... lane-strided.
+//   mode 2 (tile, bucket = (t - t_lo) % le), le <= 64: a wave walks its quarter of the row in chunks of
+//          floor(64/le)*le samples, so lane l always meets bucket l % le and keeps a private sum;
+//          the 4 x floor(64/le) partials of a bucket are added in a fixed order through LDS.
+//   mode 2 with le > 64 (not used by the shipped configs): one bucket per thread, strided walk.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cond_grad_k(const float* __restrict__ in, long in_bstride, int in_pitch, int t_lo,
                                                    int t_hi, int mode, int le, int q, float* __restrict__ out,
                                                    long out_bstride, int out_pitch) {
-    __shared__ float bucket[1024];
+    __shared__ float part[4][64];
     const int row = blockIdx.x, b = blockIdx.y;
-    for (int j = threadIdx.x; j < le; j += 256) bucket[j] = 0.f;
-    __syncthreads();
-    const float* p = in + (size_t)b * in_bstride + (size_t)row * in_pitch;
-    for (int t = t_lo + threadIdx.x; t < t_hi; t += 256) {
-        const int tr = t - t_lo;
-        int ix = mode == 1 ? tr / q : tr % le;
-        ix = ix < le ? ix : le - 1;
-        atomicAdd(&bucket[ix], p[t]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* p = in + (size_t)b * in_bstride + (size_t)row * in_pitch + t_lo;
+    float* o = out + (size_t)b * out_bstride + (size_t)row * out_pitch;
+    const int L = t_hi - t_lo;
+    if (mode == 1) {
+        for (int j = wave; j < le; j += 4) {
+            const int s0 = j * q;
+            const int s1 = (j == le - 1) ? L : (s0 + q < L ? s0 + q : L);
+            float acc = 0.f;
+            for (int t = s0 + lane; t < s1; t += 64) acc += p[t];
+            acc = wave_sum(acc);
+            if (lane == 0) o[j] = acc;
+        }
+        return;
     }
-    __syncthreads();
-    for (int j = threadIdx.x; j < le; j += 256) out[(size_t)b * out_bstride + (size_t)row * out_pitch + j] = bucket[j];
+    if (le <= 64) {
+        const int rep = 64 / le, chunk = rep * le;
+        const int nchunks = (L + chunk - 1) / chunk;
+        const int per = (nchunks + 3) / 4;                     // chunks per wave
+        const int c0 = wave * per, c1 = (c0 + per < nchunks) ? c0 + per : nchunks;
+        float acc = 0.f;
+        if (lane < chunk) {
+            for (int ch = c0; ch < c1; ++ch) {
+                const int t = ch * chunk + lane;
+                if (t < L) acc += p[t];
+            }
+        }
+        part[wave][lane] = lane < chunk ? acc : 0.f;
+        __syncthreads();
+        if (threadIdx.x < le) {
+            float sacc = 0.f;
+            for (int w = 0; w < 4; ++w)
+                for (int r = 0; r < rep; ++r) sacc += part[w][r * le + threadIdx.x];
+            o[threadIdx.x] = sacc;
+        }
+        return;
+    }
+    for (int j = threadIdx.x; j < le; j += 256) {
+        float acc = 0.f;
+        for (int t = j; t < L; t += le) acc += p[t];
+        o[j] = acc;
+    }
 }
 int wn_launch_cond_grad(const float* in, long in_bstride, int in_pitch, int rows, int t_lo, int t_hi, int mode, int le,
                         int q, float* out, long out_bstride, int out_pitch, int batch, hipStream_t st) {

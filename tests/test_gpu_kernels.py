@@ -379,3 +379,31 @@ def test_wgrad_big_lds_path():
     err = (c.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     print("wgrad big rel err", err)
     assert err < 1e-4
+
+
+@pytest.mark.parametrize("mode,le,q", [(1, 7, 41), (1, 31, 16), (2, 31, 0), (2, 5, 0), (2, 64, 0), (2, 100, 0)])
+def test_cond_grad_bucket_sums(mode, le, q):
+    """wn_cond_grad (conditioning-table gradient, model1.py:227-247 backward): bucket sums of every row
+    over time, stretch (bucket = (t-t_lo)//q, clamped) and tile (bucket = (t-t_lo) % le) layouts,
+    including the le > 64 path; deterministic (two runs bit-identical)."""
+    B, rows, pitch, t_lo, t_hi = 2, 24, 1200, 37, 37 + 1103
+    if mode == 1:
+        t_hi = t_lo + le * q + 13            # a ragged tail that the last bucket absorbs
+    src = _buf(B, rows, pitch, fill=1.0, seed=5)
+    x = _view(src, B, rows, pitch).cpu().double().numpy()
+    out = torch.full((B, rows, le), 7.0, dtype=torch.float32, device=DEV)
+    for _ in range(2):
+        call("wn_cond_grad", ptr(src, SLACK), rows * pitch, pitch, rows, t_lo, t_hi, mode, le, max(q, 1),
+             ptr(out), rows * le, le, B, _lib.stream())
+        if _ == 0:
+            first = out.clone()
+    assert torch.equal(first, out)
+    L = t_hi - t_lo
+    tr = np.arange(L)
+    ix = np.minimum(tr // q, le - 1) if mode == 1 else tr % le
+    ref = np.zeros((B, rows, le))
+    for j in range(le):
+        ref[:, :, j] = x[:, :, t_lo:t_hi][:, :, ix == j].sum(-1)
+    err = np.abs(out.cpu().numpy() - ref).max()
+    print("cond_grad mode %d le %d: max err %.2e" % (mode, le, err))
+    assert err < 2e-4
