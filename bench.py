@@ -201,7 +201,7 @@ def main():
                      "frac": (ach * 1e9 / HBM_PEAK) if ach else None, "traffic": traffic,
                      "algorithmic_bytes_per_launch": fwd_b / n_layers,
                      "avg_launch_ms": fwd_ms / n_layers},
-        # the same stack, backward (resblock_bwd_k + 2 wgrad_k + chan_gemm_k per block) and forward+backward
+        # the same stack, backward (resblock_bwd_ms_k + chan_gemm_k per block) and forward+backward
         "roofline_stack_bwd": {"bound": "hbm", "achieved": gbs(bwd_b, bwd_ms), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": (gbs(bwd_b, bwd_ms) * 1e9 / HBM_PEAK) if gbs(bwd_b, bwd_ms) else None,
                                "algorithmic_bytes_per_step": bwd_b},
