@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--precision", default="f16x3,bf16x3")
     ap.add_argument("--pair", type=int, default=0)
-    ap.add_argument("--overlap", type=int, default=0)
+    ap.add_argument("--overlap", type=int, default=1)
     ap.add_argument("--fused", type=int, default=0)
     args = ap.parse_args()
     from music_amd.model import wavenet
