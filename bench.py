@@ -87,6 +87,26 @@ def cpu_baseline(seconds_budget=25.0):
                       "torch CPU threads=%d, best of %d after 1 warm-up" % (len(times), cores, max(1, len(times) - 1))}
 
 
+def measured_copy_gbs():
+    """Device-to-device copy rate (read + write bytes / time) of a 1 GiB buffer, best of 5."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device="cuda")
+    b = torch.empty(n, dtype=torch.float32, device="cuda")
+    a.fill_(1.0)
+    b.copy_(a)
+    best = None
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None or ms < best else best
+    del a, b
+    return 2.0 * n * 4 / (best * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,6 +201,7 @@ def main():
         except Exception:
             traffic = None
     ach = gbs(fwd_b, fwd_ms)
+    copy_gbs = measured_copy_gbs() if rank == 0 else None
     out = {
         "metric": "audio samples/sec trained (whole node), 30-layer WaveNet @16kHz",
         "value": world * B_LOCAL * T * args.steps / dt,
@@ -200,7 +221,11 @@ def main():
                      "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": (ach * 1e9 / HBM_PEAK) if ach else None, "traffic": traffic,
                      "algorithmic_bytes_per_launch": fwd_b / n_layers,
-                     "avg_launch_ms": fwd_ms / n_layers},
+                     "avg_launch_ms": fwd_ms / n_layers,
+                     # the nominal peak next to what a plain device copy reaches on this box
+                     # (read + write bytes of a 1 GiB float4 copy / its time)
+                     "measured_copy_GBs": copy_gbs,
+                     "frac_of_measured_copy": (ach / copy_gbs) if (ach and copy_gbs) else None},
         # the same stack, backward (resblock_bwd_ms_k + chan_gemm_k per block) and forward+backward
         "roofline_stack_bwd": {"bound": "hbm", "achieved": gbs(bwd_b, bwd_ms), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": (gbs(bwd_b, bwd_ms) * 1e9 / HBM_PEAK) if gbs(bwd_b, bwd_ms) else None,
