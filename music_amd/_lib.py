@@ -58,6 +58,8 @@ SIGNATURES = {
     "wn_mulaw_decode_lut": [_p, _p, _p, _l, _p],
     "wn_decode": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l,
                   _i, _i, _p, _p],
+    "wn_decode_batch": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l,
+                        _i, _i, _p, _i, _l, _p],
 }
 
 _lib = None

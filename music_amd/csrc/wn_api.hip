@@ -227,12 +227,31 @@ int wn_avgpool(const float* in, int64_t in_bstride, int in_pitch, int t0, int po
                              (hipStream_t)stream);
 }
 
+int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
+                    float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
+                    int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
+                    const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
+                    float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
+                    int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, wn_stream_t stream);
+
 int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
               float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
               int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
               const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
               float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
               int n_steps, int push_input, uint64_t* sync, wn_stream_t stream) {
+    return wn_decode_batch(n_layers, R, D, S, Q, dilations_host, q_off_host, queues, w_causal, b_causal, w_layers, layer_stride,
+                           b_layers, w_p1, b_p1, w_p2, b_p2, note0, prev0, note_out, prev_out, forced, codes_out, probs_out,
+                           step0, n_steps, push_input, sync, 1, 0, stream);
+}
+
+int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
+                    float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
+                    int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
+                    const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
+                    float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
+                    int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, wn_stream_t stream) {
+    if (n_utt <= 0) return 0;
     if (n_layers > WN_DEC_MAX_LAYERS || n_layers <= 0) return wn_set_error_msg(-4, "wn_decode: 1..64 layers supported");
     WnDecodeArgs a;
     memset(&a, 0, sizeof(a));
@@ -244,6 +263,7 @@ int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations
     a.codes_out = codes_out; a.probs_out = probs_out; a.step0 = step0; a.n_steps = n_steps; a.push_input = push_input;
     { const char* e = getenv("WN_DEC_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.sync = reinterpret_cast<unsigned long long*>(sync);
+    a.n_utt = n_utt; a.queues_ustride = queues_ustride;
     return wn_launch_decode(a, (hipStream_t)stream);
 }
 

@@ -39,7 +39,20 @@ __device__ __forceinline__ void dec_matvec(const float* __restrict__ W, int ldw,
     }
 }
 
+
 __global__ __launch_bounds__(DEC_THREADS) void decode_k(WnDecodeArgs a) {
+    // utterance of a batched launch: per-utterance pointers as LOCALS (the argument struct itself must stay
+    // untouched: a modified copy would be moved to scratch and every dil[] / q_off[] lookup with it)
+    const size_t utt = blockIdx.x;
+    float* const u_queues = a.queues + utt * a.queues_ustride;
+    const float* const u_note0 = a.note0 + utt * a.Q;
+    const float* const u_prev0 = a.prev0 + utt * a.Q;
+    float* const u_note_out = a.note_out + utt * a.Q;
+    float* const u_prev_out = a.prev_out + utt * a.Q;
+    const int32_t* const u_forced = a.forced ? a.forced + utt * a.n_steps : nullptr;
+    int32_t* const u_codes_out = a.codes_out + utt * a.n_steps;
+    float* const u_probs_out = a.probs_out ? a.probs_out + utt * (size_t)a.n_steps * a.Q : nullptr;
+    unsigned long long* const u_sync = a.sync ? a.sync + utt * ((size_t)a.n_layers * a.D + 2) : nullptr;
     extern __shared__ float sm[];
     float* prev = sm;                       // [Q] previous input column (the causal layer's queue)
     float* note = prev + a.Q;               // [Q] current input column (dense); [prev|note] is contiguous
@@ -55,7 +68,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_k(WnDecodeArgs a) {
     __shared__ int s_arg;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < a.Q; i += DEC_THREADS) { note[i] = a.note0[i]; prev[i] = a.prev0[i]; }
+    for (int i = tid; i < a.Q; i += DEC_THREADS) { note[i] = u_note0[i]; prev[i] = u_prev0[i]; }
     __syncthreads();
 
     for (int step = 0; step < a.n_steps; ++step) {
@@ -67,7 +80,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_k(WnDecodeArgs a) {
         __syncthreads();
         for (int l = 0; l < a.n_layers; ++l) {
             const int d = a.dil[l];
-            float* q = a.queues + a.q_off[l];
+            float* q = u_queues + a.q_off[l];
             const int slot = (int)(gstep % d);                  // oldest column == the one replaced now
             for (int i = tid; i < a.R; i += DEC_THREADS) old[i] = q[(size_t)slot * a.R + i];
             __syncthreads();
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_k(WnDecodeArgs a) {
             float best = -1.f; int bi = 0;
             for (int e = 0; e < 4; ++e) {
                 v[e] *= inv;
-                if (a.probs_out) a.probs_out[(size_t)step * a.Q + tid * 4 + e] = v[e];
+                if (u_probs_out) u_probs_out[(size_t)step * a.Q + tid * 4 + e] = v[e];
                 if (v[e] > best) { best = v[e]; bi = tid * 4 + e; }
             }
             for (int off = 32; off > 0; off >>= 1) {
@@ -117,18 +130,18 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_k(WnDecodeArgs a) {
                 int oi = __shfl_xor(bi, off, 64);
                 if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
             }
-            if (tid == 0) { s_arg = bi; a.codes_out[step] = bi; }
+            if (tid == 0) { s_arg = bi; u_codes_out[step] = bi; }
         }
         __syncthreads();
         // next input column: the forced code if given (teacher forcing), else the prediction
-        const int nextc = a.forced ? a.forced[step] : s_arg;
+        const int nextc = u_forced ? u_forced[step] : s_arg;
         for (int i = tid; i < a.Q; i += DEC_THREADS) { prev[i] = note[i]; }
         __syncthreads();
         for (int i = tid; i < a.Q; i += DEC_THREADS) note[i] = (i == nextc) ? 1.0f : 0.0f;
         __syncthreads();
     }
     // hand the two input columns back (prev = causal queue, note = next input)
-    for (int i = tid; i < a.Q; i += DEC_THREADS) { a.prev_out[i] = prev[i]; a.note_out[i] = note[i]; }
+    for (int i = tid; i < a.Q; i += DEC_THREADS) { u_prev_out[i] = prev[i]; u_note_out[i] = note[i]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -200,6 +213,18 @@ __device__ __forceinline__ void dec_sync() {
 }
 
 __global__ __launch_bounds__(DEC_THREADS) void decode_v4_k(WnDecodeArgs a) {
+    // utterance of a batched launch: per-utterance pointers as LOCALS (the argument struct itself must stay
+    // untouched: a modified copy would be moved to scratch and every dil[] / q_off[] lookup with it)
+    const size_t utt = blockIdx.x;
+    float* const u_queues = a.queues + utt * a.queues_ustride;
+    const float* const u_note0 = a.note0 + utt * a.Q;
+    const float* const u_prev0 = a.prev0 + utt * a.Q;
+    float* const u_note_out = a.note_out + utt * a.Q;
+    float* const u_prev_out = a.prev_out + utt * a.Q;
+    const int32_t* const u_forced = a.forced ? a.forced + utt * a.n_steps : nullptr;
+    int32_t* const u_codes_out = a.codes_out + utt * a.n_steps;
+    float* const u_probs_out = a.probs_out ? a.probs_out + utt * (size_t)a.n_steps * a.Q : nullptr;
+    unsigned long long* const u_sync = a.sync ? a.sync + utt * ((size_t)a.n_layers * a.D + 2) : nullptr;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* prev = sm;                       // [Q]
     float* note = prev + a.Q;               // [Q]   ([prev|note] contiguous)
@@ -219,7 +244,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_v4_k(WnDecodeArgs a) {
     const size_t lstride = (size_t)a.layer_stride;
     const size_t o_d = (size_t)2 * D * 2 * R, o_s = o_d + (size_t)R * D;
 
-    for (int i = tid; i < Q; i += DEC_THREADS) { note[i] = a.note0[i]; prev[i] = a.prev0[i]; }
+    for (int i = tid; i < Q; i += DEC_THREADS) { note[i] = u_note0[i]; prev[i] = u_prev0[i]; }
     if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
     dec_sync();
 
@@ -230,7 +255,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_v4_k(WnDecodeArgs a) {
         dec_loadw4(wd, md, a.w_layers + o_d, D, R);
         dec_loadw4(ws, ms, a.w_layers + o_s, D, S);
         float oldv = 0.f;
-        if (tid < R) oldv = a.queues[a.q_off[0] + (size_t)slots[0] * R + tid];
+        if (tid < R) oldv = u_queues[a.q_off[0] + (size_t)slots[0] * R + tid];
         if (!(a.dbg & 8)) {
             const float s = dec_dot_stream(mc, a.w_causal, 2 * Q, R, prev);
             if (mc.o < R && mc.p == 0) cur0[mc.o] = s;
@@ -249,7 +274,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_v4_k(WnDecodeArgs a) {
             float oldn = 0.f;
             if (ln < a.n_layers) {
                 dec_loadw4(wfg, mfg, wn, 2 * R, 2 * D);
-                if (tid < R && !(a.dbg & 2)) oldn = a.queues[a.q_off[ln] + (size_t)slots[ln] * R + tid];
+                if (tid < R && !(a.dbg & 2)) oldn = u_queues[a.q_off[ln] + (size_t)slots[ln] * R + tid];
             }
             dec_sync();
             if (tid < D) zz[tid] = (a.dbg & 1) ? wn_tanh(fg[tid]) * wn_sigmoid(fg[D + tid])
@@ -261,7 +286,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_v4_k(WnDecodeArgs a) {
             if (md.o < R && md.p == 0) {
                 const float v = sd + cur[md.o];
                 nxt[md.o] = v;
-                if (!(a.dbg & 2)) a.queues[a.q_off[l] + (size_t)slots[l] * R + md.o] = a.push_input ? cur[md.o] : v;   // Q5: output by default
+                if (!(a.dbg & 2)) u_queues[a.q_off[l] + (size_t)slots[l] * R + md.o] = a.push_input ? cur[md.o] : v;   // Q5: output by default
             }
             if (ms.o < S && ms.p == 0) skip[ms.o] += ss;
             if (ln < a.n_layers) {
@@ -296,7 +321,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_v4_k(WnDecodeArgs a) {
             float best = -1.f; int bi = 0;
             for (int e = 0; e < 4; ++e) {
                 v[e] *= inv;
-                if (a.probs_out) a.probs_out[(size_t)step * Q + tid * 4 + e] = v[e];
+                if (u_probs_out) u_probs_out[(size_t)step * Q + tid * 4 + e] = v[e];
                 if (v[e] > best) { best = v[e]; bi = tid * 4 + e; }
             }
             for (int off = 32; off > 0; off >>= 1) {
@@ -304,17 +329,17 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_v4_k(WnDecodeArgs a) {
                 int oi = __shfl_xor(bi, off, 64);
                 if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
             }
-            if (tid == 0) { s_arg = bi; a.codes_out[step] = bi; }
+            if (tid == 0) { s_arg = bi; u_codes_out[step] = bi; }
         }
         dec_sync();
-        const int nextc = a.forced ? a.forced[step] : s_arg;
+        const int nextc = u_forced ? u_forced[step] : s_arg;
         for (int i = tid; i < Q; i += DEC_THREADS) prev[i] = note[i];
         if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
         dec_sync();
         for (int i = tid; i < Q; i += DEC_THREADS) note[i] = (i == nextc) ? 1.0f : 0.0f;
         dec_sync();
     }
-    for (int i = tid; i < Q; i += DEC_THREADS) { a.prev_out[i] = prev[i]; a.note_out[i] = note[i]; }
+    for (int i = tid; i < Q; i += DEC_THREADS) { u_prev_out[i] = prev[i]; u_note_out[i] = note[i]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -350,18 +375,31 @@ __device__ __forceinline__ bool dec_poll(const unsigned long long* p, unsigned t
 }
 
 __global__ __launch_bounds__(DEC_THREADS) void decode_duo_k(WnDecodeArgs a) {
+    // workgroups 2u (chain) and 2u+1 (skip + post) serve utterance u of a batched launch: per-utterance pointers as LOCALS (the argument struct itself must stay
+    // untouched: a modified copy would be moved to scratch and every dil[] / q_off[] lookup with it)
+    const size_t utt = blockIdx.x >> 1;
+    float* const u_queues = a.queues + utt * a.queues_ustride;
+    const float* const u_note0 = a.note0 + utt * a.Q;
+    const float* const u_prev0 = a.prev0 + utt * a.Q;
+    float* const u_note_out = a.note_out + utt * a.Q;
+    float* const u_prev_out = a.prev_out + utt * a.Q;
+    const int32_t* const u_forced = a.forced ? a.forced + utt * a.n_steps : nullptr;
+    int32_t* const u_codes_out = a.codes_out + utt * a.n_steps;
+    float* const u_probs_out = a.probs_out ? a.probs_out + utt * (size_t)a.n_steps * a.Q : nullptr;
+    unsigned long long* const u_sync = a.sync ? a.sync + utt * ((size_t)a.n_layers * a.D + 2) : nullptr;
+    const int role = blockIdx.x & 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ int s_arg;
     __shared__ int slots[WN_DEC_MAX_LAYERS];
     const int tid = threadIdx.x;
     const int R = a.R, D = a.D, S = a.S, Q = a.Q;
-    unsigned long long* zg = a.sync;                         // [n_layers][D] z granules
-    unsigned long long* cg = a.sync + (size_t)a.n_layers * D;    // code granule
+    unsigned long long* zg = u_sync;                         // [n_layers][D] z granules
+    unsigned long long* cg = u_sync + (size_t)a.n_layers * D;    // code granule
     unsigned long long* err = cg + 1;
     const size_t lstride = (size_t)a.layer_stride;
     const size_t o_d = (size_t)2 * D * 2 * R, o_s = o_d + (size_t)R * D;
 
-    if (blockIdx.x == 0) {
+    if (role == 0) {
         // ------------------------------------------------------------------ chain
         float* prev = sm;
         float* note = prev + Q;
@@ -372,7 +410,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_duo_k(WnDecodeArgs a) {
         float* oldb = zz + D;                    // [n_layers][R] oldest queue columns of this sample
         float* pushb = oldb + a.n_layers * R;    // [n_layers][R] columns pushed by this sample
         const DecMap mc = dec_map(R, 2 * Q), mfg = dec_map(2 * D, 2 * R), md = dec_map(R, D);
-        for (int i = tid; i < Q; i += DEC_THREADS) { note[i] = a.note0[i]; prev[i] = a.prev0[i]; }
+        for (int i = tid; i < Q; i += DEC_THREADS) { note[i] = u_note0[i]; prev[i] = u_prev0[i]; }
         if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
         dec_sync();
         f32x4 wfg[4], wd[1];
@@ -383,7 +421,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_duo_k(WnDecodeArgs a) {
             // in-order vmcnt queue (~2 us each) in front of every wait for prefetched weights
             for (int i = tid; i < a.n_layers * R; i += DEC_THREADS) {
                 const int l = i / R, r = i - l * R;
-                oldb[i] = __hip_atomic_load(a.queues + a.q_off[l] + (size_t)slots[l] * R + r, __ATOMIC_RELAXED,
+                oldb[i] = __hip_atomic_load(u_queues + a.q_off[l] + (size_t)slots[l] * R + r, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_AGENT);
             }
             dec_loadw4(wfg, mfg, a.w_layers, 2 * R, 2 * D);
@@ -427,7 +465,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_duo_k(WnDecodeArgs a) {
             }
             for (int i = tid; i < a.n_layers * R; i += DEC_THREADS) {            // queue columns out
                 const int l = i / R, r = i - l * R;
-                a.queues[a.q_off[l] + (size_t)slots[l] * R + r] = pushb[i];
+                u_queues[a.q_off[l] + (size_t)slots[l] * R + r] = pushb[i];
             }
             // the prediction comes back from the skip block
             if (tid == 0) {
@@ -436,14 +474,14 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_duo_k(WnDecodeArgs a) {
                 s_arg = (int)cv;
             }
             __syncthreads();                       // full fence: the queue stores are complete before the next sample reads
-            const int nextc = a.forced ? a.forced[step] : s_arg;
+            const int nextc = u_forced ? u_forced[step] : s_arg;
             for (int i = tid; i < Q; i += DEC_THREADS) prev[i] = note[i];
             if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
             dec_sync();
             for (int i = tid; i < Q; i += DEC_THREADS) note[i] = (i == nextc) ? 1.0f : 0.0f;
             dec_sync();
         }
-        for (int i = tid; i < Q; i += DEC_THREADS) { a.prev_out[i] = prev[i]; a.note_out[i] = note[i]; }
+        for (int i = tid; i < Q; i += DEC_THREADS) { u_prev_out[i] = prev[i]; u_note_out[i] = note[i]; }
     } else {
         // ------------------------------------------------------------------ skip + post-processing
         float* zz0 = sm;                       // [2][D]
@@ -502,7 +540,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_duo_k(WnDecodeArgs a) {
                 float best = -1.f; int bi = 0;
                 for (int e = 0; e < 4; ++e) {
                     v[e] *= inv;
-                    if (a.probs_out) a.probs_out[(size_t)step * Q + tid * 4 + e] = v[e];
+                    if (u_probs_out) u_probs_out[(size_t)step * Q + tid * 4 + e] = v[e];
                     if (v[e] > best) { best = v[e]; bi = tid * 4 + e; }
                 }
                 for (int off = 32; off > 0; off >>= 1) {
@@ -511,7 +549,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_duo_k(WnDecodeArgs a) {
                     if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
                 }
                 if (tid == 0) {
-                    a.codes_out[step] = bi;
+                    u_codes_out[step] = bi;
                     __hip_atomic_store(cg, dec_pack((float)bi, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -523,6 +561,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_duo_k(WnDecodeArgs a) {
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
     if (a.n_steps <= 0) return 0;
     if (a.n_layers > WN_DEC_MAX_LAYERS) return wn_set_error_msg(-4, "decode: too many layers");
+    const int nu = a.n_utt > 0 ? a.n_utt : 1;
+    // the two workgroups of an utterance spin on each other's hand-offs, so every pair must be resident
+    // at once: one workgroup per CU -> at most 128 utterances per launch on this part
+    if (nu > 128) return wn_set_error_msg(-4, "decode: at most 128 utterances per launch");
     // the float4 kernel needs: no biases, one pass per product, exactly 16 / 4 / 16 weights per thread for
     // the per-block products and a multiple of 16 for the streamed ones
     auto nw = [](int M, int K) {
@@ -536,18 +578,18 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
                     nw(a.R, 2 * a.Q) > 0 && nw(a.R, 2 * a.Q) % 16 == 0 && nw(a.S, a.S) > 0 && nw(a.S, a.S) % 16 == 0 &&
                     nw(a.Q, a.S) > 0 && nw(a.Q, a.S) % 16 == 0 && (a.layer_stride % 4) == 0;
     if (v4 && a.sync && a.n_steps >= 4 && !(a.dbg & 31)) {
-        const size_t nsync = ((size_t)a.n_layers * a.D + 2) * sizeof(unsigned long long);
+        const size_t nsync = ((size_t)a.n_layers * a.D + 2) * sizeof(unsigned long long) * (size_t)nu;
         hipError_t e = hipMemsetAsync(a.sync, 0, nsync, st);              // tags start at 1
         if (e != hipSuccess) return wn_set_error(e, __FILE__, __LINE__);
         size_t sh0 = sizeof(float) * (size_t)(2 * a.Q + 4 * a.R + 3 * a.D + 2 * a.n_layers * a.R);
         size_t sh1 = sizeof(float) * (size_t)(2 * a.D + 2 * a.S + a.Q);
-        hipLaunchKernelGGL(decode_duo_k, dim3(2), dim3(DEC_THREADS), sh0 > sh1 ? sh0 : sh1, st, a);
+        hipLaunchKernelGGL(decode_duo_k, dim3(2 * nu), dim3(DEC_THREADS), sh0 > sh1 ? sh0 : sh1, st, a);
     } else if (v4) {
         size_t sh = sizeof(float) * (size_t)(3 * a.Q + 4 * a.R + 3 * a.D + 2 * a.S);
-        hipLaunchKernelGGL(decode_v4_k, dim3(1), dim3(DEC_THREADS), sh, st, a);
+        hipLaunchKernelGGL(decode_v4_k, dim3(nu), dim3(DEC_THREADS), sh, st, a);
     } else {
         size_t sh = sizeof(float) * (size_t)(3 * a.Q + 3 * a.R + 3 * a.D + 2 * a.S + 64);
-        hipLaunchKernelGGL(decode_k, dim3(1), dim3(DEC_THREADS), sh, st, a);
+        hipLaunchKernelGGL(decode_k, dim3(nu), dim3(DEC_THREADS), sh, st, a);
     }
     WN_CHECK_LAUNCH();
     return 0;

@@ -152,5 +152,8 @@ struct WnDecodeArgs {
     long step0; int n_steps; int push_input;
     int dbg;                                             // WN_DEC_DBG timing diagnostics (wrong results)
     unsigned long long* sync;                            // (n_layers*D + 2) x 8 B hand-off area for the 2-workgroup kernel, or null
+    // independent utterances decoded side by side (one workgroup, or one pair, each): element strides
+    // between utterances of queues / [Q] state vectors / per-step outputs; weights are shared
+    int n_utt; long queues_ustride;
 };
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st);

@@ -197,6 +197,58 @@ def generate_codes(net, start_piece, note_num, correct_queue=False):
     return torch.cat([first.to(codes.device).to(torch.int64), codes.to(torch.int64)])
 
 
+def generate_codes_batch(net, start_pieces, note_num, correct_queue=False):
+    """SURVEY 8f2 (batched utterances; the reference generates one at a time): greedy generation of
+    ``note_num`` codes for U independent start pieces ``(U, Q, receptive_field)`` in ONE persistent
+    launch - every utterance gets its own workgroup pair, the weights are shared.  Returns int64
+    ``(U, note_num)`` on the device; row u equals ``generate_codes(net, start_pieces[u:u+1], note_num)``."""
+    assert start_pieces.dim() == 3 and start_pieces.size(2) == net.receptive_field
+    U = start_pieces.size(0)
+    if U > 128:
+        raise ValueError("at most 128 utterances per launch")
+    dev = start_pieces.device if start_pieces.is_cuda else torch.device("cuda")
+    x = start_pieces.detach().to(dev).float().contiguous()
+    with torch.no_grad():
+        probs = net(x)                                            # (U, Q): W == 1
+    eng = net._engine
+    ws = eng.workspace(U, x.size(2))
+    T, pitch, CH, R, N, Q = x.size(2), ws["pitch"], eng.CH, eng.R, eng.N, eng.Q
+    X = ws["X"][SLACK:SLACK + (N + 1) * U * CH * pitch].view(N + 1, U, CH, pitch)
+    # ring of block i of utterance u = the last d_i columns of that block's input, time-major
+    rings = torch.stack([torch.cat([X[i, u, :R, T - d:T].t().reshape(-1) for i, d in enumerate(eng.dil)]) for u in range(U)])
+    rings = rings.contiguous()
+    first = probs.view(U, Q).argmax(1)
+    if note_num <= 1:
+        return first.view(U, 1)[:, :note_num]
+    pack = getattr(net, "_decode_pack", None)
+    if pack is None or pack.eng is not eng:
+        pack = net._decode_pack = _DecodePack(eng)
+    pack.refresh()
+    n_steps = note_num - 1
+    note0 = torch.zeros(U, Q, dtype=torch.float32, device=dev)
+    note0[torch.arange(U, device=dev), first] = 1.0
+    prev0 = x[:, :, -1].contiguous()
+    codes = torch.empty(U, n_steps, dtype=torch.int32, device=dev)
+    note_out = torch.empty(U, Q, dtype=torch.float32, device=dev)
+    prev_out = torch.empty(U, Q, dtype=torch.float32, device=dev)
+    sync = torch.zeros(U * (N * eng.D + 2), dtype=torch.int64, device=dev)
+    dil = (ctypes.c_int32 * N)(*eng.dil)
+    q_off = np.cumsum([0] + [d * R for d in eng.dil[:-1]]).astype(np.int64)
+    qoff = (ctypes.c_int64 * N)(*[int(v) for v in q_off])
+    bias = pack.o_bias is not None
+    call("wn_decode_batch", N, R, eng.D, eng.S, Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
+         ptr(rings), pack.p(pack.o_causal), pack.p(pack.ob_causal) if bias else None,
+         pack.p(pack.o_layers), pack.layer_stride, pack.p(pack.ob_layers) if bias else None,
+         pack.p(pack.o_p1), pack.p(pack.ob_p1) if bias else None, pack.p(pack.o_p2), pack.p(pack.ob_p2) if bias else None,
+         ptr(note0), ptr(prev0), ptr(note_out), ptr(prev_out), None, ptr(codes), None,
+         0, n_steps, 1 if correct_queue else 0, ptr(sync), U, rings.size(1), _lib.stream())
+    if n_steps >= 4:
+        flags = sync.view(U, -1)[:, -1]
+        if int(flags.abs().max().item()) != 0:
+            raise _lib.WavenetHipError("wn_decode_batch: a hand-off between two decode workgroups timed out")
+    return torch.cat([first.view(U, 1).to(torch.int64), codes.to(torch.int64)], 1)
+
+
 def generate(model_path, model_name, generate_path, generate_name, start_piece=None, sr=16000, duration=10):
     """wavenet/fast_generate.py:144-179."""
     if os.path.exists(generate_path) is False:

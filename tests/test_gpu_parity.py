@@ -459,6 +459,33 @@ def test_autoencoder_backward_vs_oracle():
         print("autoencoder", tag, "worst relative grad err %.2e" % worst)
 
 
+def test_batched_decode_equals_single_utterances():
+    """wn_decode_batch: U utterances side by side in one launch give, row by row, exactly
+    the codes of U single-utterance launches (same arithmetic, independent state), with the as-written
+    and with the corrected queue recurrence."""
+    from music_amd.model import wavenet
+    from music_amd import fast_generate as fg
+    cfg = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 32, 1, 2, 4, 8], dilation_channels=64, residual_channels=64,
+               skip_channels=256, quantization_channels=256, use_bias=False)
+    torch.manual_seed(3)
+    net = wavenet(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(3.0)
+    net = net.cuda()
+    rng = np.random.default_rng(4)
+    U, n = 5, 200
+    starts = scrambled_input(rng.integers(0, 256, size=(U, net.receptive_field))).cuda()
+    for correct in (False, True):
+        batch = fg.generate_codes_batch(net, starts, n, correct_queue=correct)
+        assert batch.shape == (U, n)
+        for u in range(U):
+            single = fg.generate_codes(net, starts[u:u + 1], n, correct_queue=correct)
+            assert torch.equal(batch[u], single.view(-1)), (correct, u)
+        assert len(torch.unique(batch)) > 8           # not a degenerate constant stream
+    print("batched decode: %d utterances x %d codes identical to single-utterance launches" % (U, n))
+
+
 def test_autoencoder_backward_64_channels_vs_oracle():
     """The autoencoder at 64 decoder channels (BASELINE config-4 width): its decoder blocks run the
     channel-split backward kernel WITH the conditioning table (stretch and tile layers): loss and every

@@ -138,6 +138,19 @@ def main():
         res["decode_16000_samples_s"] = round(dt, 4)
         res["decode_samples_per_s"] = round(16000 / dt, 1)
         res["decode_distinct_codes"] = int(torch.unique(codes).numel())
+        # batched utterances: U independent streams in one launch
+        for U in (16, 64, 128):
+            starts = start.repeat(U, 1, 1).clone()
+            for u in range(U):                      # different start classes so the streams differ
+                starts[u].zero_()
+                starts[u, (128 + u) % 256, :] = 1.0
+            fg.generate_codes_batch(net, starts, 50)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cb = fg.generate_codes_batch(net, starts, 4000)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res["decode_batch%d_samples_per_s" % U] = round(U * 4000 / dt, 1)
     if args.what in ("ae", "all"):
         # BASELINE config 4: autoencoder, 30+30 blocks, 64 ch, skip 256, bottleneck 64, pool 512, batch 8 x 16000:
         # forward + CE + backward (fresh conditioning projections every forward, as in the reference)
