@@ -217,13 +217,16 @@ int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations
 /* The same loop for n_utt (<= 128) INDEPENDENT utterances side by side in one launch (batched
  * utterances; the reference generates one at a time): weights shared, everything else per utterance with
  * utterance u at queues + u*queues_ustride, note0/prev0/note_out/prev_out + u*Q, forced/codes_out +
- * u*n_steps, probs_out + u*n_steps*Q, sync + u*(n_layers*D + 2).  All utterances share step0 / n_steps. */
+ * u*n_steps, probs_out + u*n_steps*Q, sync + u*(n_layers*D + 2).  All utterances share step0 / n_steps.
+ * temperature > 0: SAMPLE each code from softmax(logits / temperature) (inverse CDF, uniform numbers from
+ * a counter-based generator keyed by (seed, step0 + step, u): reproducible); <= 0: greedy argmax. */
 int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
                     float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
                     int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
                     const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
                     float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
-                    int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, wn_stream_t stream);
+                    int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, float temperature,
+                    uint64_t seed, wn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -59,7 +59,7 @@ SIGNATURES = {
     "wn_decode": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l,
                   _i, _i, _p, _p],
     "wn_decode_batch": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l,
-                        _i, _i, _p, _i, _l, _p],
+                        _i, _i, _p, _i, _l, _f, _l, _p],
 }
 
 _lib = None

@@ -232,7 +232,8 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
                     int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
                     const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
                     float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
-                    int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, wn_stream_t stream);
+                    int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, float temperature,
+                    uint64_t seed, wn_stream_t stream);
 
 int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
               float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
@@ -242,7 +243,7 @@ int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations
               int n_steps, int push_input, uint64_t* sync, wn_stream_t stream) {
     return wn_decode_batch(n_layers, R, D, S, Q, dilations_host, q_off_host, queues, w_causal, b_causal, w_layers, layer_stride,
                            b_layers, w_p1, b_p1, w_p2, b_p2, note0, prev0, note_out, prev_out, forced, codes_out, probs_out,
-                           step0, n_steps, push_input, sync, 1, 0, stream);
+                           step0, n_steps, push_input, sync, 1, 0, 0.0f, 0, stream);
 }
 
 int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
@@ -250,7 +251,8 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
                     int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
                     const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
                     float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
-                    int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, wn_stream_t stream) {
+                    int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, float temperature,
+                    uint64_t seed, wn_stream_t stream) {
     if (n_utt <= 0) return 0;
     if (n_layers > WN_DEC_MAX_LAYERS || n_layers <= 0) return wn_set_error_msg(-4, "wn_decode: 1..64 layers supported");
     WnDecodeArgs a;
@@ -264,6 +266,7 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
     { const char* e = getenv("WN_DEC_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.sync = reinterpret_cast<unsigned long long*>(sync);
     a.n_utt = n_utt; a.queues_ustride = queues_ustride;
+    a.sample = temperature > 0.0f ? 1 : 0; a.inv_temp = temperature > 0.0f ? 1.0f / temperature : 1.0f; a.seed = seed;
     return wn_launch_decode(a, (hipStream_t)stream);
 }
 

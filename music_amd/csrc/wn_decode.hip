@@ -40,6 +40,58 @@ __device__ __forceinline__ void dec_matvec(const float* __restrict__ W, int ldw,
 }
 
 
+// Next code from the 256 pre-softmax logits (one wave, lane l owns entries 4l..4l+3): probabilities =
+// softmax(logit * inv_temp) (written to probs_dst if given), then either the first-index argmax (the
+// reference's greedy topk(1), fast_generate.py:139) or - SURVEY 8f2 - a draw from that distribution by
+// inverse CDF with the uniform number u in [0,1).  The result is valid in every lane.
+__device__ __forceinline__ int dec_choose(const float* logit, int lane, float* probs_dst, float inv_temp, bool sample, float u) {
+    float v[4], m = -INFINITY;
+    for (int e = 0; e < 4; ++e) { v[e] = logit[lane * 4 + e]; m = fmaxf(m, v[e]); }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float s = 0.f;
+    for (int e = 0; e < 4; ++e) { v[e] = expf((v[e] - m) * inv_temp); s += v[e]; }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float inv = 1.0f / s;
+    float best = -1.f; int bi = 0;
+    for (int e = 0; e < 4; ++e) {
+        v[e] *= inv;
+        if (probs_dst) probs_dst[lane * 4 + e] = v[e];
+        if (v[e] > best) { best = v[e]; bi = lane * 4 + e; }
+    }
+    if (!sample) {
+        for (int off = 32; off > 0; off >>= 1) {
+            float ob = __shfl_xor(best, off, 64);
+            int oi = __shfl_xor(bi, off, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        return bi;
+    }
+    // inclusive scan of the lane sums, then the first entry whose cumulative probability exceeds u
+    const float mine = (v[0] + v[1]) + (v[2] + v[3]);
+    float incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    float c = incl - mine;
+    int pick = 1 << 20;
+    for (int e = 0; e < 4; ++e) {
+        c += v[e];
+        if (pick == (1 << 20) && c > u) pick = lane * 4 + e;
+    }
+    for (int off = 32; off > 0; off >>= 1) pick = min(pick, __shfl_xor(pick, off, 64));
+    return pick < 256 ? pick : 255;                 // (u above the rounded total: last entry)
+}
+
+// Uniform number in [0,1) for (seed, global step, utterance): splitmix64 finaliser, 24 random bits.
+__device__ __forceinline__ float dec_uniform(unsigned long long seed, unsigned long long step, unsigned long long utt) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (step + 1) + 0xD1B54A32D192ED03ull * (utt + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
 __global__ __launch_bounds__(DEC_THREADS) void decode_k(WnDecodeArgs a) {
     // utterance of a batched launch: per-utterance pointers as LOCALS (the argument struct itself must stay
     // untouched: a modified copy would be moved to scratch and every dil[] / q_off[] lookup with it)
@@ -112,24 +164,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_k(WnDecodeArgs a) {
         __syncthreads();
         // softmax over the Q (=256) logits and first-index argmax of the PROBABILITIES, wave 0
         if (tid < 64) {
-            float v[4], m = -INFINITY;
-            for (int e = 0; e < 4; ++e) { v[e] = logit[tid * 4 + e]; m = fmaxf(m, v[e]); }
-            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-            float s = 0.f;
-            for (int e = 0; e < 4; ++e) { v[e] = expf(v[e] - m); s += v[e]; }
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-            const float inv = 1.0f / s;
-            float best = -1.f; int bi = 0;
-            for (int e = 0; e < 4; ++e) {
-                v[e] *= inv;
-                if (u_probs_out) u_probs_out[(size_t)step * a.Q + tid * 4 + e] = v[e];
-                if (v[e] > best) { best = v[e]; bi = tid * 4 + e; }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                float ob = __shfl_xor(best, off, 64);
-                int oi = __shfl_xor(bi, off, 64);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
+            const float ur = a.sample ? dec_uniform(a.seed, (unsigned long long)(a.step0 + step), utt) : 0.f;
+            const int bi = dec_choose(logit, tid, u_probs_out ? u_probs_out + (size_t)step * a.Q : nullptr, a.inv_temp, a.sample != 0, ur);
             if (tid == 0) { s_arg = bi; u_codes_out[step] = bi; }
         }
         __syncthreads();
@@ -311,24 +347,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_v4_k(WnDecodeArgs a) {
         }
         dec_sync();
         if (tid < 64) {
-            float v[4], m = -INFINITY;
-            for (int e = 0; e < 4; ++e) { v[e] = logit[tid * 4 + e]; m = fmaxf(m, v[e]); }
-            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-            float s = 0.f;
-            for (int e = 0; e < 4; ++e) { v[e] = expf(v[e] - m); s += v[e]; }
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-            const float inv = 1.0f / s;
-            float best = -1.f; int bi = 0;
-            for (int e = 0; e < 4; ++e) {
-                v[e] *= inv;
-                if (u_probs_out) u_probs_out[(size_t)step * Q + tid * 4 + e] = v[e];
-                if (v[e] > best) { best = v[e]; bi = tid * 4 + e; }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                float ob = __shfl_xor(best, off, 64);
-                int oi = __shfl_xor(bi, off, 64);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
+            const float ur = a.sample ? dec_uniform(a.seed, (unsigned long long)(a.step0 + step), utt) : 0.f;
+            const int bi = dec_choose(logit, tid, u_probs_out ? u_probs_out + (size_t)step * a.Q : nullptr, a.inv_temp, a.sample != 0, ur);
             if (tid == 0) { s_arg = bi; u_codes_out[step] = bi; }
         }
         dec_sync();
@@ -530,24 +550,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_duo_k(WnDecodeArgs a) {
             }
             dec_sync();
             if (tid < 64) {
-                float v[4], m = -INFINITY;
-                for (int e = 0; e < 4; ++e) { v[e] = logit[tid * 4 + e]; m = fmaxf(m, v[e]); }
-                for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-                float s = 0.f;
-                for (int e = 0; e < 4; ++e) { v[e] = expf(v[e] - m); s += v[e]; }
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-                const float inv = 1.0f / s;
-                float best = -1.f; int bi = 0;
-                for (int e = 0; e < 4; ++e) {
-                    v[e] *= inv;
-                    if (u_probs_out) u_probs_out[(size_t)step * Q + tid * 4 + e] = v[e];
-                    if (v[e] > best) { best = v[e]; bi = tid * 4 + e; }
-                }
-                for (int off = 32; off > 0; off >>= 1) {
-                    float ob = __shfl_xor(best, off, 64);
-                    int oi = __shfl_xor(bi, off, 64);
-                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-                }
+                const float ur = a.sample ? dec_uniform(a.seed, (unsigned long long)(a.step0 + step), utt) : 0.f;
+                const int bi = dec_choose(logit, tid, u_probs_out ? u_probs_out + (size_t)step * Q : nullptr, a.inv_temp, a.sample != 0, ur);
                 if (tid == 0) {
                     u_codes_out[step] = bi;
                     __hip_atomic_store(cg, dec_pack((float)bi, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

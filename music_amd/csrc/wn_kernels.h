@@ -155,5 +155,7 @@ struct WnDecodeArgs {
     // independent utterances decoded side by side (one workgroup, or one pair, each): element strides
     // between utterances of queues / [Q] state vectors / per-step outputs; weights are shared
     int n_utt; long queues_ustride;
+    // sampling: sample != 0 draws from softmax(logit * inv_temp) instead of taking the argmax
+    int sample; float inv_temp; unsigned long long seed;
 };
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st);

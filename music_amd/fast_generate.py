@@ -127,7 +127,7 @@ class DecodeState(OrderedDict):
         return DecodeState(eng, rings.contiguous(), prev, 0)
 
 
-def _decode(net, state, note0, n_steps, forced=None, want_probs=False, correct_queue=False):
+def _decode(net, state, note0, n_steps, forced=None, want_probs=False, correct_queue=False, temperature=None, seed=0):
     eng = state.eng
     pack = getattr(net, "_decode_pack", None)
     if pack is None or pack.eng is not eng:
@@ -145,12 +145,13 @@ def _decode(net, state, note0, n_steps, forced=None, want_probs=False, correct_q
     if sync is None or sync.device != dev or sync.numel() < eng.N * eng.D + 2:
         sync = net._decode_sync = torch.zeros(eng.N * eng.D + 2, dtype=torch.int64, device=dev)
     bias = pack.o_bias is not None
-    call("wn_decode", eng.N, eng.R, eng.D, eng.S, eng.Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
+    call("wn_decode_batch", eng.N, eng.R, eng.D, eng.S, eng.Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
          ptr(state.rings), pack.p(pack.o_causal), pack.p(pack.ob_causal) if bias else None,
          pack.p(pack.o_layers), pack.layer_stride, pack.p(pack.ob_layers) if bias else None,
          pack.p(pack.o_p1), pack.p(pack.ob_p1) if bias else None, pack.p(pack.o_p2), pack.p(pack.ob_p2) if bias else None,
          ptr(note0), ptr(state.prev), ptr(note_out), ptr(prev_out), ptr(forced_t), ptr(codes), ptr(probs),
-         state.steps, n_steps, 1 if correct_queue else 0, ptr(sync), _lib.stream())
+         state.steps, n_steps, 1 if correct_queue else 0, ptr(sync), 1, 0,
+         float(temperature) if temperature else 0.0, int(seed), _lib.stream())
     if n_steps >= 4 and int(sync[-1].item()) != 0:
         raise _lib.WavenetHipError("wn_decode: a hand-off between the two decode workgroups timed out")
     state.prev = prev_out
@@ -184,20 +185,22 @@ def predict_next(net, note, state_queue=None, correct_queue=False):
     return codes.to(torch.int64).to(note.device), state_queue
 
 
-def generate_codes(net, start_piece, note_num, correct_queue=False):
+def generate_codes(net, start_piece, note_num, correct_queue=False, temperature=None, seed=0):
     """The greedy loop of fast_generate.py:162-172 as one init forward + ONE persistent launch.
-    Returns the note_num generated codes (int64, on the device)."""
+    Returns the note_num generated codes (int64, on the device).
+    ``temperature`` (the reference is greedy only): if given and > 0, every code after the
+    first is SAMPLED from softmax(logits / temperature), reproducibly for a given ``seed``."""
     with torch.no_grad():
         first, state = predict_next(net, start_piece, None)
     if note_num <= 1:
         return first.to(state.eng.device)[:note_num]
     note0 = torch.zeros(net.quantization_channels, dtype=torch.float32, device=state.eng.device)
     note0[int(first[0])] = 1.0
-    codes, _, _ = _decode(net, state, note0, note_num - 1, correct_queue=correct_queue)
+    codes, _, _ = _decode(net, state, note0, note_num - 1, correct_queue=correct_queue, temperature=temperature, seed=seed)
     return torch.cat([first.to(codes.device).to(torch.int64), codes.to(torch.int64)])
 
 
-def generate_codes_batch(net, start_pieces, note_num, correct_queue=False):
+def generate_codes_batch(net, start_pieces, note_num, correct_queue=False, temperature=None, seed=0):
     """SURVEY 8f2 (batched utterances; the reference generates one at a time): greedy generation of
     ``note_num`` codes for U independent start pieces ``(U, Q, receptive_field)`` in ONE persistent
     launch - every utterance gets its own workgroup pair, the weights are shared.  Returns int64
@@ -241,7 +244,8 @@ def generate_codes_batch(net, start_pieces, note_num, correct_queue=False):
          pack.p(pack.o_layers), pack.layer_stride, pack.p(pack.ob_layers) if bias else None,
          pack.p(pack.o_p1), pack.p(pack.ob_p1) if bias else None, pack.p(pack.o_p2), pack.p(pack.ob_p2) if bias else None,
          ptr(note0), ptr(prev0), ptr(note_out), ptr(prev_out), None, ptr(codes), None,
-         0, n_steps, 1 if correct_queue else 0, ptr(sync), U, rings.size(1), _lib.stream())
+         0, n_steps, 1 if correct_queue else 0, ptr(sync), U, rings.size(1),
+         float(temperature) if temperature else 0.0, int(seed), _lib.stream())
     if n_steps >= 4:
         flags = sync.view(U, -1)[:, -1]
         if int(flags.abs().max().item()) != 0:

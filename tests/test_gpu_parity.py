@@ -486,6 +486,67 @@ def test_batched_decode_equals_single_utterances():
     print("batched decode: %d utterances x %d codes identical to single-utterance launches" % (U, n))
 
 
+def test_sampled_decode_follows_the_distribution():
+    """Sampling (an extension: the reference is greedy): with teacher forcing the kernel
+    returns, per step, the distribution it drew from and the drawn code.  Checks: (1) every drawn code is
+    what inverse-CDF sampling of THAT distribution gives for the kernel's own uniform number (restated on
+    the CPU: splitmix64 of (seed, step, utterance)); (2) same seed -> same codes, other seed -> other codes;
+    (3) temperature -> 0 reproduces the greedy codes; (4) the distribution at temperature T is the
+    renormalised T = 1 distribution to the power 1/T."""
+    from music_amd.model import wavenet
+    from music_amd import fast_generate as fg
+    cfg = dict(filter_width=2, dilations=[1, 2, 4, 8, 16], dilation_channels=64, residual_channels=64,
+               skip_channels=256, quantization_channels=256, use_bias=False)
+    torch.manual_seed(9)
+    net = wavenet(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    net = net.cuda()
+    rng = np.random.default_rng(10)
+    start = scrambled_input(rng.integers(0, 256, size=(1, net.receptive_field))).cuda()
+    n = 300
+    forced = torch.from_numpy(rng.integers(0, 256, size=(n,)).astype(np.int32)).cuda()
+
+    def run(temperature, seed):
+        with torch.no_grad():
+            first, state = fg.predict_next(net, start, None)
+        note0 = torch.zeros(256, device="cuda")
+        note0[int(first[0])] = 1.0
+        codes, probs, _ = fg._decode(net, state, note0, n, forced=forced, want_probs=True, temperature=temperature, seed=seed)
+        return codes.cpu().numpy(), probs.cpu().numpy().astype(np.float64)
+
+    def uniform(seed, step, utt=0):
+        M = (1 << 64) - 1
+        z = (seed + 0x9E3779B97F4A7C15 * (step + 1) + 0xD1B54A32D192ED03 * (utt + 1)) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        return (z >> 40) / 16777216.0
+
+    c1, p1 = run(1.0, 7)
+    assert np.allclose(p1.sum(1), 1.0, atol=1e-5)
+    for t in range(n):                               # (1) the draw is the inverse CDF of the reported distribution
+        u = uniform(7, t)
+        cdf = np.cumsum(p1[t])
+        k = int(c1[t])
+        lo = cdf[k - 1] if k > 0 else 0.0
+        assert lo - 1e-5 <= u < cdf[k] + 1e-5, (t, k, u, lo, cdf[k])
+    c1b, _ = run(1.0, 7)
+    c2, _ = run(1.0, 8)
+    assert (c1 == c1b).all() and (c1 != c2).any()    # (2)
+    cg, pg = run(None, 0)                            # greedy
+    c0, _ = run(1e-9, 5)
+    assert (c0 == cg).mean() >= 0.99                 # (3) (an exact fp32 tie of the two largest logits may go either way)
+    assert (cg == pg.argmax(1)).all()
+    _, ph = run(0.5, 3)                              # (4) T = 0.5: p^2 renormalised
+    ref = pg ** 2
+    ref /= ref.sum(1, keepdims=True)
+    assert np.abs(ph - ref).max() < 1e-5
+    assert len(np.unique(c1)) > 20
+    print("sampled decode: %d draws consistent with their distributions; %d distinct codes" % (n, len(np.unique(c1))))
+
+
 def test_autoencoder_backward_64_channels_vs_oracle():
     """The autoencoder at 64 decoder channels (BASELINE config-4 width): its decoder blocks run the
     channel-split backward kernel WITH the conditioning table (stretch and tile layers): loss and every
