@@ -12,7 +12,10 @@ Differences, all additive:
     (``torchrun --nproc-per-node N train.py``) with ONE flat RCCL all-reduce per step
     (music_amd/dist.py); each rank builds only its own shard of every global batch.
   * optional keys in train_params.json: ``"seed"`` (int), ``"fused_step"`` (bool: Adam only — the
-    whole step runs as forward+CE+backward+flat-Adam kernels without autograd).
+    whole step runs as forward+CE+backward+flat-Adam kernels without autograd), ``"save_optimizer_state"``
+    (bool, SURVEY 8f4: the reference drops the optimizer state at every checkpoint, so a resumed Adam /
+    momentum run restarts cold; with this key ``wavenet{N}.opt`` is written next to ``wavenet{N}.model``
+    and read back when that model is restored — the .model file itself stays the reference's format).
 """
 from collections import OrderedDict
 from functools import cmp_to_key
@@ -88,6 +91,34 @@ def _rotate_checkpoints(restore_dir, max_check_points):
             return int(p.split('/')[-1].split('.')[0][7:])
         stored = sorted(stored, key=cmp_to_key(lambda a, b: number(a) - number(b)))
         os.remove(stored[0])
+        if os.path.exists(stored[0][:-len(".model")] + ".opt"):       # its optimizer state, if one was written
+            os.remove(stored[0][:-len(".model")] + ".opt")
+
+
+def _optimizer_state(optimizer, engine):
+    """What wavenet{N}.opt holds: the torch optimizer's state_dict, or the flat Adam buffers of the fused step."""
+    if engine is not None and engine.adam_state is not None:
+        st = engine.adam_state
+        return {"kind": "fused_adam", "m": st["m"].detach().cpu().clone(), "v": st["v"].detach().cpu().clone(), "t": int(st["t"])}
+    return {"kind": "torch", "state": optimizer.state_dict()}
+
+
+def _restore_optimizer_state(path, optimizer, engine_factory):
+    """Load wavenet{N}.opt if it exists.  Returns the engine if the fused Adam state was restored."""
+    if not os.path.exists(path):
+        return None
+    blob = torch.load(path, map_location="cpu")
+    if blob.get("kind") == "fused_adam":
+        engine = engine_factory()
+        if engine is None:
+            return None
+        engine.adam_state["m"].copy_(blob["m"])
+        engine.adam_state["v"].copy_(blob["v"])
+        engine.adam_state["t"] = int(blob["t"])
+        return engine
+    if blob.get("kind") == "torch" and optimizer is not None:
+        optimizer.load_state_dict(blob["state"])
+    return None
 
 
 def _resume_counter(log_dir):
@@ -106,6 +137,7 @@ def train():
 
     net = wavenet(**wavenet_params)
     epoch_trained = 0
+    restored_from = None
     if train_params["restore_model"]:
         net = load_model(net, train_params["restore_dir"], train_params["restore_model"])
         if net is None:
@@ -113,6 +145,7 @@ def train():
             net = wavenet(**wavenet_params)
         else:
             epoch_trained = int(train_params["restore_model"].split('.')[0][7:])
+            restored_from = train_params["restore_dir"] + train_params["restore_model"]
 
     if cuda_available is False and train_params["device_ids"] is not None:
         raise ValueError("Cuda is not avalable,", " can not train model using multi-gpu.")
@@ -149,6 +182,16 @@ def train():
     device = next(net.parameters()).device
     total_loss = torch.zeros((), dtype=torch.float64, device=device)     # summed without host syncs
     engine = None
+    keep_opt = bool(train_params.get("save_optimizer_state"))
+    if keep_opt and restored_from is not None:
+
+        def _fused_engine():
+            if not fused:
+                return None
+            e = net._engine_for(device)
+            e.adam_init(lr=train_params["learning_rate"])
+            return e
+        engine = _restore_optimizer_state(restored_from[:-len(".model")] + ".opt", optimizer, _fused_engine)
     for epoch in range(train_params["num_epochs"]):
         for i_batch, sampled_batch in enumerate(dataloader):
             piece = sampled_batch["audio_piece"]
@@ -187,6 +230,9 @@ def train():
         if (epoch + 1) % train_params["check_point_every"] == 0 and is_writer:
             _rotate_checkpoints(train_params["restore_dir"], train_params["max_check_points"])
             save_model(net, epoch_trained + epoch + 1, train_params["restore_dir"])
+            if keep_opt:
+                torch.save(_optimizer_state(optimizer, engine),
+                           train_params["restore_dir"] + "wavenet" + str(epoch_trained + epoch + 1) + ".opt")
             store_log_file.writelines("Epoch " + str(epoch_trained + epoch + 1) + ", model saved!\n")
             store_log_file.flush()
     if is_writer:

@@ -669,6 +669,44 @@ def test_g7_train_loop_on_gpu(tmp_path, monkeypatch, fused):
         assert abs(float(v.double().abs().sum()) - s) <= 2e-3 * max(1.0, s)
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_optimizer_state_survives_a_restart_on_gpu(tmp_path, monkeypatch, fused):
+    """SURVEY 8f4 on the device: stop after epoch 2, resume from wavenet2.model + wavenet2.opt for one
+    epoch == an uninterrupted 3-epoch run, bit for bit (the HIP path is deterministic), for the torch
+    optimizer and for the flat Adam buffers of the fused step."""
+    import json
+    import os
+    from music_amd import train as T
+    from music_amd.model import wavenet
+    finals = {}
+    for mode in ("straight", "resumed"):
+        root = tmp_path / mode
+        os.makedirs(root)
+        extra = {"fused_step": fused, "optimizer": "adam", "learning_rate": 1e-3, "save_optimizer_state": True,
+                 "check_point_every": 1, "max_check_points": 10, "num_epochs": 3 if mode == "straight" else 2}
+        g7 = _g7_run(root, monkeypatch, "gain", extra)
+
+        def ctor(**kw):
+            net = wavenet(**kw)
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.mul_(g7["gain"])
+            return net
+        monkeypatch.setattr(T, "wavenet", ctor)
+        torch.manual_seed(0)
+        T.train()
+        if mode == "resumed":
+            assert os.path.exists(root / "restore" / "wavenet2.opt")
+            tp = dict(g7["train_params"], **extra)
+            tp.update(num_epochs=1, restore_model="wavenet2.model")
+            json.dump(tp, open(root / "params" / "train_params.json", "w"))
+            T.train()
+        finals[mode] = torch.load(root / "restore" / "wavenet3.model")
+        monkeypatch.undo()
+    for (k, a), b in zip(finals["straight"].items(), finals["resumed"].values()):
+        assert torch.equal(a, b), k
+
+
 def test_autoencoder_train_harness_on_gpu(tmp_path, monkeypatch):
     import json
     import os

@@ -133,3 +133,36 @@ def test_autoencoder_harness_surface(tmp_path):
     assert isinstance(A.get_optimizer(net, "sgd", 1e-3, 0.5), torch.optim.SGD)
     assert isinstance(A.get_optimizer(net, "lbfgs", 1e-3), torch.optim.LBFGS)
     import music_amd.ae_generate  # noqa: F401  (no import-time generation)
+
+
+def test_optimizer_state_survives_a_restart(tmp_path, monkeypatch):
+    """with "save_optimizer_state" a run that is stopped after epoch 2 and resumed from
+    wavenet2.model (+ wavenet2.opt) for one more epoch ends with the same weights as an uninterrupted
+    3-epoch run (Adam: the moments and the step count come back); without the .opt file it does not."""
+    import shutil
+    g7 = json.load(open(os.path.join(GOLDEN, "g7_train.json")))
+    finals = {}
+    for mode in ("straight", "resumed", "resumed_cold"):
+        root = tmp_path / mode
+        os.makedirs(root)
+        T = _setup_run(root, g7, monkeypatch, g7["gain"])
+        base = dict(g7["train_params"], optimizer="adam", learning_rate=1e-3, save_optimizer_state=True,
+                    check_point_every=1, max_check_points=10)
+        if mode == "straight":
+            json.dump(dict(base, num_epochs=3), open(root / "params" / "train_params.json", "w"))
+            torch.manual_seed(0)
+            T.train()
+        else:
+            json.dump(dict(base, num_epochs=2), open(root / "params" / "train_params.json", "w"))
+            torch.manual_seed(0)
+            T.train()
+            assert os.path.exists(root / "restore" / "wavenet2.opt")
+            if mode == "resumed_cold":
+                os.remove(root / "restore" / "wavenet2.opt")
+            json.dump(dict(base, num_epochs=1, restore_model="wavenet2.model"), open(root / "params" / "train_params.json", "w"))
+            T.train()
+        finals[mode] = torch.load(root / "restore" / "wavenet3.model")
+        monkeypatch.undo()
+    same = all(torch.equal(a, b) for a, b in zip(finals["straight"].values(), finals["resumed"].values()))
+    cold_same = all(torch.equal(a, b) for a, b in zip(finals["straight"].values(), finals["resumed_cold"].values()))
+    assert same and not cold_same
