@@ -547,6 +547,36 @@ def test_sampled_decode_follows_the_distribution():
     print("sampled decode: %d draws consistent with their distributions; %d distinct codes" % (n, len(np.unique(c1))))
 
 
+def test_wav_to_numpy_prep_on_device(tmp_path):
+    """.wav files -> np_audio.pkl with the companding on the device: the codes are bit-exact
+    against the oracle's restatement of the reference encoder (audio_func.py:5-22), the pickle has the
+    reference's format (list of int32 arrays) and feeds audio_dataset unchanged."""
+    import pickle
+    from scipy.io import wavfile
+    from music_amd import wav_to_numpy as w2n
+    from music_amd.faster_audio_data import audio_dataset
+    from oracle import intops
+    thr = load_npz("g5_mulaw.npz")["thresholds"]             # the reference encoder's 255 float32 decision thresholds (G5)
+    rng = np.random.default_rng(13)
+    waves = [np.clip(0.3 * rng.standard_normal(n), -1.2, 1.2).astype(np.float32) for n in (5000, 12345)]
+    waves[0][:6] = [0.0, 1.0, -1.0, 1.5, -1.5, 1e-9]              # clipping and the centre code
+    codes = w2n.encode_waveforms(waves)
+    for w, c in zip(waves, codes):
+        assert c.dtype == np.int32 and c.shape == w.shape
+        assert np.array_equal(c, intops.mu_law_encode_table(w, thr).astype(np.int32))
+    d = str(tmp_path) + "/"
+    pcm = (np.clip(waves[1], -1, 1) * 32767).astype(np.int16)
+    wavfile.write(d + "a.wav", 16000, pcm)
+    wavfile.write(d + "b.wav", 32000, np.repeat(pcm, 2))          # resampled to 16 kHz on load
+    out = w2n.main(d)
+    stored = pickle.load(open(d + "np_audio.pkl", "rb"))
+    assert len(stored) == 2 and all(a.dtype == np.int32 for a in stored)
+    assert np.array_equal(stored[0], intops.mu_law_encode_table(pcm.astype(np.float32) / 32768.0, thr).astype(np.int32))
+    assert abs(len(stored[1]) - len(pcm)) <= 1
+    ds = audio_dataset(d + "np_audio.pkl", 1025, 2000)
+    assert len(ds) > 0 and ds[0]["audio_piece"].dtype == torch.int32
+
+
 def test_autoencoder_backward_64_channels_vs_oracle():
     """The autoencoder at 64 decoder channels (BASELINE config-4 width): its decoder blocks run the
     channel-split backward kernel WITH the conditioning table (stretch and tile layers): loss and every
