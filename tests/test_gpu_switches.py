@@ -1,0 +1,31 @@
+"""Every documented developer switch (README.md) selects an alternative kernel path that must stay
+CORRECT: the 64-channel ragged-shape parity case and the channel-split parity test are re-run in a
+fresh interpreter per switch (the switches are read once per process).  Run with -m gpu."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SWITCHES = [
+    {"WN_MS_BWD": "0"},            # resblock_bwd_k + 2 x wgrad_k instead of the channel-split block
+    {"WN_XCD": "0"},               # no XCD-aware block remap
+    {"WN_GEMM_WIDE": "1"},         # first wide-GEMM version
+    {"WN_FWD_NT": "0"},            # first forward block kernel
+    {"WN_FWD_NT": "2"},            # 16 waves x 2 N-tiles
+    {"WN_FWD_CS": "1"},            # channel-split forward block
+]
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_alternative_paths_stay_correct(env):
+    e = dict(os.environ, **env)
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_gpu_sweep.py"), "-k", "d10_R64 or d2_R64 or d4_R48",
+           os.path.join(ROOT, "tests", "test_gpu_parity.py") + "::test_fused_train_step_matches_autograd_path_and_oracle"]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
