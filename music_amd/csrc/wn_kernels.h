@@ -79,6 +79,10 @@ struct WnResMsArgs {
 };
 int wn_launch_resblock_bwd_ms(const WnResMsArgs& a, int ch, int batch, int mode_fwd, int mode_bwd, hipStream_t st);
 int wn_resms_slabs(int t_lo, int t_hi, int batch);
+// two-role form of the same block (wn_resrw.hip): 8 waves, 32-column items; same arguments and slab format
+int wn_launch_resblock_bwd_rw(const WnResMsArgs& a, int batch, hipStream_t st);
+void wn_resrw_plan(int t_lo, int t_hi, int batch, int& t_base, int& steps, int& ipw, int& nwg);
+int wn_ms_two_role();              // host: env WN_MS_RW (default 1)
 
 struct WnWgradArgs {
     const float* a; long a_bstride; int a_pitch; int a_shift; int a_cols;   // A: [M rows][time]

@@ -23,6 +23,7 @@
 //     the columns the workgroup walks (persistent workgroups, one slab each, reduced by reduce_slabs_k).
 // HBM traffic per block: x, dy, dz-crop in, [df;dg] out (the dx product still reads it): ~4.8
 // activation-sized tensors against ~10.8 for resblock_bwd_k + 2 x wgrad_k.  z never leaves the CU.
+#include <stdlib.h>
 #include <type_traits>
 #include "wn_common.h"
 #include "wn_kernels.h"
@@ -385,6 +386,15 @@ __global__ __launch_bounds__(MS_THREADS) void resblock_bwd_ms_k(WnResMsArgs a) {
     }
 }
 
+int wn_ms_two_role() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WN_MS_RW");
+        v = e ? (atoi(e) != 0) : 1;
+    }
+    return v;
+}
+
 static void ms_plan(int t_lo, int t_hi, int batch, int& t_base, int& steps, int& ipw, int& nwg) {
     t_base = t_lo & ~3;
     steps = (t_hi - t_base + 63) / 64;
@@ -398,7 +408,8 @@ static void ms_plan(int t_lo, int t_hi, int batch, int& t_base, int& steps, int&
 int wn_resms_slabs(int t_lo, int t_hi, int batch) {
     if (t_hi <= t_lo || batch <= 0) return 0;
     int tb, steps, ipw, nwg;
-    ms_plan(t_lo, t_hi, batch, tb, steps, ipw, nwg);
+    if (wn_ms_two_role()) wn_resrw_plan(t_lo, t_hi, batch, tb, steps, ipw, nwg);
+    else ms_plan(t_lo, t_hi, batch, tb, steps, ipw, nwg);
     return nwg;
 }
 
@@ -407,6 +418,7 @@ int wn_launch_resblock_bwd_ms(const WnResMsArgs& a, int ch, int batch, int mode_
     if (ch != MS_CH) return wn_set_error_msg(-3, "resblock_bwd_ms: 64 padded channels only");
     if (mode_fwd != WN_MODE_F16X3 || mode_bwd != WN_MODE_BF16X3)
         return wn_set_error_msg(-2, "resblock_bwd_ms: (f16x3, bf16x3) only");
+    if (wn_ms_two_role()) return wn_launch_resblock_bwd_rw(a, batch, st);
     WnResMsArgs k = a;
     int nwg;
     ms_plan(a.t_lo, a.t_hi, batch, k.t_base, k.steps_per_clip, k.items_per_wg, nwg);

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SWITCHES = [
     {"WN_MS_BWD": "0"},            # resblock_bwd_k + 2 x wgrad_k instead of the channel-split block
+    {"WN_MS_RW": "0"},             # one-role channel-split block (4 waves) instead of the two-role one (8 waves)
     {"WN_XCD": "0"},               # no XCD-aware block remap
     {"WN_GEMM_WIDE": "1"},         # first wide-GEMM version
     {"WN_FWD_NT": "0"},            # first forward block kernel
