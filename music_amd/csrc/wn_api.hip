@@ -12,6 +12,16 @@ int wn_set_error(hipError_t e, const char* file, int line) {
     snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
     return -1;
 }
+int wn_tile_origin(int t_lo) {
+    static int align = -1;
+    if (align < 0) {
+        const char* e = getenv("WN_TALIGN");
+        align = e ? atoi(e) : 64;
+        if (align < 4 || (align & (align - 1))) align = 4;
+    }
+    return t_lo & ~(align - 1);
+}
+
 int wn_xcd_swizzle_enabled() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("WN_XCD"); on = e ? atoi(e) : 1; }

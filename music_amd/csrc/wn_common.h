@@ -158,6 +158,10 @@ __device__ __forceinline__ WnBlock wn_block(int swz) {
     return o;
 }
 int wn_xcd_swizzle_enabled();      // host: env WN_XCD (default 1)
+// host: first column of a launch's tiling.  A multiple of WN_TALIGN (default 64) samples of absolute time, so that
+// the 256-byte row segment of a 64-column wave tile is exactly two 128-byte lines (pitch and bases are
+// multiples of 128 B); columns in front of t_lo are masked.  Must stay a multiple of 4 (float4 lanes).
+int wn_tile_origin(int t_lo);
 
 #define WN_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return wn_set_error(e_, __FILE__, __LINE__); } while (0)
 int wn_set_error(hipError_t e, const char* file, int line);

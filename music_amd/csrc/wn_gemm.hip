@@ -588,7 +588,7 @@ static int launch_gemm(const WnGemmArgs& k, int batch, hipStream_t st) {
 int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st) {
     if (a.t_hi <= a.t_lo || batch <= 0) return 0;
     WnGemmArgs k = a;
-    k.t_base = a.t_lo & ~3;                 // lanes own 4 consecutive, 4-aligned columns
+    k.t_base = wn_tile_origin(a.t_lo);
     k.swz = wn_xcd_swizzle_enabled();
     switch (mode) {
         case WN_MODE_F16X3: launch_gemm<F16, 3>(k, batch, st); break;

@@ -206,7 +206,7 @@ template <class T, int NS>
 static int launch_fwd(const WnResArgs& a, int ch, int batch, hipStream_t st) {
     WnResArgs k = a;
     k.swz = wn_xcd_swizzle_enabled();
-    k.t_base = a.t_lo & ~3;
+    k.t_base = wn_tile_origin(a.t_lo);
     int ncol = a.t_hi - k.t_base;
     dim3 g((ncol + WN_RES_COLS - 1) / WN_RES_COLS, batch), b(WN_RES_THREADS);
     const size_t fr = (NS == 3 ? 1024 : 512) * sizeof(uint16_t);
@@ -425,7 +425,7 @@ template <class TF, int NSF, class TB, int NSB>
 static int launch_bwd(const WnResBwdArgs& a, int ch, int batch, hipStream_t st) {
     WnResBwdArgs k = a;
     k.swz = wn_xcd_swizzle_enabled();
-    k.t_base = a.t_lo & ~3;
+    k.t_base = wn_tile_origin(a.t_lo);
     int ncol = a.t_hi - k.t_base;
     dim3 g((ncol + WN_RES_COLS - 1) / WN_RES_COLS, batch), b(WN_RES_THREADS);
     const size_t frf = (NSF == 3 ? 1024 : 512) * 2, frb = (NSB == 3 ? 1024 : 512) * 2;

@@ -260,7 +260,7 @@ template <class T, int NS, int NT>
 static int launch_fwd_nt(const WnResArgs& a, int ch, int batch, hipStream_t st) {
     WnResArgs k = a;
     k.swz = wn_xcd_swizzle_enabled();
-    k.t_base = a.t_lo & ~3;
+    k.t_base = wn_tile_origin(a.t_lo);
     const int ncol = a.t_hi - k.t_base;
     constexpr int COLS = NtCfg<NT>::WAVES * 16 * NT;
     dim3 g((ncol + COLS - 1) / COLS, batch), b(64 * NtCfg<NT>::WAVES);

@@ -22,6 +22,7 @@
 //
 // RW_T_* macros are timing-build switches (remove one ingredient; results are then wrong) used to see
 // what a launch is made of: -DRW_T_NOREC / NOWG / NOFILL / NOGATE / NOCR via `make EXTRA=...`.
+#include <stdlib.h>
 #include "wn_common.h"
 #include "wn_kernels.h"
 
@@ -37,12 +38,41 @@ __device__ __forceinline__ f32x2 ld2u(const float* p) {
     return r;
 }
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// (a, b) -> packed bf16 pairs hi = (bf16(a), bf16(b)) and lo = (bf16(a - hi_a), bf16(b - hi_b)): 6 VALU per pair
+__device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f32x2 v = {a, b};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+}
+
 // LDS map of one stage, in halfs (uint16): 8 x fragments | 4 dy fragments | 12 operand tiles | 12 result tiles
 #define RW_XF 0
 #define RW_DYF 8192
 #define RW_WO 12288
 #define RW_T 24576
 #define RW_STAGE 36864
+
+#ifdef RW_DBG
+// phase clock sums (developer build): [role 0/1][phase 0..3]
+__device__ unsigned long long rw_dbg[8];
+#define RW_TICK(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+#define RW_ACC(slot, dt) dbg_acc[(slot) & 3] += (unsigned long long)(dt)
+#define RW_FLUSH(base) do { if (lane == 0) for (int z_ = 0; z_ < 3; ++z_) atomicAdd(&rw_dbg[(base) + z_], dbg_acc[z_]); } while (0)
+extern "C" int wn_rw_dbg_read(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(rw_dbg), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(rw_dbg), z, sizeof(z));
+    }
+    return (int)e;
+}
+#else
+#define RW_TICK(var)
+#define RW_ACC(slot, dt)
+#define RW_FLUSH(base)
+#endif
 
 template <class T>
 __device__ __forceinline__ void rw_store_frag(uint16_t* base, int idx, int lane, const Frag<T>& f) {
@@ -58,6 +88,9 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
 
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = wv & 3;
+#ifdef RW_DBG
+    unsigned long long dbg_acc[4] = {0, 0, 0, 0};
+#endif
     const int c = lane & 15, q = lane >> 4;
     // 16-byte chunk (row, q) of a [16 rows][32 samples] tile plane sits at slot 16q + ((row + q) & 15):
     // the b128 reads/writes of lanes (row = c, q) and the b32 writes of lanes (row = 4q + i, samples 2c, 2c+1)
@@ -141,14 +174,17 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
 #endif
         };
 
-        Pos p_cur = pos_k(0);
-        f32x2 cr[4];
-        load_cr(cr, p_cur);
+        // The loop is unrolled by two so that every prefetch register set is re-armed TWO items ahead without
+        // copies (a loaded HBM latency is about one item long); an odd item count is padded with a void item
+        // (clamped position, everything masked: zeros in LDS, no stores).
+        f32x2 crA[4], crB[4];
+        load_cr(crA, pos_k(0));
+        load_cr(crB, pos_k(1));
         __syncthreads();                                    // stage 0 operands of the first item are in LDS
-        for (int it = 0; it < n_items; ++it) {
-            const Pos p_n1 = pos_k(it + 1);
-            f32x2 cr_next[4];
-            load_cr(cr_next, p_n1);
+        auto r_body = [&](const int it, f32x2* cr) {
+            RW_TICK(k0);
+            const Pos p_cur = pos_k(it);
+            const bool live = it < n_items;
             const int b = p_cur.b, t0 = p_cur.t0;
             const int tl = t0 + 2 * c;
             uint16_t* st = lds + (size_t)(it & 1) * RW_STAGE;
@@ -192,6 +228,7 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
                 }
             }
 #endif
+            RW_TICK(k1);
             if (a.cond) {       // same conditioning bias as the forward (wavenet_autoencoder/model1.py:183)
                 const float* cb = a.cond + (size_t)b * a.cond_bstride;
                 int idx[2];
@@ -212,7 +249,7 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
             }
             float* dfg = a.dfg + (size_t)b * a.dfg_bstride;
             uint16_t* tt = st + RW_T;
-            const bool ok0 = tl >= a.t_lo && tl < a.t_hi, ok1 = tl + 1 >= a.t_lo && tl + 1 < a.t_hi;
+            const bool ok0 = live && tl >= a.t_lo && tl < a.t_hi, ok1 = live && tl + 1 >= a.t_lo && tl + 1 < a.t_hi;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = 16 * g + 4 * q + i;
@@ -243,23 +280,27 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
                 }
                 // 16-bit hi/lo pairs of (sample 2c, sample 2c+1) -> one dword each in the [channel][time] tiles
                 auto put = [&](int kind, const float* v) {
-                    const __bf16 h0 = BF16::cvt(v[0]), h1 = BF16::cvt(v[1]);
-                    const __bf16 l0 = BF16::cvt(v[0] - BF16::back(h0)), l1 = BF16::cvt(v[1] - BF16::back(h1));
+                    uint32_t hi, lo;
+                    split2_bf16(v[0], v[1], hi, lo);
                     uint16_t* p = tt + (kind * 4 + g) * 1024 + t_wr[i];
-                    *reinterpret_cast<uint32_t*>(p) =
-                        (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
-                    *reinterpret_cast<uint32_t*>(p + 512) =
-                        (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+                    *reinterpret_cast<uint32_t*>(p) = hi;
+                    *reinterpret_cast<uint32_t*>(p + 512) = lo;
                 };
                 put(0, vf);
                 put(1, vg);
                 if (HAS_DY) put(2, vz);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cr[i] = cr_next[i];
-            p_cur = p_n1;
+            load_cr(cr, pos_k(it + 2));
+            RW_TICK(k2);
             __syncthreads();
+            RW_TICK(k3);
+            RW_ACC(0, k1 - k0); RW_ACC(1, k2 - k1); RW_ACC(2, k3 - k2);
+        };
+        for (int it = 0; it < n_items; it += 2) {
+            r_body(it, crA);
+            r_body(it + 1, crB);
         }
+        RW_FLUSH(0);
         return;
     }
 
@@ -281,11 +322,21 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         const int tl = ps.t0 + 2 * c;
         const float* xin = a.x_in + (size_t)ps.b * a.x_bstride;
         const float* p = xin + (size_t)(32 * (g & 1) + 8 * q) * a.pitch + ((g >> 1) == 0 ? tl - a.d : tl);
+#ifdef RW_T_NOLOAD
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.x[j] = f32x2{(float)(tl + j), (float)ps.b};
+#else
 #pragma unroll
         for (int j = 0; j < 8; ++j) r.x[j] = ld2u(p + (size_t)j * a.pitch);
+#endif
         const float* pd = dy_or_x + (size_t)ps.b * a.x_bstride + (size_t)(32 * (g >> 1) + 8 * q + 4 * (g & 1)) * a.pitch + tl;
+#ifdef RW_T_NOLOAD
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.dy[j] = f32x2{(float)(tl - j), (float)ps.b};
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.dy[j] = ld2u(pd + (size_t)j * a.pitch);
+#endif
     };
     auto fill_xd = [&](const RawXD& r, Pos ps, int stage) {
         const int tl = ps.t0 + 2 * c;
@@ -305,17 +356,13 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const bool ok = tl + n >= a.t_lo && tl + n < a.t_hi;      // columns outside hold no gradient
-                uint16_t hh[4], ll[4];
+                uint32_t hh[2], ll[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x = ok ? r.dy[j][n] : 0.f;
-                    const __bf16 hv = BF16::cvt(x);
-                    hh[j] = __builtin_bit_cast(uint16_t, hv);
-                    ll[j] = __builtin_bit_cast(uint16_t, BF16::cvt(x - BF16::back(hv)));
-                }
+                for (int j = 0; j < 2; ++j)
+                    split2_bf16(ok ? r.dy[2 * j][n] : 0.f, ok ? r.dy[2 * j + 1][n] : 0.f, hh[j], ll[j]);
                 uint16_t* fb = dyf + (size_t)(ks * 2 + n) * 1024 + lane * 8 + h * 4;
-                *reinterpret_cast<uint2*>(fb) = uint2{(uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16)};
-                *reinterpret_cast<uint2*>(fb + 512) = uint2{(uint32_t)ll[0] | ((uint32_t)ll[1] << 16), (uint32_t)ll[2] | ((uint32_t)ll[3] << 16)};
+                *reinterpret_cast<uint2*>(fb) = uint2{hh[0], hh[1]};
+                *reinterpret_cast<uint2*>(fb + 512) = uint2{ll[0], ll[1]};
             }
         }
     };
@@ -325,8 +372,13 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         for (int kind = 0; kind < (HAS_DY ? 3 : 2); ++kind) {
             const float* base = (kind == 2 ? dy_or_x : a.x_in) + (size_t)ps.b * a.x_bstride;
             const float* p = base + (size_t)(16 * g + c) * a.pitch + ps.t0 + 8 * q + (kind == 0 ? -a.d : 0);
+#ifdef RW_T_NOLOAD
+            r.v[kind][0] = f32x4{(float)ps.t0, (float)kind, 1.f, 2.f};
+            r.v[kind][1] = f32x4{(float)ps.b, (float)kind, 3.f, 4.f};
+#else
             r.v[kind][0] = ld4u(p);
             r.v[kind][1] = ld4u(p + 4);
+#endif
         }
     };
     auto fill_wo = [&](const RawWO& r, Pos ps, int stage) {
@@ -343,11 +395,17 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
                 }
                 w[j] = x;
             }
-            Frag<BF16> f;
-            split8<BF16, 3>(f, w);
+            u32x4 fh, fl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t hi, lo;
+                split2_bf16(w[2 * j], w[2 * j + 1], hi, lo);
+                fh[j] = hi;
+                fl[j] = lo;
+            }
             u32x4* p = reinterpret_cast<u32x4*>(wo + (kind * 4 + g) * 1024 + tile_rd);
-            p[0] = __builtin_bit_cast(u32x4, f.hi);
-            p[64] = __builtin_bit_cast(u32x4, f.lo);
+            p[0] = fh;
+            p[64] = fl;
         }
     };
     auto load_tile = [&](Frag<BF16>& f, const uint16_t* base, int tile) {
@@ -377,34 +435,41 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         }
     };
 
-    if (n_items > 0) {
-        RawXD rx;
-        RawWO rw;
-        Pos p_cur = pos_k(0);
-        Pos p_n1 = pos_k(1);
-        load_xd(rx, p_cur);
-        load_wo(rw, p_cur);
-        fill_xd(rx, p_cur, 0);
-        load_xd(rx, p_n1);
+    {
+        // rx1 / rx0 hold the raw recompute rows of items it+1 / it+2, rw0 / rw1 the raw [row][time] rows of items
+        // it / it+1; each set is re-armed two items ahead right after it was converted (see the R loop)
+        RawXD rx0, rx1;
+        RawWO rw0, rw1;
+        load_xd(rx0, pos_k(0));
+        load_wo(rw0, pos_k(0));
+        load_xd(rx1, pos_k(1));
+        load_wo(rw1, pos_k(1));
+        fill_xd(rx0, pos_k(0), 0);
+        load_xd(rx0, pos_k(2));
         __syncthreads();
-        for (int it = 0; it < n_items; ++it) {
-            const Pos p_n2 = pos_k(it + 2);
+        auto w_body = [&](const int it, RawXD& rx, RawWO& rw) {
+            RW_TICK(k0);
 #ifndef RW_T_NOFILL
-            fill_xd(rx, p_n1, (it + 1) & 1);                 // recompute operands of the next item
-            load_xd(rx, p_n2);
-            fill_wo(rw, p_cur, it & 1);                      // [row][time] operands of this item
-            load_wo(rw, p_n1);
+            fill_xd(rx, pos_k(it + 1), (it + 1) & 1);        // recompute operands of the next item
+            load_xd(rx, pos_k(it + 3));
+            fill_wo(rw, pos_k(it), it & 1);                  // [row][time] operands of this item
+            load_wo(rw, pos_k(it + 2));
 #endif
+            RW_TICK(k1);
 #ifndef RW_T_NOWG
             wgrad((it + 1) & 1);                             // products of the previous item
 #endif
-            p_cur = p_n1;
-            p_n1 = p_n2;
+            RW_TICK(k2);
             __syncthreads();
+            RW_TICK(k3);
+            RW_ACC(4, k1 - k0); RW_ACC(5, k2 - k1); RW_ACC(6, k3 - k2);
+        };
+        for (int it = 0; it < n_items; it += 2) {
+            w_body(it, rx1, rw0);
+            w_body(it + 1, rx0, rw1);
         }
-        wgrad((n_items - 1) & 1);
-    } else {
-        __syncthreads();
+        wgrad(1);                                           // the last item of the (even) padded count
+        RW_FLUSH(4);
     }
 
     // ---- slab of this workgroup (every workgroup writes one, also an idle one: zeros)
@@ -427,7 +492,11 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
 }
 
 void wn_resrw_plan(int t_lo, int t_hi, int batch, int& t_base, int& steps, int& ipw, int& nwg) {
-    t_base = t_lo & ~3;
+    // items start on multiples of 32 samples of absolute time = 128-byte lines of every row (pitch and bases
+    // are multiples of 128 B): each 32-sample row segment an item reads or writes is exactly ONE cache line
+    static int align = -1;
+    if (align < 0) { const char* e = getenv("WN_RW_ALIGN"); align = e ? atoi(e) : 32; if (align < 4) align = 4; }
+    t_base = t_lo & ~(align - 1);
     steps = (t_hi - t_base + RW_COLS - 1) / RW_COLS;
     const int total = steps * batch;
     ipw = (total + 255) / 256;
