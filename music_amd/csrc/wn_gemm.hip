@@ -590,6 +590,10 @@ int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st) {
     WnGemmArgs k = a;
     k.t_base = wn_tile_origin(a.t_lo);
     k.swz = wn_xcd_swizzle_enabled();
+    if (wn_launch_gemm_rw(k, batch, mode, st)) {
+        WN_CHECK_LAUNCH();
+        return 0;
+    }
     switch (mode) {
         case WN_MODE_F16X3: launch_gemm<F16, 3>(k, batch, st); break;
         case WN_MODE_F16X1: launch_gemm<F16, 1>(k, batch, st); break;

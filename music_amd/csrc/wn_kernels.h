@@ -25,6 +25,8 @@ struct WnGemmArgs {
     int swz;                               // XCD-aware block remap (set by the launcher)
 };
 int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
+// two-role persistent form of the narrow product (wn_gemm_rw.hip); 1 = launched, 0 = arguments not covered
+int wn_launch_gemm_rw(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 int wn_launch_pack(const float* flat, const int32_t* idx, uint16_t* out, int n, int is_bf16, int ns,
                    hipStream_t st);
 

@@ -138,6 +138,66 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         for (int k = 0; k < 6; ++k) z[k * RW_THREADS + threadIdx.x] = zero;       // 24 tiles x 2 KB = 48 KB
     }
 
+    const float* dy_or_x = HAS_DY ? a.dy : a.x_in;          // loads stay unconditional
+    struct RawX { f32x2 x[8]; };
+    struct RawD { f32x2 dy[4]; };
+    // recompute operands ("time on lanes"; lane (c, q) of N-tile n holds sample t0 + 2c + n): wave g of a role
+    // converts k-step g = (tap g>>1, channel half g&1) of x / rows 4(g&1).. of k-step g>>1 of dy, both N-tiles.
+    // The R waves do x (they have the slack: RW_XF_W moves it back to the W waves), the W waves do dy.
+    auto load_x = [&](RawX& r, Pos ps) {
+        const int tl = ps.t0 + 2 * c;
+        const float* xin = a.x_in + (size_t)ps.b * a.x_bstride;
+        const float* p = xin + (size_t)(32 * (g & 1) + 8 * q) * a.pitch + ((g >> 1) == 0 ? tl - a.d : tl);
+#ifdef RW_T_NOLOAD
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.x[j] = f32x2{(float)(tl + j), (float)ps.b};
+#else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.x[j] = ld2u(p + (size_t)j * a.pitch);
+#endif
+    };
+    auto load_dy = [&](RawD& r, Pos ps) {
+        const int tl = ps.t0 + 2 * c;
+        const float* pd = dy_or_x + (size_t)ps.b * a.x_bstride + (size_t)(32 * (g >> 1) + 8 * q + 4 * (g & 1)) * a.pitch + tl;
+#ifdef RW_T_NOLOAD
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.dy[j] = f32x2{(float)(tl - j), (float)ps.b};
+#else
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.dy[j] = ld2u(pd + (size_t)j * a.pitch);
+#endif
+    };
+    auto fill_x = [&](const RawX& r, int stage) {
+        uint16_t* xf = lds + (size_t)stage * RW_STAGE + RW_XF;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = r.x[j][n];
+            Frag<F16> f;
+            split8<F16, 3>(f, v);
+            rw_store_frag<F16>(xf, g * 2 + n, lane, f);
+        }
+    };
+    auto fill_dy = [&](const RawD& r, Pos ps, int stage) {
+        if (HAS_DY) {
+            const int tl = ps.t0 + 2 * c;
+            uint16_t* dyf = lds + (size_t)stage * RW_STAGE + RW_DYF;
+            const int ks = g >> 1, h = g & 1;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const bool ok = tl + n >= a.t_lo && tl + n < a.t_hi;      // columns outside hold no gradient
+                uint32_t hh[2], ll[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    split2_bf16(ok ? r.dy[2 * j][n] : 0.f, ok ? r.dy[2 * j + 1][n] : 0.f, hh[j], ll[j]);
+                uint16_t* fb = dyf + (size_t)(ks * 2 + n) * 1024 + lane * 8 + h * 4;
+                *reinterpret_cast<uint2*>(fb) = uint2{hh[0], hh[1]};
+                *reinterpret_cast<uint2*>(fb + 512) = uint2{ll[0], ll[1]};
+            }
+        }
+    };
+
     if (wv < 4) {
         // =========================== R waves: recompute, dz, gate ===========================
         Frag<F16> wf[4], wg[4];
@@ -180,9 +240,22 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         f32x2 crA[4], crB[4];
         load_cr(crA, pos_k(0));
         load_cr(crB, pos_k(1));
+#ifndef RW_XF_W
+        RawX x0, x1;                                        // x1 / x0 hold the raw rows of items it+1 / it+2
+        load_x(x0, pos_k(0));
+        load_x(x1, pos_k(1));
+        fill_x(x0, 0);
+        load_x(x0, pos_k(2));
+#else
+        RawX x0, x1;
+#endif
         __syncthreads();                                    // stage 0 operands of the first item are in LDS
-        auto r_body = [&](const int it, f32x2* cr) {
+        auto r_body = [&](const int it, f32x2* cr, RawX& rx) {
             RW_TICK(k0);
+#if !defined(RW_XF_W) && !defined(RW_T_NOFILL)
+            fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
+            load_x(rx, pos_k(it + 3));
+#endif
             const Pos p_cur = pos_k(it);
             const bool live = it < n_items;
             const int b = p_cur.b, t0 = p_cur.t0;
@@ -297,8 +370,8 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
             RW_ACC(0, k1 - k0); RW_ACC(1, k2 - k1); RW_ACC(2, k3 - k2);
         };
         for (int it = 0; it < n_items; it += 2) {
-            r_body(it, crA);
-            r_body(it + 1, crB);
+            r_body(it, crA, x1);
+            r_body(it + 1, crB, x0);
         }
         RW_FLUSH(0);
         return;
@@ -313,59 +386,7 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) cd[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const float* dy_or_x = HAS_DY ? a.dy : a.x_in;          // loads stay unconditional
-    struct RawXD { f32x2 x[8]; f32x2 dy[4]; };
     struct RawWO { f32x4 v[3][2]; };
-    // recompute operands ("time on lanes"): wave g converts k-step g = (tap g>>1, channel half g&1) of x and
-    // rows 4(g&1).. of k-step g>>1 of dy, for both N-tiles (lane (c, q) of N-tile n holds sample t0 + 2c + n)
-    auto load_xd = [&](RawXD& r, Pos ps) {
-        const int tl = ps.t0 + 2 * c;
-        const float* xin = a.x_in + (size_t)ps.b * a.x_bstride;
-        const float* p = xin + (size_t)(32 * (g & 1) + 8 * q) * a.pitch + ((g >> 1) == 0 ? tl - a.d : tl);
-#ifdef RW_T_NOLOAD
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r.x[j] = f32x2{(float)(tl + j), (float)ps.b};
-#else
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r.x[j] = ld2u(p + (size_t)j * a.pitch);
-#endif
-        const float* pd = dy_or_x + (size_t)ps.b * a.x_bstride + (size_t)(32 * (g >> 1) + 8 * q + 4 * (g & 1)) * a.pitch + tl;
-#ifdef RW_T_NOLOAD
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.dy[j] = f32x2{(float)(tl - j), (float)ps.b};
-#else
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.dy[j] = ld2u(pd + (size_t)j * a.pitch);
-#endif
-    };
-    auto fill_xd = [&](const RawXD& r, Pos ps, int stage) {
-        const int tl = ps.t0 + 2 * c;
-        uint16_t* xf = lds + (size_t)stage * RW_STAGE + RW_XF;
-        uint16_t* dyf = lds + (size_t)stage * RW_STAGE + RW_DYF;
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = r.x[j][n];
-            Frag<F16> f;
-            split8<F16, 3>(f, v);
-            rw_store_frag<F16>(xf, g * 2 + n, lane, f);
-        }
-        if (HAS_DY) {
-            const int ks = g >> 1, h = g & 1;
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const bool ok = tl + n >= a.t_lo && tl + n < a.t_hi;      // columns outside hold no gradient
-                uint32_t hh[2], ll[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    split2_bf16(ok ? r.dy[2 * j][n] : 0.f, ok ? r.dy[2 * j + 1][n] : 0.f, hh[j], ll[j]);
-                uint16_t* fb = dyf + (size_t)(ks * 2 + n) * 1024 + lane * 8 + h * 4;
-                *reinterpret_cast<uint2*>(fb) = uint2{hh[0], hh[1]};
-                *reinterpret_cast<uint2*>(fb + 512) = uint2{ll[0], ll[1]};
-            }
-        }
-    };
     // [row][time] operands: row tile g of x(t-d), x(t) and dy; lane (row c, q) owns samples t0 + 8q .. + 7
     auto load_wo = [&](RawWO& r, Pos ps) {
 #pragma unroll
@@ -438,20 +459,33 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
     {
         // rx1 / rx0 hold the raw recompute rows of items it+1 / it+2, rw0 / rw1 the raw [row][time] rows of items
         // it / it+1; each set is re-armed two items ahead right after it was converted (see the R loop)
-        RawXD rx0, rx1;
+        RawD d0, d1;
         RawWO rw0, rw1;
-        load_xd(rx0, pos_k(0));
+        load_dy(d0, pos_k(0));
         load_wo(rw0, pos_k(0));
-        load_xd(rx1, pos_k(1));
+        load_dy(d1, pos_k(1));
         load_wo(rw1, pos_k(1));
-        fill_xd(rx0, pos_k(0), 0);
-        load_xd(rx0, pos_k(2));
+        fill_dy(d0, pos_k(0), 0);
+        load_dy(d0, pos_k(2));
+#ifdef RW_XF_W
+        RawX x0, x1;
+        load_x(x0, pos_k(0));
+        load_x(x1, pos_k(1));
+        fill_x(x0, 0);
+        load_x(x0, pos_k(2));
+#else
+        RawX x0, x1;
+#endif
         __syncthreads();
-        auto w_body = [&](const int it, RawXD& rx, RawWO& rw) {
+        auto w_body = [&](const int it, RawD& rd, RawX& rx, RawWO& rw) {
             RW_TICK(k0);
 #ifndef RW_T_NOFILL
-            fill_xd(rx, pos_k(it + 1), (it + 1) & 1);        // recompute operands of the next item
-            load_xd(rx, pos_k(it + 3));
+#ifdef RW_XF_W
+            fill_x(rx, (it + 1) & 1);
+            load_x(rx, pos_k(it + 3));
+#endif
+            fill_dy(rd, pos_k(it + 1), (it + 1) & 1);        // recompute operands of the next item
+            load_dy(rd, pos_k(it + 3));
             fill_wo(rw, pos_k(it), it & 1);                  // [row][time] operands of this item
             load_wo(rw, pos_k(it + 2));
 #endif
@@ -465,8 +499,8 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
             RW_ACC(4, k1 - k0); RW_ACC(5, k2 - k1); RW_ACC(6, k3 - k2);
         };
         for (int it = 0; it < n_items; it += 2) {
-            w_body(it, rx1, rw0);
-            w_body(it + 1, rx0, rw1);
+            w_body(it, d1, x1, rw0);
+            w_body(it + 1, d0, x0, rw1);
         }
         wgrad(1);                                           // the last item of the (even) padded count
         RW_FLUSH(4);

@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SWITCHES = [
     {"WN_MS_BWD": "0"},            # resblock_bwd_k + 2 x wgrad_k instead of the channel-split block
     {"WN_MS_RW": "0"},             # one-role channel-split block (4 waves) instead of the two-role one (8 waves)
+    {"WN_GEMM_RW": "0"},           # one-pass narrow product (chan_gemm_k) for the per-layer data gradient
+    {"WN_TALIGN": "4"},            # tile origins at t_lo & ~3 instead of 64-sample lines (also disables the two-role narrow product)
     {"WN_XCD": "0"},               # no XCD-aware block remap
     {"WN_GEMM_WIDE": "1"},         # first wide-GEMM version
     {"WN_FWD_NT": "0"},            # first forward block kernel
