@@ -60,14 +60,16 @@ __global__ __launch_bounds__(GR_THREADS, 2) void chan_gemm_rw_k(WnGemmArgs a, Gr
     if (i_hi > total) i_hi = total;
     const int n_items = i_lo < i_hi ? (i_hi - i_lo + cnt - 1) / cnt : 0;
 
-    struct Pos { int b, t0; };
+    struct Pos { int b, t0; bool live; };
     auto pos_k = [&](int k) {
+        const bool live = k < n_items;
         k = k < n_items ? k : n_items - 1;
         int it = i_lo + (k < 0 ? 0 : k) * cnt;
         it = it < total ? it : total - 1;
         Pos p;
         p.b = it / pl.steps_per_clip;
         p.t0 = a.t_base + GR_COLS * (it - p.b * pl.steps_per_clip);
+        p.live = live;
         return p;
     };
 
@@ -138,9 +140,12 @@ __global__ __launch_bounds__(GR_THREADS, 2) void chan_gemm_rw_k(WnGemmArgs a, Gr
             const bool tap1 = s >= a.ks0;
             const float* base = (tap1 ? a.in1 : a.in0) + (size_t)ps.b * a.in_bstride;
             const int blk = tap1 ? s - a.ks0 : s;
-            const float* p = base + (size_t)(32 * blk + 8 * q) * a.in_pitch + tl + (tap1 ? a.shift1 : a.shift0);
+            // a position past the end (prefetch beyond the last item) reads ONE address in every lane: no traffic,
+            // and the loads stay unconditional (a load under a run-time condition loses its prefetch)
+            const float* p = ps.live ? base + (size_t)(32 * blk + 8 * q) * a.in_pitch + tl + (tap1 ? a.shift1 : a.shift0) : a.in0;
+            const size_t rp = ps.live ? (size_t)a.in_pitch : 0;
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) r.v[u][jj] = gr_ld2u(p + (size_t)jj * a.in_pitch);
+            for (int jj = 0; jj < 8; ++jj) r.v[u][jj] = gr_ld2u(p + jj * rp);
         }
     };
     auto fill = [&](const Raw& r, Pos ps, int stage) {

@@ -239,8 +239,13 @@ int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipS
     // whole GPU suite passes with it) but 8-10 % SLOWER than the kernel below at config 2 (28.8 vs
     // 26.2 us per block): the forward is bound by its HBM share (390 KB per CU and launch), not by the
     // length of a wave's dependency chain, so shortening the chain buys nothing.  Off by default.
+    // WN_FWD_RW (default 1): the two-role persistent kernel of wn_resfwd_rw.hip takes 64-channel x3 launches
     static int cs = -1;
     if (cs < 0) { const char* e = getenv("WN_FWD_CS"); cs = e ? atoi(e) : 0; }
+    if (!cs && wn_launch_resblock_fwd_rw(a, ch, batch, mode, st)) {
+        WN_CHECK_LAUNCH();
+        return 0;
+    }
     if (cs && ch == 64 && mode == WN_MODE_F16X3) return wn_launch_resblock_fwd_cs(a, batch, st);
     static int nt = -1;
     if (nt < 0) { const char* e = getenv("WN_FWD_NT"); nt = e ? atoi(e) : 4; }

@@ -119,14 +119,16 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
     if (i_hi > total) i_hi = total;
     const int n_items = i_lo < i_hi ? (i_hi - i_lo + cnt - 1) / cnt : 0;
 
-    struct Pos { int b, t0; };
+    struct Pos { int b, t0; bool live; };
     auto pos_k = [&](int k) {                                  // position of this workgroup's k-th item, clamped
+        const bool live = k < n_items;
         k = k < n_items ? k : n_items - 1;
         int it = i_lo + (k < 0 ? 0 : k) * cnt;
         it = it < total ? it : total - 1;
         Pos p;
         p.b = it / a.steps_per_clip;
         p.t0 = a.t_base + RW_COLS * (it - p.b * a.steps_per_clip);
+        p.live = live;
         return p;
     };
 
@@ -147,24 +149,28 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
     auto load_x = [&](RawX& r, Pos ps) {
         const int tl = ps.t0 + 2 * c;
         const float* xin = a.x_in + (size_t)ps.b * a.x_bstride;
-        const float* p = xin + (size_t)(32 * (g & 1) + 8 * q) * a.pitch + ((g >> 1) == 0 ? tl - a.d : tl);
+        // a position past the end (prefetch beyond the last item) reads ONE address in every lane: no traffic,
+        // and the loads stay unconditional
+        const float* p = ps.live ? xin + (size_t)(32 * (g & 1) + 8 * q) * a.pitch + ((g >> 1) == 0 ? tl - a.d : tl) : a.x_in;
+        const size_t rp = ps.live ? (size_t)a.pitch : 0;
 #ifdef RW_T_NOLOAD
 #pragma unroll
         for (int j = 0; j < 8; ++j) r.x[j] = f32x2{(float)(tl + j), (float)ps.b};
 #else
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.x[j] = ld2u(p + (size_t)j * a.pitch);
+        for (int j = 0; j < 8; ++j) r.x[j] = ld2u(p + j * rp);
 #endif
     };
     auto load_dy = [&](RawD& r, Pos ps) {
         const int tl = ps.t0 + 2 * c;
-        const float* pd = dy_or_x + (size_t)ps.b * a.x_bstride + (size_t)(32 * (g >> 1) + 8 * q + 4 * (g & 1)) * a.pitch + tl;
+        const float* pd = ps.live ? dy_or_x + (size_t)ps.b * a.x_bstride + (size_t)(32 * (g >> 1) + 8 * q + 4 * (g & 1)) * a.pitch + tl : dy_or_x;
+        const size_t rp = ps.live ? (size_t)a.pitch : 0;
 #ifdef RW_T_NOLOAD
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.dy[j] = f32x2{(float)(tl - j), (float)ps.b};
 #else
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r.dy[j] = ld2u(pd + (size_t)j * a.pitch);
+        for (int j = 0; j < 4; ++j) r.dy[j] = ld2u(pd + j * rp);
 #endif
     };
     auto fill_x = [&](const RawX& r, int stage) {
@@ -224,13 +230,14 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         for (int i = 0; i < 4; ++i) t_wr[i] = (16 * (c >> 2) + ((4 * q + i + (c >> 2)) & 15)) * 8 + (c & 3) * 2;
 
         auto load_cr = [&](f32x2* cr, Pos ps) {
-            const float* dzc = a.dz + (size_t)ps.b * a.dz_bstride + (size_t)(16 * g + 4 * q) * a.pitch + ps.t0 + 2 * c;
+            const float* dzc = ps.live ? a.dz + (size_t)ps.b * a.dz_bstride + (size_t)(16 * g + 4 * q) * a.pitch + ps.t0 + 2 * c : a.dz;
+            const size_t rp = ps.live ? (size_t)a.pitch : 0;
 #ifdef RW_T_NOCR
 #pragma unroll
             for (int i = 0; i < 4; ++i) cr[i] = f32x2{(float)ps.t0, 0.f};
 #else
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cr[i] = ld2u(dzc + (size_t)i * a.pitch);
+            for (int i = 0; i < 4; ++i) cr[i] = ld2u(dzc + i * rp);
 #endif
         };
 
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
 #pragma unroll
         for (int kind = 0; kind < (HAS_DY ? 3 : 2); ++kind) {
             const float* base = (kind == 2 ? dy_or_x : a.x_in) + (size_t)ps.b * a.x_bstride;
-            const float* p = base + (size_t)(16 * g + c) * a.pitch + ps.t0 + 8 * q + (kind == 0 ? -a.d : 0);
+            const float* p = ps.live ? base + (size_t)(16 * g + c) * a.pitch + ps.t0 + 8 * q + (kind == 0 ? -a.d : 0) : a.x_in;
 #ifdef RW_T_NOLOAD
             r.v[kind][0] = f32x4{(float)ps.t0, (float)kind, 1.f, 2.f};
             r.v[kind][1] = f32x4{(float)ps.b, (float)kind, 3.f, 4.f};

@@ -21,6 +21,7 @@ SWITCHES = [
     {"WN_FWD_NT": "0"},            # first forward block kernel
     {"WN_FWD_NT": "2"},            # 16 waves x 2 N-tiles
     {"WN_FWD_CS": "1"},            # channel-split forward block
+    {"WN_FWD_RW": "1"},            # two-role persistent forward block
 ]
 
 
