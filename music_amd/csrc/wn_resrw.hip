@@ -280,31 +280,33 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
             }
 #ifndef RW_T_NOREC
             {
-                Frag<F16> bx[2];
-                load_a<F16, 3>(bx[0], xf, 0, lane);
-#pragma unroll
-                for (int idx = 0; idx < 8; ++idx) {
-                    if (idx + 1 < 8) load_a<F16, 3>(bx[(idx + 1) & 1], xf, idx + 1, lane);
-                    mma<F16, 3>(af[idx & 1], wf[idx >> 1], bx[idx & 1]);
-                    mma<F16, 3>(ag[idx & 1], wg[idx >> 1], bx[idx & 1]);
-                }
-#ifndef RW_NO_SGB
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-                for (int idx = 0; idx < 7; ++idx) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-#endif
-            }
-            if (HAS_DY) {
+                // One accumulator is touched by every 4th (5th) MFMA only: the three products of an x3 term and
+                // the f / g / N-tile accumulators are walked in rotation, with the dz products woven in, so no
+                // MFMA waits for the result of the one in front of it.
+                auto term = [](auto tr, f32x4& acc, const auto& wa, const auto& xb, int t) {
+                    typedef decltype(tr) TT;
+                    acc = t == 0 ? TT::mfma(wa.lo, xb.hi, acc) : t == 1 ? TT::mfma(wa.hi, xb.lo, acc) : TT::mfma(wa.hi, xb.hi, acc);
+                };
+                Frag<F16> bx[2][2];
                 Frag<BF16> by[2];
-                load_a<BF16, 3>(by[0], dyf, 0, lane);
+                load_a<F16, 3>(bx[0][0], xf, 0, lane);
+                load_a<F16, 3>(bx[0][1], xf, 1, lane);
+                if (HAS_DY) load_a<BF16, 3>(by[0], dyf, 0, lane);
 #pragma unroll
-                for (int idx = 0; idx < 4; ++idx) {
-                    if (idx + 1 < 4) load_a<BF16, 3>(by[(idx + 1) & 1], dyf, idx + 1, lane);
-                    mma<BF16, 3>(dz[idx & 1], wd[idx >> 1], by[idx & 1]);
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks + 1 < 4) {
+                        load_a<F16, 3>(bx[(ks + 1) & 1][0], xf, 2 * ks + 2, lane);
+                        load_a<F16, 3>(bx[(ks + 1) & 1][1], xf, 2 * ks + 3, lane);
+                        if (HAS_DY) load_a<BF16, 3>(by[(ks + 1) & 1], dyf, ks + 1, lane);      // dy fragment (k-step (ks+1)>>1, N-tile (ks+1)&1)
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        term(F16(), af[0], wf[ks], bx[ks & 1][0], t);
+                        term(F16(), ag[0], wg[ks], bx[ks & 1][0], t);
+                        term(F16(), af[1], wf[ks], bx[ks & 1][1], t);
+                        term(F16(), ag[1], wg[ks], bx[ks & 1][1], t);
+                        if (HAS_DY) term(BF16(), dz[ks & 1], wd[ks >> 1], by[ks & 1], t);
+                    }
                 }
             }
 #endif
