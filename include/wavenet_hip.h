@@ -110,7 +110,11 @@ int wn_resblock_bwd_fused_tiles(int t_lo, int t_hi);
  * slab per workgroup: slab_fg[w] = partial dWfg (2ch x 2ch, columns = tap0 ch | tap1 ch), slab_d[w] =
  * partial dWd (ch x ch); wn_resblock_bwd_ms_slabs gives the number of slabs (sum them with
  * wn_reduce_slabs).  dy NULL (last block): no dz product, no dWd.  z is not written at all.
- * cond*: the conditioning table of wn_resblock_fwd (the recompute adds it as well); NULL = none. */
+ * cond*: the conditioning table of wn_resblock_fwd (the recompute adds it as well); NULL = none.
+ * Two kernels implement it (same results up to the order of fp32 sums): the two-role one (8 waves,
+ * wn_resrw.hip, default) and the one-role one (wn_resms.hip, env WN_MS_RW=0); the slab count differs, always
+ * ask wn_resblock_bwd_ms_slabs in the same process.  The buffers need the usual slack: rows are read up to
+ * 63 columns outside [t_lo - d, t_hi). */
 int wn_resblock_bwd_ms(const float* x_in, const float* dy, const float* dz, float* dfg, int64_t x_bstride,
                        int64_t dz_bstride, int64_t dfg_bstride, int pitch, const uint16_t* wfg, const uint16_t* wdT,
                        const float* bias_f, const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
