@@ -16,7 +16,7 @@ Reference behaviours that are reproduced on purpose:
   * gate = FIRST half of the filter_gate channels, filter = second half (model1.py:188-190).
 The arithmetic runs through libwavenet_hip.so only (no CPU path).  ``forward`` is differentiable
 (``loss.backward()`` fills every parameter's gradient, the encoder's through the random projections
-exactly as in the reference); the backward is implemented for ``use_bias=False``.
+exactly as in the reference).
 """
 import os
 
@@ -327,10 +327,27 @@ class _AutoencoderEngine:
 
     def backward(self, ws, dprobs):
         """Fills self.flat_grad from d loss / d probabilities (B*W, Q)."""
-        if self.use_bias:
-            raise NotImplementedError("autoencoder backward with use_bias=True is not implemented")
         bw = self._bwd_workspace(ws)
         st = _lib.stream()
+        # bias gradients (use_bias=True): row sums of the matching output gradient, collected in one small buffer
+        # and copied to their flat-parameter positions after the weight gradients were gathered
+        if self.use_bias and getattr(self, "_bias_plan", None) is None:
+            names = [n for n in self.param_names if n.endswith(".bias")]
+            off, o = {}, 0
+            for n in names:
+                off[n[:-5]] = o
+                o += int(np.prod(self.spec.shape[n]))
+            idx = np.concatenate([np.arange(self.spec.off[n], self.spec.off[n] + int(np.prod(self.spec.shape[n]))) for n in names])
+            self._bias_plan = (off, torch.from_numpy(idx.astype(np.int64)).to(self.device),
+                               torch.zeros(o, dtype=torch.float32, device=self.device))
+        if self.use_bias:
+            b_off, b_idx, b_grad = self._bias_plan
+
+            def bias_grad(name, a, a_bstride, a_pitch, a_shift, rows, t_lo, t_hi, dst=0):
+                call("wn_bias_grad", a, a_bstride, a_pitch, a_shift, rows, t_lo, t_hi, ws["B"], ptr(b_grad, b_off[name] + dst), st)
+        else:
+            def bias_grad(*a, **k):
+                pass
         B, T, W, pitch, Le = ws["B"], ws["T"], ws["W"], ws["pitch"], ws["Le"]
         N, CHe, CHd, SP, BwP, Q = self.N, self.CHe, self.CHd, self.SP, self.BwP, self.Q
         Dd, Sd, Rd, Re, De, Bw = self.Dd, self.Sd, self.Rd, self.Re, self.De, self.Bw
@@ -363,6 +380,10 @@ class _AutoencoderEngine:
         wgrad("c1", dR1, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
         gemm("c1T", dR1, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, SP // 16, Sd, dU, sb, pitch, 0, None, NONE3,
              (U, sb, pitch), lo, T, 0)
+        bias_grad("connection_2", dO, Q * W, W, -lo, Q, lo, T)
+        bias_grad("connection_1", dR1, sb, pitch, 0, Sd, lo, T)
+        for i in range(N if self.use_bias else 0):
+            bias_grad("de_dilation_layer_stack.%d" % (3 * i + 2), dU, sb, pitch, 0, Sd, lo, T)
         wgrad("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CHd // 16, SP // 16, 0, N * CHd, lo, T)
         gemm("skipT", dU, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, N * CHd // 16, N * CHd, dZ, zb, pitch, 0, None, NONE3,
              NONE3, lo, T, 0)
@@ -374,21 +395,34 @@ class _AutoencoderEngine:
             d, t_lo = self.dil[i], self.off[i + 1]
             dy = ptr(bw["dXd"][(i + 1) % 2], SLACK) if i < N - 1 else None
             mode_c, q = ws["cmodes"][i]
+            bias_fg = self._bias("de_dilation_layer_stack.%d" % (3 * i))
+            bf = bias_fg + 4 * Dd if bias_fg is not None else None      # filter_gate bias: gate rows first
+
+            def block_bias_grads():
+                if not self.use_bias:
+                    return
+                nm = "de_dilation_layer_stack.%d" % (3 * i)
+                bias_grad(nm, dfg + 4 * CHd * pitch, 2 * CHd * pitch, pitch, 0, Dd, t_lo, T)          # gate rows = dg
+                bias_grad(nm, dfg, 2 * CHd * pitch, pitch, 0, Dd, t_lo, T, dst=Dd)                    # filter rows = df
+                if dy is not None:
+                    bias_grad("de_dilation_layer_stack.%d" % (3 * i + 1), dy, db, pitch, 0, Rd, t_lo, T)
             if bw["ms"]:
                 call("wn_resblock_bwd_ms", xd(i), dy, ptr(bw["dZ"], SLACK + i * CHd * pitch), dfg, db, zb, 2 * CHd * pitch, pitch,
-                     fr("de_fg%d" % i), br("de_dT%d" % i), None, None, Dd, CHd, d, t_lo, T, lo,
+                     fr("de_fg%d" % i), br("de_dT%d" % i), bf, bias_fg, Dd, CHd, d, t_lo, T, lo,
                      ptr(bw["slab"], plan["de_fg%d" % i][0]), ptr(bw["slab"], plan["de_d%d" % i][0]) if i < N - 1 else None,
                      ptr(ws["tab"][i]), 2 * CHd * Le, Le, mode_c, Le, max(q, 1), B, mf, mb, st)
                 call("wn_cond_grad", dfg, 2 * CHd * pitch, pitch, 2 * CHd, t_lo, T, mode_c, Le, max(q, 1),
                      ptr(d_tab[i]), 2 * CHd * Le, Le, B, st)
+                block_bias_grads()
                 gemm("de_fgT%d" % i, dfg, dfg, 2 * CHd * pitch, pitch, t_lo, T, 0, d, 2 * CHd // 32, 2 * CHd // 32, CHd // 16, Rd,
                      ptr(bw["dXd"][i % 2], SLACK), db, pitch, 0, None, (dy, db, pitch, t_lo) if dy else NONE3, NONE3, self.off[i], T, 0)
                 continue
             call("wn_resblock_bwd", xd(i), dy, ptr(bw["dZ"], SLACK + i * CHd * pitch), dfg, None,
-                 db, zb, 2 * CHd * pitch, db, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), None, None, Dd, CHd, d, t_lo, T, lo,
+                 db, zb, 2 * CHd * pitch, db, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), bf, bias_fg, Dd, CHd, d, t_lo, T, lo,
                  ptr(ws["tab"][i]), 2 * CHd * Le, Le, mode_c, Le, max(q, 1), B, mf, mb, st)
             call("wn_cond_grad", dfg, 2 * CHd * pitch, pitch, 2 * CHd, t_lo, T, mode_c, Le, max(q, 1),
                  ptr(d_tab[i]), 2 * CHd * Le, Le, B, st)
+            block_bias_grads()
             wgrad("de_fg%d" % i, dfg, 2 * CHd * pitch, pitch, 0, pitch, xd(i), xd(i), db, pitch, -d, 0, pitch,
                   CHd // 16, 2 * CHd // 16, 0, 2 * CHd, t_lo, T)
             if i < N - 1:
@@ -399,6 +433,7 @@ class _AutoencoderEngine:
         x = ws["x_in"]
         wgrad("de_causal", ptr(bw["dXd"][0], SLACK), db, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CHd // 16, 0,
               2 * Q, 1, T)
+        bias_grad("de_causal_layer", ptr(bw["dXd"][0], SLACK), db, pitch, 0, Rd, 1, T)
         # ---- conditioning: en_i = cw_i enc + b (rows in the reference order: gate first), enf = cfw enc + b
         d_en = torch.cat([d_tab[:, :, CHd:CHd + Dd], d_tab[:, :, :Dd]], 2)            # (N,B,2Dd,Le) reference row order
         d_enc = torch.einsum("nck,nbcl->bkl", ws["cw"], d_en) + torch.einsum("ck,bcl->bkl", ws["cfw"][:, :, 0], d_enf)
@@ -409,6 +444,7 @@ class _AutoencoderEngine:
         xe = lambda i: self._lay(ws["Xe"], i, CHe, ws)
         he = lambda i: self._lay(ws["He"], i, CHe, ws)
         wgrad("bottleneck", dE, BwP * pitch, pitch, 0, pitch, xe(N), None, eb, pitch, 0, 0, pitch, CHe // 16, BwP // 16, 0, CHe, lo, T)
+        bias_grad("bottleneck_layer", dE, BwP * pitch, pitch, 0, Bw, lo, T)
         dxe = [ptr(t, SLACK) for t in bw["dXe"]]
         dHe = ptr(bw["dHe"], SLACK)
         gemm("bottleneckT", dE, None, BwP * pitch, pitch, lo, T, 0, 0, BwP // 32, 0, CHe // 16, Re, dxe[N % 2], eb, pitch, 0, None,
@@ -419,16 +455,21 @@ class _AutoencoderEngine:
             dy = dxe[(i + 1) % 2]
             # dh = (W1^T dy) * [h > 0];  dW1 = sum dy relu(h)^T
             wgrad("en_dense%d" % i, dy, eb, pitch, 0, pitch, he(i), None, eb, pitch, 0, 0, pitch, CHe // 16, CHe // 16, 1, CHe, y_lo, T)
+            bias_grad("en_dense_layer_stack.%d" % i, dy, eb, pitch, 0, Re, y_lo, T)
             gemm("en_denseT%d" % i, dy, None, eb, pitch, y_lo, T, 0, 0, CHe // 32, 0, CHe // 16, De, dHe, eb, pitch, 0, None, NONE3,
                  (he(i), eb, pitch), t_lo, T, 0)
             # dWdil = sum dh [relu(x)(t-d) | relu(x)(t)]^T
             wgrad("en_dil%d" % i, dHe, eb, pitch, 0, pitch, xe(i), xe(i), eb, pitch, -d, 0, pitch, CHe // 16, CHe // 16, 1, 2 * CHe, t_lo, T)
+            bias_grad("en_dilation_layer_stack.%d" % i, dHe, eb, pitch, 0, De, t_lo, T)
             # dx_i[t] = [x_i > 0] (Wdil1^T dh[t] + Wdil0^T dh[t+d]) + dy[t]
             gemm("en_dilT%d" % i, dHe, dHe, eb, pitch, t_lo, T, 0, d, CHe // 32, CHe // 32, CHe // 16, Re, dxe[i % 2], eb, pitch, 0,
                  None, (dy, eb, pitch, y_lo), (xe(i), eb, pitch), self.off[i], T, 0)
         wgrad("en_causal", dxe[0], eb, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CHe // 16, 0, 2 * Q, 1, T)
+        bias_grad("en_causal_layer", dxe[0], eb, pitch, 0, Re, 1, T)
         call("wn_reduce_slabs", ptr(bw["desc"]), bw["nops"], bw["vec"], ptr(bw["slab"]), ptr(self.gpack), st)
         call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
+        if self.use_bias:
+            self.flat_grad.index_copy_(0, b_idx, b_grad)
 
 
 class _AutoencoderFunction(torch.autograd.Function):

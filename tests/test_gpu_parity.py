@@ -623,6 +623,54 @@ def test_autoencoder_backward_64_channels_vs_oracle():
         print("autoencoder 64 ch (B=%d, W=%d): worst relative grad err %.2e" % (B, W, worst))
 
 
+@pytest.mark.parametrize("width", [16, 64], ids=["16ch", "64ch"])
+def test_autoencoder_backward_with_bias_vs_oracle(width):
+    """use_bias=True through the whole autoencoder (every conv of model1.py:33-134 has a bias then): loss and
+    every gradient, bias gradients included, vs autograd on the CPU oracle.  64 decoder channels take the
+    channel-split backward block (bias added in its recompute), 16 the generic path."""
+    from music_amd.model1 import wavenet_autoencoder
+    from oracle import intops
+    cfg = dict(filter_width=2, quantization_channel=256, dilations=[1, 2, 4, 3, 8], en_residual_channel=width - 3,
+               en_dilation_channel=width - 5, en_bottleneck_width=10, en_pool_kernel_size=40, de_residual_channel=width,
+               de_dilation_channel=width - 2, de_skip_channel=48, use_bias=True)
+    torch.manual_seed(51 + width)
+    net = wavenet_autoencoder(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
+    assert any(k.endswith(".bias") for k in params)
+    net = net.cuda()
+    rng = np.random.default_rng(43)
+    rf = net.receptive_field
+    for B, W in ((2, 320), (1, 517)):            # 320 = 8 pooled frames (some layers stretch), 517: ragged (tile)
+        idx = rng.integers(0, 256, size=(B, rf + W - 1))
+        x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx]))
+        target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64))
+        torch.manual_seed(79)
+        net.zero_grad()
+        probs = net(x.cuda())
+        loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
+        loss.backward()
+        torch.manual_seed(79)
+        cond = wo.draw_conditioning(len(cfg["dilations"]), cfg["en_bottleneck_width"], cfg["de_dilation_channel"],
+                                    cfg["de_skip_channel"])
+        leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        p_ref, _ = wo.autoencoder_forward(leaf, cfg["dilations"], x, cfg["en_pool_kernel_size"], cond)
+        l_ref = torch.nn.functional.cross_entropy(p_ref, target)
+        g_ref = torch.autograd.grad(l_ref, list(leaf.values()), allow_unused=True)
+        assert (probs.detach().cpu() - p_ref.detach()).abs().max().item() <= LOGIT_TOL
+        assert abs(loss.item() - l_ref.item()) < 1e-4
+        gs = [torch.zeros_like(leaf[n]) if g is None else g for (n, _), g in zip(net.named_parameters(), g_ref)]
+        floor = 1e-3 * max(g.abs().max().item() for g in gs)
+        worst = 0.0
+        for (name, p), g in zip(net.named_parameters(), gs):
+            err = (p.grad.cpu() - g).abs().max().item() / max(g.abs().max().item(), floor)
+            worst = max(worst, err)
+            assert err <= GRAD_RTOL, (B, W, name, err)
+        print("autoencoder with bias, %d ch (B=%d, W=%d): worst relative grad err %.2e" % (width, B, W, worst))
+
+
 def test_training_reduces_the_loss_64_channels():
     """End-to-end sanity of the production kernels (channel-split backward block, fused CE, flat
     Adam): 60 fused steps on one fixed small batch drive the loss from ln(256) towards its floor.
