@@ -671,6 +671,74 @@ def test_autoencoder_backward_with_bias_vs_oracle(width):
         print("autoencoder with bias, %d ch (B=%d, W=%d): worst relative grad err %.2e" % (width, B, W, worst))
 
 
+@pytest.mark.parametrize("use_bias", [False, True], ids=["nobias", "bias"])
+def test_autoencoder_cached_generation_matches_decoder(use_bias):
+    """encoder once + fixed conditioning projections + the persistent cached-queue decode kernel.
+    (a) teacher forced, the decode kernel's probabilities equal the CPU oracle's conditioned decoder
+    (model1.py:158-225 restated, same encoding and projections) on the sliding receptive-field window, step by
+    step; (b) the greedy roll-out of ``generate_cached`` equals the oracle's greedy roll-out."""
+    from music_amd.model1 import wavenet_autoencoder
+    from music_amd import ae_generate as ag
+    from music_amd import fast_generate as fg
+    from oracle import intops
+    cfg = dict(filter_width=2, quantization_channel=256, dilations=[1, 2, 4, 8, 3, 1, 2], en_residual_channel=24,
+               en_dilation_channel=20, en_bottleneck_width=6, en_pool_kernel_size=32, de_residual_channel=40,
+               de_dilation_channel=36, de_skip_channel=72, use_bias=use_bias)
+    torch.manual_seed(61)
+    net = wavenet_autoencoder(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.5)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    rf, dil = net.receptive_field, cfg["dilations"]
+    rng = np.random.default_rng(62)
+    start = rng.integers(0, 256, size=(rf + 32 + 5,))            # pools to exactly one frame
+    forced = rng.integers(0, 256, size=(24,))
+
+    def onehot(ix):
+        return torch.from_numpy(intops.one_hot_proper(np.atleast_1d(ix)))[None]
+
+    x0 = onehot(start)
+    with torch.no_grad():
+        net(x0.cuda())
+    enc = net.last_encoding.cpu()
+    assert tuple(enc.shape) == (1, 6, 1)
+    enc_ref = wo.autoencoder_encode(params, dil, x0, cfg["en_pool_kernel_size"])
+    assert (enc - enc_ref).abs().max().item() < 1e-4
+    torch.manual_seed(63)
+    cond = net._draw_conditioning()
+    wnet = ag.cached_decoder(net, enc, cond)
+
+    def ref_probs(seq):
+        return wo.autoencoder_decode(params, dil, onehot(np.asarray(seq[-rf:])), enc_ref, 1, cond).reshape(-1)
+
+    # (a) teacher forced
+    seq = list(start)
+    want = [ref_probs(seq)]
+    for c in forced:
+        seq.append(int(c))
+        want.append(ref_probs(seq))
+    pred, st = fg.predict_next(wnet, onehot(start[-rf:]).cuda(), None)
+    nxt = torch.from_numpy(np.concatenate([forced[1:], [0]]).astype(np.int32))
+    codes, probs, _ = fg._decode(wnet, st, onehot(forced[0]).reshape(-1).cuda(), len(forced), forced=nxt, want_probs=True,
+                                 correct_queue=True)
+    assert int(pred[0]) == int(want[0].argmax())
+    err = (probs.cpu() - torch.stack(want[1:])).abs().max().item()
+    assert err <= LOGIT_TOL, err
+    assert codes.cpu().tolist() == [int(w.argmax()) for w in want[1:]]
+    # (b) greedy roll-out
+    n = 16
+    got, _, _ = ag.generate_cached(net, x0, n, cond=cond)
+    seq, ref = list(start), []
+    for _ in range(n):
+        c = int(ref_probs(seq).argmax())
+        ref.append(c)
+        seq.append(c)
+    assert got.cpu().tolist() == ref
+    print("autoencoder cached generation (bias=%s): teacher-forced probs err %.2e, %d greedy codes equal" % (use_bias, err, n))
+
+
 def test_training_reduces_the_loss_64_channels():
     """End-to-end sanity of the production kernels (channel-split backward block, fused CE, flat
     Adam): 60 fused steps on one fixed small batch drive the loss from ln(256) towards its floor.
