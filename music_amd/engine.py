@@ -467,7 +467,10 @@ class WaveNetEngine:
         main = torch.cuda.current_stream()
         overlap = self.overlap_wgrad
         if overlap and self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # HIGH priority = its own hardware queue.  A default-priority stream is dealt one of a few hardware
+            # queues round-robin; once RCCL has created its streams (torchrun) the side stream landed on the
+            # MAIN stream's queue and the overlap silently disappeared (epilogue_bwd 0.99 -> 1.26 ms).
+            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("WN_SIDE_PRIO", "-1")))
         side = self._side if overlap else main
 
         def on_side(fn):
