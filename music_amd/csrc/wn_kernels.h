@@ -27,6 +27,7 @@ struct WnGemmArgs {
 int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 // two-role persistent form of the narrow product (wn_gemm_rw.hip); 1 = launched, 0 = arguments not covered
 int wn_launch_gemm_rw(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
+int wn_launch_gemm_wide_rw(const WnGemmArgs& a, int batch, int mode, hipStream_t st);   // wn_gemm_wide_rw.hip, same convention
 struct WnResArgs;
 // two-role persistent forward block (wn_resfwd_rw.hip); 1 = launched, 0 = arguments not covered
 int wn_launch_resblock_fwd_rw(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);

@@ -22,6 +22,7 @@ SWITCHES = [
     {"WN_FWD_NT": "2"},            # 16 waves x 2 N-tiles
     {"WN_FWD_CS": "1"},            # channel-split forward block
     {"WN_FWD_RW": "1"},            # two-role persistent forward block
+    {"WN_GEMM_WIDE_RW": "1"},      # two-role persistent wide GEMM (skip / post-processing products and their data gradients)
 ]
 
 
