@@ -12,8 +12,8 @@
 // One barrier per item; two workgroups (16 waves, <= 128 registers) per CU; the workgroups of an XCD walk
 // their range of items interleaved, so the shifted tap finds its rows in that XCD's L2.
 // Preconditions (checked by the launcher, otherwise chan_gemm_k runs): x3 mode, 4 row tiles, 8 k-steps,
-// no mask, no relu_in, out_shift 0; every address t + shift of a launch lies inside the input allocation
-// (columns outside [in_lo, in_hi) are loaded and then replaced by zeros, not skipped).
+// no mask, no relu_in, out_shift 0.  Columns outside [in_lo, in_hi) are never dereferenced (load addresses are
+// clamped into the range, the values replaced by zeros).
 #include <stdlib.h>
 #include <type_traits>
 #include "wn_common.h"
@@ -140,9 +140,14 @@ __global__ __launch_bounds__(GR_THREADS, 2) void chan_gemm_rw_k(WnGemmArgs a, Gr
             const bool tap1 = s >= a.ks0;
             const float* base = (tap1 ? a.in1 : a.in0) + (size_t)ps.b * a.in_bstride;
             const int blk = tap1 ? s - a.ks0 : s;
-            // a position past the end (prefetch beyond the last item) reads ONE address in every lane: no traffic,
-            // and the loads stay unconditional (a load under a run-time condition loses its prefetch)
-            const float* p = ps.live ? base + (size_t)(32 * blk + 8 * q) * a.in_pitch + tl + (tap1 ? a.shift1 : a.shift0) : a.in0;
+            // Load address: the lane's column pair clamped INTO [in_lo, in_hi - 2] (columns outside the range are never
+            // dereferenced - wn_chan_gemm's contract; fill() picks the right element / zero); a position past the end
+            // (prefetch beyond the last item) reads ONE address in every lane: no traffic.  The loads stay
+            // unconditional (a load under a run-time condition loses its prefetch)
+            int cc = tl + (tap1 ? a.shift1 : a.shift0);
+            cc = cc < a.in_lo ? a.in_lo : cc;
+            cc = cc > a.in_hi - 2 ? a.in_hi - 2 : cc;
+            const float* p = ps.live ? base + (size_t)(32 * blk + 8 * q) * a.in_pitch + cc : a.in0 + a.in_lo;
             const size_t rp = ps.live ? (size_t)a.in_pitch : 0;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) r.v[u][jj] = gr_ld2u(p + jj * rp);
@@ -162,11 +167,15 @@ __global__ __launch_bounds__(GR_THREADS, 2) void chan_gemm_rw_k(WnGemmArgs a, Gr
                 float v[8];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) v[jj] = r.v[u][jj][n];
-                if (!inner) {
+                if (!inner) {                                   // edge item: undo the address clamp of load_raw
                     const int col = tl + n + sh;
+                    int cc = tl + sh;
+                    cc = cc < a.in_lo ? a.in_lo : cc;
+                    cc = cc > a.in_hi - 2 ? a.in_hi - 2 : cc;
                     const bool ok = col >= a.in_lo && col < a.in_hi;
+                    const bool second = col - cc == 1;
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) v[jj] = ok ? v[jj] : 0.f;
+                    for (int jj = 0; jj < 8; ++jj) v[jj] = ok ? (second ? r.v[u][jj][1] : r.v[u][jj][0]) : 0.f;
                 }
                 u32x4 fh, fl;
                 if (std::is_same<T, BF16>::value) {
@@ -225,7 +234,7 @@ int wn_launch_gemm_rw(const WnGemmArgs& k, int batch, int mode, hipStream_t st) 
     if (mode != WN_MODE_BF16X3 && mode != WN_MODE_F16X3) return 0;
     if (k.mt != 4 || k.ks0 + k.ks1 != GR_KS || (k.ks1 > 0 && !k.in1) || (k.ks0 & 1) || k.mask || k.relu_in || k.out_shift != 0) return 0;
     if (k.t_base & (GR_COLS - 1)) return 0;
-    if (k.shift0 < 0 || k.shift1 < 0 || k.shift0 > 1024 || k.shift1 > 1024) return 0;      // loads are unguarded: see the header
+    if (k.in_hi - k.in_lo < 2) return 0;
     GrPlan pl;
     pl.batch = batch;
     pl.steps_per_clip = (k.t_hi - k.t_base + GR_COLS - 1) / GR_COLS;

@@ -100,6 +100,41 @@ def test_chan_gemm_two_taps_epilogues():
     assert err <= 3e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("mode", [_lib.BF16X3, _lib.F16X3])
+@pytest.mark.parametrize("d,in_lo,in_hi,t_lo,t_hi", [(5, 41, 930, 36, 925), (64, 100, 1024, 36, 1000), (1, 7, 300, 6, 299)])
+def test_chan_gemm_two_role_window_and_canaries(mode, d, in_lo, in_hi, t_lo, t_hi):
+    """The per-layer data-gradient shape (64 rows, two taps of 128 rows = 8 k-steps, residual) runs on the two-role
+    persistent kernel (chan_gemm_rw_k).  Input columns outside [in_lo, in_hi) must read as 0 AND must never be
+    dereferenced: they hold NaN here, as does everything around the output window."""
+    rng = np.random.default_rng(6)
+    B, M, K, pitch = 3, 64, 128, 1024
+    w = rng.standard_normal((M, 2 * K)).astype(np.float32) * 0.1
+    pk = _packed(w, mode)
+    xin = _buf(B, K, pitch, 1.0, 7)
+    _view(xin, B, K, pitch)[:, :, :in_lo] = float("nan")
+    _view(xin, B, K, pitch)[:, :, in_hi:] = float("nan")
+    res = _buf(B, M, pitch, 1.0, 8)
+    out = _buf(B, M, pitch)
+    out.fill_(float("nan"))
+    resid_lo = t_lo + d
+    call("wn_chan_gemm", ptr(xin, SLACK), ptr(xin, SLACK), K * pitch, pitch, in_lo, in_hi, 0, d, K // 32, K // 32, ptr(pk),
+         M // 16, M - 5, ptr(out, SLACK), M * pitch, pitch, 0, None, ptr(res, SLACK), M * pitch, pitch, resid_lo,
+         None, 0, 0, t_lo, t_hi, 0, B, mode, _lib.stream())
+    torch.cuda.synchronize()
+    x = torch.nan_to_num(_view(xin, B, K, pitch).cpu().double(), nan=0.0)
+    xpad = torch.cat([x, torch.zeros(B, K, d + 8, dtype=torch.float64)], 2)
+    wt = torch.from_numpy(w).double()
+    ts = torch.arange(t_lo, t_hi)
+    ref = torch.einsum("mk,bkt->bmt", wt[:, :K], xpad[:, :, ts]) + torch.einsum("mk,bkt->bmt", wt[:, K:], xpad[:, :, ts + d])
+    r = _view(res, B, M, pitch).cpu().double()[:, :, ts]
+    r[:, :, ts < resid_lo] = 0
+    ref = ref + r
+    got = _view(out, B, M, pitch).cpu().double()
+    err = (got[:, :M - 5, t_lo:t_hi] - ref[:, :M - 5]).abs().max().item()
+    assert err <= TOL[mode] * ref.abs().max().item(), err          # also fails on any NaN that leaked in
+    assert torch.isnan(got[:, :, :t_lo]).all() and torch.isnan(got[:, :, t_hi:]).all() and torch.isnan(got[:, M - 5:]).all()
+
+
 def test_chan_gemm_user_tensor_unaligned_pitch():
     """Causal-conv use: input is a plain contiguous (B,Q,T) tensor with T % 4 != 0."""
     mode = _lib.F16X3
