@@ -92,10 +92,11 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
     unsigned long long dbg_acc[4] = {0, 0, 0, 0};
 #endif
     const int c = lane & 15, q = lane >> 4;
-    // 16-byte chunk (row, q) of a [16 rows][32 samples] tile plane sits at slot 16q + ((row + q) & 15):
-    // the b128 reads/writes of lanes (row = c, q) and the b32 writes of lanes (row = 4q + i, samples 2c, 2c+1)
-    // are both bank-conflict free
-    const int tile_rd = (16 * q + ((c + q) & 15)) * 8;              // halfs; this lane's chunk as an MFMA operand
+    // 16-byte chunk (row, q) of a [16 rows][32 samples] tile plane sits at slot 16q + (row ^ q): conflict free for
+    // the ds_read_b128 lane groups and the 8-lane ds_write_b128 groups of lanes (row = c, q) AND for the 32-lane
+    // ds_write_b32 groups of lanes (row = 4q + i, samples 2c, 2c+1) (checked against the LDS banking table of
+    // MI355X_MICROARCH.md; SQ_LDS_BANK_CONFLICT 28 % -> see profiles)
+    const int tile_rd = (16 * q + (c ^ q)) * 8;                     // halfs; this lane's chunk as an MFMA operand
 
     // Items of this workgroup.  The workgroups that share an XCD (one contiguous run of logical ids, see
     // wn_block) own one contiguous range of items and walk it INTERLEAVED: workgroup j takes items
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         // this lane's dwords in the result tiles: row 4q + i, samples 2c, 2c+1 -> chunk c>>2, dword c&3
         int t_wr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) t_wr[i] = (16 * (c >> 2) + ((4 * q + i + (c >> 2)) & 15)) * 8 + (c & 3) * 2;
+        for (int i = 0; i < 4; ++i) t_wr[i] = (16 * (c >> 2) + ((4 * q + i) ^ (c >> 2))) * 8 + (c & 3) * 2;
 
         auto load_cr = [&](f32x2* cr, Pos ps) {
             const float* dzc = ps.live ? a.dz + (size_t)ps.b * a.dz_bstride + (size_t)(16 * g + 4 * q) * a.pitch + ps.t0 + 2 * c : a.dz;
