@@ -202,6 +202,37 @@ def main():
             traffic = None
     ach = gbs(fwd_b, fwd_ms)
     copy_gbs = measured_copy_gbs() if rank == 0 else None
+    # Per-kernel split of the backward stack, from 3 extra (untimed) steps with one HIP event per launch
+    # (the events would cost ~1 % inside the timed region): the block kernel and the data-gradient product.
+    bwd_kernels = None
+    if rank == 0 and getattr(eng, "_use_ms", lambda: False)():
+        eng.fine_marks, eng.marks = True, []
+        for _ in range(3):
+            x = eng.onehot(piece, scrambled=True)
+            eng.loss_and_grad(x, target)
+        torch.cuda.synchronize()
+        m2, eng.marks, eng.fine_marks = eng.marks, None, False
+        tot, cnt = {}, {}
+        for (n0, e0), (n1, e1) in zip(m2[:-1], m2[1:]):
+            if n1 in ("b_block", "b_dx"):
+                tot[n1] = tot.get(n1, 0.0) + e0.elapsed_time(e1)
+                cnt[n1] = cnt.get(n1, 0) + 1
+        dil, off = CFG["dilations"], [1]
+        for d in dil:
+            off.append(off[-1] + d)
+        Wc = T - off[-1]                                          # columns of the skip crop
+        ch = 64
+        blk_b = sum(4 * B_LOCAL * ch * ((T - off[i]) + (T - off[i + 1]) + Wc + 2 * (T - off[i + 1])) for i in range(len(dil))) / len(dil)
+        dx_b = sum(4 * B_LOCAL * ch * (2 * (T - off[i + 1]) + (T - off[i + 1]) + (T - off[i])) for i in range(len(dil))) / len(dil)
+        bwd_kernels = []
+        for key, name, nbytes, what in (("b_block", "resblock_bwd_rw_k", blk_b, "x, dy, dz-crop in; [df;dg] out (+ 20 MB of weight-gradient slabs, not counted)"),
+                                        ("b_dx", "chan_gemm_rw_k", dx_b, "[df;dg], dy in; dx out")):
+            if cnt.get(key):
+                ms = tot[key] / cnt[key]
+                bwd_kernels.append({"kernel": name, "avg_launch_ms": ms, "bytes_per_launch": nbytes, "bytes": what,
+                                    "achieved": gbs(nbytes, ms), "unit": "GB/s",
+                                    "frac": gbs(nbytes, ms) * 1e9 / HBM_PEAK,
+                                    "frac_of_measured_copy": (gbs(nbytes, ms) / copy_gbs) if copy_gbs else None})
     out = {
         "metric": "audio samples/sec trained (whole node), 30-layer WaveNet @16kHz",
         "value": world * B_LOCAL * T * args.steps / dt,
@@ -226,7 +257,7 @@ def main():
                      # (read + write bytes of a 1 GiB float4 copy / its time)
                      "measured_copy_GBs": copy_gbs,
                      "frac_of_measured_copy": (ach / copy_gbs) if (ach and copy_gbs) else None},
-        # the same stack, backward (resblock_bwd_ms_k + chan_gemm_k per block) and forward+backward
+        # the same stack, backward (resblock_bwd_rw_k + chan_gemm_rw_k per block) and forward+backward
         "roofline_stack_bwd": {"bound": "hbm", "achieved": gbs(bwd_b, bwd_ms), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": (gbs(bwd_b, bwd_ms) * 1e9 / HBM_PEAK) if gbs(bwd_b, bwd_ms) else None,
                                "algorithmic_bytes_per_step": bwd_b},
@@ -237,6 +268,10 @@ def main():
                                    "algorithmic_bytes_per_step": fwd_b + bwd_b},
         "phase_ms_per_step": {k: round(v, 4) for k, v in phase.items()},
     }
+    if bwd_kernels:
+        # per launch, kernel-level bytes ([df;dg] goes through HBM); avg_launch_ms is the time between two HIP events
+        # around the lone launch (3 untimed steps), ~10 % above its back-to-back time inside the timed region
+        out["roofline_bwd_kernels"] = bwd_kernels
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -542,6 +542,7 @@ class WaveNetEngine:
                      pitch, fr("fg%d" % i), br("dT%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),
                      self.D, CH, d, t_lo, T, lo, ptr(bw["slab"], plan["fg%d" % i][0]),
                      ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None, None, 0, 0, 0, 0, 0, B, mf, mb, st)
+                self.fmark("b_block")
                 if self.use_bias:
                     bo = self.gp_bias_off
                     call("wn_bias_grad", dfg, 2 * CH * pitch, pitch, 0, self.D, t_lo, T, B, ptr(self.gpack, bo[bn % (4 * i)]), st)
@@ -556,6 +557,7 @@ class WaveNetEngine:
                 call("wn_chan_gemm", dfg, dfg, 2 * CH * pitch, pitch, t_lo, pitch, 0, d, 2 * CH // 32, 2 * CH // 32, br("fgT%d" % i),
                      CH // 16, self.R, ptr(bw["dX"][i % 2], SLACK), xb, pitch, 0, None,
                      dy, xb, pitch, t_lo, None, 0, 0, self.off[i], T, 0, B, mb, st)
+                self.fmark("b_dx")
                 continue
             zs = None if self.z_from_fwd else zs
             call("wn_resblock_bwd", self._x(ws, i), dy, ptr(bw["dZ"], SLACK + i * CH * pitch), dfg, zs,
