@@ -205,7 +205,7 @@ def main():
     # Per-kernel split of the backward stack, from 3 extra (untimed) steps with one HIP event per launch
     # (the events would cost ~1 % inside the timed region): the block kernel and the data-gradient product.
     bwd_kernels = None
-    if rank == 0 and getattr(eng, "_use_ms", lambda: False)():
+    if rank == 0 and world == 1 and getattr(eng, "_use_ms", lambda: False)():
         eng.fine_marks, eng.marks = True, []
         for _ in range(3):
             x = eng.onehot(piece, scrambled=True)
