@@ -21,13 +21,13 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* if WORLD_SIZE > 1.
-    Returns (rank, world, local_rank)."""
+def init_from_env(backend=None, force=False):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* if WORLD_SIZE > 1 (``force``: also for one rank
+    under a launcher, so that a 1-GPU box exercises the RCCL path).  Returns (rank, world, local_rank)."""
     w = int(os.environ.get("WORLD_SIZE", "1"))
     r = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
-    if w > 1 and not dist.is_initialized():
+    if (w > 1 or (force and "MASTER_ADDR" in os.environ)) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
