@@ -50,16 +50,24 @@ __global__ __launch_bounds__(256) void softmax256_bwd_k(const float* __restrict_
 // Fused: p = softmax(x_row); loss_row = logsumexp(p) - p[y]; dp = (softmax(p) - e_y) * inv_n;
 // dx = p * (dp - <dp,p>).  probs / dx may be null.  loss_part[blockIdx.x] = this block's share of
 // mean_r loss_r (the caller sums the WN_CE_PARTIALS partials; no contended atomics).
-__global__ __launch_bounds__(256) void softmax256_ce_k(const float* __restrict__ x, const int64_t* __restrict__ target,
-                                                       float* __restrict__ probs, float* __restrict__ dx,
-                                                       float* __restrict__ loss_part, long nrows, float inv_n) {
-    __shared__ float red[4];
+#define CE_WAVES 8
+__global__ __launch_bounds__(64 * CE_WAVES) void softmax256_ce_k(const float* __restrict__ x, const int64_t* __restrict__ target,
+                                                                 float* __restrict__ probs, float* __restrict__ dx,
+                                                                 float* __restrict__ loss_part, long nrows, float inv_n) {
+    __shared__ float red[CE_WAVES];
     const int lane = threadIdx.x & 63;
-    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long stride = (long)gridDim.x * 4;
+    long row = (long)blockIdx.x * CE_WAVES + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * CE_WAVES;
     float lacc = 0.f;
+    // the next row is on its way while this one goes through its five wave reductions (unconditional load of a
+    // clamped row index: a load under a run-time condition would not be a prefetch)
+    long rc = row < nrows ? row : nrows - 1;
+    f32x4 v = ld4(x + rc * 256 + lane * 4);
+    int y = (int)target[rc];
     for (; row < nrows; row += stride) {
-        f32x4 v = ld4(x + row * 256 + lane * 4);
+        const long rn = row + stride < nrows ? row + stride : nrows - 1;
+        const f32x4 vn = ld4(x + rn * 256 + lane * 4);
+        const int yn = (int)target[rn];
         float m = wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
         f32x4 e = {expf(v[0] - m), expf(v[1] - m), expf(v[2] - m), expf(v[3] - m)};
         float inv = 1.0f / wave_sum((e[0] + e[1]) + (e[2] + e[3]));
@@ -68,7 +76,6 @@ __global__ __launch_bounds__(256) void softmax256_ce_k(const float* __restrict__
         // second (log-)softmax over the probabilities: p in [0,1] so no max shift is needed
         f32x4 e2 = {expf(p[0]), expf(p[1]), expf(p[2]), expf(p[3])};
         float s2 = wave_sum((e2[0] + e2[1]) + (e2[2] + e2[3]));
-        int y = (int)target[row];
         int yl = y >> 2, ye = y & 3;
         float py = __shfl(ye == 0 ? p[0] : ye == 1 ? p[1] : ye == 2 ? p[2] : p[3], yl, 64);
         lacc += logf(s2) - py;
@@ -80,10 +87,17 @@ __global__ __launch_bounds__(256) void softmax256_ce_k(const float* __restrict__
             f32x4 r = {p[0] * (dp[0] - dot), p[1] * (dp[1] - dot), p[2] * (dp[2] - dot), p[3] * (dp[3] - dot)};
             *reinterpret_cast<f32x4*>(dx + row * 256 + lane * 4) = r;
         }
+        v = vn;
+        y = yn;
     }
     if (lane == 0) red[threadIdx.x >> 6] = lacc * inv_n;
     __syncthreads();
-    if (threadIdx.x == 0 && loss_part) loss_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0 && loss_part) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < CE_WAVES; ++w) t += red[w];
+        loss_part[blockIdx.x] = t;
+    }
 }
 
 static inline int sm_grid(long nrows) {
@@ -106,7 +120,7 @@ int wn_launch_softmax_ce(const float* x, const int64_t* target, float* probs, fl
                          long nrows, float inv_n, hipStream_t st) {
     if (nrows <= 0) return 0;
     // always WN_CE_PARTIALS blocks so that every partial is (re)written each call
-    hipLaunchKernelGGL(softmax256_ce_k, dim3(WN_CE_PARTIALS), dim3(256), 0, st, x, target, probs, dx,
+    hipLaunchKernelGGL(softmax256_ce_k, dim3(WN_CE_PARTIALS), dim3(64 * CE_WAVES), 0, st, x, target, probs, dx,
                        loss_part, nrows, inv_n);
     WN_CHECK_LAUNCH();
     return 0;
