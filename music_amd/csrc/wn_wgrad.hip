@@ -427,8 +427,21 @@ __global__ __launch_bounds__(256) void reduce_slabs_k(const long* __restrict__ d
     const float* sp = slab + d[1] + e;
     float* op = out + d[4] + e;
     if (e + 3 < n) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < ns; ++i) s += ld4u(sp + (size_t)i * stride);
+        // 8 slabs in flight per thread (8 partial sums, combined in a fixed order: still deterministic); with one
+        // running sum the loop waits out a memory latency per couple of slabs
+        f32x4 s8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s8[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int i = 0;
+        for (; i + 8 <= ns; i += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = ld4u(sp + (size_t)(i + k) * stride);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s8[k] += t[k];
+        }
+        for (; i < ns; ++i) s8[0] += ld4u(sp + (size_t)i * stride);
+        const f32x4 s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         op[0] = s[0]; op[1] = s[1]; op[2] = s[2]; op[3] = s[3];
     } else {
         for (long k = 0; e + k < n; ++k) {
