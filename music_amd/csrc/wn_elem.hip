@@ -333,9 +333,12 @@ __global__ __launch_bounds__(256) void cond_grad_k(const float* __restrict__ in,
         for (int j = wave; j < le; j += 4) {
             const int s0 = j * q;
             const int s1 = (j == le - 1) ? L : (s0 + q < L ? s0 + q : L);
-            float acc = 0.f;
-            for (int t = s0 + lane; t < s1; t += 64) acc += p[t];
-            acc = wave_sum(acc);
+            // four loads in flight per lane, four partial sums combined in a fixed order
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int t = s0 + lane;
+            for (; t + 192 < s1; t += 256) { a0 += p[t]; a1 += p[t + 64]; a2 += p[t + 128]; a3 += p[t + 192]; }
+            for (; t < s1; t += 64) a0 += p[t];
+            float acc = wave_sum((a0 + a1) + (a2 + a3));
             if (lane == 0) o[j] = acc;
         }
         return;
@@ -347,10 +350,17 @@ __global__ __launch_bounds__(256) void cond_grad_k(const float* __restrict__ in,
         const int c0 = wave * per, c1 = (c0 + per < nchunks) ? c0 + per : nchunks;
         float acc = 0.f;
         if (lane < chunk) {
-            for (int ch = c0; ch < c1; ++ch) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int ch = c0;
+            for (; ch + 3 < c1 && (ch + 3) * chunk + lane < L; ch += 4) {
                 const int t = ch * chunk + lane;
-                if (t < L) acc += p[t];
+                a0 += p[t]; a1 += p[t + chunk]; a2 += p[t + 2 * chunk]; a3 += p[t + 3 * chunk];
             }
+            for (; ch < c1; ++ch) {
+                const int t = ch * chunk + lane;
+                if (t < L) a0 += p[t];
+            }
+            acc = (a0 + a1) + (a2 + a3);
         }
         part[wave][lane] = lane < chunk ? acc : 0.f;
         __syncthreads();
