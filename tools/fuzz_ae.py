@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Randomised parity fuzz of the autoencoder (GPU): random widths (decoder 64 channels half of the time, so that the
+two-role backward block runs WITH the conditioning table), dilations, pooling (stretch and tile conditioning), batch,
+clip length and bias; loss and every gradient against autograd on oracle/wavenet_oracle.py with the same per-forward
+projections.  Test infrastructure (imports oracle/); not part of the product path.
+
+    python tools/fuzz_ae.py [--cases N] [--seed S]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import wavenet_oracle as wo  # noqa: E402
+from oracle import intops  # noqa: E402
+
+
+def one_case(rng, k):
+    from music_amd.model1 import wavenet_autoencoder
+    n = int(rng.integers(2, 7))
+    dil = [int(rng.choice([1, 2, 3, 4, 8, 16, 5])) for _ in range(n)]
+    wide = rng.random() < 0.5
+    cfg = dict(filter_width=2, quantization_channel=256, dilations=dil,
+               en_residual_channel=int(rng.integers(8, 65)), en_dilation_channel=int(rng.integers(8, 65)),
+               en_bottleneck_width=int(rng.integers(2, 17)), en_pool_kernel_size=int(rng.choice([7, 16, 25, 50, 64])),
+               de_residual_channel=int(rng.integers(33, 65)) if wide else int(rng.integers(8, 33)),
+               de_dilation_channel=int(rng.integers(33, 65)) if wide else int(rng.integers(8, 33)),
+               de_skip_channel=int(rng.choice([16, 40, 64, 100])), use_bias=bool(rng.random() < 0.5))
+    torch.manual_seed(500 + k)
+    net = wavenet_autoencoder(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    params = {kk: v.clone() for kk, v in net.state_dict().items()}
+    net = net.cuda()
+    rf = net.receptive_field
+    B = int(rng.integers(1, 4))
+    W = int(cfg["en_pool_kernel_size"] * rng.integers(1, 9) + rng.choice([0, 0, 1, 3, 17]))
+    idx = rng.integers(0, 256, size=(B, rf + W - 1))
+    x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx]))
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64))
+    torch.manual_seed(900 + k)
+    net.zero_grad()
+    probs = net(x.cuda())
+    loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
+    loss.backward()
+    torch.manual_seed(900 + k)
+    cond = wo.draw_conditioning(n, cfg["en_bottleneck_width"], cfg["de_dilation_channel"], cfg["de_skip_channel"])
+    leaf = {kk: v.clone().requires_grad_(True) for kk, v in params.items()}
+    p_ref, _ = wo.autoencoder_forward(leaf, dil, x, cfg["en_pool_kernel_size"], cond)
+    l_ref = torch.nn.functional.cross_entropy(p_ref, target)
+    g_ref = torch.autograd.grad(l_ref, list(leaf.values()), allow_unused=True)
+    e_p = (probs.detach().cpu() - p_ref.detach()).abs().max().item()
+    gs = [torch.zeros_like(leaf[nm]) if g is None else g for (nm, _), g in zip(net.named_parameters(), g_ref)]
+    floor = 1e-3 * max(g.abs().max().item() for g in gs)
+    worst, wname = 0.0, ""
+    for (name, p), g in zip(net.named_parameters(), gs):
+        err = (p.grad.cpu() - g).abs().max().item() / max(g.abs().max().item(), floor)
+        if err > worst:
+            worst, wname = err, name
+    ok = e_p <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and worst <= 2e-3
+    print("%s case %3d dil=%s en=%d/%d bw=%d pool=%d de=%d/%d S=%d bias=%d B=%d W=%d  p %.1e grad %.1e %s"
+          % ("ok  " if ok else "FAIL", k, dil, cfg["en_residual_channel"], cfg["en_dilation_channel"], cfg["en_bottleneck_width"],
+             cfg["en_pool_kernel_size"], cfg["de_residual_channel"], cfg["de_dilation_channel"], cfg["de_skip_channel"],
+             cfg["use_bias"], B, W, e_p, worst, "" if ok else wname), flush=True)
+    return ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    bad = sum(0 if one_case(rng, k) else 1 for k in range(args.cases))
+    print("%d / %d cases failed" % (bad, args.cases))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
