@@ -103,6 +103,15 @@ int wn_resblock_bwd_fused(const float* x_in, const float* dP_in, const float* dQ
                           wn_stream_t stream);
 int wn_resblock_bwd_fused_tiles(int t_lo, int t_hi);
 
+/* Encoder block of the autoencoder, forward (wavenet_autoencoder/model1.py:137-152 for one dilation d), one launch:
+ *   h = Wdil [relu x(t-d); relu x(t)] (+ bias_dil) ; x_out = Wd relu(h) (+ bias_d) + x(t)   on [t_lo, t_hi);
+ *   h (the pre-activation the backward masks with) is stored on the same range.  wdil: packed [ch/16][2ch/32] (natural
+ *   k: tap 0 channels then tap 1 channels), wd: packed [ch/16][ch/32] in the chained k order (as wn_resblock_fwd's
+ *   dense weights).  ch = padded channels (32|64); n_h / n_d = real dilation / residual channel counts. */
+int wn_enc_resblock_fwd(const float* x_in, float* x_out, float* h_out, int64_t x_bstride, int64_t h_bstride, int pitch,
+                        const uint16_t* wdil, const uint16_t* wd, const float* bias_dil, const float* bias_d, int n_h,
+                        int n_d, int ch, int d, int t_lo, int t_hi, int batch, int mode, wn_stream_t stream);
+
 /* Backward of one residual block with BOTH weight gradients in the launch (channel-split form,
  * 64 padded channels, modes (f16x3, bf16x3)): what wn_resblock_bwd + the two per-layer wn_wgrad calls
  * compute (autograd of wavenet/model.py:111-129 for one layer except the data gradient of the

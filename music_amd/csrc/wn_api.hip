@@ -65,6 +65,19 @@ int wn_chan_gemm(const float* in0, const float* in1, int64_t in_bstride, int in_
     return wn_launch_gemm(a, batch, mode, (hipStream_t)stream);
 }
 
+int wn_enc_resblock_fwd(const float* x_in, float* x_out, float* h_out, int64_t x_bstride, int64_t h_bstride, int pitch,
+                        const uint16_t* wdil, const uint16_t* wd, const float* bias_dil, const float* bias_d, int n_h,
+                        int n_d, int ch, int d, int t_lo, int t_hi, int batch, int mode, wn_stream_t stream) {
+    if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_enc_resblock_fwd: pitch must be a multiple of 4");
+    if (t_lo < d + 1) return wn_set_error_msg(-4, "wn_enc_resblock_fwd: t_lo must be >= d + 1");
+    WnResArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x_in = x_in; a.x_out = x_out; a.z_out = h_out; a.x_bstride = x_bstride; a.z_bstride = h_bstride; a.pitch = pitch;
+    a.wfg = wdil; a.wd = wd; a.bias_f = bias_dil; a.bias_g = nullptr; a.bias_d = bias_d; a.n_f = n_h; a.n_d = n_d;
+    a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = t_lo; a.write_x = 1;
+    return wn_launch_enc_resblock_fwd(a, ch, batch, mode, (hipStream_t)stream);
+}
+
 int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bstride, int64_t z_bstride,
                     int pitch, const uint16_t* wfg, const uint16_t* wd, const float* bias_f,
                     const float* bias_g, const float* bias_d, int n_f, int n_d, int ch, int d,

@@ -31,6 +31,7 @@ int wn_launch_gemm_wide_rw(const WnGemmArgs& a, int batch, int mode, hipStream_t
 struct WnResArgs;
 // two-role persistent forward block (wn_resfwd_rw.hip); 1 = launched, 0 = arguments not covered
 int wn_launch_resblock_fwd_rw(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);
+int wn_launch_enc_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);   // wn_resblock2.hip (ENC)
 int wn_launch_pack(const float* flat, const int32_t* idx, uint16_t* out, int n, int is_bf16, int ns,
                    hipStream_t st);
 

@@ -42,12 +42,15 @@ __device__ __forceinline__ float wn_gate(float f, float g) {
 
 template <int NT> struct NtCfg { static constexpr int WAVES = NT == 4 ? 8 : 16; };     // 512 columns per workgroup either way
 
-template <class T, int NS, int CH, int NT>
+// ENC = the autoencoder's ENCODER block (wavenet_autoencoder/model1.py:137-152) on the same skeleton:
+//   h = Wdil [relu x(t-d); relu x(t)] (+ bias) ; x_out = Wd relu(h) (+ bias) + x(t) ; h (pre-activation) is stored where
+//   the decoder block stores z.  One row group (no gate), ReLU on load and in front of the dense product.
+template <class T, int NS, int CH, int NT, bool ENC = false>
 __global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnResArgs a) {
     typedef typename VecN<NT>::t fvec;
     constexpr int THREADS = 64 * NtCfg<NT>::WAVES;
     constexpr int COLS = NtCfg<NT>::WAVES * 16 * NT;
-    constexpr int MT = 2 * CH / 16;        // fg row tiles (f rows then g rows)
+    constexpr int MT = (ENC ? 1 : 2) * CH / 16;        // fg row tiles (f rows then g rows); encoder: h rows only
     constexpr int KS = 2 * CH / 32;        // fg k-steps (tap 0 channels then tap 1 channels)
     constexpr int KT = CH / 32;            // k-steps per tap
     constexpr int MT2 = CH / 16;           // dense row tiles
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnRes
         for (int n = 0; n < NT; ++n) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = raw[j][n];
+            for (int j = 0; j < 8; ++j) v[j] = ENC ? fmaxf(raw[j][n], 0.f) : raw[j][n];
             split8<T, NS>(bf[n], v);
         }
         if (s + 1 < KS) issue(s + 1);
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnRes
         }
     }
 
-    if (a.cond) {       // per-(channel, time-bucket) conditioning bias, gathered from a tiny table
+    if (!ENC && a.cond) {       // per-(channel, time-bucket) conditioning bias, gathered from a tiny table
         const float* cb = a.cond + (size_t)b * a.cond_bstride;
         int idx[NT];
 #pragma unroll
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnRes
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                z[m][n][i] = wn_gate(acc[m][n][i], acc[m + MT2][n][i]);
+                z[m][n][i] = ENC ? acc[m][n][i] : wn_gate(acc[m][n][i], acc[ENC ? m : m + MT2][n][i]);
 
     // z-crop store (rows 16m+4q+i; the lane's 4 N-tiles are 4 consecutive samples)
     {
@@ -225,7 +228,10 @@ __global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnRes
         for (int n = 0; n < NT; ++n) {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] = z[2 * s][n][i]; v[4 + i] = z[2 * s + 1][n][i]; }
+            for (int i = 0; i < 4; ++i) {
+                v[i] = ENC ? fmaxf(z[2 * s][n][i], 0.f) : z[2 * s][n][i];
+                v[4 + i] = ENC ? fmaxf(z[2 * s + 1][n][i], 0.f) : z[2 * s + 1][n][i];
+            }
             split8<T, NS>(bf[n], v);
         }
 #pragma unroll
@@ -283,6 +289,37 @@ static int launch_fwd_nt(const WnResArgs& a, int ch, int batch, hipStream_t st) 
     }
     WN_CHECK_LAUNCH();
     return 0;
+}
+
+template <class T, int NS>
+static int launch_enc(const WnResArgs& a, int ch, int batch, hipStream_t st) {
+    WnResArgs k = a;
+    k.swz = wn_xcd_swizzle_enabled();
+    k.t_base = wn_tile_origin(a.t_lo);
+    const int ncol = a.t_hi - k.t_base;
+    constexpr int COLS = NtCfg<4>::WAVES * 64;
+    dim3 g((ncol + COLS - 1) / COLS, batch), b(64 * NtCfg<4>::WAVES);
+    const size_t fr = (NS == 3 ? 1024 : 512) * sizeof(uint16_t);
+    if (ch == 32) {
+        hipLaunchKernelGGL((resblock_fwd_nt_k<T, NS, 32, 4, true>), g, b, (size_t)(2 * 2 + 2 * 1) * fr, st, k);
+    } else if (ch == 64) {
+        hipLaunchKernelGGL((resblock_fwd_nt_k<T, NS, 64, 4, true>), g, b, (size_t)(4 * 4 + 4 * 2) * fr, st, k);
+    } else {
+        return wn_set_error_msg(-3, "enc_resblock: padded channel count must be 32 or 64");
+    }
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
+int wn_launch_enc_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st) {
+    if (a.t_hi <= a.t_lo || batch <= 0) return 0;
+    switch (mode) {
+        case WN_MODE_F16X3: return launch_enc<F16, 3>(a, ch, batch, st);
+        case WN_MODE_F16X1: return launch_enc<F16, 1>(a, ch, batch, st);
+        case WN_MODE_BF16X3: return launch_enc<BF16, 3>(a, ch, batch, st);
+        case WN_MODE_BF16X1: return launch_enc<BF16, 1>(a, ch, batch, st);
+    }
+    return wn_set_error_msg(-2, "enc_resblock_fwd: bad mode");
 }
 
 int wn_launch_resblock_fwd_nt(const WnResArgs& a, int ch, int batch, int mode, int nt, hipStream_t st) {

@@ -60,6 +60,8 @@ class _AutoencoderEngine:
         for d in self.dil:
             self.off.append(self.off[-1] + d)
         self.use_bias = bool(net.use_bias)
+        # one launch per encoder block (wn_enc_resblock_fwd) instead of two channel GEMMs; WN_AE_FUSED_ENC=0 = the GEMMs
+        self.fused_encoder = os.environ.get("WN_AE_FUSED_ENC", "1") == "1"
         named = list(net.named_parameters())
         self.param_names = [n for n, _ in named]
         self.spec = _Spec([(n, tuple(p.shape)) for n, p in named])
@@ -116,6 +118,7 @@ class _AutoencoderEngine:
             w = full(CHe, CHe)
             w[:Re, :De] = sp.conv("en_dense_layer_stack.%d.weight" % i)[:, :, 0]
             add("en_dense%d" % i, w)
+            fwd.append(("en_dense_c%d" % i, pack_index(w, True)))               # chained k order: the fused encoder block
             bwd.append(("en_denseT%d" % i, pack_index(np.ascontiguousarray(w.T))))
             wfg = sp.conv("de_dilation_layer_stack.%d.weight" % (3 * i))       # [2Dd,Rd,2], gate rows first
             w = full(2 * CHd, 2 * CHd)
@@ -221,6 +224,11 @@ class _AutoencoderEngine:
         for i, d in enumerate(self.dil):
             t_lo = self.off[i + 1]
             # h = dilated_conv(relu(x));   x' = dense(relu(h)) + x[tail]
+            if self.fused_encoder:
+                call("wn_enc_resblock_fwd", xe(i), xe(i + 1), he(i), eb, eb, pitch, fr("en_dil%d" % i), fr("en_dense_c%d" % i),
+                     self._bias("en_dilation_layer_stack.%d" % i), self._bias("en_dense_layer_stack.%d" % i), self.De, self.Re,
+                     CHe, d, t_lo, T, B, m, st)
+                continue
             gemm("en_dil%d" % i, xe(i), xe(i), eb, pitch, self.off[i], T, -d, 0, CHe // 32, CHe // 32, CHe // 16, self.De,
                  he(i), eb, pitch, 0, self._bias("en_dilation_layer_stack.%d" % i), NONE3, NONE3, t_lo, T, 1)
             gemm("en_dense%d" % i, he(i), None, eb, pitch, t_lo, T, 0, 0, CHe // 32, 0, CHe // 16, self.Re,

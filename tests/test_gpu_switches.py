@@ -34,3 +34,14 @@ def test_alternative_paths_stay_correct(env):
            os.path.join(ROOT, "tests", "test_gpu_parity.py") + "::test_fused_train_step_matches_autograd_path_and_oracle"]
     r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("env", [{"WN_AE_FUSED_ENC": "0"}, {"WN_MS_RW": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_autoencoder_alternative_paths_stay_correct(env):
+    """The autoencoder with its encoder blocks as two channel GEMMs (instead of wn_enc_resblock_fwd) / its decoder
+    blocks on the one-role backward kernel: the G8 forward fixture and the 64-channel backward parity test."""
+    e = dict(os.environ, **env)
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", "g8_autoencoder_forward or autoencoder_backward_64"]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
