@@ -112,6 +112,17 @@ int wn_enc_resblock_fwd(const float* x_in, float* x_out, float* h_out, int64_t x
                         const uint16_t* wdil, const uint16_t* wd, const float* bias_dil, const float* bias_d, int n_h,
                         int n_d, int ch, int d, int t_lo, int t_hi, int batch, int mode, wn_stream_t stream);
 
+/* Encoder block of the autoencoder, backward except the data gradient (64 padded channels, bf16x3), one launch:
+ *   dh = (Wd^T dy) * [h > 0]  written on [t_lo, t_hi) (dy counts as 0 below y_lo: the top block's gradient only exists on
+ *   the pooled crop);  one slab per workgroup: slab_dil[w] = partial dWdil (ch x 2ch, columns = tap0 ch | tap1 ch, the
+ *   x operand is relu x), slab_d[w] = partial dWd (ch x ch, rows = dy rows, the other operand is relu h);
+ *   wn_enc_resblock_bwd_slabs gives the number of slabs (sum them with wn_reduce_slabs).  The data gradient
+ *   dx = [x > 0] (Wdil1^T dh[t] + Wdil0^T dh[t+d]) + dy is a wn_chan_gemm launch on dh.  wdT: packed Wd^T. */
+int wn_enc_resblock_bwd(const float* x_in, const float* dy, const float* h, float* dh, int64_t x_bstride,
+                        int64_t h_bstride, int64_t dh_bstride, int pitch, const uint16_t* wdT, int ch, int d, int t_lo,
+                        int t_hi, int y_lo, float* slab_dil, float* slab_d, int batch, int mode_bwd, wn_stream_t stream);
+int wn_enc_resblock_bwd_slabs(int t_lo, int t_hi, int batch);
+
 /* Backward of one residual block with BOTH weight gradients in the launch (channel-split form,
  * 64 padded channels, modes (f16x3, bf16x3)): what wn_resblock_bwd + the two per-layer wn_wgrad calls
  * compute (autograd of wavenet/model.py:111-129 for one layer except the data gradient of the

@@ -31,6 +31,8 @@ SIGNATURES = {
     "wn_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i,
                         _i, _i, _i, _i, _p, _l, _i, _i, _i, _i, _i, _i, _p],
     "wn_enc_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "wn_enc_resblock_bwd": [_p, _p, _p, _p, _l, _l, _l, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p],
+    "wn_enc_resblock_bwd_slabs": [_i, _i, _i],
     "wn_avgpool": [_p, _l, _i, _i, _i, _i, _i, _p, _l, _i, _i, _p],
     "wn_resblock_bwd": [_p, _p, _p, _p, _p, _l, _l, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
                         _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -107,6 +109,11 @@ def fused_tiles(t_lo, t_hi):
 def ms_slabs(t_lo, t_hi, batch):
     """Number of slabs one wn_resblock_bwd_ms call writes (plain int return, not a status)."""
     return load().wn_resblock_bwd_ms_slabs(t_lo, t_hi, batch)
+
+
+def enc_slabs(t_lo, t_hi, batch):
+    """Number of slabs one wn_enc_resblock_bwd call writes (plain int return, not a status)."""
+    return load().wn_enc_resblock_bwd_slabs(t_lo, t_hi, batch)
 
 
 def call(name, *args):

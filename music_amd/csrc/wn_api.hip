@@ -227,6 +227,19 @@ int wn_resblock_bwd_ms(const float* x_in, const float* dy, const float* dz, floa
     a.cond_le = cond_le; a.cond_q = cond_q;
     return wn_launch_resblock_bwd_ms(a, ch, batch, mode_fwd, mode_bwd, (hipStream_t)stream);
 }
+int wn_enc_resblock_bwd(const float* x_in, const float* dy, const float* h, float* dh, int64_t x_bstride,
+                        int64_t h_bstride, int64_t dh_bstride, int pitch, const uint16_t* wdT, int ch, int d, int t_lo,
+                        int t_hi, int y_lo, float* slab_dil, float* slab_d, int batch, int mode_bwd, wn_stream_t stream) {
+    if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_enc_resblock_bwd: pitch must be a multiple of 4");
+    if (!x_in || !dy || !h || !dh || !wdT || !slab_dil || !slab_d) return wn_set_error_msg(-4, "wn_enc_resblock_bwd: null argument");
+    WnResMsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x_in = x_in; a.dy = dy; a.dz = h; a.dfg = dh; a.x_bstride = x_bstride; a.dz_bstride = h_bstride;
+    a.dfg_bstride = dh_bstride; a.pitch = pitch; a.wdT = wdT; a.slab_fg = slab_dil; a.slab_d = slab_d;
+    a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = y_lo < t_lo ? t_lo : y_lo;
+    return wn_launch_enc_bwd_rw(a, ch, batch, mode_bwd, (hipStream_t)stream);
+}
+int wn_enc_resblock_bwd_slabs(int t_lo, int t_hi, int batch) { return wn_enc_bwd_slabs(t_lo, t_hi, batch); }
 int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch) { return wn_resms_slabs(t_lo, t_hi, batch); }
 int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,
                  int t_lo, int t_hi, int batch, wn_stream_t stream) {

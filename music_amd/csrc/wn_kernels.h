@@ -90,6 +90,9 @@ int wn_resms_slabs(int t_lo, int t_hi, int batch);
 int wn_launch_resblock_bwd_rw(const WnResMsArgs& a, int batch, hipStream_t st);
 void wn_resrw_plan(int t_lo, int t_hi, int batch, int& t_base, int& steps, int& ipw, int& nwg);
 int wn_ms_two_role();              // host: env WN_MS_RW (default 1)
+// backward of an autoencoder ENCODER block with both weight gradients (wn_encrw.hip); WnResMsArgs fields as documented there
+int wn_launch_enc_bwd_rw(const WnResMsArgs& a, int ch, int batch, int mode_bwd, hipStream_t st);
+int wn_enc_bwd_slabs(int t_lo, int t_hi, int batch);
 
 struct WnWgradArgs {
     const float* a; long a_bstride; int a_pitch; int a_shift; int a_cols;   // A: [M rows][time]

@@ -313,16 +313,21 @@ class _AutoencoderEngine:
         ms = (self.CHd == 64 and self.mode == _lib.F16X3 and self.mode_b == _lib.BF16X3
               and os.environ.get("WN_MS_BWD", "1") == "1")
         bw["ms"] = ms
+        # encoder blocks: wn_enc_resblock_bwd (dh + both weight gradients in one launch) where it applies
+        enc_fused = (self.CHe == 64 and self.mode_b == _lib.BF16X3 and os.environ.get("WN_AE_FUSED_ENC_BWD", "1") == "1")
+        bw["enc_fused"] = enc_fused
         for i in range(N):
-            ops += [("de_fg%d" % i, self.off[i + 1], T, -1 if ms else 512), ("en_dil%d" % i, self.off[i + 1], T, 512),
-                    ("en_dense%d" % i, self.off[i + 1], T, 512)]
+            ench = -2 if enc_fused else 512
+            ops += [("de_fg%d" % i, self.off[i + 1], T, -1 if ms else 512), ("en_dil%d" % i, self.off[i + 1], T, ench),
+                    ("en_dense%d" % i, self.off[i + 1], T, ench)]
             if i < N - 1:
                 ops.append(("de_d%d" % i, self.off[i + 1], T, -1 if ms else 512))
         plan, desc, so, vs = {}, [], 0, 0
         for name, t_lo, t_hi, chunk in ops:
             go, r, c = self.gp_off[name]
             n = r * c
-            ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B) if chunk > 0 else _lib.ms_slabs(t_lo, t_hi, B)
+            ns = (_lib.wgrad_slabs(t_lo, t_hi, chunk, B) if chunk > 0 else
+                  _lib.ms_slabs(t_lo, t_hi, B) if chunk == -1 else _lib.enc_slabs(t_lo, t_hi, B))
             plan[name] = (so, n, chunk)
             desc.append([vs, so, ns, n, go, n])
             so += ns * n
@@ -461,6 +466,15 @@ class _AutoencoderEngine:
             d, t_lo = self.dil[i], self.off[i + 1]
             y_lo = lo if i == N - 1 else t_lo                     # the top gradient only exists on the crop
             dy = dxe[(i + 1) % 2]
+            if bw["enc_fused"]:
+                # dh, dW1 = sum dy relu(h)^T and dWdil = sum dh [relu x(t-d) | relu x(t)]^T in one launch
+                call("wn_enc_resblock_bwd", xe(i), dy, he(i), dHe, eb, eb, eb, pitch, br("en_denseT%d" % i), CHe, d, t_lo, T, y_lo,
+                     ptr(bw["slab"], plan["en_dil%d" % i][0]), ptr(bw["slab"], plan["en_dense%d" % i][0]), B, mb, st)
+                bias_grad("en_dense_layer_stack.%d" % i, dy, eb, pitch, 0, Re, y_lo, T)
+                bias_grad("en_dilation_layer_stack.%d" % i, dHe, eb, pitch, 0, De, t_lo, T)
+                gemm("en_dilT%d" % i, dHe, dHe, eb, pitch, t_lo, T, 0, d, CHe // 32, CHe // 32, CHe // 16, Re, dxe[i % 2], eb, pitch, 0,
+                     None, (dy, eb, pitch, y_lo), (xe(i), eb, pitch), self.off[i], T, 0)
+                continue
             # dh = (W1^T dy) * [h > 0];  dW1 = sum dy relu(h)^T
             wgrad("en_dense%d" % i, dy, eb, pitch, 0, pitch, he(i), None, eb, pitch, 0, 0, pitch, CHe // 16, CHe // 16, 1, CHe, y_lo, T)
             bias_grad("en_dense_layer_stack.%d" % i, dy, eb, pitch, 0, Re, y_lo, T)
