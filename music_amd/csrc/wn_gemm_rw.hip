@@ -11,8 +11,8 @@
 //     multiply the current item out of LDS, add the residual rows and store.
 // One barrier per item; two workgroups (16 waves, <= 128 registers) per CU; the workgroups of an XCD walk
 // their range of items interleaved, so the shifted tap finds its rows in that XCD's L2.
-// Preconditions (checked by the launcher, otherwise chan_gemm_k runs): x3 mode, 4 row tiles, 8 k-steps,
-// no mask, no relu_in, out_shift 0.  Columns outside [in_lo, in_hi) are never dereferenced (load addresses are
+// Preconditions (checked by the launcher, otherwise chan_gemm_k runs): x3 mode, 4 row tiles, 8 or 4 k-steps,
+// no relu_in, out_shift 0 (bias, residual and mask are supported).  Columns outside [in_lo, in_hi) are never dereferenced (load addresses are
 // clamped into the range, the values replaced by zeros).
 #include <stdlib.h>
 #include <type_traits>
@@ -21,7 +21,6 @@
 
 #define GR_THREADS 512
 #define GR_COLS 32
-#define GR_KS 8
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -34,10 +33,11 @@ __device__ __forceinline__ f32x2 gr_ld2u(const float* p) {
 
 struct GrPlan { int steps_per_clip, items_per_wg, batch; };
 
-template <class T>
+template <class T, int GR_KS>        // GR_KS = 8 (two taps of 128 rows: decoder / WaveNet blocks) or 4 (two taps of 64 rows: encoder blocks)
 __global__ __launch_bounds__(GR_THREADS, 2) void chan_gemm_rw_k(WnGemmArgs a, GrPlan pl) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];        // 2 stages x 16 fragments x 2 KB
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];        // 2 stages x 2 GR_KS fragments x 2 KB
     constexpr int STAGE = 2 * GR_KS * 1024;                                // halfs
+    constexpr int PER = GR_KS / 4;                                         // k-steps per L wave
 
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = wv & 3;
@@ -94,6 +94,12 @@ __global__ __launch_bounds__(GR_THREADS, 2) void chan_gemm_rw_k(WnGemmArgs a, Gr
                               (size_t)(16 * g + 4 * q) * (a.resid ? a.resid_pitch : a.in_pitch) + tl;
 #pragma unroll
             for (int i = 0; i < 4; ++i) rr[i] = gr_ld2u(rp + (size_t)i * (a.resid ? a.resid_pitch : a.in_pitch));
+            // mask rows (keep where > 0; applied before the residual, as chan_gemm_k does)
+            f32x2 mk[4];
+            const float* mp = (a.mask ? a.mask : a.in0) + (size_t)ps.b * (a.mask ? a.mask_bstride : a.in_bstride) +
+                              (size_t)(16 * g + 4 * q) * (a.mask ? a.mask_pitch : a.in_pitch) + tl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mk[i] = gr_ld2u(mp + (size_t)i * (a.mask ? a.mask_pitch : a.in_pitch));
 
             const uint16_t* st = lds + (size_t)(it & 1) * STAGE;
             f32x4 acc[2];
@@ -113,6 +119,10 @@ __global__ __launch_bounds__(GR_THREADS, 2) void chan_gemm_rw_k(WnGemmArgs a, Gr
             for (int i = 0; i < 4; ++i) {
                 const int row = 16 * g + 4 * q + i;
                 float v0 = acc[0][i], v1 = acc[1][i];
+                if (a.mask) {
+                    v0 = mk[i][0] > 0.f ? v0 : 0.f;
+                    v1 = mk[i][1] > 0.f ? v1 : 0.f;
+                }
                 if (r0) v0 += rr[i][0];
                 if (r1) v1 += rr[i][1];
                 float* o = op + (size_t)row * a.out_pitch;
@@ -130,13 +140,13 @@ __global__ __launch_bounds__(GR_THREADS, 2) void chan_gemm_rw_k(WnGemmArgs a, Gr
         return;
     }
 
-    // =========================== L waves: k-steps 2g, 2g+1 ===========================
-    struct Raw { f32x2 v[2][8]; };
+    // =========================== L waves: k-steps PER*g .. PER*g + PER-1 ===========================
+    struct Raw { f32x2 v[PER][8]; };
     auto load_raw = [&](Raw& r, Pos ps) {
         const int tl = ps.t0 + 2 * c;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int s = 2 * g + u;
+        for (int u = 0; u < PER; ++u) {
+            const int s = PER * g + u;
             const bool tap1 = s >= a.ks0;
             const float* base = (tap1 ? a.in1 : a.in0) + (size_t)ps.b * a.in_bstride;
             const int blk = tap1 ? s - a.ks0 : s;
@@ -157,8 +167,8 @@ __global__ __launch_bounds__(GR_THREADS, 2) void chan_gemm_rw_k(WnGemmArgs a, Gr
         uint16_t* st = lds + (size_t)stage * STAGE;
         const int tl = ps.t0 + 2 * c;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int s = 2 * g + u;
+        for (int u = 0; u < PER; ++u) {
+            const int s = PER * g + u;
             const int sh = s >= a.ks0 ? a.shift1 : a.shift0;
             const int t0s = __builtin_amdgcn_readfirstlane(ps.t0) + sh;
             const bool inner = t0s >= a.in_lo && t0s + GR_COLS <= a.in_hi;       // wave-uniform
@@ -232,7 +242,8 @@ static int gr_enabled() {
 int wn_launch_gemm_rw(const WnGemmArgs& k, int batch, int mode, hipStream_t st) {
     if (!gr_enabled()) return 0;
     if (mode != WN_MODE_BF16X3 && mode != WN_MODE_F16X3) return 0;
-    if (k.mt != 4 || k.ks0 + k.ks1 != GR_KS || (k.ks1 > 0 && !k.in1) || (k.ks0 & 1) || k.mask || k.relu_in || k.out_shift != 0) return 0;
+    const int ks = k.ks0 + k.ks1;
+    if (k.mt != 4 || (ks != 8 && ks != 4) || (k.ks1 > 0 && !k.in1) || k.relu_in || k.out_shift != 0) return 0;
     if (k.t_base & (GR_COLS - 1)) return 0;
     if (k.in_hi - k.in_lo < 2) return 0;
     GrPlan pl;
@@ -242,18 +253,24 @@ int wn_launch_gemm_rw(const WnGemmArgs& k, int batch, int mode, hipStream_t st) 
     pl.items_per_wg = (total + 511) / 512;
     if (pl.items_per_wg < 1) pl.items_per_wg = 1;
     const int nwg = (total + pl.items_per_wg - 1) / pl.items_per_wg;
-    const size_t sh = (size_t)2 * 2 * GR_KS * 1024 * sizeof(uint16_t);
+    const size_t sh = (size_t)2 * 2 * ks * 1024 * sizeof(uint16_t);
     static unsigned long long done = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((done >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_gemm_rw_k<BF16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_gemm_rw_k<F16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_gemm_rw_k<BF16, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_gemm_rw_k<F16, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         done |= 1ull << dev;
     }
-    if (mode == WN_MODE_BF16X3) hipLaunchKernelGGL(chan_gemm_rw_k<BF16>, dim3(nwg), dim3(GR_THREADS), sh, st, k, pl);
-    else hipLaunchKernelGGL(chan_gemm_rw_k<F16>, dim3(nwg), dim3(GR_THREADS), sh, st, k, pl);
+    const dim3 gr(nwg), bl(GR_THREADS);
+    if (mode == WN_MODE_BF16X3) {
+        if (ks == 8) hipLaunchKernelGGL((chan_gemm_rw_k<BF16, 8>), gr, bl, sh, st, k, pl);
+        else hipLaunchKernelGGL((chan_gemm_rw_k<BF16, 4>), gr, bl, sh, st, k, pl);
+    } else {
+        if (ks == 8) hipLaunchKernelGGL((chan_gemm_rw_k<F16, 8>), gr, bl, sh, st, k, pl);
+        else hipLaunchKernelGGL((chan_gemm_rw_k<F16, 4>), gr, bl, sh, st, k, pl);
+    }
     return 1;
 }

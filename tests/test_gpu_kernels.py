@@ -135,6 +135,40 @@ def test_chan_gemm_two_role_window_and_canaries(mode, d, in_lo, in_hi, t_lo, t_h
     assert torch.isnan(got[:, :, :t_lo]).all() and torch.isnan(got[:, :, t_hi:]).all() and torch.isnan(got[:, M - 5:]).all()
 
 
+def test_chan_gemm_two_role_four_ksteps_with_mask():
+    """The encoder's data-gradient shape: two taps of 64 rows (4 k-steps), ReLU mask, residual from resid_lo on - also
+    on the two-role persistent kernel."""
+    mode = _lib.BF16X3
+    rng = np.random.default_rng(9)
+    B, M, K, pitch = 2, 64, 64, 1280
+    d, in_lo, in_hi, t_lo, t_hi, resid_lo = 6, 50, 1100, 44, 1094, 70
+    w = rng.standard_normal((M, 2 * K)).astype(np.float32) * 0.1
+    pk = _packed(w, mode)
+    xin = _buf(B, K, pitch, 1.0, 10)
+    _view(xin, B, K, pitch)[:, :, :in_lo] = float("nan")
+    _view(xin, B, K, pitch)[:, :, in_hi:] = float("nan")
+    res = _buf(B, M, pitch, 1.0, 11)
+    msk = _buf(B, M, pitch, 1.0, 12)
+    out = _buf(B, M, pitch)
+    call("wn_chan_gemm", ptr(xin, SLACK), ptr(xin, SLACK), K * pitch, pitch, in_lo, in_hi, 0, d, K // 32, K // 32, ptr(pk),
+         M // 16, M, ptr(out, SLACK), M * pitch, pitch, 0, None, ptr(res, SLACK), M * pitch, pitch, resid_lo,
+         ptr(msk, SLACK), M * pitch, pitch, t_lo, t_hi, 0, B, mode, _lib.stream())
+    torch.cuda.synchronize()
+    x = torch.nan_to_num(_view(xin, B, K, pitch).cpu().double(), nan=0.0)
+    xpad = torch.cat([x, torch.zeros(B, K, d + 8, dtype=torch.float64)], 2)
+    wt = torch.from_numpy(w).double()
+    ts = torch.arange(t_lo, t_hi)
+    ref = torch.einsum("mk,bkt->bmt", wt[:, :K], xpad[:, :, ts]) + torch.einsum("mk,bkt->bmt", wt[:, K:], xpad[:, :, ts + d])
+    ref = torch.where(_view(msk, B, M, pitch).cpu().double()[:, :, ts] > 0, ref, torch.zeros_like(ref))
+    r = _view(res, B, M, pitch).cpu().double()[:, :, ts]
+    r[:, :, ts < resid_lo] = 0
+    ref = ref + r
+    got = _view(out, B, M, pitch).cpu().double()
+    err = (got[:, :, t_lo:t_hi] - ref).abs().max().item()
+    assert err <= TOL[mode] * ref.abs().max().item(), err
+    assert got[:, :, :t_lo].abs().max().item() == 0 and got[:, :, t_hi:].abs().max().item() == 0
+
+
 def test_chan_gemm_user_tensor_unaligned_pitch():
     """Causal-conv use: input is a plain contiguous (B,Q,T) tensor with T % 4 != 0."""
     mode = _lib.F16X3
