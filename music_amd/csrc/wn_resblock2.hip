@@ -201,6 +201,11 @@ __global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnRes
                 fvec v;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) v[n] = z[m][n][i];
+                // z is not read again before the whole stack is done (skip product, backward): a streaming store keeps it
+                // from pushing x_out - which the NEXT launch reads - out of L2 (about 1 % on the stack and on the skip product)
+                if (NT == 4 && tl >= a.z_lo && tl + 3 < a.t_hi)
+                    __builtin_nontemporal_store(v, reinterpret_cast<fvec*>(zo + (size_t)(16 * m + 4 * q + i) * a.pitch + tl));
+                else
                 VecN<NT>::stm(zo + (size_t)(16 * m + 4 * q + i) * a.pitch + tl, v, tl, a.z_lo, a.t_hi);
             }
     }
