@@ -524,14 +524,14 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                sfg[(size_t)(h * CH + 16 * g + 4 * q + i) * (2 * CH) + nt * 16 + c] = cfg[h][nt][i];
+                __builtin_nontemporal_store(cfg[h][nt][i], &sfg[(size_t)(h * CH + 16 * g + 4 * q + i) * (2 * CH) + nt * 16 + c]);
     if (HAS_DY && a.slab_d) {
         float* sd = a.slab_d + (size_t)wgid * (CH * CH);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                sd[(size_t)(r * 16 + c) * CH + 16 * g + 4 * q + i] = cd[r][i];
+                __builtin_nontemporal_store(cd[r][i], &sd[(size_t)(r * 16 + c) * CH + 16 * g + 4 * q + i]);
     }
 }
 
