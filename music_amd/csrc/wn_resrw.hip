@@ -7,18 +7,22 @@
 // splits, gate) and its memory waits simply add up.  Here the workgroup has 8 waves of <= 256
 // registers, two per SIMD, with complementary jobs:
 //   * R waves (0..3; wave g owns dilation channels 16g..16g+15) keep the packed f/g/Wd^T weights in
-//     registers (80), recompute f, g, form dz, gate, write [df;dg] to HBM, and leave df, dg, z in LDS
-//     as 16-bit hi/lo arrays [channel][time];
-//   * W waves (4..7) keep the weight-gradient tiles in registers (80), turn the raw fp32 rows of the
-//     NEXT items into MFMA operands for everybody (x(t-d), x(t), dy both as "time on lanes" fragments
-//     for the R waves and as [row][time] arrays for themselves) and multiply [df;dg;z] by them.  The
-//     [channel][time] arrays ARE the "time on k" operands (a lane reads 8 consecutive samples of one
-//     row with one ds_read_b128), so the transposition the weight gradients need is the LDS round trip
-//     itself - no matrix-core transposition, no accumulator read-back.
-// Items are 32 columns, every LDS buffer has two stages (2 x 72 KB), and there is ONE barrier per item:
-// in iteration i the R waves work on item i (stage i&1) while the W waves fill item i+1's recompute
-// operands (stage (i+1)&1), item i's [row][time] operands (stage i&1) and multiply item i-1 (stage (i-1)&1).
-// While one wave of a SIMD is in its MFMA phase the other is in its VALU phase.
+//     registers (80), split the raw x rows of the NEXT item into its recompute fragments (k-step g;
+//     they had the slack: -DRW_XF_W gives that job back to the W waves), recompute f, g, form dz, gate,
+//     write [df;dg] to HBM, and leave df, dg, z in LDS as 16-bit hi/lo arrays [channel][time];
+//   * W waves (4..7) keep the weight-gradient tiles in registers (80), turn dy into the recompute
+//     fragments of the next item and x(t-d), x(t), dy of the current one into [row][time] arrays, and
+//     multiply [df;dg;z] of the previous item by them.  The [channel][time] arrays ARE the "time on k"
+//     operands (a lane reads 8 consecutive samples of one row with one ds_read_b128), so the
+//     transposition the weight gradients need is the LDS round trip itself - no matrix-core
+//     transposition, no accumulator read-back.
+// Items are 32 columns, every LDS buffer has two stages (2 x 72 KB), there is ONE barrier per item, and
+// every prefetch register set is re-armed two items ahead (the loops are unrolled by two: no copies):
+// in iteration i the R waves fill item i+1's x fragments and work on item i (stage i&1) while the W waves
+// fill item i+1's dy fragments and item i's [row][time] operands and multiply item i-1 (stage (i-1)&1).
+// While one wave of a SIMD is in its MFMA phase the other is mostly in its VALU phase.  The workgroups of
+// an XCD walk their item range interleaved (every dilated tap an L2 hit); tile slots in LDS are XOR-placed
+// (bank-conflict free for the three access patterns); the slabs leave with streaming stores.
 //
 // RW_T_* macros are timing-build switches (remove one ingredient; results are then wrong) used to see
 // what a launch is made of: -DRW_T_NOREC / NOWG / NOFILL / NOGATE / NOCR via `make EXTRA=...`.
