@@ -11,6 +11,9 @@ names (:77-78).  This module keeps its surface and file formats and fixes only w
     save_model(model, num_epoch, path)   -> path + "wavenet_autoencoder{N}.model"
     load_model(model, path, model_name)
     train()      reads ./params/train_params.json, ./params/model_params.json, ./params/dataset_params.json
+
+Optional key in train_params.json (as in music_amd/train.py): ``"fused_step"`` (bool, Adam only) - the whole step runs
+as forward + one softmax/CE/backward kernel + backward + flat Adam on the engine, without autograd.
 """
 import glob
 import os
@@ -100,6 +103,12 @@ def train():
     device = next(net.parameters()).device
     total_loss = torch.zeros((), dtype=torch.float64, device=device)
     step_seed = int(train_params.get("seed") or 0)
+    fused = (bool(train_params.get("fused_step")) and cuda_available and
+             str(train_params.get("optimizer_type", train_params.get("optimizer", "Adam"))).lower() == "adam")
+    engine = None
+    if fused:
+        engine = net._engine_for(device)
+        engine.adam_init(lr=train_params["learning_rate"])
     for epoch in range(train_params["num_epochs"]):
         for i_batch, sampled_batch in enumerate(dataloader):
             piece, target = sampled_batch["audio_piece"], sampled_batch["audio_target"].view(-1)
@@ -113,9 +122,14 @@ def train():
                 loss.backward()
                 wdist.allreduce_gradients(net.parameters(), average=True)
                 return loss
-            loss = optimizer.step(closure) if isinstance(optimizer, optim.LBFGS) else closure()
-            if not isinstance(optimizer, optim.LBFGS):
-                optimizer.step()
+            if fused:
+                loss = engine.loss_and_grad(piece.to(device).float().contiguous(), target.to(device), net._draw_conditioning())
+                wdist.allreduce_flat_(engine.flat_grad, average=False)
+                engine.adam_step(gscale=1.0 / wdist.world())
+            else:
+                loss = optimizer.step(closure) if isinstance(optimizer, optim.LBFGS) else closure()
+                if not isinstance(optimizer, optim.LBFGS):
+                    optimizer.step()
             total_loss += loss.detach().double()
             num_trained += 1
             if num_trained % train_params["print_every"] == 0:

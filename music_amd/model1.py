@@ -196,8 +196,9 @@ class _AutoencoderEngine:
              out, out_bs, out_pitch, out_shift, bias, resid[0], resid[1], resid[2], resid[3] if len(resid) > 3 else 0,
              mask[0], mask[1], mask[2], t_lo, t_hi, relu_in, B, mode, st)
 
-    def forward(self, x, cond):
-        """cond: list of N+1 (weight (C,Bw,1), bias (C,)) CPU tensors (see wavenet_autoencoder.forward)."""
+    def forward(self, x, cond, want_probs=True):
+        """cond: list of N+1 (weight (C,Bw,1), bias (C,)) CPU tensors (see wavenet_autoencoder.forward).
+        want_probs=False stops at the pre-softmax logits in ws["O"] (the fused training step)."""
         B, Q, T = x.shape
         W = T - self.rf + 1
         Le = W // self.pool
@@ -287,8 +288,10 @@ class _AutoencoderEngine:
              R1, sb, pitch, 0, self._bias("connection_1"), (C1, sb, pitch, lo), NONE3, lo, T, 1)
         gemm("c2", R1, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, Q // 16, Q,
              ptr(ws["O"]), Q * W, W, -lo, self._bias("connection_2"), NONE3, NONE3, lo, T, 1)
-        probs = torch.empty(B * W, Q, dtype=torch.float32, device=self.device)
-        call("wn_chunk_softmax256_fwd", ptr(ws["O"]), ptr(probs), B * W, st)
+        probs = None
+        if want_probs:
+            probs = torch.empty(B * W, Q, dtype=torch.float32, device=self.device)
+            call("wn_chunk_softmax256_fwd", ptr(ws["O"]), ptr(probs), B * W, st)
         ws["probs"] = probs
         return probs, enc, ws
 
@@ -338,8 +341,36 @@ class _AutoencoderEngine:
         ws["bwd"] = bw
         return bw
 
+    def loss_and_grad(self, x, target, cond):
+        """Fused training step body (the autoencoder counterpart of engine.loss_and_grad): forward to the logits, ONE
+        kernel for chunk softmax + CrossEntropyLoss on the probabilities (wavenet_autoencoder/train.py:146-160) + both
+        backward steps, then the backward.  Returns the loss (0-d device tensor); gradients land in self.flat_grad."""
+        _, enc, ws = self.forward(x, cond, want_probs=False)
+        bw = self._bwd_workspace(ws)
+        n = ws["B"] * ws["W"]
+        target = target.reshape(-1)
+        assert target.numel() == n and target.dtype == torch.int64 and target.is_cuda
+        if "loss_part" not in ws:
+            ws["loss_part"] = torch.zeros(_lib.CE_NUM_PARTIALS, dtype=torch.float32, device=self.device)
+        call("wn_chunk_softmax256_ce", ptr(ws["O"]), ptr(target), None, ptr(bw["dO"]), ptr(ws["loss_part"]), n, 1.0 / n,
+             _lib.stream())
+        self.backward(ws, None)
+        return ws["loss_part"].sum()
+
+    def adam_init(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.adam_state = dict(m=torch.zeros_like(self.flat), v=torch.zeros_like(self.flat), t=0,
+                               lr=lr, b1=betas[0], b2=betas[1], eps=eps)
+
+    def adam_step(self, gscale=1.0):
+        """torch.optim.Adam semantics on the flat parameter buffer (the nn.Parameters are views of it)."""
+        s = self.adam_state
+        s["t"] += 1
+        call("wn_adam_flat", ptr(self.flat), ptr(self.flat_grad), ptr(s["m"]), ptr(s["v"]), self.spec.total,
+             s["lr"], s["b1"], s["b2"], s["eps"], 1.0 - s["b1"] ** s["t"], 1.0 - s["b2"] ** s["t"], gscale, _lib.stream())
+
     def backward(self, ws, dprobs):
-        """Fills self.flat_grad from d loss / d probabilities (B*W, Q)."""
+        """Fills self.flat_grad from d loss / d probabilities (B*W, Q); dprobs None = bw["dO"] already holds
+        d loss / d logits (loss_and_grad)."""
         bw = self._bwd_workspace(ws)
         st = _lib.stream()
         # bias gradients (use_bias=True): row sums of the matching output gradient, collected in one small buffer
@@ -378,8 +409,9 @@ class _AutoencoderEngine:
             head, (ldc, t_lo, t_hi) = args[:-3], args[-3:]
             call("wn_wgrad", *head, ptr(bw["slab"], so), ldc, n, t_lo, t_hi, chunk, B, mb, st)
 
-        dprobs = dprobs.contiguous()
-        call("wn_chunk_softmax256_bwd", ptr(ws["probs"]), ptr(dprobs), ptr(bw["dO"]), B * W, st)
+        if dprobs is not None:
+            dprobs = dprobs.contiguous()
+            call("wn_chunk_softmax256_bwd", ptr(ws["probs"]), ptr(dprobs), ptr(bw["dO"]), B * W, st)
         dO, dR1, dU, dZ = ptr(bw["dO"]), ptr(bw["dR1"], SLACK), ptr(bw["dU"], SLACK), ptr(bw["dZ"], SLACK)
         U, R1, Z = ptr(ws["U"], SLACK), ptr(ws["R1"], SLACK), ptr(ws["Z"], SLACK)
         sb, db, zb, eb = SP * pitch, CHd * pitch, N * CHd * pitch, CHe * pitch

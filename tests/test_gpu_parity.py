@@ -739,6 +739,54 @@ def test_autoencoder_cached_generation_matches_decoder(use_bias):
     print("autoencoder cached generation (bias=%s): teacher-forced probs err %.2e, %d greedy codes equal" % (use_bias, err, n))
 
 
+def test_autoencoder_fused_step_equals_autograd_path():
+    """The autoencoder engine's fused training step (forward to logits, ONE softmax + CE + backward kernel, backward,
+    flat Adam) against the drop-in path (forward -> nn.CrossEntropyLoss -> autograd -> torch.optim.Adam) with the same
+    conditioning projections: loss, every gradient and the parameters after one Adam step."""
+    from music_amd.model1 import wavenet_autoencoder
+    from oracle import intops
+    cfg = dict(filter_width=2, quantization_channel=256, dilations=[1, 2, 4, 8, 3], en_residual_channel=60,
+               en_dilation_channel=52, en_bottleneck_width=10, en_pool_kernel_size=40, de_residual_channel=64,
+               de_dilation_channel=60, de_skip_channel=72, use_bias=True)
+    rng = np.random.default_rng(71)
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(72)
+        net = wavenet_autoencoder(**cfg)
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(2.0)
+        nets.append(net.cuda())
+    a, b = nets
+    rf, B, W = a.receptive_field, 2, 333
+    idx = rng.integers(0, 256, size=(B, rf + W - 1))
+    x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx])).cuda()
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).cuda()
+    # (a) drop-in path
+    opt = torch.optim.Adam(a.parameters(), lr=1e-3)
+    torch.manual_seed(73)
+    opt.zero_grad()
+    loss_a = torch.nn.CrossEntropyLoss()(a(x), target)
+    loss_a.backward()
+    grads_a = {n: p.grad.detach().clone() for n, p in a.named_parameters()}
+    opt.step()
+    # (b) fused path, same projections
+    eng = b._engine_for(x.device)
+    eng.adam_init(lr=1e-3)
+    torch.manual_seed(73)
+    cond = b._draw_conditioning()
+    loss_b = eng.loss_and_grad(x, target, cond)
+    assert abs(loss_a.item() - loss_b.item()) < 1e-6
+    gmax = max(g.abs().max().item() for g in grads_a.values())
+    for n, p in b.named_parameters():
+        o = eng.spec.off[n]
+        g = eng.flat_grad[o:o + p.numel()].view(p.shape)
+        assert (g - grads_a[n]).abs().max().item() <= 2e-4 * max(grads_a[n].abs().max().item(), 1e-3 * gmax), n      # two CE formulations
+    eng.adam_step()
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert (pa - pb).abs().max().item() <= 2e-6 + 1e-3 * 1e-3, n      # lr * O(1e-3) slack for near-zero gradients
+
+
 def test_training_reduces_the_loss_64_channels():
     """End-to-end sanity of the production kernels (channel-split backward block, fused CE, flat
     Adam): 60 fused steps on one fixed small batch drive the loss from ln(256) towards its floor.
@@ -853,7 +901,8 @@ def test_optimizer_state_survives_a_restart_on_gpu(tmp_path, monkeypatch, fused)
         assert torch.equal(a, b), k
 
 
-def test_autoencoder_train_harness_on_gpu(tmp_path, monkeypatch):
+@pytest.mark.parametrize("fused", [False, True], ids=["autograd", "fused_step"])
+def test_autoencoder_train_harness_on_gpu(tmp_path, monkeypatch, fused):
     import json
     import os
     import pickle
@@ -867,7 +916,7 @@ def test_autoencoder_train_harness_on_gpu(tmp_path, monkeypatch):
               receptive_field=32, window_length=100, cuda_available=True, quantization_channels=256)
     tp = dict(log_dir="./log/", restore_dir="./restore/", restore_model="", check_point_every=1, print_every=1,
               num_epochs=2, optimizer_type="Adam", max_check_points=2, learning_rate=1e-3, momentum=0.9,
-              device_ids=None, seed=5)
+              device_ids=None, seed=5, fused_step=fused)
     for n, p in (("model", cfg), ("dataset", dp), ("train", tp)):
         json.dump(p, open(tmp_path / "params" / (n + "_params.json"), "w"))
     monkeypatch.chdir(tmp_path)

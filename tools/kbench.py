@@ -180,6 +180,24 @@ def main():
         res["autoencoder_step_ms"] = round(dt * 1e3, 2)
         res["autoencoder_samples_per_s"] = round(B_LOCAL * T / dt, 1)
         res["autoencoder_loss"] = round(float(loss.item()), 5)
+        # the fused step of the engine (one softmax + CE + backward kernel, flat Adam; no autograd, no per-tensor optimizer)
+        aeng = ae._engine_for(x.device)
+        aeng.adam_init(lr=1e-4)
+
+        def ae_fused():
+            loss = aeng.loss_and_grad(x, target, ae._draw_conditioning())
+            aeng.adam_step()
+            return loss
+        for _ in range(2):
+            ae_fused()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            loss = ae_fused()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.reps
+        res["autoencoder_fused_step_ms"] = round(dt * 1e3, 2)
+        res["autoencoder_fused_samples_per_s"] = round(B_LOCAL * T / dt, 1)
     print(json.dumps(res))
 
 
