@@ -251,6 +251,25 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
                     float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
                     int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, float temperature,
                     uint64_t seed, wn_stream_t stream);
+/* wn_decode_batch with the chain's products on the matrix cores: pk = the packed f16 hi/lo weight fragments of the
+ * forward blocks (wn_pack_weights, mode WN_F16X3: per block l "fg" at pk + pk_fg0 + l*pk_lstride halfs in natural k
+ * order, "d" at pk + pk_d0 + l*pk_lstride in chained k order, as wn_resblock_fwd takes them; pk_skip / pk_p1 / pk_p2 >= 0:
+ * the skip product and the two post-processing products as well (S = Q = 256), else -1).  Used when R = D = 64 and
+ * there are no biases; NULL = wn_decode_batch.
+ * sync here holds wn_decode_sync_granules(n_layers, D, S) uint64 PER UTTERANCE (error flag = the last word of an
+ * utterance's region): with all of pk given and n_utt <= 8 the loop runs as a PIPELINE of ceil(n_layers/2) + 2
+ * workgroups per utterance that keep their weight fragments in registers for the whole call (two blocks per stage,
+ * then the two post-processing products) and pass x, the partial skip sum, h1 and the code along through the same
+ * tagged granules; otherwise as the two-workgroup form. */
+int64_t wn_decode_sync_granules(int n_layers, int D, int S);
+int wn_decode_batch_pk(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
+                       float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
+                       int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
+                       const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
+                       float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
+                       int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, float temperature,
+                       uint64_t seed, const uint16_t* pk, int64_t pk_fg0, int64_t pk_d0, int64_t pk_lstride, int64_t pk_skip,
+                       int64_t pk_p1, int64_t pk_p2, wn_stream_t stream);
 
 #ifdef __cplusplus
 }

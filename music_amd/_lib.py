@@ -63,6 +63,9 @@ SIGNATURES = {
                   _i, _i, _p, _p],
     "wn_decode_batch": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l,
                         _i, _i, _p, _i, _l, _f, _l, _p],
+    "wn_decode_sync_granules": [_i, _i, _i],
+    "wn_decode_batch_pk": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l,
+                           _i, _i, _p, _i, _l, _f, _l, _p, _l, _l, _l, _l, _l, _l, _p],
 }
 
 _lib = None
@@ -89,6 +92,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError here = header/library out of sync
         fn.argtypes = args
         fn.restype = ctypes.c_int
+    lib.wn_decode_sync_granules.restype = ctypes.c_int64
     lib.wn_last_error.argtypes = []
     lib.wn_last_error.restype = ctypes.c_char_p
     if lib.wn_version() != ABI_VERSION:
@@ -114,6 +118,11 @@ def ms_slabs(t_lo, t_hi, batch):
 def enc_slabs(t_lo, t_hi, batch):
     """Number of slabs one wn_enc_resblock_bwd call writes (plain int return, not a status)."""
     return load().wn_enc_resblock_bwd_slabs(t_lo, t_hi, batch)
+
+
+def decode_sync_granules(n_layers, D, S):
+    """uint64 words of hand-off scratch wn_decode_batch_pk wants per utterance (plain int return, not a status)."""
+    return int(load().wn_decode_sync_granules(n_layers, D, S))
 
 
 def call(name, *args):

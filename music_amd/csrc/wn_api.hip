@@ -263,6 +263,17 @@ int wn_avgpool(const float* in, int64_t in_bstride, int in_pitch, int t0, int po
                              (hipStream_t)stream);
 }
 
+}  // extern "C"
+static int decode_impl(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
+                       float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
+                       int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
+                       const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
+                       float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
+                       int n_steps, int push_input, uint64_t* sync, int64_t sync_ustride, int n_utt, int64_t queues_ustride,
+                       float temperature, uint64_t seed, const uint16_t* pk, int64_t pk_fg0, int64_t pk_d0, int64_t pk_lstride,
+                       int64_t pk_skip, int64_t pk_p1, int64_t pk_p2, wn_stream_t stream);
+extern "C" {
+int64_t wn_decode_sync_granules(int n_layers, int D, int S);
 int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
                     float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
                     int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
@@ -270,6 +281,14 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
                     float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
                     int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, float temperature,
                     uint64_t seed, wn_stream_t stream);
+int wn_decode_batch_pk(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
+                       float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
+                       int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
+                       const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
+                       float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
+                       int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, float temperature,
+                       uint64_t seed, const uint16_t* pk, int64_t pk_fg0, int64_t pk_d0, int64_t pk_lstride, int64_t pk_skip,
+                       int64_t pk_p1, int64_t pk_p2, wn_stream_t stream);
 
 int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
               float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
@@ -289,6 +308,41 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
                     float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
                     int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, float temperature,
                     uint64_t seed, wn_stream_t stream) {
+    return decode_impl(n_layers, R, D, S, Q, dilations_host, q_off_host, queues, w_causal, b_causal, w_layers, layer_stride,
+                       b_layers, w_p1, b_p1, w_p2, b_p2, note0, prev0, note_out, prev_out, forced, codes_out, probs_out,
+                       step0, n_steps, push_input, sync, (int64_t)n_layers * D + 2, n_utt, queues_ustride, temperature, seed,
+                       nullptr, 0, 0, 0, -1, -1, -1, stream);
+}
+
+int64_t wn_decode_sync_granules(int n_layers, int D, int S) {
+    const int64_t duo = (int64_t)n_layers * D + 2, pipe = wn_decode_pipe_granules(n_layers, D, S);
+    return duo > pipe ? duo : pipe;
+}
+
+int wn_decode_batch_pk(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
+                       float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
+                       int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
+                       const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
+                       float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
+                       int n_steps, int push_input, uint64_t* sync, int n_utt, int64_t queues_ustride, float temperature,
+                       uint64_t seed, const uint16_t* pk, int64_t pk_fg0, int64_t pk_d0, int64_t pk_lstride, int64_t pk_skip,
+                       int64_t pk_p1, int64_t pk_p2, wn_stream_t stream) {
+    return decode_impl(n_layers, R, D, S, Q, dilations_host, q_off_host, queues, w_causal, b_causal, w_layers, layer_stride,
+                       b_layers, w_p1, b_p1, w_p2, b_p2, note0, prev0, note_out, prev_out, forced, codes_out, probs_out,
+                       step0, n_steps, push_input, sync, wn_decode_sync_granules(n_layers, D, S), n_utt, queues_ustride,
+                       temperature, seed, pk, pk_fg0, pk_d0, pk_lstride, pk_skip, pk_p1, pk_p2, stream);
+}
+
+}  // extern "C"
+
+static int decode_impl(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
+                       float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
+                       int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
+                       const float* w_p2, const float* b_p2, const float* note0, const float* prev0, float* note_out,
+                       float* prev_out, const int32_t* forced, int32_t* codes_out, float* probs_out, int64_t step0,
+                       int n_steps, int push_input, uint64_t* sync, int64_t sync_ustride, int n_utt, int64_t queues_ustride,
+                       float temperature, uint64_t seed, const uint16_t* pk, int64_t pk_fg0, int64_t pk_d0, int64_t pk_lstride,
+                       int64_t pk_skip, int64_t pk_p1, int64_t pk_p2, wn_stream_t stream) {
     if (n_utt <= 0) return 0;
     if (n_layers > WN_DEC_MAX_LAYERS || n_layers <= 0) return wn_set_error_msg(-4, "wn_decode: 1..64 layers supported");
     WnDecodeArgs a;
@@ -301,9 +355,13 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
     a.codes_out = codes_out; a.probs_out = probs_out; a.step0 = step0; a.n_steps = n_steps; a.push_input = push_input;
     { const char* e = getenv("WN_DEC_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.sync = reinterpret_cast<unsigned long long*>(sync);
+    a.sync_ustride = sync_ustride;
     a.n_utt = n_utt; a.queues_ustride = queues_ustride;
     a.sample = temperature > 0.0f ? 1 : 0; a.inv_temp = temperature > 0.0f ? 1.0f / temperature : 1.0f; a.seed = seed;
+    a.pk_skip = -1;
+    if (pk && R == 64 && D == 64 && !b_layers && !b_causal) {
+        a.pk = pk; a.pk_fg0 = pk_fg0; a.pk_d0 = pk_d0; a.pk_lstride = pk_lstride;
+        if (S == 256 && Q == 256 && !b_p1 && !b_p2 && pk_skip >= 0 && pk_p1 >= 0 && pk_p2 >= 0) { a.pk_skip = pk_skip; a.pk_p1 = pk_p1; a.pk_p2 = pk_p2; }
+    }
     return wn_launch_decode(a, (hipStream_t)stream);
 }
-
-}  // extern "C"

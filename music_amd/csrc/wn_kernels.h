@@ -165,11 +165,17 @@ struct WnDecodeArgs {
     int32_t* codes_out; float* probs_out;                // [n_steps], [n_steps][Q] or null
     long step0; int n_steps; int push_input;
     int dbg;                                             // WN_DEC_DBG timing diagnostics (wrong results)
-    unsigned long long* sync;                            // (n_layers*D + 2) x 8 B hand-off area for the 2-workgroup kernel, or null
+    unsigned long long* sync;                            // hand-off area of the multi-workgroup kernels (sync_ustride granules of 8 B per utterance), or null
+    long sync_ustride;                                   // code granule at [stride-2], error flag at [stride-1] of an utterance's region
     // independent utterances decoded side by side (one workgroup, or one pair, each): element strides
     // between utterances of queues / [Q] state vectors / per-step outputs; weights are shared
     int n_utt; long queues_ustride;
     // sampling: sample != 0 draws from softmax(logit * inv_temp) instead of taking the argmax
     int sample; float inv_temp; unsigned long long seed;
+    // optional MFMA form of the chain (R = D = 64, no biases): the training engine's packed f16 hi/lo weight fragments
+    // ("fg<l>" natural k order, "d<l>" chained k order), offsets in halfs: fragment base of block l = pk + pk_*0 + l * pk_lstride
+    const uint16_t* pk; long pk_fg0, pk_d0, pk_lstride;
+    long pk_skip, pk_p1, pk_p2;          // "skip" ([S/16][n_layers*D/32]), "p1" ([S/16][S/32]), "p2" ([Q/16][S/32]) fragment bases, natural k order (S = Q = 256)
 };
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st);
+long wn_decode_pipe_granules(int n_layers, int D, int S);   // hand-off granules per utterance of the pipelined decoder

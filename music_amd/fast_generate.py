@@ -127,6 +127,25 @@ class DecodeState(OrderedDict):
         return DecodeState(eng, rings.contiguous(), prev, 0)
 
 
+def _packed_chain(eng):
+    """(pk pointer, fg offset, d offset, per-block stride) of the training engine's packed f16x3 forward weights for the
+    matrix-core form of the decode chain (wn_decode_batch_pk), or (None, 0, 0, 0) when it does not apply (64 residual /
+    dilation channels, f16x3 forward mode, no biases) or WN_DEC_MFMA=0; plus the fragment bases of the skip and
+    post-processing products (256 skip / quantisation channels), or -1."""
+    import os
+    if (os.environ.get("WN_DEC_MFMA", "1") != "1" or eng.R != 64 or eng.D != 64 or eng.use_bias or eng.mode_fwd != _lib.F16X3):
+        return None, 0, 0, 0, -1, -1, -1
+    off = eng.pk_f_off
+    fg0, d0 = off["fg0"], off["d0"]
+    stride = off["fg1"] - fg0 if eng.N > 1 else 0
+    for i in range(eng.N):
+        if off["fg%d" % i] != fg0 + i * stride or off["d%d" % i] != d0 + i * stride:
+            return None, 0, 0, 0, -1, -1, -1
+    eng.pack_weights()
+    post = (off["skip"], off["p1"], off["p2"]) if (eng.S == 256 and eng.Q == 256 and os.environ.get("WN_DEC_MFMA_POST", "1") == "1") else (-1, -1, -1)
+    return (ptr(eng.pk_f), fg0, d0, stride) + post
+
+
 def _decode(net, state, note0, n_steps, forced=None, want_probs=False, correct_queue=False, temperature=None, seed=0):
     eng = state.eng
     pack = getattr(net, "_decode_pack", None)
@@ -142,16 +161,18 @@ def _decode(net, state, note0, n_steps, forced=None, want_probs=False, correct_q
     qoff = (ctypes.c_int64 * eng.N)(*[int(v) for v in state.q_off])
     forced_t = forced.to(device=dev, dtype=torch.int32).contiguous() if forced is not None else None
     sync = getattr(net, "_decode_sync", None)
-    if sync is None or sync.device != dev or sync.numel() < eng.N * eng.D + 2:
-        sync = net._decode_sync = torch.zeros(eng.N * eng.D + 2, dtype=torch.int64, device=dev)
+    n_sync = _lib.decode_sync_granules(eng.N, eng.D, eng.S)
+    if sync is None or sync.device != dev or sync.numel() != n_sync:
+        sync = net._decode_sync = torch.zeros(n_sync, dtype=torch.int64, device=dev)
     bias = pack.o_bias is not None
-    call("wn_decode_batch", eng.N, eng.R, eng.D, eng.S, eng.Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
+    pk = _packed_chain(eng)
+    call("wn_decode_batch_pk", eng.N, eng.R, eng.D, eng.S, eng.Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
          ptr(state.rings), pack.p(pack.o_causal), pack.p(pack.ob_causal) if bias else None,
          pack.p(pack.o_layers), pack.layer_stride, pack.p(pack.ob_layers) if bias else None,
          pack.p(pack.o_p1), pack.p(pack.ob_p1) if bias else None, pack.p(pack.o_p2), pack.p(pack.ob_p2) if bias else None,
          ptr(note0), ptr(state.prev), ptr(note_out), ptr(prev_out), ptr(forced_t), ptr(codes), ptr(probs),
          state.steps, n_steps, 1 if correct_queue else 0, ptr(sync), 1, 0,
-         float(temperature) if temperature else 0.0, int(seed), _lib.stream())
+         float(temperature) if temperature else 0.0, int(seed), pk[0], pk[1], pk[2], pk[3], pk[4], pk[5], pk[6], _lib.stream())
     if n_steps >= 4 and int(sync[-1].item()) != 0:
         raise _lib.WavenetHipError("wn_decode: a hand-off between the two decode workgroups timed out")
     state.prev = prev_out
@@ -234,18 +255,19 @@ def generate_codes_batch(net, start_pieces, note_num, correct_queue=False, tempe
     codes = torch.empty(U, n_steps, dtype=torch.int32, device=dev)
     note_out = torch.empty(U, Q, dtype=torch.float32, device=dev)
     prev_out = torch.empty(U, Q, dtype=torch.float32, device=dev)
-    sync = torch.zeros(U * (N * eng.D + 2), dtype=torch.int64, device=dev)
+    sync = torch.zeros(U * _lib.decode_sync_granules(N, eng.D, eng.S), dtype=torch.int64, device=dev)
     dil = (ctypes.c_int32 * N)(*eng.dil)
     q_off = np.cumsum([0] + [d * R for d in eng.dil[:-1]]).astype(np.int64)
     qoff = (ctypes.c_int64 * N)(*[int(v) for v in q_off])
     bias = pack.o_bias is not None
-    call("wn_decode_batch", N, R, eng.D, eng.S, Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
+    pk = _packed_chain(eng)
+    call("wn_decode_batch_pk", N, R, eng.D, eng.S, Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
          ptr(rings), pack.p(pack.o_causal), pack.p(pack.ob_causal) if bias else None,
          pack.p(pack.o_layers), pack.layer_stride, pack.p(pack.ob_layers) if bias else None,
          pack.p(pack.o_p1), pack.p(pack.ob_p1) if bias else None, pack.p(pack.o_p2), pack.p(pack.ob_p2) if bias else None,
          ptr(note0), ptr(prev0), ptr(note_out), ptr(prev_out), None, ptr(codes), None,
          0, n_steps, 1 if correct_queue else 0, ptr(sync), U, rings.size(1),
-         float(temperature) if temperature else 0.0, int(seed), _lib.stream())
+         float(temperature) if temperature else 0.0, int(seed), pk[0], pk[1], pk[2], pk[3], pk[4], pk[5], pk[6], _lib.stream())
     if n_steps >= 4:
         flags = sync.view(U, -1)[:, -1]
         if int(flags.abs().max().item()) != 0:
