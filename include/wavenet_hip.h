@@ -255,7 +255,7 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
  * forward blocks (wn_pack_weights, mode WN_F16X3: per block l "fg" at pk + pk_fg0 + l*pk_lstride halfs in natural k
  * order, "d" at pk + pk_d0 + l*pk_lstride in chained k order, as wn_resblock_fwd takes them; pk_skip / pk_p1 / pk_p2 >= 0:
  * the skip product and the two post-processing products as well (S = Q = 256), else -1).  Used when R = D = 64 and
- * there are no biases; NULL = wn_decode_batch.
+ * S = Q = 256 with all of pk given (biases allowed); NULL or other shapes = wn_decode_batch.
  * sync here holds wn_decode_sync_granules(n_layers, D, S) uint64 PER UTTERANCE (error flag = the last word of an
  * utterance's region): with all of pk given and n_utt <= 8 the loop runs as a PIPELINE of ceil(n_layers/2) + 2
  * workgroups per utterance that keep their weight fragments in registers for the whole call (two blocks per stage,

@@ -632,6 +632,7 @@ __device__ __forceinline__ void dec_get8(const uint16_t* v, int n, int i, Frag<F
     f.hi = *reinterpret_cast<const f16x8*>(v + i);
     f.lo = *reinterpret_cast<const f16x8*>(v + n + i);
 }
+template <bool BIAS>      // BIAS: the model has biases (any of them may still be null)
 __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
     // workgroups 2u (chain) and 2u+1 (skip + post) serve utterance u of a batched launch: per-utterance pointers as LOCALS (the argument struct itself must stay
     // untouched: a modified copy would be moved to scratch and every dil[] / q_off[] lookup with it)
@@ -675,6 +676,9 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
         uint16_t* ch0 = reinterpret_cast<uint16_t*>(pushb + a.n_layers * R);   // split halfs of x: [hi R | lo R] (+ spare)
         uint16_t* ch1 = ch0 + 4 * R;
         uint16_t* zh = ch1 + 4 * R;                                            // split halfs of z, chained k order
+        float* bias = reinterpret_cast<float*>(zh + 2 * D);                    // [n_layers][bf D | bg D | bd R] when the model has biases
+        const int BL = 2 * D + R;
+        if (BIAS && a.b_layers) for (int i = tid; i < a.n_layers * BL; i += 256) { const int l = i / BL, e = i - l * BL; bias[i] = a.b_layers[(size_t)l * (BL + S) + e]; }
         for (int i = tid; i < Q; i += 256) { note[i] = u_note0[i]; prev[i] = u_prev0[i]; }
         if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
         dec_sync();
@@ -726,7 +730,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
                 else for (int k = p4 * (Q / 4); k < (p4 + 1) * (Q / 4); ++k) s = fmaf(wrow[Q + k], note[k], s);
                 s += __shfl_xor(s, 1, 64);
                 s += __shfl_xor(s, 2, 64);
-                if (p4 == 0) { cur0[o] = s; dec_put(ch0, R, o, s); }
+                if (p4 == 0) { if (BIAS && a.b_causal) s += a.b_causal[o]; cur0[o] = s; dec_put(ch0, R, o, s); }
             }
             dec_sync();
             float* cur = cur0;
@@ -768,8 +772,9 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
                     DSET(b2w, b2);
                     DACC(5, b1 - b0); DACC(6, b2 - b1);
                     const int gi = c & 3;
-                    const float fv = gi == 0 ? af[0] : gi == 1 ? af[1] : gi == 2 ? af[2] : af[3];
-                    const float gv = gi == 0 ? ag[0] : gi == 1 ? ag[1] : gi == 2 ? ag[2] : ag[3];
+                    float fv = gi == 0 ? af[0] : gi == 1 ? af[1] : gi == 2 ? af[2] : af[3];
+                    float gv = gi == 0 ? ag[0] : gi == 1 ? ag[1] : gi == 2 ? ag[2] : ag[3];
+                    if (BIAS && a.b_layers) { fv += bias[l * BL + 16 * w + 4 * q + gi]; gv += bias[l * BL + D + 16 * w + 4 * q + gi]; }
                     const float z1 = wn_tanh(fv) * wn_sigmoid(gv);
                     if (c < 4) {          // z[16w + 4q + c], stored where the chained k order of the dense weights wants it
                         dec_put(zh, D, 32 * (w >> 1) + 8 * q + 4 * (w & 1) + c, z1);
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
                     for (int s2 = 0; s2 < 2; ++s2) load_a<F16, 3>(wd2[s2], dn, w * 2 + s2, lane);
                     if (c < 4) {                              // lane c owns row 16w + 4q + c
                         const int row = 16 * w + 4 * q + c;
-                        const float xc = cur[row], v = dec_pick4(ad, c) + xc;
+                        const float xc = cur[row], v = dec_pick4(ad, c) + xc + (BIAS && a.b_layers ? bias[l * BL + 2 * D + row] : 0.f);
                         nxt[row] = v;
                         dec_put(nxth, R, row, v);
                         pushb[l * R + row] = a.push_input ? xc : v;       // Q5: output by default
@@ -848,12 +853,21 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
         uint16_t* skip = zz0 + 4 * D;          // [hi S | lo S]
         uint16_t* h1 = skip + 2 * S;           // [hi S | lo S]
         float* logit = sm + 2 * D + 2 * S;     // [Q]
+        float* bsk = logit + Q;                // [S] sum of the blocks' skip biases, [S] post_process_1 bias, [Q] post_process_2 bias
+        if (BIAS && a.b_layers) {
+            float t = 0.f;
+            for (int l = 0; l < a.n_layers; ++l) t += a.b_layers[(size_t)l * (2 * D + R + S) + 2 * D + R + tid];
+            bsk[tid] = t;
+        }
+        if (BIAS && a.b_p1) bsk[S + tid] = a.b_p1[tid];
+        if (BIAS && a.b_p2) bsk[2 * S + tid] = a.b_p2[tid];
+        dec_sync();
         const int KSS = a.n_layers * D / 32;   // k-steps of the skip product
         const uint16_t* skb = a.pk + a.pk_skip;
         const uint16_t* p1b = a.pk + a.pk_p1;
         const uint16_t* p2b = a.pk + a.pk_p2;
         // out[64w + 16m + 4q + i] = sum_k W[row][k] in[k] for the 256 x 256 post-processing products (8 k-steps)
-        auto post = [&](const uint16_t* wb, const uint16_t* in, uint16_t* outh, float* outf) {      // outh: relu + split halfs
+        auto post = [&](const uint16_t* wb, const uint16_t* in, uint16_t* outh, float* outf, const float* bvec) {      // outh: relu + split halfs
             f32x4 acc[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -878,6 +892,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     f32x4 v = acc[m];
+                    if (bvec) v += *reinterpret_cast<const f32x4*>(bvec + 64 * w + 16 * m + 4 * q);
                     if (outh) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
@@ -930,15 +945,16 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     f32x4 v = ssum[m];
+                    if (BIAS && a.b_layers) v += *reinterpret_cast<const f32x4*>(bsk + 64 * w + 16 * m + 4 * q);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
                     dec_put4(skip, S, 64 * w + 16 * m + 4 * q, v);
                 }
             }
             dec_sync();
-            post(p1b, skip, h1, nullptr);
+            post(p1b, skip, h1, nullptr, BIAS && a.b_p1 ? bsk + S : nullptr);
             dec_sync();
-            post(p2b, h1, nullptr, logit);
+            post(p2b, h1, nullptr, logit, BIAS && a.b_p2 ? bsk + 2 * S : nullptr);
             dec_sync();
             if (tid < 64) {
                 const float ur = a.sample ? dec_uniform(a.seed, (unsigned long long)(a.step0 + step), utt) : 0.f;
@@ -1295,20 +1311,24 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
                     nw(2 * a.D, 2 * a.R) == 16 && nw(a.R, a.D) == 4 && nw(a.S, a.D) == 16 &&
                     nw(a.R, 2 * a.Q) > 0 && nw(a.R, 2 * a.Q) % 16 == 0 && nw(a.S, a.S) > 0 && nw(a.S, a.S) % 16 == 0 &&
                     nw(a.Q, a.S) > 0 && nw(a.Q, a.S) % 16 == 0 && (a.layer_stride % 4) == 0;
-    if (v4 && a.sync && a.n_steps >= 4 && !(a.dbg & 31)) {
+    const bool mf = a.pk && a.pk_skip >= 0;         // matrix-core pair of workgroups (biases allowed)
+    if ((v4 || mf) && a.sync && a.n_steps >= 4 && !(a.dbg & 31)) {
         const size_t nsync = (size_t)a.sync_ustride * sizeof(unsigned long long) * (size_t)nu;
         hipError_t e = hipMemsetAsync(a.sync, 0, nsync, st);              // tags start at 1
         if (e != hipSuccess) return wn_set_error(e, __FILE__, __LINE__);
-        size_t sh0 = sizeof(float) * (size_t)(2 * a.Q + 4 * a.R + 3 * a.D + 2 * a.n_layers * a.R) + sizeof(uint16_t) * (size_t)(8 * a.R + 2 * a.D);
-        size_t sh1 = sizeof(float) * (size_t)(2 * a.D + 2 * a.S + a.Q);
+        size_t sh0 = sizeof(float) * (size_t)(2 * a.Q + 4 * a.R + 3 * a.D + 2 * a.n_layers * a.R + (a.b_layers ? a.n_layers * (2 * a.D + a.R) : 0)) + sizeof(uint16_t) * (size_t)(8 * a.R + 2 * a.D);
+        size_t sh1 = sizeof(float) * (size_t)(2 * a.D + 2 * a.S + a.Q + 2 * a.S + a.Q);
         static const int pipe_on = [] { const char* e = getenv("WN_DEC_PIPE"); return e ? atoi(e) : 0; }();
         const int nc = (a.n_layers + 1) / 2;
-        if (a.pk && a.pk_skip >= 0 && pipe_on && nu <= DP_XCDS && a.sync_ustride >= wn_decode_pipe_granules(a.n_layers, a.D, a.S)) {
+        if (mf && pipe_on && !a.b_layers && !a.b_causal && !a.b_p1 && !a.b_p2 && nu <= DP_XCDS && a.sync_ustride >= wn_decode_pipe_granules(a.n_layers, a.D, a.S)) {
             const size_t shp = sizeof(float) * (size_t)(2 * a.Q + 5 * a.R) + sizeof(uint16_t) * (size_t)(8 * a.R + 8 * a.D);
             if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] pipeline: %d utterances x %d workgroups, %d steps\n", nu, nc + 2, a.n_steps);
             hipLaunchKernelGGL(decode_pipe_k, dim3(DP_XCDS * (nc + 2)), dim3(DEC_MT), shp, st, a);
-        } else if (a.pk && a.pk_skip >= 0) hipLaunchKernelGGL(decode_duo_mfma_k, dim3(2 * nu), dim3(DEC_MT), sh0 > sh1 ? sh0 : sh1, st, a);
-        else hipLaunchKernelGGL(decode_duo_k, dim3(2 * nu), dim3(DEC_THREADS), sh0 > sh1 ? sh0 : sh1, st, a);
+        } else if (mf) {
+            if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pair of workgroups: %d utterances, %d steps, biases %d\n", nu, a.n_steps, a.b_layers ? 1 : 0);
+            if (a.b_layers || a.b_causal || a.b_p1 || a.b_p2) hipLaunchKernelGGL(decode_duo_mfma_k<true>, dim3(2 * nu), dim3(DEC_MT), sh0 > sh1 ? sh0 : sh1, st, a);
+            else hipLaunchKernelGGL(decode_duo_mfma_k<false>, dim3(2 * nu), dim3(DEC_MT), sh0 > sh1 ? sh0 : sh1, st, a);
+        } else hipLaunchKernelGGL(decode_duo_k, dim3(2 * nu), dim3(DEC_THREADS), sh0 > sh1 ? sh0 : sh1, st, a);
     } else if (v4) {
         size_t sh = sizeof(float) * (size_t)(3 * a.Q + 4 * a.R + 3 * a.D + 2 * a.S);
         hipLaunchKernelGGL(decode_v4_k, dim3(nu), dim3(DEC_THREADS), sh, st, a);

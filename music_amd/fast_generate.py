@@ -130,10 +130,10 @@ class DecodeState(OrderedDict):
 def _packed_chain(eng):
     """(pk pointer, fg offset, d offset, per-block stride) of the training engine's packed f16x3 forward weights for the
     matrix-core form of the decode chain (wn_decode_batch_pk), or (None, 0, 0, 0) when it does not apply (64 residual /
-    dilation channels, f16x3 forward mode, no biases) or WN_DEC_MFMA=0; plus the fragment bases of the skip and
+    dilation channels, f16x3 forward mode; biases are fine) or WN_DEC_MFMA=0; plus the fragment bases of the skip and
     post-processing products (256 skip / quantisation channels), or -1."""
     import os
-    if (os.environ.get("WN_DEC_MFMA", "1") != "1" or eng.R != 64 or eng.D != 64 or eng.use_bias or eng.mode_fwd != _lib.F16X3):
+    if (os.environ.get("WN_DEC_MFMA", "1") != "1" or eng.R != 64 or eng.D != 64 or eng.mode_fwd != _lib.F16X3):
         return None, 0, 0, 0, -1, -1, -1
     off = eng.pk_f_off
     fg0, d0 = off["fg0"], off["d0"]

@@ -373,14 +373,15 @@ def test_grads_64_channels_channel_split_block(bias):
     assert torch.equal(g1, eng.flat_grad)            # still bit-reproducible
 
 
-def test_decode_config5_vs_oracle():
-    """BASELINE config 5 shape (30 blocks, 64/64/256): the float4 persistent decode kernel vs the
-    oracle's cached-queue recurrence - argmax ids exact, probabilities within 1e-4."""
+@pytest.mark.parametrize("bias", [False, True], ids=["nobias", "bias"])
+def test_decode_config5_vs_oracle(bias):
+    """BASELINE config 5 shape (30 blocks, 64/64/256): the persistent decode kernel (matrix-core pair of workgroups;
+    with biases too) vs the oracle's cached-queue recurrence - argmax ids exact, probabilities within 1e-4."""
     from music_amd import fast_generate as fg
     from music_amd.model import wavenet
     from oracle import intops
     cfg = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 3, dilation_channels=64,
-               residual_channels=64, skip_channels=256, quantization_channels=256, use_bias=False)
+               residual_channels=64, skip_channels=256, quantization_channels=256, use_bias=bias)
     torch.manual_seed(21)
     net = wavenet(**cfg)
     with torch.no_grad():

@@ -151,6 +151,16 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             res["decode_batch%d_samples_per_s" % U] = round(U * 4000 / dt, 1)
+        # the same model with biases (what the autoencoder's cached decoder looks like to the kernel)
+        from music_amd.model import wavenet as _wn
+        torch.manual_seed(1)
+        netb = _wn(**dict(CFG, use_bias=True)).cuda()
+        fg.generate_codes(netb, start, 200)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fg.generate_codes(netb, start, 8000)
+        torch.cuda.synchronize()
+        res["decode_bias_samples_per_s"] = round(8000 / (time.perf_counter() - t0), 1)
     if args.what in ("ae", "all"):
         # BASELINE config 4: autoencoder, 30+30 blocks, 64 ch, skip 256, bottleneck 64, pool 512, batch 8 x 16000:
         # forward + CE + backward (fresh conditioning projections every forward, as in the reference)
