@@ -208,6 +208,19 @@ def main():
         dt = (time.perf_counter() - t0) / args.reps
         res["autoencoder_fused_step_ms"] = round(dt * 1e3, 2)
         res["autoencoder_fused_samples_per_s"] = round(B_LOCAL * T / dt, 1)
+        # cached-queue generation from the autoencoder (one pooled frame of encoding, conditioning folded into biases)
+        from music_amd import ae_generate as ag
+        piece = torch.zeros(1, 256, ae.receptive_field + 512, device="cuda")
+        piece[:, 128, :] = 1.0
+        try:
+            ag.generate_cached(ae, piece, 200)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ag.generate_cached(ae, piece, 8000)
+            torch.cuda.synchronize()
+            res["autoencoder_cached_generation_samples_per_s"] = round(8000 / (time.perf_counter() - t0), 1)
+        except ValueError as e:           # (the piece must pool to exactly one frame)
+            res["autoencoder_cached_generation"] = str(e)[:120]
     print(json.dumps(res))
 
 
