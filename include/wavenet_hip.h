@@ -260,7 +260,9 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
  * utterance's region): with all of pk given and n_utt <= 8 the loop runs as a PIPELINE of ceil(n_layers/2) + 2
  * workgroups per utterance that keep their weight fragments in registers for the whole call (two blocks per stage,
  * then the two post-processing products) and pass x, the partial skip sum, h1 and the code along through the same
- * tagged granules; otherwise as the two-workgroup form. */
+ * tagged granules; otherwise as the two-workgroup form.  n_utt > 128 (up to 1024, a multiple of 8): eight utterances
+ * per workgroup pair, one pair of MFMA result columns each (same arithmetic per utterance, rows stay bit-identical to
+ * single launches). */
 int64_t wn_decode_sync_granules(int n_layers, int D, int S);
 int wn_decode_batch_pk(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
                        float* queues, const float* w_causal, const float* b_causal, const float* w_layers,

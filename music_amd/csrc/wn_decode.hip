@@ -970,6 +970,301 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// EIGHT utterances per workgroup pair (batched decoding).  A matrix-vector product uses 2 of the MFMA's 16
+// result columns; here column pair (2u, 2u+1) carries utterance u of the pair's eight (x_hi | x_lo of ITS vector), so
+// the same MFMAs and the same weight stream serve eight utterances and only the vector work (queue columns, gates,
+// epilogues, hand-offs, softmax) is done eight times - by lanes that were idle before: lane (c, q) works for
+// utterance c >> 1 on rows 4q + 2(c & 1) and + 1 of its wave's 16.  Per column the arithmetic is exactly that of
+// decode_duo_mfma_k, so a row of a batch equals the single-utterance launch bit for bit.
+__device__ __forceinline__ void dec_put2(uint16_t* v, int n, int i, float x0, float x1) {       // i even
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<f16x2*>(v + i) = f16x2{h0, h1};
+    *reinterpret_cast<f16x2*>(v + n + i) = f16x2{l0, l1};
+}
+template <bool BIAS>
+__global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
+    constexpr int NU = 8, R = 64, D = 64, S = 256, Q = 256;
+    const int pair = blockIdx.x >> 1, role = blockIdx.x & 1;
+    const size_t ubase = (size_t)pair * NU;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, q = lane >> 4;
+    const int u = c >> 1, h = c & 1;                       // this lane's utterance of the eight and its half (hi / lo columns)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ int s_code[NU], s_pc[NU], s_nc[NU];
+    __shared__ int slots[WN_DEC_MAX_LAYERS];
+    auto zg_of = [&](int uu) { return a.sync + (ubase + uu) * (size_t)a.sync_ustride; };
+    auto cg_of = [&](int uu) { return a.sync + (ubase + uu + 1) * (size_t)a.sync_ustride - 2; };
+    unsigned long long* const zg = zg_of(u);                 // [n_layers][D] z granules of this lane's utterance
+
+    if (role == 0) {
+        // ------------------------------------------------------------------ chain
+        constexpr int BL = 2 * D + R;
+        float* prev = sm;                                   // [NU][Q]
+        float* note = prev + NU * Q;                        // [NU][Q]
+        float* xc0 = note + NU * Q;                         // [NU][R] fp32 residual stream (two buffers)
+        float* xc1 = xc0 + NU * R;
+        float* bias = xc1 + NU * R;                         // [n_layers][bf D | bg D | bd R] (BIAS)
+        uint16_t* xh0 = reinterpret_cast<uint16_t*>(bias + (BIAS && a.b_layers ? a.n_layers * BL : 0));   // [NU][hi R | lo R]
+        uint16_t* xh1 = xh0 + NU * 2 * R;
+        uint16_t* zh = xh1 + NU * 2 * R;                    // [NU][hi D | lo D], chained k order
+        uint16_t* oldh = zh + NU * 2 * D;                   // [n_layers][NU][hi R | lo R] queue columns of this sample
+        for (int i = tid; i < NU * Q; i += 256) { const int uu = i / Q, e = i - uu * Q; note[i] = a.note0[(ubase + uu) * Q + e]; prev[i] = a.prev0[(ubase + uu) * Q + e]; }
+        if (BIAS && a.b_layers) for (int i = tid; i < a.n_layers * BL; i += 256) { const int l = i / BL, e = i - l * BL; bias[i] = a.b_layers[(size_t)l * (BL + S) + e]; }
+        if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
+        if (tid < NU) { s_pc[tid] = -1; s_nc[tid] = -1; }
+        dec_sync();
+        const uint16_t* fgb = a.pk + a.pk_fg0;
+        const uint16_t* db = a.pk + a.pk_d0;
+        float* const uq = a.queues + (ubase + u) * (size_t)a.queues_ustride;       // this lane's utterance
+        const int ra = 16 * w + 4 * q + 2 * h;                                       // its two rows: ra, ra + 1
+        for (int step = 0; step < a.n_steps; ++step) {
+            const unsigned tag = (unsigned)step + 1u;
+            const int n_q = a.n_layers * NU * R;
+            for (int i0 = 0; i0 < n_q; i0 += 8 * 256) {      // queue columns: a batch of loads in flight, then the splits
+                float qv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = i0 + j * 256 + tid, ec = e < n_q ? e : 0;
+                    const int l = ec / (NU * R), uu = (ec >> 6) & (NU - 1), r = ec & 63;
+                    qv[j] = __hip_atomic_load(a.queues + (ubase + uu) * (size_t)a.queues_ustride + a.q_off[l] + (size_t)slots[l] * R + r,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = i0 + j * 256 + tid;
+                    if (e < n_q) dec_put(oldh + (size_t)(e >> 6) * 2 * R, R, e & 63, qv[j]);       // (e >> 6) = l * NU + uu
+                }
+            }
+            // weight fragments: two register sets, each re-armed two blocks ahead (as in decode_duo_mfma_k)
+            Frag<F16> wfA[4], wgA[4], wdA[2], wfB[4], wgB[4], wdB[2];
+            const size_t lb1 = a.n_layers > 1 ? (size_t)a.pk_lstride : 0;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                load_a<F16, 3>(wfA[s2], fgb, w * 4 + s2, lane);
+                load_a<F16, 3>(wgA[s2], fgb, (4 + w) * 4 + s2, lane);
+                load_a<F16, 3>(wfB[s2], fgb + lb1, w * 4 + s2, lane);
+                load_a<F16, 3>(wgB[s2], fgb + lb1, (4 + w) * 4 + s2, lane);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                load_a<F16, 3>(wdA[s2], db, w * 2 + s2, lane);
+                load_a<F16, 3>(wdB[s2], db + lb1, w * 2 + s2, lane);
+            }
+            {   // causal layer, 2 rows of one utterance per thread: x0 = Wc[:, tap0] prev + Wc[:, tap1] note (one-hot: a gather)
+                const int uu = tid >> 5, o0 = (tid & 31) * 2;
+                const int pc = s_pc[uu], nc = s_nc[uu];
+                float sv[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float* wrow = a.w_causal + (size_t)(o0 + e) * 2 * Q;
+                    float t = 0.f;
+                    if (pc >= 0) t += wrow[pc];
+                    else for (int kk = 0; kk < Q; ++kk) t = fmaf(wrow[kk], prev[uu * Q + kk], t);
+                    if (nc >= 0) t += wrow[Q + nc];
+                    else for (int kk = 0; kk < Q; ++kk) t = fmaf(wrow[Q + kk], note[uu * Q + kk], t);
+                    if (BIAS && a.b_causal) t += a.b_causal[o0 + e];
+                    sv[e] = t;
+                }
+                xc0[uu * R + o0] = sv[0]; xc0[uu * R + o0 + 1] = sv[1];
+                dec_put2(xh0 + uu * 2 * R, R, o0, sv[0], sv[1]);
+            }
+            dec_sync();
+            float* cur = xc0;
+            float* nxt = xc1;
+            uint16_t* curh = xh0;
+            uint16_t* nxth = xh1;
+            auto blk = [&](const int l, Frag<F16> (&wf)[4], Frag<F16> (&wg)[4], Frag<F16> (&wd2)[2]) {
+                const int l2 = l + 2 < a.n_layers ? l + 2 : a.n_layers - 1;      // the set's next use (clamped: harmless reload)
+                const uint16_t* fgn = fgb + (size_t)l2 * a.pk_lstride;
+                const uint16_t* dn = db + (size_t)l2 * a.pk_lstride;
+                const uint16_t* ob = oldh + ((size_t)l * NU + u) * 2 * R + h * R;
+                const uint16_t* xb = curh + u * 2 * R + h * R;
+                f16x8 bx[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) bx[ks] = *reinterpret_cast<const f16x8*>(ks < 2 ? ob + 32 * ks + 8 * q : xb + 32 * (ks - 2) + 8 * q);
+                f32x4 pf[4], pg[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { pf[ks] = f32x4{0.f, 0.f, 0.f, 0.f}; pg[ks] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { pf[ks] = F16::mfma(wf[ks].hi, bx[ks], pf[ks]); pg[ks] = F16::mfma(wg[ks].hi, bx[ks], pg[ks]); }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { pf[ks] = F16::mfma(wf[ks].lo, bx[ks], pf[ks]); pg[ks] = F16::mfma(wg[ks].lo, bx[ks], pg[ks]); }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    load_a<F16, 3>(wf[ks], fgn, w * 4 + ks, lane);
+                    load_a<F16, 3>(wg[ks], fgn, (4 + w) * 4 + ks, lane);
+                }
+                const f32x4 af = dec_pairsum((pf[0] + pf[1]) + (pf[2] + pf[3])), ag = dec_pairsum((pg[0] + pg[1]) + (pg[2] + pg[3]));
+                float f0 = h ? af[2] : af[0], f1 = h ? af[3] : af[1], g0 = h ? ag[2] : ag[0], g1 = h ? ag[3] : ag[1];
+                if (BIAS && a.b_layers) {
+                    f0 += bias[l * BL + ra]; f1 += bias[l * BL + ra + 1];
+                    g0 += bias[l * BL + D + ra]; g1 += bias[l * BL + D + ra + 1];
+                }
+                const float z0 = wn_tanh(f0) * wn_sigmoid(g0), z1 = wn_tanh(f1) * wn_sigmoid(g1);
+                dec_put2(zh + u * 2 * D, D, 32 * (w >> 1) + 8 * q + 4 * (w & 1) + 2 * h, z0, z1);     // chained k order of the dense weights
+                __hip_atomic_store(zg + (size_t)l * D + ra, dec_pack(z0, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(zg + (size_t)l * D + ra + 1, dec_pack(z1, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dec_sync();
+                f16x8 bz[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) bz[s2] = *reinterpret_cast<const f16x8*>(zh + u * 2 * D + h * D + 32 * s2 + 8 * q);
+                f32x4 pd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) pd[s2] = F16::mfma(wd2[s2].hi, bz[s2], pd[s2]);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) pd[s2] = F16::mfma(wd2[s2].lo, bz[s2], pd[s2]);
+                const f32x4 ad = dec_pairsum(pd[0] + pd[1]);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) load_a<F16, 3>(wd2[s2], dn, w * 2 + s2, lane);
+                const float xa = cur[u * R + ra], xb1 = cur[u * R + ra + 1];
+                float v0 = (h ? ad[2] : ad[0]) + xa, v1 = (h ? ad[3] : ad[1]) + xb1;
+                if (BIAS && a.b_layers) { v0 += bias[l * BL + 2 * D + ra]; v1 += bias[l * BL + 2 * D + ra + 1]; }
+                nxt[u * R + ra] = v0; nxt[u * R + ra + 1] = v1;
+                dec_put2(nxth + u * 2 * R, R, ra, v0, v1);
+                float* qd = uq + a.q_off[l] + (size_t)slots[l] * R + ra;          // the slot read at the top of this sample
+                qd[0] = a.push_input ? xa : v0;                                     // Q5: output by default
+                qd[1] = a.push_input ? xb1 : v1;
+                dec_sync();
+                float* t2 = cur; cur = nxt; nxt = t2;
+                uint16_t* t3 = curh; curh = nxth; nxth = t3;
+            };
+            for (int l = 0; l < a.n_layers; l += 2) {
+                blk(l, wfA, wgA, wdA);
+                if (l + 1 < a.n_layers) blk(l + 1, wfB, wgB, wdB);
+            }
+            if (tid < NU) {
+                float cv = 0.f;
+                dec_poll(cg_of(tid), tag, cv, cg_of(tid) + 1);
+                s_code[tid] = a.forced ? a.forced[(ubase + tid) * a.n_steps + step] : (int)cv;
+            }
+            __syncthreads();                       // codes known; all queue stores of this sample issued before the next sample's loads
+            for (int i = tid; i < NU * Q; i += 256) prev[i] = note[i];
+            if (tid < NU) { s_pc[tid] = s_nc[tid]; s_nc[tid] = s_code[tid]; }
+            if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
+            dec_sync();
+            for (int i = tid; i < NU * Q; i += 256) note[i] = ((i & (Q - 1)) == s_code[i / Q]) ? 1.0f : 0.0f;
+            dec_sync();
+        }
+        for (int i = tid; i < NU * Q; i += 256) { const int uu = i / Q, e = i - uu * Q; a.prev_out[(ubase + uu) * Q + e] = prev[i]; a.note_out[(ubase + uu) * Q + e] = note[i]; }
+    } else {
+        // ------------------------------------------------------------------ skip sum + post-processing
+        uint16_t* zz0 = reinterpret_cast<uint16_t*>(sm);        // [2][NU][hi D | lo D]
+        uint16_t* skip = zz0 + 2 * NU * 2 * D;                  // [NU][hi S | lo S]
+        uint16_t* h1 = skip + NU * 2 * S;                       // [NU][hi S | lo S]
+        float* logit = reinterpret_cast<float*>(h1 + NU * 2 * S);   // [NU][Q]
+        float* bsk = logit + NU * Q;                            // [S] summed skip biases, [S] post_process_1 bias, [Q] post_process_2 bias
+        if (BIAS && a.b_layers) {
+            float t = 0.f;
+            for (int l = 0; l < a.n_layers; ++l) t += a.b_layers[(size_t)l * (2 * D + R + S) + 2 * D + R + tid];
+            bsk[tid] = t;
+        }
+        if (BIAS && a.b_p1) bsk[S + tid] = a.b_p1[tid];
+        if (BIAS && a.b_p2) bsk[2 * S + tid] = a.b_p2[tid];
+        dec_sync();
+        const int KSS = a.n_layers * D / 32;
+        const uint16_t* skb = a.pk + a.pk_skip;
+        const uint16_t* p1b = a.pk + a.pk_p1;
+        const uint16_t* p2b = a.pk + a.pk_p2;
+        // rows 64w + 16m + 4q + 2h, + 1 of this lane's utterance
+        auto post = [&](const uint16_t* wb, const uint16_t* in, uint16_t* outh, float* outf, const float* bvec) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            Frag<F16> wa[2][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) load_a<F16, 3>(wa[0][m], wb, (4 * w + m) * 8, lane);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 1 < 8) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) load_a<F16, 3>(wa[(ks + 1) & 1][m], wb, (4 * w + m) * 8 + ks + 1, lane);
+                }
+                const f16x8 bx = *reinterpret_cast<const f16x8*>(in + u * 2 * S + h * S + 32 * ks + 8 * q);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = F16::mfma(wa[ks & 1][m].hi, bx, acc[m]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = F16::mfma(wa[ks & 1][m].lo, bx, acc[m]);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 t = dec_pairsum(acc[m]);
+                const int row = 64 * w + 16 * m + 4 * q + 2 * h;
+                float v0 = h ? t[2] : t[0], v1 = h ? t[3] : t[1];
+                if (bvec) { v0 += bvec[row]; v1 += bvec[row + 1]; }
+                if (outh) dec_put2(outh + u * 2 * S, S, row, fmaxf(v0, 0.f), fmaxf(v1, 0.f));
+                else { outf[u * Q + row] = v0; outf[u * Q + row + 1] = v1; }
+            }
+        };
+        for (int step = 0; step < a.n_steps; ++step) {
+            const unsigned tag = (unsigned)step + 1u;
+            f32x4 acc2[2][4];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc2[s2][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            Frag<F16> ws[2][4];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) load_a<F16, 3>(ws[s2][m], skb, (4 * w + m) * KSS + s2, lane);
+            for (int l = 0; l < a.n_layers; ++l) {
+                uint16_t* zz = zz0 + (l & 1) * NU * 2 * D;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int idx = tid + e * 256, uu = idx >> 6, j = idx & 63;
+                    float z;
+                    dec_poll(zg_of(uu) + (size_t)l * D + j, tag, z, cg_of(uu) + 1);
+                    dec_put(zz + uu * 2 * D, D, j, z);
+                }
+                dec_sync();
+                const int ln = l + 1 < a.n_layers ? l + 1 : l;
+                const f16x8 bz[2] = {*reinterpret_cast<const f16x8*>(zz + u * 2 * D + h * D + 8 * q),
+                                     *reinterpret_cast<const f16x8*>(zz + u * 2 * D + h * D + 32 + 8 * q)};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc2[s2][m] = F16::mfma(ws[s2][m].hi, bz[s2], acc2[s2][m]);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc2[s2][m] = F16::mfma(ws[s2][m].lo, bz[s2], acc2[s2][m]);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) load_a<F16, 3>(ws[s2][m], skb, (4 * w + m) * KSS + 2 * ln + s2, lane);      // next block (unconditional)
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 t = dec_pairsum(acc2[0][m] + acc2[1][m]);
+                const int row = 64 * w + 16 * m + 4 * q + 2 * h;
+                float v0 = h ? t[2] : t[0], v1 = h ? t[3] : t[1];
+                if (BIAS && a.b_layers) { v0 += bsk[row]; v1 += bsk[row + 1]; }
+                dec_put2(skip + u * 2 * S, S, row, fmaxf(v0, 0.f), fmaxf(v1, 0.f));
+            }
+            dec_sync();
+            post(p1b, skip, h1, nullptr, BIAS && a.b_p1 ? bsk + S : nullptr);
+            dec_sync();
+            post(p2b, h1, nullptr, logit, BIAS && a.b_p2 ? bsk + 2 * S : nullptr);
+            dec_sync();
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {          // wave w chooses for utterances 2w and 2w + 1
+                const int uu = 2 * w + e;
+                const size_t ug = ubase + uu;
+                const float ur = a.sample ? dec_uniform(a.seed, (unsigned long long)(a.step0 + step), ug) : 0.f;
+                float* pdst = a.probs_out ? a.probs_out + (ug * (size_t)a.n_steps + step) * Q : nullptr;
+                const int bi = dec_choose(logit + uu * Q, lane, pdst, a.inv_temp, a.sample != 0, ur);
+                if (lane == 0) {
+                    a.codes_out[ug * a.n_steps + step] = bi;
+                    __hip_atomic_store(cg_of(uu), dec_pack((float)bi, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            dec_sync();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Pipelined decoder for 1..8 utterances (R = D = 64, S = Q = 256, no biases): THE WEIGHTS NEVER MOVE.
 //
 // The two-workgroup kernels above stream every block's weights from L2 for every sample (2.4 MB through one CU for the
@@ -1298,7 +1593,14 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
     const int nu = a.n_utt > 0 ? a.n_utt : 1;
     // the two workgroups of an utterance spin on each other's hand-offs, so every pair must be resident
     // at once: one workgroup per CU -> at most 128 utterances per launch on this part
-    if (nu > 128) return wn_set_error_msg(-4, "decode: at most 128 utterances per launch");
+    // (the matrix-core form puts eight utterances on a pair when their number is a multiple of 8: at most 1024 then)
+    // WN_DEC_U8: 1 (default) = eight per pair when there are more utterances than pairs fit (> 128: one per pair is faster
+    // while the CUs last - 2.05 M vs 1.58 M samples/s at 128), 2 = from 16 utterances on (tests), 0 = never
+    const char* u8_env = getenv("WN_DEC_U8");
+    const int u8_on = u8_env ? atoi(u8_env) : 1;
+    const bool any_bias = a.b_layers || a.b_causal || a.b_p1 || a.b_p2;
+    const bool u8 = u8_on && a.pk && a.pk_skip >= 0 && nu >= (u8_on >= 2 ? 16 : 129) && nu % 8 == 0 && nu <= 1024 && a.sync && a.n_steps >= 4 && !(a.dbg & 31);
+    if (nu > 128 && !u8) return wn_set_error_msg(-4, "decode: at most 128 utterances per launch (1024 in multiples of 8 on the matrix-core path)");
     // the float4 kernel needs: no biases, one pass per product, exactly 16 / 4 / 16 weights per thread for
     // the per-block products and a multiple of 16 for the streamed ones
     auto nw = [](int M, int K) {
@@ -1324,6 +1626,14 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
             const size_t shp = sizeof(float) * (size_t)(2 * a.Q + 5 * a.R) + sizeof(uint16_t) * (size_t)(8 * a.R + 8 * a.D);
             if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] pipeline: %d utterances x %d workgroups, %d steps\n", nu, nc + 2, a.n_steps);
             hipLaunchKernelGGL(decode_pipe_k, dim3(DP_XCDS * (nc + 2)), dim3(DEC_MT), shp, st, a);
+        } else if (mf && u8) {
+            // eight utterances per workgroup pair
+            const size_t s80 = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R + (a.b_layers ? a.n_layers * (2 * a.D + a.R) : 0)) +
+                               sizeof(uint16_t) * (size_t)(32 * a.R + 16 * a.D + (size_t)a.n_layers * 16 * a.R);
+            const size_t s81 = sizeof(uint16_t) * (size_t)(32 * a.D + 32 * a.S) + sizeof(float) * (size_t)(8 * a.Q + 2 * a.S + a.Q);
+            if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pairs x 8 utterances: %d utterances, %d steps, biases %d\n", nu, a.n_steps, any_bias ? 1 : 0);
+            if (any_bias) hipLaunchKernelGGL(decode_duo_mfma8_k<true>, dim3(2 * (nu / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
+            else hipLaunchKernelGGL(decode_duo_mfma8_k<false>, dim3(2 * (nu / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
         } else if (mf) {
             if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pair of workgroups: %d utterances, %d steps, biases %d\n", nu, a.n_steps, a.b_layers ? 1 : 0);
             if (a.b_layers || a.b_causal || a.b_p1 || a.b_p2) hipLaunchKernelGGL(decode_duo_mfma_k<true>, dim3(2 * nu), dim3(DEC_MT), sh0 > sh1 ? sh0 : sh1, st, a);

@@ -487,6 +487,38 @@ def test_batched_decode_equals_single_utterances():
     print("batched decode: %d utterances x %d codes identical to single-utterance launches" % (U, n))
 
 
+@pytest.mark.parametrize("bias", [False, True], ids=["nobias", "bias"])
+def test_batched_decode_eight_per_pair_equals_single_utterances(bias, monkeypatch):
+    """More than 128 utterances (a multiple of 8; here forced from 16 on with WN_DEC_U8=2) run eight to a workgroup
+    pair, one pair of MFMA result columns per utterance (decode_duo_mfma8_k): every row must still equal the
+    single-utterance launch exactly, for both queue recurrences, with and without biases, greedy and sampled."""
+    monkeypatch.setenv("WN_DEC_U8", "2")
+    from music_amd.model import wavenet
+    from music_amd import fast_generate as fg
+    cfg = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 32, 1, 2, 4, 8, 3], dilation_channels=64, residual_channels=64,
+               skip_channels=256, quantization_channels=256, use_bias=bias)
+    torch.manual_seed(13)
+    net = wavenet(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(3.0)
+    net = net.cuda()
+    rng = np.random.default_rng(14)
+    U, n = 24, 150
+    starts = scrambled_input(rng.integers(0, 256, size=(U, net.receptive_field))).cuda()
+    for correct in (False, True):
+        batch = fg.generate_codes_batch(net, starts, n, correct_queue=correct)
+        assert batch.shape == (U, n)
+        for u in (0, 1, 7, 8, 15, 23):
+            single = fg.generate_codes(net, starts[u:u + 1], n, correct_queue=correct)
+            assert torch.equal(batch[u], single.view(-1)), (correct, u)
+        assert len(torch.unique(batch)) > 8
+    sampled = fg.generate_codes_batch(net, starts, n, temperature=0.9, seed=5)
+    again = fg.generate_codes_batch(net, starts, n, temperature=0.9, seed=5)
+    assert torch.equal(sampled, again) and not torch.equal(sampled, batch)
+    print("eight-per-pair batched decode (bias=%s): %d utterances x %d codes identical to single launches" % (bias, U, n))
+
+
 def test_sampled_decode_follows_the_distribution():
     """Sampling (an extension: the reference is greedy): with teacher forcing the kernel
     returns, per step, the distribution it drew from and the drawn code.  Checks: (1) every drawn code is

@@ -139,7 +139,7 @@ def main():
         res["decode_samples_per_s"] = round(16000 / dt, 1)
         res["decode_distinct_codes"] = int(torch.unique(codes).numel())
         # batched utterances: U independent streams in one launch
-        for U in (16, 64, 128):
+        for U in (16, 64, 128, 512, 1024):
             starts = start.repeat(U, 1, 1).clone()
             for u in range(U):                      # different start classes so the streams differ
                 starts[u].zero_()
