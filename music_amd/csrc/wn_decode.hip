@@ -983,9 +983,31 @@ __device__ __forceinline__ void dec_put2(uint16_t* v, int n, int i, float x0, fl
     *reinterpret_cast<f16x2*>(v + i) = f16x2{h0, h1};
     *reinterpret_cast<f16x2*>(v + n + i) = f16x2{l0, l1};
 }
+// Two adjacent granules (16-byte aligned) in one store / one load: a granule is still only trusted when ITS tag matches.
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void dec_send2(unsigned long long* p, float v0, float v1, unsigned tag) {
+    u64x2 g = {dec_pack(v0, tag), dec_pack(v1, tag)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(g) : "memory");
+}
+__device__ __forceinline__ bool dec_poll2(const unsigned long long* p, unsigned tag, float& v0, float& v1, unsigned long long* err) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        u64x2 g;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(g) : "v"(p) : "memory");
+        if ((unsigned)(g[0] >> 32) == tag && (unsigned)(g[1] >> 32) == tag) { v0 = __uint_as_float((unsigned)g[0]); v1 = __uint_as_float((unsigned)g[1]); return true; }
+        if ((spin & 255) == 255 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v0 = v1 = 0.f;
+    return false;
+}
 template <bool BIAS>
 __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
     constexpr int NU = 8, R = 64, D = 64, S = 256, Q = 256;
+    // LDS strides between utterances (halfs): the eight utterances of a 16-lane group read 16-byte pieces at the same offset of
+    // their own vectors - with the natural strides (256 B, 1 KB) all of them in the same banks.  +16 B per utterance spreads the
+    // group over all 64 banks (hi | lo halves are 128 B apart for the 64-vectors; 640 B for the 256-vectors)
+    constexpr int VS = 2 * R + 8, WS = 648, WLO = 320;
     const int pair = blockIdx.x >> 1, role = blockIdx.x & 1;
     const size_t ubase = (size_t)pair * NU;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, q = lane >> 4;
@@ -1006,9 +1028,9 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
         float* xc1 = xc0 + NU * R;
         float* bias = xc1 + NU * R;                         // [n_layers][bf D | bg D | bd R] (BIAS)
         uint16_t* xh0 = reinterpret_cast<uint16_t*>(bias + (BIAS && a.b_layers ? a.n_layers * BL : 0));   // [NU][hi R | lo R]
-        uint16_t* xh1 = xh0 + NU * 2 * R;
-        uint16_t* zh = xh1 + NU * 2 * R;                    // [NU][hi D | lo D], chained k order
-        uint16_t* oldh = zh + NU * 2 * D;                   // [n_layers][NU][hi R | lo R] queue columns of this sample
+        uint16_t* xh1 = xh0 + NU * VS;
+        uint16_t* zh = xh1 + NU * VS;                    // [NU][hi D | lo D], chained k order
+        uint16_t* oldh = zh + NU * VS;                   // [n_layers][NU][hi R | lo R] queue columns of this sample
         for (int i = tid; i < NU * Q; i += 256) { const int uu = i / Q, e = i - uu * Q; note[i] = a.note0[(ubase + uu) * Q + e]; prev[i] = a.prev0[(ubase + uu) * Q + e]; }
         if (BIAS && a.b_layers) for (int i = tid; i < a.n_layers * BL; i += 256) { const int l = i / BL, e = i - l * BL; bias[i] = a.b_layers[(size_t)l * (BL + S) + e]; }
         if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
@@ -1018,24 +1040,30 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
         const uint16_t* db = a.pk + a.pk_d0;
         float* const uq = a.queues + (ubase + u) * (size_t)a.queues_ustride;       // this lane's utterance
         const int ra = 16 * w + 4 * q + 2 * h;                                       // its two rows: ra, ra + 1
-        for (int step = 0; step < a.n_steps; ++step) {
-            const unsigned tag = (unsigned)step + 1u;
+        // the queue columns x(t - d) of ALL blocks for one sample, split into halfs: a batch of 32 loads per thread in flight
+        // (hand-off-scope loads go out to memory: ~1 us alone, 2-3 us on a busy chip), then the splits.  Called for sample
+        // t + 1 while the chain waits for the codes of sample t (the columns do not depend on them).
+        auto load_queues = [&]() {
             const int n_q = a.n_layers * NU * R;
-            for (int i0 = 0; i0 < n_q; i0 += 8 * 256) {      // queue columns: a batch of loads in flight, then the splits
-                float qv[8];
+            for (int i0 = 0; i0 < n_q; i0 += 32 * 256) {      // queue columns: a batch of 32 loads in flight (the hand-off-scope loads
+                float qv[32];                                  // go out to memory: ~1 us each alone, 2-3 us on a busy chip), then the splits
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 32; ++j) {
                     const int e = i0 + j * 256 + tid, ec = e < n_q ? e : 0;
                     const int l = ec / (NU * R), uu = (ec >> 6) & (NU - 1), r = ec & 63;
                     qv[j] = __hip_atomic_load(a.queues + (ubase + uu) * (size_t)a.queues_ustride + a.q_off[l] + (size_t)slots[l] * R + r,
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 32; ++j) {
                     const int e = i0 + j * 256 + tid;
-                    if (e < n_q) dec_put(oldh + (size_t)(e >> 6) * 2 * R, R, e & 63, qv[j]);       // (e >> 6) = l * NU + uu
+                    if (e < n_q) dec_put(oldh + (size_t)(e >> 6) * VS, R, e & 63, qv[j]);       // (e >> 6) = l * NU + uu
                 }
             }
+        };
+        load_queues();
+        for (int step = 0; step < a.n_steps; ++step) {
+            const unsigned tag = (unsigned)step + 1u;
             // weight fragments: two register sets, each re-armed two blocks ahead (as in decode_duo_mfma_k)
             Frag<F16> wfA[4], wgA[4], wdA[2], wfB[4], wgB[4], wdB[2];
             const size_t lb1 = a.n_layers > 1 ? (size_t)a.pk_lstride : 0;
@@ -1067,7 +1095,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                     sv[e] = t;
                 }
                 xc0[uu * R + o0] = sv[0]; xc0[uu * R + o0 + 1] = sv[1];
-                dec_put2(xh0 + uu * 2 * R, R, o0, sv[0], sv[1]);
+                dec_put2(xh0 + uu * VS, R, o0, sv[0], sv[1]);
             }
             dec_sync();
             float* cur = xc0;
@@ -1078,8 +1106,8 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                 const int l2 = l + 2 < a.n_layers ? l + 2 : a.n_layers - 1;      // the set's next use (clamped: harmless reload)
                 const uint16_t* fgn = fgb + (size_t)l2 * a.pk_lstride;
                 const uint16_t* dn = db + (size_t)l2 * a.pk_lstride;
-                const uint16_t* ob = oldh + ((size_t)l * NU + u) * 2 * R + h * R;
-                const uint16_t* xb = curh + u * 2 * R + h * R;
+                const uint16_t* ob = oldh + ((size_t)l * NU + u) * VS + h * R;
+                const uint16_t* xb = curh + u * VS + h * R;
                 f16x8 bx[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) bx[ks] = *reinterpret_cast<const f16x8*>(ks < 2 ? ob + 32 * ks + 8 * q : xb + 32 * (ks - 2) + 8 * q);
@@ -1102,13 +1130,13 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                     g0 += bias[l * BL + D + ra]; g1 += bias[l * BL + D + ra + 1];
                 }
                 const float z0 = wn_tanh(f0) * wn_sigmoid(g0), z1 = wn_tanh(f1) * wn_sigmoid(g1);
-                dec_put2(zh + u * 2 * D, D, 32 * (w >> 1) + 8 * q + 4 * (w & 1) + 2 * h, z0, z1);     // chained k order of the dense weights
-                __hip_atomic_store(zg + (size_t)l * D + ra, dec_pack(z0, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(zg + (size_t)l * D + ra + 1, dec_pack(z1, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dec_put2(zh + u * VS, D, 32 * (w >> 1) + 8 * q + 4 * (w & 1) + 2 * h, z0, z1);     // chained k order of the dense weights
+                // both granules in ONE 16-byte store (ra is even): each 8-byte granule still validates itself by its tag
+                dec_send2(zg + (size_t)l * D + ra, z0, z1, tag);
                 dec_sync();
                 f16x8 bz[2];
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) bz[s2] = *reinterpret_cast<const f16x8*>(zh + u * 2 * D + h * D + 32 * s2 + 8 * q);
+                for (int s2 = 0; s2 < 2; ++s2) bz[s2] = *reinterpret_cast<const f16x8*>(zh + u * VS + h * D + 32 * s2 + 8 * q);
                 f32x4 pd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) pd[s2] = F16::mfma(wd2[s2].hi, bz[s2], pd[s2]);
@@ -1121,7 +1149,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                 float v0 = (h ? ad[2] : ad[0]) + xa, v1 = (h ? ad[3] : ad[1]) + xb1;
                 if (BIAS && a.b_layers) { v0 += bias[l * BL + 2 * D + ra]; v1 += bias[l * BL + 2 * D + ra + 1]; }
                 nxt[u * R + ra] = v0; nxt[u * R + ra + 1] = v1;
-                dec_put2(nxth + u * 2 * R, R, ra, v0, v1);
+                dec_put2(nxth + u * VS, R, ra, v0, v1);
                 float* qd = uq + a.q_off[l] + (size_t)slots[l] * R + ra;          // the slot read at the top of this sample
                 qd[0] = a.push_input ? xa : v0;                                     // Q5: output by default
                 qd[1] = a.push_input ? xb1 : v1;
@@ -1133,15 +1161,18 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                 blk(l, wfA, wgA, wdA);
                 if (l + 1 < a.n_layers) blk(l + 1, wfB, wgB, wdB);
             }
+            __syncthreads();                       // all queue stores of this sample are complete (dilation 1 reads them back next)
+            if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
+            dec_sync();
+            if (step + 1 < a.n_steps) load_queues();
             if (tid < NU) {
                 float cv = 0.f;
                 dec_poll(cg_of(tid), tag, cv, cg_of(tid) + 1);
                 s_code[tid] = a.forced ? a.forced[(ubase + tid) * a.n_steps + step] : (int)cv;
             }
-            __syncthreads();                       // codes known; all queue stores of this sample issued before the next sample's loads
+            dec_sync();
             for (int i = tid; i < NU * Q; i += 256) prev[i] = note[i];
             if (tid < NU) { s_pc[tid] = s_nc[tid]; s_nc[tid] = s_code[tid]; }
-            if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
             dec_sync();
             for (int i = tid; i < NU * Q; i += 256) note[i] = ((i & (Q - 1)) == s_code[i / Q]) ? 1.0f : 0.0f;
             dec_sync();
@@ -1150,9 +1181,9 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
     } else {
         // ------------------------------------------------------------------ skip sum + post-processing
         uint16_t* zz0 = reinterpret_cast<uint16_t*>(sm);        // [2][NU][hi D | lo D]
-        uint16_t* skip = zz0 + 2 * NU * 2 * D;                  // [NU][hi S | lo S]
-        uint16_t* h1 = skip + NU * 2 * S;                       // [NU][hi S | lo S]
-        float* logit = reinterpret_cast<float*>(h1 + NU * 2 * S);   // [NU][Q]
+        uint16_t* skip = zz0 + 2 * NU * VS;                  // [NU][hi S | lo S]
+        uint16_t* h1 = skip + NU * WS;                       // [NU][hi S | lo S]
+        float* logit = reinterpret_cast<float*>(h1 + NU * WS);   // [NU][Q]
         float* bsk = logit + NU * Q;                            // [S] summed skip biases, [S] post_process_1 bias, [Q] post_process_2 bias
         if (BIAS && a.b_layers) {
             float t = 0.f;
@@ -1180,7 +1211,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m) load_a<F16, 3>(wa[(ks + 1) & 1][m], wb, (4 * w + m) * 8 + ks + 1, lane);
                 }
-                const f16x8 bx = *reinterpret_cast<const f16x8*>(in + u * 2 * S + h * S + 32 * ks + 8 * q);
+                const f16x8 bx = *reinterpret_cast<const f16x8*>(in + u * WS + h * WLO + 32 * ks + 8 * q);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = F16::mfma(wa[ks & 1][m].hi, bx, acc[m]);
 #pragma unroll
@@ -1192,10 +1223,12 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                 const int row = 64 * w + 16 * m + 4 * q + 2 * h;
                 float v0 = h ? t[2] : t[0], v1 = h ? t[3] : t[1];
                 if (bvec) { v0 += bvec[row]; v1 += bvec[row + 1]; }
-                if (outh) dec_put2(outh + u * 2 * S, S, row, fmaxf(v0, 0.f), fmaxf(v1, 0.f));
+                if (outh) dec_put2(outh + u * WS, WLO, row, fmaxf(v0, 0.f), fmaxf(v1, 0.f));
                 else { outf[u * Q + row] = v0; outf[u * Q + row + 1] = v1; }
             }
         };
+        const unsigned long long* const zmine = zg_of(tid >> 5) + (tid & 31) * 2;       // this thread's two granules of block 0
+        unsigned long long pa = 0, pb = 0;                                               // prefetched pair (tag 0 = nothing yet)
         for (int step = 0; step < a.n_steps; ++step) {
             const unsigned tag = (unsigned)step + 1u;
             f32x4 acc2[2][4];
@@ -1209,18 +1242,21 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) load_a<F16, 3>(ws[s2][m], skb, (4 * w + m) * KSS + s2, lane);
             for (int l = 0; l < a.n_layers; ++l) {
-                uint16_t* zz = zz0 + (l & 1) * NU * 2 * D;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int idx = tid + e * 256, uu = idx >> 6, j = idx & 63;
-                    float z;
-                    dec_poll(zg_of(uu) + (size_t)l * D + j, tag, z, cg_of(uu) + 1);
-                    dec_put(zz + uu * 2 * D, D, j, z);
+                uint16_t* zz = zz0 + (l & 1) * NU * VS;
+                {   // two adjacent granules per thread.  They were asked for one block EARLIER (a hand-off-scope load is a
+                    // round trip to memory, 2-3 us on a busy chip): usually they are there; else poll, one 16-byte load per try
+                    float za, zb;
+                    if ((unsigned)(pa >> 32) == tag && (unsigned)(pb >> 32) == tag) { za = __uint_as_float((unsigned)pa); zb = __uint_as_float((unsigned)pb); }
+                    else dec_poll2(zmine + (size_t)l * D, tag, za, zb, cg_of(tid >> 5) + 1);
+                    const unsigned long long* nx = zmine + (size_t)(l + 1 < a.n_layers ? l + 1 : 0) * D;      // (block 0: the next sample's)
+                    pa = __hip_atomic_load(nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pb = __hip_atomic_load(nx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dec_put2(zz + (tid >> 5) * VS, D, (tid & 31) * 2, za, zb);
                 }
                 dec_sync();
                 const int ln = l + 1 < a.n_layers ? l + 1 : l;
-                const f16x8 bz[2] = {*reinterpret_cast<const f16x8*>(zz + u * 2 * D + h * D + 8 * q),
-                                     *reinterpret_cast<const f16x8*>(zz + u * 2 * D + h * D + 32 + 8 * q)};
+                const f16x8 bz[2] = {*reinterpret_cast<const f16x8*>(zz + u * VS + h * D + 8 * q),
+                                     *reinterpret_cast<const f16x8*>(zz + u * VS + h * D + 32 + 8 * q)};
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -1240,7 +1276,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                 const int row = 64 * w + 16 * m + 4 * q + 2 * h;
                 float v0 = h ? t[2] : t[0], v1 = h ? t[3] : t[1];
                 if (BIAS && a.b_layers) { v0 += bsk[row]; v1 += bsk[row + 1]; }
-                dec_put2(skip + u * 2 * S, S, row, fmaxf(v0, 0.f), fmaxf(v1, 0.f));
+                dec_put2(skip + u * WS, WLO, row, fmaxf(v0, 0.f), fmaxf(v1, 0.f));
             }
             dec_sync();
             post(p1b, skip, h1, nullptr, BIAS && a.b_p1 ? bsk + S : nullptr);
@@ -1629,8 +1665,8 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
         } else if (mf && u8) {
             // eight utterances per workgroup pair
             const size_t s80 = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R + (a.b_layers ? a.n_layers * (2 * a.D + a.R) : 0)) +
-                               sizeof(uint16_t) * (size_t)(32 * a.R + 16 * a.D + (size_t)a.n_layers * 16 * a.R);
-            const size_t s81 = sizeof(uint16_t) * (size_t)(32 * a.D + 32 * a.S) + sizeof(float) * (size_t)(8 * a.Q + 2 * a.S + a.Q);
+                               sizeof(uint16_t) * (size_t)(8 * 136 * (3 + (size_t)a.n_layers));
+            const size_t s81 = sizeof(uint16_t) * (size_t)(2 * 8 * 136 + 2 * 8 * 648) + sizeof(float) * (size_t)(8 * a.Q + 2 * a.S + a.Q);
             if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pairs x 8 utterances: %d utterances, %d steps, biases %d\n", nu, a.n_steps, any_bias ? 1 : 0);
             if (any_bias) hipLaunchKernelGGL(decode_duo_mfma8_k<true>, dim3(2 * (nu / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
             else hipLaunchKernelGGL(decode_duo_mfma8_k<false>, dim3(2 * (nu / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);

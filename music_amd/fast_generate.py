@@ -240,8 +240,7 @@ def generate_codes_batch(net, start_pieces, note_num, correct_queue=False, tempe
     T, pitch, CH, R, N, Q = x.size(2), ws["pitch"], eng.CH, eng.R, eng.N, eng.Q
     X = ws["X"][SLACK:SLACK + (N + 1) * U * CH * pitch].view(N + 1, U, CH, pitch)
     # ring of block i of utterance u = the last d_i columns of that block's input, time-major
-    rings = torch.stack([torch.cat([X[i, u, :R, T - d:T].t().reshape(-1) for i, d in enumerate(eng.dil)]) for u in range(U)])
-    rings = rings.contiguous()
+    rings = torch.cat([X[i, :, :R, T - d:T].transpose(1, 2).reshape(U, d * R) for i, d in enumerate(eng.dil)], 1).contiguous()
     first = probs.view(U, Q).argmax(1)
     if note_num <= 1:
         return first.view(U, 1)[:, :note_num]
