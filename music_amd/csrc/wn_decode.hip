@@ -686,9 +686,9 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
         DINIT;
         const uint16_t* fgb = a.pk + a.pk_fg0;
         const uint16_t* db = a.pk + a.pk_d0;
-        for (int step = 0; step < a.n_steps; ++step) {
-            const unsigned tag = (unsigned)step + 1u;
-            DCLK(c0);
+        // the queue columns x(t - d) of all blocks for one sample, split into halfs.  Called for sample t + 1 while the chain
+        // waits for the code of sample t (they do not depend on it; a thread re-reads only slots it stored itself)
+        auto load_queues = [&]() {
             for (int i0 = 0; i0 < a.n_layers * R; i0 += 8 * 256) {      // all loads of a batch in flight, then the splits
                 float qv[8];
 #pragma unroll
@@ -703,6 +703,11 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
                     if (i < a.n_layers * R) { const int l = i / R, r = i - l * R; dec_put(oldh + l * 2 * R, R, r, qv[j]); }
                 }
             }
+        };
+        load_queues();
+        for (int step = 0; step < a.n_steps; ++step) {
+            const unsigned tag = (unsigned)step + 1u;
+            DCLK(c0);
             // weight fragments of blocks l and l+1 in two register sets (A: even, B: odd blocks); a set is re-armed TWO
             // blocks ahead right after its last use - an L2 round trip is longer than one block of this chain
             Frag<F16> wfA[4], wgA[4], wdA[2], wfB[4], wgB[4], wdB[2];
@@ -822,6 +827,10 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
                 const int l = i / R, r = i - l * R;
                 u_queues[a.q_off[l] + (size_t)slots[l] * R + r] = pushb[i];
             }
+            dec_sync();                            // every thread has used slots[] for its stores
+            if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
+            dec_sync();
+            if (step + 1 < a.n_steps) load_queues();
             DCLK(c3);
             if (tid == 0) {
                 float cv = 0.f;
@@ -829,14 +838,13 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
                 s_arg = (int)cv;
             }
             DCLK(c4);
-            __syncthreads();                       // full fence: the queue stores are complete before the next sample reads
+            __syncthreads();
             DCLK(c5);
             DACC(0, c1 - c0); DACC(1, c2 - c1); DACC(2, c3 - c2); DACC(3, c4 - c3); DACC(4, c5 - c4);
             const int nextc = u_forced ? u_forced[step] : s_arg;
             for (int i = tid; i < Q; i += 256) prev[i] = note[i];
             pcode = ncode;
             ncode = nextc;
-            if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
             dec_sync();
             for (int i = tid; i < Q; i += 256) note[i] = (i == nextc) ? 1.0f : 0.0f;
             dec_sync();
