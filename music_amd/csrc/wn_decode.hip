@@ -21,16 +21,12 @@ extern "C" int wn_dec_clk_read(unsigned long long* out) { return (int)hipMemcpyF
 #define DCLK(v) const unsigned long long v = __builtin_readcyclecounter()
 #define DACC(i, d) dacc[i] += (d)
 #define DINIT unsigned long long dacc[16] = {}
-#define DSET0(v, x) unsigned long long v = (x)
-#define DSET(v, x) v = (x)
 #define DFLUSH do { if (tid == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&dec_clk[i_], dacc[i_]); } while (0)
 #else
 #define DCLK(v)
 #define DACC(i, d)
 #define DINIT
 #define DFLUSH
-#define DSET0(v, x)
-#define DSET(v, x)
 #endif
 
 // out[o] = epi( bias[o] + sum_k W[o*ldw + k] * x[k] ), o < M.  `parts` lanes share one output.
@@ -748,8 +744,6 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
                 const int l2 = l + 2 < a.n_layers ? l + 2 : a.n_layers - 1;      // the set's next use (clamped: harmless reload)
                 const uint16_t* fgn = fgb + (size_t)l2 * a.pk_lstride;
                 const uint16_t* dn = db + (size_t)l2 * a.pk_lstride;
-                DCLK(b0);
-                DSET0(b2w, b0);
                 {
                     // k order: tap 0 = queue column x(t-d), then tap 1 = x(t).  All four B fragments first (their LDS reads
                     // overlap), then the 16 MFMAs (A.hi, then A.lo: two-column form) over 8 independent accumulators (one per k-step and f / g)
@@ -757,7 +751,6 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
                         bx[ks] = ks < 2 ? dec_get8c(oldh + l * 2 * R, R, 32 * ks + 8 * q, c) : dec_get8c(curh, R, 32 * (ks - 2) + 8 * q, c);
-                    DCLK(b1);
                     f32x4 pf[4], pg[4];
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) { pf[ks] = f32x4{0.f, 0.f, 0.f, 0.f}; pg[ks] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -773,9 +766,6 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
                     const f32x4 af = dec_pairsum((pf[0] + pf[1]) + (pf[2] + pf[3])), ag = dec_pairsum((pg[0] + pg[1]) + (pg[2] + pg[3]));
                     // all 16 columns of the products are equal: lane (c, q) gates ONE of its four rows (i = c & 3), so a
                     // wave pays one tanh / sigmoid latency per block instead of four
-                    DCLK(b2);
-                    DSET(b2w, b2);
-                    DACC(5, b1 - b0); DACC(6, b2 - b1);
                     const int gi = c & 3;
                     float fv = gi == 0 ? af[0] : gi == 1 ? af[1] : gi == 2 ? af[2] : af[3];
                     float gv = gi == 0 ? ag[0] : gi == 1 ? ag[1] : gi == 2 ? ag[2] : ag[3];
@@ -787,10 +777,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
                                            __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                DCLK(b3);
                 dec_sync();
-                DCLK(b4);
-                DACC(7, b4 - b3); DACC(8, b3 - b2w);
                 {
                     f16x8 bz[2];
 #pragma unroll
@@ -811,10 +798,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
                         pushb[l * R + row] = a.push_input ? xc : v;       // Q5: output by default
                     }
                 }
-                DCLK(b5);
                 dec_sync();
-                DCLK(b6);
-                DACC(9, b5 - b4); DACC(10, b6 - b5);
                 float* t2 = cur; cur = nxt; nxt = t2;
                 uint16_t* t3 = curh; curh = nxth; nxth = t3;
             };
