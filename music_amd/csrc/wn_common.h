@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -43,6 +44,9 @@ struct F16 {
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {      // 32x32x16: twice the arithmetic per issue slot
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
 };
 struct BF16 {
     typedef bf16x8 vec8;
@@ -51,6 +55,9 @@ struct BF16 {
     static __device__ __forceinline__ float back(elem h) { return (float)h; }
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
 };
 

@@ -18,6 +18,7 @@ SWITCHES = [
     {"WN_TALIGN": "4"},            # tile origins at t_lo & ~3 instead of 64-sample lines (also disables the two-role narrow product)
     {"WN_XCD": "0"},               # no XCD-aware block remap
     {"WN_GEMM_WIDE": "1"},         # first wide-GEMM version
+    {"WN_GEMM_WIDE": "3"},         # wide GEMM on 32x32x16 MFMAs
     {"WN_FWD_NT": "0"},            # first forward block kernel
     {"WN_FWD_NT": "2"},            # 16 waves x 2 N-tiles
     {"WN_FWD_CS": "1"},            # channel-split forward block
