@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Randomised parity fuzz of the cached-queue decoder at the matrix-core shapes (64 / 64 / 256 / 256 channels): random
+depth (1..30 blocks, odd depths too) and dilations, with and without biases, both queue recurrences, teacher-forced
+codes; argmax ids and probabilities of every step against the oracle's cached recurrence (oracle/wavenet_oracle.py),
+and a multiple-of-8 batch (eight utterances per workgroup pair) against single-utterance launches.  Test
+infrastructure (imports oracle/); not part of the product path.
+
+    python tools/fuzz_decode.py [--cases N] [--seed S]          (WN_DEC_PIPE=1 / WN_DEC_MFMA=0 select the other kernels)"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import wavenet_oracle as wo  # noqa: E402
+from oracle import intops  # noqa: E402
+
+
+def onehot(ix):
+    return torch.from_numpy(intops.one_hot_proper(np.atleast_1d(ix)))[None]
+
+
+def one_case(rng, k):
+    from music_amd import fast_generate as fg
+    from music_amd.model import wavenet
+    n = int(rng.integers(1, 31))
+    dil = [int(rng.choice([1, 2, 3, 4, 8, 16, 5, 32])) for _ in range(n)]
+    bias = bool(rng.random() < 0.5)
+    correct = bool(rng.random() < 0.5)
+    cfg = dict(filter_width=2, dilations=dil, dilation_channels=64, residual_channels=64, skip_channels=256,
+               quantization_channels=256, use_bias=bias)
+    torch.manual_seed(900 + k)
+    net = wavenet(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(float(rng.uniform(1.5, 3.0)))
+    params = {kk: v.clone() for kk, v in net.state_dict().items()}
+    net = net.cuda()
+    steps = int(rng.integers(6, 16))
+    start = rng.integers(0, 256, size=(net.receptive_field,))
+    forced = rng.integers(0, 256, size=(steps,))
+    pred_o, q_o, _ = wo.fast_predict_next(params, dil, onehot(start), None, return_probs=True)
+    want, want_p = [int(pred_o[0])], []
+    for s in forced:
+        pred_o, q_o, pr = wo.fast_predict_next(params, dil, onehot(s), q_o, correct_queue=correct, return_probs=True)
+        want.append(int(pred_o[0]))
+        want_p.append(pr.numpy())
+    pred, st = fg.predict_next(net, onehot(start).cuda(), None)
+    got = [int(pred[0])]
+    nxt = torch.from_numpy(np.concatenate([forced[1:], [0]]).astype(np.int32))
+    codes, probs, _ = fg._decode(net, st, onehot(forced[0]).reshape(-1).cuda(), steps, forced=nxt, want_probs=True,
+                                 correct_queue=correct)
+    got += codes.cpu().tolist()
+    err = float(np.abs(probs.cpu().numpy() - np.stack(want_p)).max())
+    ok = got == want and err < 1e-4
+    # eight utterances per pair against single launches (greedy, free-running)
+    U, m = 16, 40
+    starts = torch.zeros(U, 256, net.receptive_field)
+    idx = torch.from_numpy(rng.integers(0, 256, size=(U, net.receptive_field)))
+    starts.scatter_(1, idx[:, None, :], 1.0)
+    os.environ["WN_DEC_U8"] = "2"
+    batch = fg.generate_codes_batch(net, starts.cuda(), m, correct_queue=correct)
+    os.environ["WN_DEC_U8"] = "1"
+    same = all(torch.equal(batch[u], fg.generate_codes(net, starts[u:u + 1].cuda(), m, correct_queue=correct).view(-1)) for u in (0, 5, 8, 15))
+    print("%s case %3d  blocks=%2d dil=%s bias=%d correct_queue=%d steps=%d  probs err %.1e  codes %s  batch-of-8 rows %s" % (
+        "ok  " if ok and same else "FAIL", k, n, dil[:6] + (["..."] if n > 6 else []), bias, correct, steps, err,
+        "equal" if got == want else "DIFFER", "equal" if same else "DIFFER"))
+    return ok and same
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=30)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    torch.set_num_threads(8)
+    bad = sum(0 if one_case(rng, k) else 1 for k in range(a.cases))
+    print("%d / %d cases failed" % (bad, a.cases))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
