@@ -1036,20 +1036,23 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
         // (hand-off-scope loads go out to memory: ~1 us alone, 2-3 us on a busy chip), then the splits.  Called for sample
         // t + 1 while the chain waits for the codes of sample t (the columns do not depend on them).
         auto load_queues = [&]() {
-            const int n_q = a.n_layers * NU * R;
-            for (int i0 = 0; i0 < n_q; i0 += 32 * 256) {      // queue columns: a batch of 32 loads in flight (the hand-off-scope loads
-                float qv[32];                                  // go out to memory: ~1 us each alone, 2-3 us on a busy chip), then the splits
+            // four consecutive channels per load (a queue column is 64 contiguous floats): 15 loads of 16 bytes per thread for
+            // 30 blocks x 8 utterances, all in flight, then the splits.  Non-temporal loads: the columns were stored by THIS
+            // workgroup (write-through L1, completed by the barrier before this call) or by an earlier launch, and are read once
+            const int n_q4 = a.n_layers * NU * (R / 4);
+            for (int i0 = 0; i0 < n_q4; i0 += 16 * 256) {
+                f32x4 qv[16];
 #pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    const int e = i0 + j * 256 + tid, ec = e < n_q ? e : 0;
-                    const int l = ec / (NU * R), uu = (ec >> 6) & (NU - 1), r = ec & 63;
-                    qv[j] = __hip_atomic_load(a.queues + (ubase + uu) * (size_t)a.queues_ustride + a.q_off[l] + (size_t)slots[l] * R + r,
-                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int j = 0; j < 16; ++j) {
+                    const int e = i0 + j * 256 + tid, ec = e < n_q4 ? e : 0;
+                    const int l = ec / (NU * (R / 4)), uu = (ec >> 4) & (NU - 1), r4 = ec & 15;
+                    qv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(
+                        a.queues + (ubase + uu) * (size_t)a.queues_ustride + a.q_off[l] + (size_t)slots[l] * R + 4 * r4));
                 }
 #pragma unroll
-                for (int j = 0; j < 32; ++j) {
+                for (int j = 0; j < 16; ++j) {
                     const int e = i0 + j * 256 + tid;
-                    if (e < n_q) dec_put(oldh + (size_t)(e >> 6) * VS, R, e & 63, qv[j]);       // (e >> 6) = l * NU + uu
+                    if (e < n_q4) dec_put4(oldh + (size_t)(e >> 4) * VS, R, 4 * (e & 15), qv[j]);       // (e >> 4) = l * NU + uu
                 }
             }
         };
