@@ -1002,13 +1002,17 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
     constexpr int VS = 2 * R + 8, WS = 648, WLO = 320;
     const int pair = blockIdx.x >> 1, role = blockIdx.x & 1;
     const size_t ubase = (size_t)pair * NU;
+    // a pair with fewer than eight utterances left (n_utt not a multiple of 8; a single utterance): the spare columns MIRROR the
+    // last real one - same inputs, same arithmetic, same addresses, so their stores only repeat identical values
+    const size_t ulast = (size_t)(a.n_utt > 0 ? a.n_utt : 1) - 1;
+    auto ux = [&](int uu) { const size_t g = ubase + uu; return g < ulast ? g : ulast; };
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, q = lane >> 4;
     const int u = c >> 1, h = c & 1;                       // this lane's utterance of the eight and its half (hi / lo columns)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ int s_code[NU], s_pc[NU], s_nc[NU];
     __shared__ int slots[WN_DEC_MAX_LAYERS];
-    auto zg_of = [&](int uu) { return a.sync + (ubase + uu) * (size_t)a.sync_ustride; };
-    auto cg_of = [&](int uu) { return a.sync + (ubase + uu + 1) * (size_t)a.sync_ustride - 2; };
+    auto zg_of = [&](int uu) { return a.sync + ux(uu) * (size_t)a.sync_ustride; };
+    auto cg_of = [&](int uu) { return a.sync + (ux(uu) + 1) * (size_t)a.sync_ustride - 2; };
     unsigned long long* const zg = zg_of(u);                 // [n_layers][D] z granules of this lane's utterance
 
     if (role == 0) {
@@ -1023,14 +1027,14 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
         uint16_t* xh1 = xh0 + NU * VS;
         uint16_t* zh = xh1 + NU * VS;                    // [NU][hi D | lo D], chained k order
         uint16_t* oldh = zh + NU * VS;                   // [n_layers][NU][hi R | lo R] queue columns of this sample
-        for (int i = tid; i < NU * Q; i += 256) { const int uu = i / Q, e = i - uu * Q; note[i] = a.note0[(ubase + uu) * Q + e]; prev[i] = a.prev0[(ubase + uu) * Q + e]; }
+        for (int i = tid; i < NU * Q; i += 256) { const int uu = i / Q, e = i - uu * Q; note[i] = a.note0[ux(uu) * Q + e]; prev[i] = a.prev0[ux(uu) * Q + e]; }
         if (BIAS && a.b_layers) for (int i = tid; i < a.n_layers * BL; i += 256) { const int l = i / BL, e = i - l * BL; bias[i] = a.b_layers[(size_t)l * (BL + S) + e]; }
         if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
         if (tid < NU) { s_pc[tid] = -1; s_nc[tid] = -1; }
         dec_sync();
         const uint16_t* fgb = a.pk + a.pk_fg0;
         const uint16_t* db = a.pk + a.pk_d0;
-        float* const uq = a.queues + (ubase + u) * (size_t)a.queues_ustride;       // this lane's utterance
+        float* const uq = a.queues + ux(u) * (size_t)a.queues_ustride;       // this lane's utterance
         const int ra = 16 * w + 4 * q + 2 * h;                                       // its two rows: ra, ra + 1
         // the queue columns x(t - d) of ALL blocks for one sample, split into halfs: a batch of 32 loads per thread in flight
         // (hand-off-scope loads go out to memory: ~1 us alone, 2-3 us on a busy chip), then the splits.  Called for sample
@@ -1047,7 +1051,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                     const int e = i0 + j * 256 + tid, ec = e < n_q4 ? e : 0;
                     const int l = ec / (NU * (R / 4)), uu = (ec >> 4) & (NU - 1), r4 = ec & 15;
                     qv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(
-                        a.queues + (ubase + uu) * (size_t)a.queues_ustride + a.q_off[l] + (size_t)slots[l] * R + 4 * r4));
+                        a.queues + ux(uu) * (size_t)a.queues_ustride + a.q_off[l] + (size_t)slots[l] * R + 4 * r4));
                 }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
@@ -1163,7 +1167,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
             if (tid < NU) {
                 float cv = 0.f;
                 dec_poll(cg_of(tid), tag, cv, cg_of(tid) + 1);
-                s_code[tid] = a.forced ? a.forced[(ubase + tid) * a.n_steps + step] : (int)cv;
+                s_code[tid] = a.forced ? a.forced[ux(tid) * a.n_steps + step] : (int)cv;
             }
             dec_sync();
             for (int i = tid; i < NU * Q; i += 256) prev[i] = note[i];
@@ -1172,7 +1176,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
             for (int i = tid; i < NU * Q; i += 256) note[i] = ((i & (Q - 1)) == s_code[i / Q]) ? 1.0f : 0.0f;
             dec_sync();
         }
-        for (int i = tid; i < NU * Q; i += 256) { const int uu = i / Q, e = i - uu * Q; a.prev_out[(ubase + uu) * Q + e] = prev[i]; a.note_out[(ubase + uu) * Q + e] = note[i]; }
+        for (int i = tid; i < NU * Q; i += 256) { const int uu = i / Q, e = i - uu * Q; a.prev_out[ux(uu) * Q + e] = prev[i]; a.note_out[ux(uu) * Q + e] = note[i]; }
     } else {
         // ------------------------------------------------------------------ skip sum + post-processing
         uint16_t* zz0 = reinterpret_cast<uint16_t*>(sm);        // [2][NU][hi D | lo D]
@@ -1281,7 +1285,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {          // wave w chooses for utterances 2w and 2w + 1
                 const int uu = 2 * w + e;
-                const size_t ug = ubase + uu;
+                const size_t ug = ux(uu);
                 const float ur = a.sample ? dec_uniform(a.seed, (unsigned long long)(a.step0 + step), ug) : 0.f;
                 float* pdst = a.probs_out ? a.probs_out + (ug * (size_t)a.n_steps + step) * Q : nullptr;
                 const int bi = dec_choose(logit + uu * Q, lane, pdst, a.inv_temp, a.sample != 0, ur);
@@ -1625,13 +1629,13 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
     // the two workgroups of an utterance spin on each other's hand-offs, so every pair must be resident
     // at once: one workgroup per CU -> at most 128 utterances per launch on this part
     // (the matrix-core form puts eight utterances on a pair when their number is a multiple of 8: at most 1024 then)
-    // WN_DEC_U8: 1 (default) = eight per pair when there are more utterances than pairs fit (> 128: one per pair is faster
-    // while the CUs last - 2.05 M vs 1.58 M samples/s at 128), 2 = from 16 utterances on (tests), 0 = never
+    // WN_DEC_U8: 1 (default) = the eight-per-pair kernel for every launch of the matrix-core path (a single utterance too: the spare
+    // columns mirror it - 21.9 k samples/s against 20.8 k for the one-per-pair kernel; 2.78 M against 2.55 M at 128), 0 = one per pair
     const char* u8_env = getenv("WN_DEC_U8");
     const int u8_on = u8_env ? atoi(u8_env) : 1;
     const bool any_bias = a.b_layers || a.b_causal || a.b_p1 || a.b_p2;
-    const bool u8 = u8_on && a.pk && a.pk_skip >= 0 && nu >= (u8_on >= 2 ? 16 : 129) && nu % 8 == 0 && nu <= 1024 && a.sync && a.n_steps >= 4 && !(a.dbg & 31);
-    if (nu > 128 && !u8) return wn_set_error_msg(-4, "decode: at most 128 utterances per launch (1024 in multiples of 8 on the matrix-core path)");
+    const bool u8 = u8_on && a.pk && a.pk_skip >= 0 && nu <= 1024 && a.sync && a.n_steps >= 4 && !(a.dbg & 31);
+    if (nu > 128 && !u8) return wn_set_error_msg(-4, "decode: at most 128 utterances per launch (1024 on the matrix-core path)");
     // the float4 kernel needs: no biases, one pass per product, exactly 16 / 4 / 16 weights per thread for
     // the per-block products and a multiple of 16 for the streamed ones
     auto nw = [](int M, int K) {
@@ -1663,8 +1667,8 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
                                sizeof(uint16_t) * (size_t)(8 * 136 * (3 + (size_t)a.n_layers));
             const size_t s81 = sizeof(uint16_t) * (size_t)(2 * 8 * 136 + 2 * 8 * 648) + sizeof(float) * (size_t)(8 * a.Q + 2 * a.S + a.Q);
             if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pairs x 8 utterances: %d utterances, %d steps, biases %d\n", nu, a.n_steps, any_bias ? 1 : 0);
-            if (any_bias) hipLaunchKernelGGL(decode_duo_mfma8_k<true>, dim3(2 * (nu / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
-            else hipLaunchKernelGGL(decode_duo_mfma8_k<false>, dim3(2 * (nu / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
+            if (any_bias) hipLaunchKernelGGL(decode_duo_mfma8_k<true>, dim3(2 * ((nu + 7) / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
+            else hipLaunchKernelGGL(decode_duo_mfma8_k<false>, dim3(2 * ((nu + 7) / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
         } else if (mf) {
             if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pair of workgroups: %d utterances, %d steps, biases %d\n", nu, a.n_steps, a.b_layers ? 1 : 0);
             if (a.b_layers || a.b_causal || a.b_p1 || a.b_p2) hipLaunchKernelGGL(decode_duo_mfma_k<true>, dim3(2 * nu), dim3(DEC_MT), sh0 > sh1 ? sh0 : sh1, st, a);

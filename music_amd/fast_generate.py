@@ -224,13 +224,13 @@ def generate_codes(net, start_piece, note_num, correct_queue=False, temperature=
 def generate_codes_batch(net, start_pieces, note_num, correct_queue=False, temperature=None, seed=0):
     """SURVEY 8f2 (batched utterances; the reference generates one at a time): greedy generation of
     ``note_num`` codes for U independent start pieces ``(U, Q, receptive_field)`` in ONE persistent
-    launch - every utterance gets its own workgroup pair (a multiple of 8 utterances on the matrix-core path: eight to
-    a pair, one pair of MFMA result columns each), the weights are shared.  Returns int64
+    launch - on the matrix-core path eight utterances to a workgroup pair, one pair of MFMA result columns each (else one
+    pair per utterance), the weights are shared.  Returns int64
     ``(U, note_num)`` on the device; row u equals ``generate_codes(net, start_pieces[u:u+1], note_num)``."""
     assert start_pieces.dim() == 3 and start_pieces.size(2) == net.receptive_field
     U = start_pieces.size(0)
-    if U > 128 and (U > 1024 or U % 8):
-        raise ValueError("at most 128 utterances per launch (up to 1024 in multiples of 8 on the matrix-core path)")
+    if U > 1024:
+        raise ValueError("at most 1024 utterances per launch (128 off the matrix-core path)")
     dev = start_pieces.device if start_pieces.is_cuda else torch.device("cuda")
     x = start_pieces.detach().to(dev).float().contiguous()
     with torch.no_grad():

@@ -48,12 +48,12 @@ def test_autoencoder_alternative_paths_stay_correct(env):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
-@pytest.mark.parametrize("env", [{"WN_DEC_MFMA": "0"}, {"WN_DEC_MFMA_POST": "0"}, {"WN_DEC_PIPE": "1"}],
+@pytest.mark.parametrize("env", [{"WN_DEC_MFMA": "0"}, {"WN_DEC_MFMA_POST": "0"}, {"WN_DEC_PIPE": "1"}, {"WN_DEC_U8": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_decode_alternative_paths_stay_correct(env):
     """The cached-queue decoder on its other kernels: the fp32 FMA pair of workgroups (WN_DEC_MFMA=0), the matrix-core
-    chain with FMA skip / post-processing (WN_DEC_MFMA_POST=0), and the pipeline of register-resident stages
-    (WN_DEC_PIPE=1) - the config-5 oracle test (both queue recurrences), the one-launch generation test and the
+    chain with FMA skip / post-processing (WN_DEC_MFMA_POST=0), the pipeline of register-resident stages
+    (WN_DEC_PIPE=1) and the one-utterance-per-pair matrix-core kernel (WN_DEC_U8=0) - the config-5 oracle test (both queue recurrences), the one-launch generation test and the
     batched / sampling tests."""
     e = dict(os.environ, **env)
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",

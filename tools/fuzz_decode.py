@@ -57,14 +57,12 @@ def one_case(rng, k):
     err = float(np.abs(probs.cpu().numpy() - np.stack(want_p)).max())
     ok = got == want and err < 1e-4
     # eight utterances per pair against single launches (greedy, free-running)
-    U, m = 16, 40
+    U, m = int(rng.choice([3, 8, 13, 16])), 40
     starts = torch.zeros(U, 256, net.receptive_field)
     idx = torch.from_numpy(rng.integers(0, 256, size=(U, net.receptive_field)))
     starts.scatter_(1, idx[:, None, :], 1.0)
-    os.environ["WN_DEC_U8"] = "2"
     batch = fg.generate_codes_batch(net, starts.cuda(), m, correct_queue=correct)
-    os.environ["WN_DEC_U8"] = "1"
-    same = all(torch.equal(batch[u], fg.generate_codes(net, starts[u:u + 1].cuda(), m, correct_queue=correct).view(-1)) for u in (0, 5, 8, 15))
+    same = all(torch.equal(batch[u], fg.generate_codes(net, starts[u:u + 1].cuda(), m, correct_queue=correct).view(-1)) for u in sorted({0, U // 2, U - 1}))
     print("%s case %3d  blocks=%2d dil=%s bias=%d correct_queue=%d steps=%d  probs err %.1e  codes %s  batch-of-8 rows %s" % (
         "ok  " if ok and same else "FAIL", k, n, dil[:6] + (["..."] if n > 6 else []), bias, correct, steps, err,
         "equal" if got == want else "DIFFER", "equal" if same else "DIFFER"))
