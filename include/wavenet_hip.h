@@ -257,12 +257,12 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
  * the skip product and the two post-processing products as well (S = Q = 256), else -1).  Used when R = D = 64 and
  * S = Q = 256 with all of pk given (biases allowed); NULL or other shapes = wn_decode_batch.
  * sync here holds wn_decode_sync_granules(n_layers, D, S) uint64 PER UTTERANCE (error flag = the last word of an
- * utterance's region): with all of pk given and n_utt <= 8 the loop runs as a PIPELINE of ceil(n_layers/2) + 2
+ * utterance's region): with all of pk given and n_utt <= 8 the loop CAN run as a PIPELINE of ceil(n_layers/2) + 2
  * workgroups per utterance that keep their weight fragments in registers for the whole call (two blocks per stage,
  * then the two post-processing products) and pass x, the partial skip sum, h1 and the code along through the same
- * tagged granules; otherwise as the two-workgroup form.  n_utt > 128 (up to 1024, a multiple of 8): eight utterances
- * per workgroup pair, one pair of MFMA result columns each (same arithmetic per utterance, rows stay bit-identical to
- * single launches). */
+ * tagged granules (opt-in, WN_DEC_PIPE=1); by default eight utterances share a workgroup pair, one pair of MFMA result
+ * columns each (n_utt <= 1024 on this path; when fewer than eight are left for a pair the spare columns mirror the last
+ * utterance; same arithmetic per utterance, so rows are bit-identical whatever the batch). */
 int64_t wn_decode_sync_granules(int n_layers, int D, int S);
 int wn_decode_batch_pk(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
                        float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
