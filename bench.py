@@ -11,14 +11,43 @@ the int32 sample codes already resident in HBM.  Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves as a CHILD
+    `python -m torch.distributed.run ... bench.py <same args>` and relay its output and exit code.  This runs before
+    torch is imported - the parent never touches the GPU, and nothing that has is ever re-exec'ed."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    known, _ = ap.parse_known_args()
+    if known.gpus <= 1:
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(known.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this host driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+if __name__ == "__main__":
+    _self_launch()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 CFG = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 3, dilation_channels=64,
            residual_channels=64, skip_channels=256, quantization_channels=256, use_bias=False)
@@ -115,15 +144,28 @@ def main():
     ap.add_argument("--precision", default="f16x3,bf16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="print the per-phase GPU time table to stderr")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch plumbing only (CPU, gloo): every rank joins the group, rank 0 prints the world size")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" %
-                             (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, which launches the "
+                         "N ranks itself, or under `python -m torch.distributed.run --nproc-per-node N`)" % (args.gpus, world))
+    if args.dry_run:
+        import torch.distributed as dist
+        if "MASTER_ADDR" in os.environ:
+            dist.init_process_group("gloo")
+            t = torch.tensor([rank + 1.0])
+            dist.all_reduce(t)
+            dist.destroy_process_group()
+        else:
+            t = torch.tensor([1.0])
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": t.item()}))
+        return
     torch.cuda.set_device(local)
     dist = None
     # under torchrun (RANK/MASTER_ADDR set) the process group is always created, also for 1 rank,

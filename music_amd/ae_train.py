@@ -68,7 +68,9 @@ def train():
     cuda_available = torch.cuda.is_available()
     train_params, model_params, dataset_params = get_arguments()
     rank, world, _ = wdist.init_from_env()
-    if train_params.get("seed") is not None:
+    if world > 1:
+        train_params = dict(train_params, seed=wdist.shared_seed(train_params.get("seed")))
+    elif train_params.get("seed") is not None:
         torch.manual_seed(int(train_params["seed"]))
     net = wavenet_autoencoder(**model_params)
     epoch_trained = 0
@@ -111,25 +113,35 @@ def train():
         engine.adam_init(lr=train_params["learning_rate"])
     for epoch in range(train_params["num_epochs"]):
         for i_batch, sampled_batch in enumerate(dataloader):
-            piece, target = sampled_batch["audio_piece"], sampled_batch["audio_target"].view(-1)
+            piece, target = sampled_batch["audio_piece"], sampled_batch["audio_target"]
+            dp_scale = float(sampled_batch.get("dp_scale", 1.0))      # ragged last batch, see faster_audio_data._Collate
+            if piece is not None:
+                target = target.view(-1)
             if world > 1:
                 # every replica must draw the SAME per-forward conditioning projections
                 torch.manual_seed(step_seed + num_trained)
 
             def closure():
                 optimizer.zero_grad()
-                loss = loss_func(net(piece), target)
-                loss.backward()
-                wdist.allreduce_gradients(net.parameters(), average=True)
+                loss = torch.zeros((), device=device)
+                if piece is not None:
+                    loss = loss_func(net(piece), target)
+                    loss.backward()
+                wdist.allreduce_gradients(net.parameters(), average=True, scale=dp_scale)
                 return loss
             if fused:
-                loss = engine.loss_and_grad(piece.to(device).float().contiguous(), target.to(device), net._draw_conditioning())
-                wdist.allreduce_flat_(engine.flat_grad, average=False)
+                loss = torch.zeros((), device=device)
+                if piece is not None:
+                    loss = engine.loss_and_grad(piece.to(device).float().contiguous(), target.to(device), net._draw_conditioning())
+                else:
+                    engine.flat_grad.zero_()
+                wdist.allreduce_flat_(engine.flat_grad, average=False, scale=dp_scale)
                 engine.adam_step(gscale=1.0 / wdist.world())
             else:
                 loss = optimizer.step(closure) if isinstance(optimizer, optim.LBFGS) else closure()
                 if not isinstance(optimizer, optim.LBFGS):
                     optimizer.step()
+            loss = loss.detach() * dp_scale
             total_loss += loss.detach().double()
             num_trained += 1
             if num_trained % train_params["print_every"] == 0:

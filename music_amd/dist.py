@@ -52,29 +52,50 @@ def broadcast_parameters(params, src=0):
             o += n
 
 
-def allreduce_flat_(flat_grad, average=True):
-    """In-place sum all-reduce of one flat gradient buffer (+ 1/world)."""
+def shared_seed(seed=None):
+    """One torch seed for every rank: `seed` if given, else one drawn on rank 0 and broadcast.  All ranks then call
+    torch.manual_seed with it, so that shuffling DataLoaders built afterwards draw the SAME permutation (each rank
+    slices its own chunk of every global batch) and per-forward random draws agree across replicas."""
+    if seed is None:
+        seed = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 31 - 1).item())
+    if world() > 1:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([int(seed)], dtype=torch.int64, device=dev)
+        dist.broadcast(t, 0)
+        seed = int(t.item())
+    torch.manual_seed(int(seed))
+    return int(seed)
+
+
+def allreduce_flat_(flat_grad, average=True, scale=1.0):
+    """In-place sum all-reduce of one flat gradient buffer (+ 1/world).  `scale` multiplies the LOCAL buffer first
+    (a ragged shard's dp_scale, see faster_audio_data._Collate)."""
     w = world()
     if w == 1:
         return flat_grad
+    if scale != 1.0:
+        flat_grad.mul_(scale)
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     if average:
         flat_grad.mul_(1.0 / w)
     return flat_grad
 
 
-def allreduce_gradients(params, average=True):
-    """All-reduce the .grad of `params` as ONE flat bucket (parameters without a grad contribute
-    zeros so that every rank issues the same collective)."""
+def allreduce_gradients(params, average=True, scale=1.0):
+    """All-reduce the .grad of `params` as ONE flat bucket.  A parameter without a grad contributes zeros (a rank
+    whose shard of a ragged batch is empty ran no backward) and RECEIVES the reduced gradient, so every rank
+    issues the same collective and takes the same optimizer step."""
     w = world()
     if w == 1:
         return
     params = list(params)
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    allreduce_flat_(flat, average)
+    allreduce_flat_(flat, average, scale)
     o = 0
     for p in params:
         n = p.numel()
         if p.grad is not None:
             p.grad.copy_(flat[o:o + n].view_as(p))
+        else:
+            p.grad = flat[o:o + n].view_as(p).clone()
         o += n

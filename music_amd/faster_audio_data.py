@@ -78,21 +78,39 @@ def one_hot_encode(sample_piece, cuda_available=False, quantization_channels=256
     return {"audio_piece": onehot_device(piece[None], quantization_channels)[0], "audio_target": target}
 
 
+def shard_bounds(n_items, rank, world):
+    """DataParallel's scatter (torch.chunk): chunks of ceil(n/world) items in rank order, the last
+    non-empty chunk takes the remainder and trailing ranks may get nothing.  Returns [lo, hi)."""
+    c = -(-n_items // world)
+    lo = min(rank * c, n_items)
+    return lo, min(lo + c, n_items)
+
+
 class _Collate:
     def __init__(self, q, shard=None):
         self.q = q
         self.shard = shard
 
     def __call__(self, items):
+        scale = 1.0
         if self.shard is not None:
-            # DataParallel's scatter: contiguous chunk r of the global batch goes to replica r
+            # DataParallel's scatter: contiguous chunk r of the global batch goes to replica r.  On the ragged last
+            # batch of an epoch the chunks differ in size (a rank may get none): "dp_scale" = n_local * world / n_global
+            # is the weight that turns `mean over ranks of (scale_r * local-mean gradient)` back into DataParallel's
+            # global-batch mean; a rank with no items gets audio_piece = None and must still join the all-reduce.
             r, w = self.shard
-            n = len(items) // w
-            items = items[r * n:(r + 1) * n] if r < w - 1 or len(items) % w == 0 else items[r * n:]
+            lo, hi = shard_bounds(len(items), r, w)
+            scale = (hi - lo) * w / float(len(items))
+            items = items[lo:hi]
+        if not items:
+            return {"audio_piece": None, "audio_target": None, "dp_scale": 0.0}
         codes = torch.stack([it['audio_piece'] for it in items]).to(torch.int32)
         target = torch.stack([it['audio_target'] for it in items])
-        return {"audio_piece": onehot_device(codes, self.q),
-                "audio_target": target.cuda(non_blocking=True) if torch.cuda.is_available() else target}
+        batch = {"audio_piece": onehot_device(codes, self.q),
+                 "audio_target": target.cuda(non_blocking=True) if torch.cuda.is_available() else target}
+        if self.shard is not None:
+            batch["dp_scale"] = scale
+        return batch
 
 
 def audio_data_loader(batch_size, shuffle, num_workers, pin_memory, shard=None, **kwargs):

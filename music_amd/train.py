@@ -132,7 +132,11 @@ def train():
     cuda_available = torch.cuda.is_available()
     train_params, wavenet_params, dataset_params = get_arguments()
     rank, world, local_rank = wdist.init_from_env()
-    if "seed" in train_params and train_params["seed"] is not None:
+    # every rank must draw the same shuffling permutation (each slices its chunk of the global batch): the JSON
+    # "seed" if there is one, else one drawn on rank 0 and broadcast
+    if world > 1:
+        wdist.shared_seed(train_params.get("seed"))
+    elif train_params.get("seed") is not None:
         torch.manual_seed(int(train_params["seed"]))
 
     net = wavenet(**wavenet_params)
@@ -196,24 +200,33 @@ def train():
         for i_batch, sampled_batch in enumerate(dataloader):
             piece = sampled_batch["audio_piece"]
             target = sampled_batch["audio_target"]
-            if cuda_available:
-                piece = piece.cuda(non_blocking=True)
-                target = target.cuda(non_blocking=True)
-            target = target.view(-1)
+            # ragged last batch under data parallelism: weight of this rank's shard (0 and piece None = no items)
+            dp_scale = float(sampled_batch.get("dp_scale", 1.0))
+            if piece is not None:
+                if cuda_available:
+                    piece = piece.cuda(non_blocking=True)
+                    target = target.cuda(non_blocking=True)
+                target = target.view(-1)
+            loss = torch.zeros((), device=device)
             if fused:
                 if engine is None:
-                    engine = net._engine_for(piece.device)
+                    engine = net._engine_for(device)
                     engine.adam_init(lr=train_params["learning_rate"])
-                loss = engine.loss_and_grad(piece.contiguous(), target)
-                wdist.allreduce_flat_(engine.flat_grad, average=True)
+                if piece is not None:
+                    loss = engine.loss_and_grad(piece.contiguous(), target)
+                else:
+                    engine.flat_grad.zero_()
+                wdist.allreduce_flat_(engine.flat_grad, average=True, scale=dp_scale)
                 engine.adam_step()
             else:
                 optimizer.zero_grad()
-                logits = net(piece)            # probabilities, named as in the reference (Q1)
-                loss = loss_func(logits, target)
-                loss.backward()
-                wdist.allreduce_gradients(net.parameters(), average=True)
+                if piece is not None:
+                    logits = net(piece)            # probabilities, named as in the reference (Q1)
+                    loss = loss_func(logits, target)
+                    loss.backward()
+                wdist.allreduce_gradients(net.parameters(), average=True, scale=dp_scale)
                 optimizer.step()
+            loss = loss.detach() * dp_scale
             total_loss += loss.detach().double()
             num_trained += 1
             if num_trained % train_params["print_every"] == 0:

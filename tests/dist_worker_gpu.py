@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     workdir = sys.argv[1]
+    shards = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # logical shards of the global batch (2 clips each)
     from music_amd import dist as wdist
     from music_amd.model import wavenet
     rank, world, local = wdist.init_from_env(force=True)
@@ -23,9 +24,11 @@ def main():
     wdist.broadcast_parameters(net.parameters())
     eng = net._engine_for(torch.device("cuda", local))
     eng.adam_init(lr=1e-3)
-    rng = np.random.default_rng(100 + rank)
-    B, T = 2, net.receptive_field + 300
-    codes = torch.from_numpy(rng.integers(0, 256, size=(B, T + 1)).astype(np.int32)).cuda()
+    rng = np.random.default_rng(100)
+    assert shards % world == 0
+    B, T = 2 * shards // world, net.receptive_field + 300
+    # the SAME global batch whatever the world size; rank r trains on its contiguous chunk of it
+    codes = torch.from_numpy(rng.integers(0, 256, size=(2 * shards, T + 1)).astype(np.int32))[rank * B:(rank + 1) * B].cuda()
     rf = net.receptive_field
     W = T - rf + 1
     losses, gsum = [], None
@@ -39,13 +42,17 @@ def main():
         if world == 1:                                              # a 1-rank sum must not change anything
             assert torch.equal(before, eng.flat_grad)
         eng.adam_step(gscale=1.0 / world)
+        if torch.distributed.is_initialized():
+            torch.distributed.all_reduce(loss)
+            loss = loss / world
         losses.append(float(loss.item()))
-        gsum = float(eng.flat_grad.abs().sum().item())
+        gsum = float(eng.flat_grad.abs().sum().item()) / world
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     if rank == 0:
-        json.dump({"backend": backend, "world": world, "losses": losses, "gsum": gsum}, open(os.path.join(workdir, "dist_gpu.json"), "w"))
+        json.dump({"backend": backend, "world": world, "losses": losses, "gsum": gsum,
+                   "psum": float(eng.flat.double().abs().sum().item())}, open(os.path.join(workdir, "dist_gpu.json"), "w"))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

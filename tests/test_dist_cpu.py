@@ -56,10 +56,10 @@ def test_allreduce_equals_global_batch_gradient(tmp_path):
         assert (got[k] - want).abs().max().item() <= 1e-6 * max(1e-3, want.abs().max().item()) + 1e-9, k
 
 
-def _write_run(tmp, batch_size):
+def _write_run(tmp, batch_size, lens=(900, 700)):
     os.makedirs(tmp / "params", exist_ok=True)
     rng = np.random.default_rng(5)
-    data = [rng.integers(0, 256, size=(l,)).astype(np.int32) for l in (900, 700)]
+    data = [rng.integers(0, 256, size=(l,)).astype(np.int32) for l in lens]
     pickle.dump(data, open(tmp / "np_audio.pkl", "wb"))
     dp = dict(batch_size=batch_size, shuffle=True, num_workers=0, pin_memory=False, audio_path=str(tmp / "np_audio.pkl"),
               receptive_field=17, window_length=100, cuda_available=False, quantization_channels=256)
@@ -70,11 +70,17 @@ def _write_run(tmp, batch_size):
         json.dump(p, open(tmp / "params" / (n + "_params.json"), "w"))
 
 
-def test_train_two_ranks_equals_one_rank(tmp_path):
+import pytest
+
+
+# (900, 700): 24 pieces = whole batches of 4; (917, 617): 15 pieces, the last batch has 3 items (shards of 2 and 1);
+# (917, 734): 17 pieces, the last batch has ONE item (rank 1 gets an empty shard and must still join the all-reduce)
+@pytest.mark.parametrize("lens", [(900, 700), (917, 617), (917, 734)])
+def test_train_two_ranks_equals_one_rank(tmp_path, lens):
     a, b = tmp_path / "one", tmp_path / "two"
     os.makedirs(a), os.makedirs(b)
-    _write_run(a, 4)
-    _write_run(b, 4)
+    _write_run(a, 4, lens)
+    _write_run(b, 4, lens)
     _launch(1, "train", a)
     _launch(2, "train", b)
     la = open(a / "log" / "loss_log.log").read().strip().split("\n")
@@ -87,3 +93,45 @@ def test_train_two_ranks_equals_one_rank(tmp_path):
     ca, cb = torch.load(a / "restore" / "wavenet2.model"), torch.load(b / "restore" / "wavenet2.model")
     for k in ca:
         assert (ca[k] - cb[k]).abs().max().item() < 1e-5, k
+
+
+def test_collate_shards_like_dataparallel_scatter():
+    """_Collate's shard=(r, w) slices are torch.chunk's (DataParallel scatter) for every batch length, and the
+    dp_scale weights sum to world (so the weighted mean over ranks is the global-batch mean)."""
+    from music_amd.faster_audio_data import shard_bounds
+    for w in (2, 3, 4, 8):
+        for n in range(1, 2 * w + 2):
+            want = [c.tolist() for c in torch.arange(n).chunk(w)]
+            got = [list(range(*shard_bounds(n, r, w))) for r in range(w)]
+            assert [g for g in got if g] == want, (n, w, got, want)
+            assert all(not g for g in got[len(want):])
+            assert abs(sum(len(g) * w / n for g in got) - w) < 1e-12
+
+
+def test_collate_ragged_batches_no_gpu(monkeypatch):
+    from music_amd import faster_audio_data as fad
+    from tests.cpu_model import onehot_oracle
+    monkeypatch.setattr(fad, "onehot_device", onehot_oracle)
+    items = [{"audio_piece": torch.full((20,), i, dtype=torch.int32), "audio_target": torch.full((4,), i)} for i in range(3)]
+    b0 = fad._Collate(256, (0, 2))(items)
+    b1 = fad._Collate(256, (1, 2))(items)
+    assert b0["audio_target"][:, 0].tolist() == [0, 1] and b1["audio_target"][:, 0].tolist() == [2]
+    assert abs(b0["dp_scale"] - 4 / 3) < 1e-12 and abs(b1["dp_scale"] - 2 / 3) < 1e-12
+    e = fad._Collate(256, (1, 2))(items[:1])
+    assert e["audio_piece"] is None and e["dp_scale"] == 0.0
+    assert "dp_scale" not in fad._Collate(256)(items)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus N` (no launcher around it) must start N ranks itself: the parent spawns
+    a torch.distributed.run child before anything touches the GPU and relays rank 0's JSON line and the exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    for n in (1, 2, 3):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-run"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == n and out["rank_sum"] == n * (n + 1) / 2
