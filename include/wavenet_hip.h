@@ -12,7 +12,13 @@
  *     exceptions cross the boundary;
  *   - no allocation, no synchronisation, no retained pointers: all workspace is the caller's,
  *     every call only enqueues work on `stream` (safe under hipGraph stream capture);
- *   - re-entrant across devices/streams: no global mutable state besides the last-error text.
+ *   - re-entrant across devices/streams and threads: no global mutable state; the last-error text is
+ *     thread-local (wn_last_error() returns the calling thread's);
+ *   - no collective is exported.  SURVEY 8(b) sketched a `wn_allreduce_flat(ncclComm_t, ...)` wrapper; it is left
+ *     out on purpose: the RCCL communicator belongs to torch.distributed (ProcessGroupNCCL owns its creation, streams
+ *     and teardown and does not hand the ncclComm_t out), and a second communicator created behind its back would
+ *     duplicate the xGMI rings and the bootstrap for one 5 MB all-reduce per step.  The data-parallel exchange is
+ *     `torch.distributed.all_reduce(flat_grad)` on the buffer these kernels fill (music_amd/dist.py).
  *
  * Data layout: activations are float32 [clip][channel][time] with time
  * contiguous, in ABSOLUTE time (column t = index of the newest input sample the value depends
@@ -87,22 +93,6 @@ int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* 
                     const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode, int cond_le, int cond_q,
                     int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
 
-/* Fully fused backward of one residual block (autograd of wavenet/model.py:111-129 for one layer,
- * SURVEY Appendix B) in ONE launch: recompute f,g,z from x_in; dy = dx_{i+1} given as the pair
- * dP_in[t] (t >= p_lo) + dQ_in[t+dn] (t+dn < t_hi) (NULL for the last block); dz = Wd^T dy + dz;
- * [df;dg]; the data gradient as the UNSHIFTED pair dP_out[t] = W1^T[df;dg] + dy, dQ_out[t] =
- * W0^T[df;dg] (so dx_i[t] = dP_out[t] + dQ_out[t+d]; wn_shift_add materialises it); and both
- * weight-gradient products, one slab per workgroup (512 columns): slab index = clip *
- * wn_resblock_bwd_fused_tiles(t_lo,t_hi) + tile; slab_fg stride 4*ch*ch, slab_d stride ch*ch.
- * scratch: (batch * tiles) * 4*ch*512 floats.  wpq = packed [W1^T ; W0^T] ([2ch rows][2ch k]). */
-int wn_resblock_bwd_fused(const float* x_in, const float* dP_in, const float* dQ_in, const float* dz, float* dP_out,
-                          float* dQ_out, float* scratch, int64_t x_bstride, int64_t dz_bstride, int pitch,
-                          const uint16_t* wfg, const uint16_t* wdT, const uint16_t* wpq, const float* bias_f,
-                          const float* bias_g, int n_f, int ch, int d, int dn, int p_lo, int t_lo, int t_hi, int z_lo,
-                          float* slab_fg, float* slab_d, int has_d, int batch, int mode_fwd, int mode_bwd,
-                          wn_stream_t stream);
-int wn_resblock_bwd_fused_tiles(int t_lo, int t_hi);
-
 /* Encoder block of the autoencoder, forward (wavenet_autoencoder/model1.py:137-152 for one dilation d), one launch:
  *   h = Wdil [relu x(t-d); relu x(t)] (+ bias_dil) ; x_out = Wd relu(h) (+ bias_d) + x(t)   on [t_lo, t_hi);
  *   h (the pre-activation the backward masks with) is stored on the same range.  wdil: packed [ch/16][2ch/32] (natural
@@ -131,10 +121,8 @@ int wn_enc_resblock_bwd_slabs(int t_lo, int t_hi, int batch);
  * partial dWd (ch x ch); wn_resblock_bwd_ms_slabs gives the number of slabs (sum them with
  * wn_reduce_slabs).  dy NULL (last block): no dz product, no dWd.  z is not written at all.
  * cond*: the conditioning table of wn_resblock_fwd (the recompute adds it as well); NULL = none.
- * Two kernels implement it (same results up to the order of fp32 sums): the two-role one (8 waves,
- * wn_resrw.hip, default) and the one-role one (wn_resms.hip, env WN_MS_RW=0); the slab count differs, always
- * ask wn_resblock_bwd_ms_slabs in the same process.  The buffers need the usual slack: rows are read up to
- * 63 columns outside [t_lo - d, t_hi). */
+ * Kernel: the two-role persistent block of wn_resrw.hip (8 waves).  The buffers need the usual slack: rows are
+ * read up to 63 columns outside [t_lo - d, t_hi). */
 int wn_resblock_bwd_ms(const float* x_in, const float* dy, const float* dz, float* dfg, int64_t x_bstride,
                        int64_t dz_bstride, int64_t dfg_bstride, int pitch, const uint16_t* wfg, const uint16_t* wdT,
                        const float* bias_f, const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
@@ -142,9 +130,6 @@ int wn_resblock_bwd_ms(const float* x_in, const float* dy, const float* dz, floa
                        int cond_mode, int cond_le, int cond_q, int batch, int mode_fwd, int mode_bwd,
                        wn_stream_t stream);
 int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch);
-/* out[b][r][t] = p[b][r][t] (t >= p_lo) + q[b][r][t+dn] (t+dn < t_hi), t in [t_lo,t_hi) */
-int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,
-                 int t_lo, int t_hi, int batch, wn_stream_t stream);
 
 /* Weight gradient: C[m][n] = sum_{b, t in [t_lo,t_hi)} A[b][m][t+a_shift] * B_tap[b][n][t+b_shift_tap]
  * C columns [0, 16*nt_per_tap) come from b0, the next 16*nt_per_tap from b1 (if not NULL).
@@ -228,9 +213,10 @@ int wn_mulaw_decode_lut(const uint8_t* codes, const float* table, float* audio, 
  * note0 / prev0: dense [Q] current and previous input columns; forced: teacher-forced next codes
  * (NULL = feed back the argmax).  codes_out[n_steps] = argmax of the probabilities (first index on
  * ties); probs_out optional.  dilations_host / q_off_host are HOST arrays.
- * sync: optional device scratch of (n_layers*D + 2) uint64; when given (and the shape qualifies) the
- * work is split over two workgroups that hand z / the predicted code over through tagged 8-byte
- * granules; the last word is an error flag (non-zero = a bounded spin timed out). */
+ * sync: optional device scratch of (n_layers*D + 2) uint64, used by the two-workgroup matrix-core form
+ * (wn_decode_batch_pk; hand-offs through tagged 8-byte granules, the last word is an error flag: non-zero = a
+ * bounded spin timed out).  wn_decode / wn_decode_batch run one workgroup of fp32 FMAs per utterance
+ * (any channel counts, with or without biases) and ignore it. */
 int wn_decode(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
               float* queues, const float* w_causal, const float* b_causal, const float* w_layers,
               int64_t layer_stride, const float* b_layers, const float* w_p1, const float* b_p1,
@@ -257,12 +243,9 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
  * the skip product and the two post-processing products as well (S = Q = 256), else -1).  Used when R = D = 64 and
  * S = Q = 256 with all of pk given (biases allowed); NULL or other shapes = wn_decode_batch.
  * sync here holds wn_decode_sync_granules(n_layers, D, S) uint64 PER UTTERANCE (error flag = the last word of an
- * utterance's region): with all of pk given and n_utt <= 8 the loop CAN run as a PIPELINE of ceil(n_layers/2) + 2
- * workgroups per utterance that keep their weight fragments in registers for the whole call (two blocks per stage,
- * then the two post-processing products) and pass x, the partial skip sum, h1 and the code along through the same
- * tagged granules (opt-in, WN_DEC_PIPE=1); by default eight utterances share a workgroup pair, one pair of MFMA result
- * columns each (n_utt <= 1024 on this path; when fewer than eight are left for a pair the spare columns mirror the last
- * utterance; same arithmetic per utterance, so rows are bit-identical whatever the batch). */
+ * utterance's region).  Eight utterances share a workgroup pair, one pair of MFMA result columns each (n_utt <= 1024
+ * on this path; when fewer than eight are left for a pair the spare columns mirror the last utterance; same arithmetic
+ * per utterance, so rows are bit-identical whatever the batch). */
 int64_t wn_decode_sync_granules(int n_layers, int D, int S);
 int wn_decode_batch_pk(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
                        float* queues, const float* w_causal, const float* b_causal, const float* w_layers,

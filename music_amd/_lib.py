@@ -41,13 +41,9 @@ SIGNATURES = {
     "wn_wgrad": [_p, _l, _i, _i, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _i,
                  _l, _i, _i, _i, _i, _i, _p],
     "wn_wgrad_slabs": [_i, _i, _i, _i],
-    "wn_resblock_bwd_fused": [_p, _p, _p, _p, _p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i,
-                              _p, _p, _i, _i, _i, _i, _p],
-    "wn_resblock_bwd_fused_tiles": [_i, _i],
     "wn_resblock_bwd_ms": [_p, _p, _p, _p, _l, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p,
                            _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_bwd_ms_slabs": [_i, _i, _i],
-    "wn_shift_add": [_p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_wgrad": [_p, _p, _p, _p, _l, _l, _l, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p],
     "wn_reduce_slabs": [_p, _i, _l, _p, _p, _p],
     "wn_bias_grad": [_p, _l, _i, _i, _i, _i, _i, _i, _p, _p],
@@ -104,10 +100,6 @@ def load():
 def wgrad_slabs(t_lo, t_hi, chunk, batch):
     """Number of slabs one wn_wgrad call writes (plain int return, not a status)."""
     return load().wn_wgrad_slabs(t_lo, t_hi, chunk, batch)
-
-
-def fused_tiles(t_lo, t_hi):
-    return load().wn_resblock_bwd_fused_tiles(t_lo, t_hi)
 
 
 def ms_slabs(t_lo, t_hi, batch):

@@ -188,26 +188,6 @@ int wn_mulaw_decode_lut(const uint8_t* codes, const float* table, float* audio, 
     return wn_launch_mulaw_decode(codes, table, audio, n, (hipStream_t)stream);
 }
 
-int wn_resblock_bwd_fused(const float* x_in, const float* dP_in, const float* dQ_in, const float* dz, float* dP_out,
-                          float* dQ_out, float* scratch, int64_t x_bstride, int64_t dz_bstride, int pitch,
-                          const uint16_t* wfg, const uint16_t* wdT, const uint16_t* wpq, const float* bias_f,
-                          const float* bias_g, int n_f, int ch, int d, int dn, int p_lo, int t_lo, int t_hi, int z_lo,
-                          float* slab_fg, float* slab_d, int has_d, int batch, int mode_fwd, int mode_bwd,
-                          wn_stream_t stream) {
-    if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_bwd_fused: pitch must be a multiple of 4");
-    WnResFusedArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x_in = x_in; a.x_bstride = x_bstride; a.pitch = pitch; a.dP_in = dP_in; a.dQ_in = dP_in ? dQ_in : nullptr;
-    a.dn = dn; a.p_lo = p_lo; a.dz = dz; a.dz_bstride = dz_bstride; a.z_lo = z_lo; a.dP_out = dP_out; a.dQ_out = dQ_out;
-    a.scratch = scratch; a.wfg = wfg; a.wdT = wdT; a.wpq = wpq; a.bias_f = bias_f; a.bias_g = bias_g; a.n_f = n_f;
-    a.slab_fg = slab_fg; a.slab_d = slab_d; a.has_d = (has_d && dP_in && slab_d) ? 1 : 0; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi;
-    static int dbg = -1;                     // WN_FUSED_SKIP=1|2|3 disables phases for TIMING experiments (wrong results)
-    if (dbg < 0) { const char* e = getenv("WN_FUSED_SKIP"); dbg = e ? atoi(e) : 0; }
-    a.dbg_skip = dbg;
-    return wn_launch_resblock_bwd_fused(a, ch, batch, mode_fwd, mode_bwd, (hipStream_t)stream);
-}
-int wn_resblock_bwd_fused_tiles(int t_lo, int t_hi) { return wn_resfused_tiles(t_lo, t_hi); }
-
 int wn_resblock_bwd_ms(const float* x_in, const float* dy, const float* dz, float* dfg, int64_t x_bstride,
                        int64_t dz_bstride, int64_t dfg_bstride, int pitch, const uint16_t* wfg, const uint16_t* wdT,
                        const float* bias_f, const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
@@ -241,10 +221,6 @@ int wn_enc_resblock_bwd(const float* x_in, const float* dy, const float* h, floa
 }
 int wn_enc_resblock_bwd_slabs(int t_lo, int t_hi, int batch) { return wn_enc_bwd_slabs(t_lo, t_hi, batch); }
 int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch) { return wn_resms_slabs(t_lo, t_hi, batch); }
-int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,
-                 int t_lo, int t_hi, int batch, wn_stream_t stream) {
-    return wn_launch_shift_add(p, q, out, bstride, pitch, rows, dn, p_lo, t_lo, t_hi, batch, (hipStream_t)stream);
-}
 
 int wn_cond_grad(const float* in, int64_t in_bstride, int in_pitch, int rows, int t_lo, int t_hi, int mode, int le,
                  int q, float* out, int64_t out_bstride, int out_pitch, int batch, wn_stream_t stream) {
@@ -315,8 +291,8 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
 }
 
 int64_t wn_decode_sync_granules(int n_layers, int D, int S) {
-    const int64_t duo = (int64_t)n_layers * D + 2, pipe = wn_decode_pipe_granules(n_layers, D, S);
-    return duo > pipe ? duo : pipe;
+    (void)S;
+    return (int64_t)n_layers * D + 2;          // z hand-offs of every block + the code granule + the error flag
 }
 
 int wn_decode_batch_pk(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,

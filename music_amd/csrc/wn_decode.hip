@@ -193,65 +193,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_k(WnDecodeArgs a) {
     for (int i = tid; i < a.Q; i += DEC_THREADS) { u_prev_out[i] = prev[i]; u_note_out[i] = note[i]; }
 }
 
-// ---------------------------------------------------------------------------------------------
-// decode_v4_k: same recurrence, built for the real bottleneck of a one-CU sequential kernel, the
-// INSTRUCTION count per multiply-add: every thread owns a CONTIGUOUS k-slice of one output row,
-// reads its weights as float4 (prefetched one block ahead, they do not depend on data) and its
-// slice of the input vector as float4 from LDS, and `parts` adjacent lanes combine with shuffles.
-// The residual stream ping-pongs between two LDS buffers, queue columns are written by the lanes
-// that own the outputs, ring positions live in LDS (no 64-bit modulo per block).
-// Requires (else decode_k): no biases, one pass per product, weights per thread = 16 / 4 / 16 for
-// the f/g, dense and skip products and multiples of 4 for causal / post-process.
-// ---------------------------------------------------------------------------------------------
-struct DecMap { int parts, p, o, nw; };
-__device__ __forceinline__ DecMap dec_map(int M, int K) {
-    int parts = DEC_THREADS / M;
-    if (parts < 1) parts = 1;
-    if (parts > 64) parts = 64;
-    while (parts & (parts - 1)) parts &= parts - 1;
-    DecMap m;
-    m.parts = parts; m.p = threadIdx.x % parts; m.o = threadIdx.x / parts; m.nw = K / parts;
-    return m;
-}
-template <int NV>      // NV float4 of weights: W[o][p*nw .. p*nw + 4*NV)
-__device__ __forceinline__ void dec_loadw4(f32x4 (&w)[NV], const DecMap& m, const float* __restrict__ W, int ldw, int M) {
-    const float* r = W + (size_t)(m.o < M ? m.o : 0) * ldw + m.p * m.nw;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) w[j] = ld4(r + 4 * j);
-}
-template <int NV>
-__device__ __forceinline__ float dec_dot4(const f32x4 (&w)[NV], const DecMap& m, const float* x) {
-    const float* xs = x + m.p * m.nw;
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + 4 * j);
-        s = fmaf(w[j][0], xv[0], s); s = fmaf(w[j][1], xv[1], s);
-        s = fmaf(w[j][2], xv[2], s); s = fmaf(w[j][3], xv[3], s);
-    }
-    for (int off = m.parts >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    return s;
-}
-// long rows (causal, post-process): weights streamed at use, 4 float4 in flight
-__device__ __forceinline__ float dec_dot_stream(const DecMap& m, const float* __restrict__ W, int ldw, int M, const float* x) {
-    const float* r = W + (size_t)(m.o < M ? m.o : 0) * ldw + m.p * m.nw;
-    const float* xs = x + m.p * m.nw;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int k = 0; k < m.nw; k += 16) {
-        f32x4 w0 = ld4(r + k), w1 = ld4(r + k + 4), w2 = ld4(r + k + 8), w3 = ld4(r + k + 12);
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + k), x1 = *reinterpret_cast<const f32x4*>(xs + k + 4);
-        const f32x4 x2 = *reinterpret_cast<const f32x4*>(xs + k + 8), x3 = *reinterpret_cast<const f32x4*>(xs + k + 12);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            s0 = fmaf(w0[e], x0[e], s0); s1 = fmaf(w1[e], x1[e], s1);
-            s2 = fmaf(w2[e], x2[e], s2); s3 = fmaf(w3[e], x3[e], s3);
-        }
-    }
-    float s = (s0 + s1) + (s2 + s3);
-    for (int off = m.parts >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    return s;
-}
-
 // Workgroup barrier that only drains LDS traffic.  __syncthreads() also waits for every outstanding
 // global access (vmcnt(0), because of the queue-column stores), which would expose the L2 latency
 // of the weight prefetches at each of the ~90 barriers of a sample.
@@ -261,136 +202,15 @@ __device__ __forceinline__ void dec_sync() {
     asm volatile("" ::: "memory");
 }
 
-__global__ __launch_bounds__(DEC_THREADS) void decode_v4_k(WnDecodeArgs a) {
-    // utterance of a batched launch: per-utterance pointers as LOCALS (the argument struct itself must stay
-    // untouched: a modified copy would be moved to scratch and every dil[] / q_off[] lookup with it)
-    const size_t utt = blockIdx.x;
-    float* const u_queues = a.queues + utt * a.queues_ustride;
-    const float* const u_note0 = a.note0 + utt * a.Q;
-    const float* const u_prev0 = a.prev0 + utt * a.Q;
-    float* const u_note_out = a.note_out + utt * a.Q;
-    float* const u_prev_out = a.prev_out + utt * a.Q;
-    const int32_t* const u_forced = a.forced ? a.forced + utt * a.n_steps : nullptr;
-    int32_t* const u_codes_out = a.codes_out + utt * a.n_steps;
-    float* const u_probs_out = a.probs_out ? a.probs_out + utt * (size_t)a.n_steps * a.Q : nullptr;
-    unsigned long long* const u_sync = a.sync ? a.sync + utt * (size_t)a.sync_ustride : nullptr;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* prev = sm;                       // [Q]
-    float* note = prev + a.Q;               // [Q]   ([prev|note] contiguous)
-    float* cur0 = note + a.Q;               // [2R]  cur (R) followed by old (R), buffer 0
-    float* cur1 = cur0 + 2 * a.R;           // [2R]  buffer 1
-    float* fg = cur1 + 2 * a.R;             // [2D]
-    float* zz = fg + 2 * a.D;               // [D]
-    float* skip = zz + a.D;                 // [S]
-    float* h1 = skip + a.S;                 // [S]
-    float* logit = h1 + a.S;                // [Q]
-    __shared__ int s_arg;
-    __shared__ int slots[WN_DEC_MAX_LAYERS];          // ring position of every block
-    const int tid = threadIdx.x;
-    const int R = a.R, D = a.D, S = a.S, Q = a.Q;
-    const DecMap mc = dec_map(R, 2 * Q), mfg = dec_map(2 * D, 2 * R), md = dec_map(R, D), ms = dec_map(S, D);
-    const DecMap mp1 = dec_map(S, S), mp2 = dec_map(Q, S);
-    const size_t lstride = (size_t)a.layer_stride;
-    const size_t o_d = (size_t)2 * D * 2 * R, o_s = o_d + (size_t)R * D;
-
-    for (int i = tid; i < Q; i += DEC_THREADS) { note[i] = u_note0[i]; prev[i] = u_prev0[i]; }
-    if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
-    dec_sync();
-
-    f32x4 wfg[4], wd[1], ws[4];
-    for (int step = 0; step < a.n_steps; ++step) {
-        // block-0 weights and queue column are fetched while the causal layer runs
-        dec_loadw4(wfg, mfg, a.w_layers, 2 * R, 2 * D);
-        dec_loadw4(wd, md, a.w_layers + o_d, D, R);
-        dec_loadw4(ws, ms, a.w_layers + o_s, D, S);
-        float oldv = 0.f;
-        if (tid < R) oldv = u_queues[a.q_off[0] + (size_t)slots[0] * R + tid];
-        if (!(a.dbg & 8)) {
-            const float s = dec_dot_stream(mc, a.w_causal, 2 * Q, R, prev);
-            if (mc.o < R && mc.p == 0) cur0[mc.o] = s;
-        }
-        for (int i = tid; i < S; i += DEC_THREADS) skip[i] = 0.f;
-        if (tid < R) cur0[R + tid] = oldv;
-        dec_sync();
-        float* cur = cur0;
-        float* nxt = cur1;
-        for (int l = 0; l < ((a.dbg & 16) ? 1 : a.n_layers); ++l) {
-            // ---- [f;g] = Wfg [cur | old]
-            const float s = dec_dot4(wfg, mfg, cur);
-            if (mfg.o < 2 * D && mfg.p == 0) fg[mfg.o] = s;
-            const int ln = l + 1;
-            const float* wn = a.w_layers + (size_t)ln * lstride;
-            float oldn = 0.f;
-            if (ln < a.n_layers) {
-                dec_loadw4(wfg, mfg, wn, 2 * R, 2 * D);
-                if (tid < R && !(a.dbg & 2)) oldn = u_queues[a.q_off[ln] + (size_t)slots[ln] * R + tid];
-            }
-            dec_sync();
-            if (tid < D) zz[tid] = (a.dbg & 1) ? wn_tanh(fg[tid]) * wn_sigmoid(fg[D + tid])
-                                               : tanhf(fg[tid]) * (1.0f / (1.0f + expf(-fg[D + tid])));
-            dec_sync();
-            // ---- dense (+ residual) and skip products
-            const float sd = dec_dot4(wd, md, zz);
-            const float ss = dec_dot4(ws, ms, zz);
-            if (md.o < R && md.p == 0) {
-                const float v = sd + cur[md.o];
-                nxt[md.o] = v;
-                if (!(a.dbg & 2)) u_queues[a.q_off[l] + (size_t)slots[l] * R + md.o] = a.push_input ? cur[md.o] : v;   // Q5: output by default
-            }
-            if (ms.o < S && ms.p == 0) skip[ms.o] += ss;
-            if (ln < a.n_layers) {
-                dec_loadw4(wd, md, wn + o_d, D, R);
-                dec_loadw4(ws, ms, wn + o_s, D, S);
-                if (tid < R) nxt[R + tid] = oldn;
-            }
-            dec_sync();
-            float* t = cur; cur = nxt; nxt = t;
-        }
-        // ---- post-processing: relu -> P1 -> relu -> P2 -> softmax -> argmax
-        for (int i = tid; i < S; i += DEC_THREADS) skip[i] = fmaxf(skip[i], 0.f);
-        dec_sync();
-        if (!(a.dbg & 4)) {
-            const float s = dec_dot_stream(mp1, a.w_p1, S, S, skip);
-            if (mp1.o < S && mp1.p == 0) h1[mp1.o] = fmaxf(s, 0.f);
-        }
-        dec_sync();
-        if (!(a.dbg & 4)) {
-            const float s = dec_dot_stream(mp2, a.w_p2, S, Q, h1);
-            if (mp2.o < Q && mp2.p == 0) logit[mp2.o] = s;
-        }
-        dec_sync();
-        if (tid < 64) {
-            const float ur = a.sample ? dec_uniform(a.seed, (unsigned long long)(a.step0 + step), utt) : 0.f;
-            const int bi = dec_choose(logit, tid, u_probs_out ? u_probs_out + (size_t)step * a.Q : nullptr, a.inv_temp, a.sample != 0, ur);
-            if (tid == 0) { s_arg = bi; u_codes_out[step] = bi; }
-        }
-        dec_sync();
-        const int nextc = u_forced ? u_forced[step] : s_arg;
-        for (int i = tid; i < Q; i += DEC_THREADS) prev[i] = note[i];
-        if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
-        dec_sync();
-        for (int i = tid; i < Q; i += DEC_THREADS) note[i] = (i == nextc) ? 1.0f : 0.0f;
-        dec_sync();
-    }
-    for (int i = tid; i < Q; i += DEC_THREADS) { u_prev_out[i] = prev[i]; u_note_out[i] = note[i]; }
-}
-
 // ---------------------------------------------------------------------------------------------
-// decode_duo_k: the recurrence split over TWO workgroups on (normally) two XCDs, because one CU can
-// only stream ~35 GB/s from beyond its XCD's 4 MB L2 and the 5 MB of fp32 weights do not fit it:
-//   block 0 "chain": causal layer, per block f/g product, gate, dense product, queue update
-//                    (2.6 MB of weights -> resident in ITS L2);
-//   block 1 "skip" : per block the skip product Ws z_l (1.97 MB), then relu/P1/relu/P2/softmax/argmax
-//                    (0.5 MB) -> resident in ITS L2.
-// z_l travels as 8-byte {value, tag} granules written with one agent-scope relaxed 64-bit store
-// and polled with agent-scope relaxed loads (tag = sample number; no fences, no flags: the
-// placement-independent hand-off of MI355X_MICROARCH.md "R2 granule"); the predicted code travels
-// back the same way.  Every spin is bounded; a timeout sets sync[err] and both blocks run out.
-// Measured (config 5): 8.1-8.4 k samples/s vs 5.1 k for one workgroup.  What bounds the chain now is
-// the ~64 KB of f/g weights a block needs per sample through ONE CU's memory pipe (~1.7 us per
-// block even from L2; bisected with the WN_DEC_DBG switches: without the f/g product the chain
-// runs 17.7 k samples/s); the next step is a block-pipelined chain over ~15 CUs with the weights
-// resident in LDS.
+// Hand-off protocol of the two-workgroup matrix-core decoder below: the recurrence is split over TWO workgroups
+// (normally on two XCDs: each one's weights then fit a 4 MB L2) -
+//   block 0 "chain": causal layer, per block f/g product, gate, dense product, queue update;
+//   block 1 "skip" : per block the skip product Ws z_l, then relu/P1/relu/P2/softmax/argmax.
+// z_l travels as {value, tag} granules written with one agent-scope relaxed 64-bit store and polled with agent-scope
+// relaxed loads (tag = sample number; no fences, no flags: the placement-independent hand-off of MI355X_MICROARCH.md
+// "R2 granule"); the predicted code travels back the same way.  Every spin is bounded; a timeout sets sync[err] and
+// both blocks run out.
 // ---------------------------------------------------------------------------------------------
 // one of the three MFMAs of an x3 product (t = 0: lo*hi, 1: hi*lo, 2: hi*hi): issued term by term ACROSS independent
 // accumulators, no product waits for the one in front of it
@@ -410,174 +230,6 @@ __device__ __forceinline__ bool dec_poll(const unsigned long long* p, unsigned t
     __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     v = 0.f;
     return false;
-}
-
-__global__ __launch_bounds__(DEC_THREADS) void decode_duo_k(WnDecodeArgs a) {
-    // workgroups 2u (chain) and 2u+1 (skip + post) serve utterance u of a batched launch: per-utterance pointers as LOCALS (the argument struct itself must stay
-    // untouched: a modified copy would be moved to scratch and every dil[] / q_off[] lookup with it)
-    const size_t utt = blockIdx.x >> 1;
-    float* const u_queues = a.queues + utt * a.queues_ustride;
-    const float* const u_note0 = a.note0 + utt * a.Q;
-    const float* const u_prev0 = a.prev0 + utt * a.Q;
-    float* const u_note_out = a.note_out + utt * a.Q;
-    float* const u_prev_out = a.prev_out + utt * a.Q;
-    const int32_t* const u_forced = a.forced ? a.forced + utt * a.n_steps : nullptr;
-    int32_t* const u_codes_out = a.codes_out + utt * a.n_steps;
-    float* const u_probs_out = a.probs_out ? a.probs_out + utt * (size_t)a.n_steps * a.Q : nullptr;
-    unsigned long long* const u_sync = a.sync ? a.sync + utt * (size_t)a.sync_ustride : nullptr;
-    const int role = blockIdx.x & 1;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ int s_arg;
-    __shared__ int slots[WN_DEC_MAX_LAYERS];
-    const int tid = threadIdx.x;
-    const int R = a.R, D = a.D, S = a.S, Q = a.Q;
-    unsigned long long* zg = u_sync;                         // [n_layers][D] z granules
-    unsigned long long* cg = u_sync + (size_t)a.sync_ustride - 2;    // code granule
-    unsigned long long* err = cg + 1;
-    const size_t lstride = (size_t)a.layer_stride;
-    const size_t o_d = (size_t)2 * D * 2 * R, o_s = o_d + (size_t)R * D;
-
-    if (role == 0) {
-        // ------------------------------------------------------------------ chain
-        float* prev = sm;
-        float* note = prev + Q;
-        float* cur0 = note + Q;
-        float* cur1 = cur0 + 2 * R;
-        float* fg = cur1 + 2 * R;
-        float* zz = fg + 2 * D;
-        float* oldb = zz + D;                    // [n_layers][R] oldest queue columns of this sample
-        float* pushb = oldb + a.n_layers * R;    // [n_layers][R] columns pushed by this sample
-        const DecMap mc = dec_map(R, 2 * Q), mfg = dec_map(2 * D, 2 * R), md = dec_map(R, D);
-        for (int i = tid; i < Q; i += DEC_THREADS) { note[i] = u_note0[i]; prev[i] = u_prev0[i]; }
-        if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
-        dec_sync();
-        f32x4 wfg[4], wd[1];
-        for (int step = 0; step < a.n_steps; ++step) {
-            const unsigned tag = (unsigned)step + 1u;
-            // all queue traffic of a sample happens here (oldest columns in, L1-bypassing loads) and after
-            // the last block (pushed columns out): global stores inside the block loop would sit in the
-            // in-order vmcnt queue (~2 us each) in front of every wait for prefetched weights
-            for (int i = tid; i < a.n_layers * R; i += DEC_THREADS) {
-                const int l = i / R, r = i - l * R;
-                oldb[i] = __hip_atomic_load(u_queues + a.q_off[l] + (size_t)slots[l] * R + r, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_AGENT);
-            }
-            dec_loadw4(wfg, mfg, a.w_layers, 2 * R, 2 * D);
-            dec_loadw4(wd, md, a.w_layers + o_d, D, R);
-            {
-                const float s = dec_dot_stream(mc, a.w_causal, 2 * Q, R, prev);
-                if (mc.o < R && mc.p == 0) cur0[mc.o] = s;
-            }
-            dec_sync();
-            if (tid < R) cur0[R + tid] = oldb[tid];
-            dec_sync();
-            float* cur = cur0;
-            float* nxt = cur1;
-            for (int l = 0; l < a.n_layers; ++l) {
-                const float s = (a.dbg & 1024) ? cur[tid & 63] : dec_dot4(wfg, mfg, cur);
-                if (mfg.o < 2 * D && mfg.p == 0) fg[mfg.o] = s;
-                const int ln = l + 1;
-                const float* wn = a.w_layers + (size_t)ln * lstride;
-                if (ln < a.n_layers && !(a.dbg & 256)) dec_loadw4(wfg, mfg, wn, 2 * R, 2 * D);
-                dec_sync();
-                if (tid < D) {
-                    const float z = (a.dbg & 64) ? wn_tanh(fg[tid]) * wn_sigmoid(fg[D + tid])
-                                                 : tanhf(fg[tid]) * (1.0f / (1.0f + expf(-fg[D + tid])));
-                    zz[tid] = z;
-                    if (!(a.dbg & 128))
-                        __hip_atomic_store(zg + (size_t)l * D + tid, dec_pack(z, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (!(a.dbg & 2048)) dec_sync();
-                const float sd = (a.dbg & 4096) ? zz[tid & 63] : dec_dot4(wd, md, zz);
-                if (md.o < R && md.p == 0) {
-                    const float v = sd + cur[md.o];
-                    nxt[md.o] = v;
-                    pushb[l * R + md.o] = a.push_input ? cur[md.o] : v;          // Q5: output by default
-                }
-                if (ln < a.n_layers) {
-                    if (!(a.dbg & 256)) dec_loadw4(wd, md, wn + o_d, D, R);
-                    if (tid < R) nxt[R + tid] = oldb[ln * R + tid];
-                }
-                dec_sync();
-                float* t = cur; cur = nxt; nxt = t;
-            }
-            for (int i = tid; i < a.n_layers * R; i += DEC_THREADS) {            // queue columns out
-                const int l = i / R, r = i - l * R;
-                u_queues[a.q_off[l] + (size_t)slots[l] * R + r] = pushb[i];
-            }
-            // the prediction comes back from the skip block
-            if (tid == 0) {
-                float cv = 0.f;
-                if (!(a.dbg & 32)) dec_poll(cg, tag, cv, err);
-                s_arg = (int)cv;
-            }
-            __syncthreads();                       // full fence: the queue stores are complete before the next sample reads
-            const int nextc = u_forced ? u_forced[step] : s_arg;
-            for (int i = tid; i < Q; i += DEC_THREADS) prev[i] = note[i];
-            if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
-            dec_sync();
-            for (int i = tid; i < Q; i += DEC_THREADS) note[i] = (i == nextc) ? 1.0f : 0.0f;
-            dec_sync();
-        }
-        for (int i = tid; i < Q; i += DEC_THREADS) { u_prev_out[i] = prev[i]; u_note_out[i] = note[i]; }
-    } else {
-        // ------------------------------------------------------------------ skip + post-processing
-        float* zz0 = sm;                       // [2][D]
-        float* skip = zz0 + 2 * D;             // [S]
-        float* h1 = skip + S;                  // [S]
-        float* logit = h1 + S;                 // [Q]
-        const DecMap ms = dec_map(S, D), mp1 = dec_map(S, S), mp2 = dec_map(Q, S);
-        f32x4 ws[4];
-        for (int step = 0; step < ((a.dbg & 32) ? 0 : a.n_steps); ++step) {
-            const unsigned tag = (unsigned)step + 1u;
-            float part = 0.f;                                    // this thread's slice of its skip row, all blocks
-            dec_loadw4(ws, ms, a.w_layers + o_s, D, S);
-            for (int l = 0; l < a.n_layers; ++l) {
-                float* zz = zz0 + (l & 1) * D;
-                if (tid < D) {
-                    float z;
-                    dec_poll(zg + (size_t)l * D + tid, tag, z, err);
-                    zz[tid] = z;
-                }
-                dec_sync();
-                f32x4 wsn[4];
-                if (l + 1 < a.n_layers) dec_loadw4(wsn, ms, a.w_layers + (size_t)(l + 1) * lstride + o_s, D, S);
-                const float* xs = zz + ms.p * ms.nw;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + 4 * j);
-                    part = fmaf(ws[j][0], xv[0], part); part = fmaf(ws[j][1], xv[1], part);
-                    part = fmaf(ws[j][2], xv[2], part); part = fmaf(ws[j][3], xv[3], part);
-                }
-                if (l + 1 < a.n_layers) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ws[j] = wsn[j];
-                }
-            }
-            for (int off = ms.parts >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-            if (ms.o < S && ms.p == 0) skip[ms.o] = fmaxf(part, 0.f);
-            dec_sync();
-            {
-                const float s = dec_dot_stream(mp1, a.w_p1, S, S, skip);
-                if (mp1.o < S && mp1.p == 0) h1[mp1.o] = fmaxf(s, 0.f);
-            }
-            dec_sync();
-            {
-                const float s = dec_dot_stream(mp2, a.w_p2, S, Q, h1);
-                if (mp2.o < Q && mp2.p == 0) logit[mp2.o] = s;
-            }
-            dec_sync();
-            if (tid < 64) {
-                const float ur = a.sample ? dec_uniform(a.seed, (unsigned long long)(a.step0 + step), utt) : 0.f;
-                const int bi = dec_choose(logit, tid, u_probs_out ? u_probs_out + (size_t)step * Q : nullptr, a.inv_temp, a.sample != 0, ur);
-                if (tid == 0) {
-                    u_codes_out[step] = bi;
-                    __hip_atomic_store(cg, dec_pack((float)bi, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            dec_sync();
-        }
-    }
 }
 
 // Matrix-core form of decode_duo_k (R = D = 64, S = Q = 256, no biases): the same two roles and hand-off protocol, 256
@@ -627,338 +279,6 @@ __device__ __forceinline__ f32x4 dec_pairsum(const f32x4& v) {
 __device__ __forceinline__ void dec_get8(const uint16_t* v, int n, int i, Frag<F16>& f) {   // i % 8 == 0
     f.hi = *reinterpret_cast<const f16x8*>(v + i);
     f.lo = *reinterpret_cast<const f16x8*>(v + n + i);
-}
-template <bool BIAS>      // BIAS: the model has biases (any of them may still be null)
-__global__ __launch_bounds__(DEC_MT) void decode_duo_mfma_k(WnDecodeArgs a) {
-    // workgroups 2u (chain) and 2u+1 (skip + post) serve utterance u of a batched launch: per-utterance pointers as LOCALS (the argument struct itself must stay
-    // untouched: a modified copy would be moved to scratch and every dil[] / q_off[] lookup with it)
-    const size_t utt = blockIdx.x >> 1;
-    float* const u_queues = a.queues + utt * a.queues_ustride;
-    const float* const u_note0 = a.note0 + utt * a.Q;
-    const float* const u_prev0 = a.prev0 + utt * a.Q;
-    float* const u_note_out = a.note_out + utt * a.Q;
-    float* const u_prev_out = a.prev_out + utt * a.Q;
-    const int32_t* const u_forced = a.forced ? a.forced + utt * a.n_steps : nullptr;
-    int32_t* const u_codes_out = a.codes_out + utt * a.n_steps;
-    float* const u_probs_out = a.probs_out ? a.probs_out + utt * (size_t)a.n_steps * a.Q : nullptr;
-    unsigned long long* const u_sync = a.sync ? a.sync + utt * (size_t)a.sync_ustride : nullptr;
-    const int role = blockIdx.x & 1;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ int s_arg;
-    __shared__ int slots[WN_DEC_MAX_LAYERS];
-    const int tid = threadIdx.x;
-    const int R = a.R, D = a.D, S = a.S, Q = a.Q;
-    unsigned long long* zg = u_sync;                         // [n_layers][D] z granules
-    unsigned long long* cg = u_sync + (size_t)a.sync_ustride - 2;    // code granule
-    unsigned long long* err = cg + 1;
-    const size_t lstride = (size_t)a.layer_stride;
-    const size_t o_d = (size_t)2 * D * 2 * R, o_s = o_d + (size_t)R * D;
-
-    if (role == 0) {
-        // ------------------------------------------------------------------ chain, matrix-core form (R = D = 64)
-        // Four waves; wave w owns rows 16w..16w+15 of f, g and of the dense product.  A = the packed f16 hi/lo weight
-        // fragments of the training engine (3 MFMAs per product: fp32-grade), B = the current 64-vectors out of LDS with
-        // all 16 columns equal; the per-block barriers are 4-wave barriers (the other 12 waves have left).
-        // (a fifth "courier" wave that alone stored the z granules measured slower)
-        const int lane = tid & 63, w = tid >> 6, c = lane & 15, q = lane >> 4;
-        float* prev = sm;
-        float* note = prev + Q;
-        float* cur0 = note + Q;
-        float* cur1 = cur0 + 2 * R;
-        float* fg = cur1 + 2 * R;
-        float* zz = fg + 2 * D;
-        uint16_t* oldh = reinterpret_cast<uint16_t*>(zz + D);      // [n_layers][hi R | lo R] queue columns x(t - d) of this sample
-        float* pushb = zz + D + a.n_layers * R;
-        uint16_t* ch0 = reinterpret_cast<uint16_t*>(pushb + a.n_layers * R);   // split halfs of x: [hi R | lo R] (+ spare)
-        uint16_t* ch1 = ch0 + 4 * R;
-        uint16_t* zh = ch1 + 4 * R;                                            // split halfs of z, chained k order
-        float* bias = reinterpret_cast<float*>(zh + 2 * D);                    // [n_layers][bf D | bg D | bd R] when the model has biases
-        const int BL = 2 * D + R;
-        if (BIAS && a.b_layers) for (int i = tid; i < a.n_layers * BL; i += 256) { const int l = i / BL, e = i - l * BL; bias[i] = a.b_layers[(size_t)l * (BL + S) + e]; }
-        for (int i = tid; i < Q; i += 256) { note[i] = u_note0[i]; prev[i] = u_prev0[i]; }
-        if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
-        dec_sync();
-        int pcode = -1, ncode = -1;                       // >= 0: that input column is a one-hot of this code
-        DINIT;
-        const uint16_t* fgb = a.pk + a.pk_fg0;
-        const uint16_t* db = a.pk + a.pk_d0;
-        // the queue columns x(t - d) of all blocks for one sample, split into halfs.  Called for sample t + 1 while the chain
-        // waits for the code of sample t (they do not depend on it; a thread re-reads only slots it stored itself)
-        auto load_queues = [&]() {
-            for (int i0 = 0; i0 < a.n_layers * R; i0 += 8 * 256) {      // all loads of a batch in flight, then the splits
-                float qv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int i = i0 + j * 256 + tid, ic = i < a.n_layers * R ? i : 0;
-                    const int l = ic / R, r = ic - l * R;
-                    qv[j] = __hip_atomic_load(u_queues + a.q_off[l] + (size_t)slots[l] * R + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int i = i0 + j * 256 + tid;
-                    if (i < a.n_layers * R) { const int l = i / R, r = i - l * R; dec_put(oldh + l * 2 * R, R, r, qv[j]); }
-                }
-            }
-        };
-        load_queues();
-        for (int step = 0; step < a.n_steps; ++step) {
-            const unsigned tag = (unsigned)step + 1u;
-            DCLK(c0);
-            // weight fragments of blocks l and l+1 in two register sets (A: even, B: odd blocks); a set is re-armed TWO
-            // blocks ahead right after its last use - an L2 round trip is longer than one block of this chain
-            Frag<F16> wfA[4], wgA[4], wdA[2], wfB[4], wgB[4], wdB[2];
-            const int wq = w;
-            const size_t lb1 = a.n_layers > 1 ? (size_t)a.pk_lstride : 0;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                load_a<F16, 3>(wfA[s2], fgb, wq * 4 + s2, lane);
-                load_a<F16, 3>(wgA[s2], fgb, (4 + wq) * 4 + s2, lane);
-                load_a<F16, 3>(wfB[s2], fgb + lb1, wq * 4 + s2, lane);
-                load_a<F16, 3>(wgB[s2], fgb + lb1, (4 + wq) * 4 + s2, lane);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                load_a<F16, 3>(wdA[s2], db, wq * 2 + s2, lane);
-                load_a<F16, 3>(wdB[s2], db + lb1, wq * 2 + s2, lane);
-            }
-            {   // causal layer: x0 = Wc[:, tap0] prev + Wc[:, tap1] note ; a one-hot column is a gather
-                const int o = tid >> 2, p4 = tid & 3;
-                const float* wrow = a.w_causal + (size_t)o * 2 * Q;
-                float s = 0.f;
-                if (pcode >= 0) { if (p4 == 0) s += wrow[pcode]; }
-                else for (int k = p4 * (Q / 4); k < (p4 + 1) * (Q / 4); ++k) s = fmaf(wrow[k], prev[k], s);
-                if (ncode >= 0) { if (p4 == 0) s += wrow[Q + ncode]; }
-                else for (int k = p4 * (Q / 4); k < (p4 + 1) * (Q / 4); ++k) s = fmaf(wrow[Q + k], note[k], s);
-                s += __shfl_xor(s, 1, 64);
-                s += __shfl_xor(s, 2, 64);
-                if (p4 == 0) { if (BIAS && a.b_causal) s += a.b_causal[o]; cur0[o] = s; dec_put(ch0, R, o, s); }
-            }
-            dec_sync();
-            float* cur = cur0;
-            float* nxt = cur1;
-            uint16_t* curh = ch0;
-            uint16_t* nxth = ch1;
-            DCLK(c1);
-            auto blk = [&](const int l, Frag<F16> (&wf)[4], Frag<F16> (&wg)[4], Frag<F16> (&wd2)[2]) {
-                const int ln = l + 1;
-                const int l2 = l + 2 < a.n_layers ? l + 2 : a.n_layers - 1;      // the set's next use (clamped: harmless reload)
-                const uint16_t* fgn = fgb + (size_t)l2 * a.pk_lstride;
-                const uint16_t* dn = db + (size_t)l2 * a.pk_lstride;
-                {
-                    // k order: tap 0 = queue column x(t-d), then tap 1 = x(t).  All four B fragments first (their LDS reads
-                    // overlap), then the 16 MFMAs (A.hi, then A.lo: two-column form) over 8 independent accumulators (one per k-step and f / g)
-                    f16x8 bx[4];
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        bx[ks] = ks < 2 ? dec_get8c(oldh + l * 2 * R, R, 32 * ks + 8 * q, c) : dec_get8c(curh, R, 32 * (ks - 2) + 8 * q, c);
-                    f32x4 pf[4], pg[4];
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) { pf[ks] = f32x4{0.f, 0.f, 0.f, 0.f}; pg[ks] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) { pf[ks] = F16::mfma(wf[ks].hi, bx[ks], pf[ks]); pg[ks] = F16::mfma(wg[ks].hi, bx[ks], pg[ks]); }
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) { pf[ks] = F16::mfma(wf[ks].lo, bx[ks], pf[ks]); pg[ks] = F16::mfma(wg[ks].lo, bx[ks], pg[ks]); }
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {          // this set's fragments for block l+2 (unconditional)
-                        load_a<F16, 3>(wf[ks], fgn, w * 4 + ks, lane);
-                        load_a<F16, 3>(wg[ks], fgn, (4 + w) * 4 + ks, lane);
-                    }
-                    const f32x4 af = dec_pairsum((pf[0] + pf[1]) + (pf[2] + pf[3])), ag = dec_pairsum((pg[0] + pg[1]) + (pg[2] + pg[3]));
-                    // all 16 columns of the products are equal: lane (c, q) gates ONE of its four rows (i = c & 3), so a
-                    // wave pays one tanh / sigmoid latency per block instead of four
-                    const int gi = c & 3;
-                    float fv = gi == 0 ? af[0] : gi == 1 ? af[1] : gi == 2 ? af[2] : af[3];
-                    float gv = gi == 0 ? ag[0] : gi == 1 ? ag[1] : gi == 2 ? ag[2] : ag[3];
-                    if (BIAS && a.b_layers) { fv += bias[l * BL + 16 * w + 4 * q + gi]; gv += bias[l * BL + D + 16 * w + 4 * q + gi]; }
-                    const float z1 = wn_tanh(fv) * wn_sigmoid(gv);
-                    if (c < 4) {          // z[16w + 4q + c], stored where the chained k order of the dense weights wants it
-                        dec_put(zh, D, 32 * (w >> 1) + 8 * q + 4 * (w & 1) + c, z1);
-                        __hip_atomic_store(zg + (size_t)l * D + 16 * w + 4 * q + c, dec_pack(z1, tag), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                dec_sync();
-                {
-                    f16x8 bz[2];
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) bz[s2] = dec_get8c(zh, D, 32 * s2 + 8 * q, c);
-                    f32x4 pd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) pd[s2] = F16::mfma(wd2[s2].hi, bz[s2], pd[s2]);
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) pd[s2] = F16::mfma(wd2[s2].lo, bz[s2], pd[s2]);
-                    const f32x4 ad = dec_pairsum(pd[0] + pd[1]);
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) load_a<F16, 3>(wd2[s2], dn, w * 2 + s2, lane);
-                    if (c < 4) {                              // lane c owns row 16w + 4q + c
-                        const int row = 16 * w + 4 * q + c;
-                        const float xc = cur[row], v = dec_pick4(ad, c) + xc + (BIAS && a.b_layers ? bias[l * BL + 2 * D + row] : 0.f);
-                        nxt[row] = v;
-                        dec_put(nxth, R, row, v);
-                        pushb[l * R + row] = a.push_input ? xc : v;       // Q5: output by default
-                    }
-                }
-                dec_sync();
-                float* t2 = cur; cur = nxt; nxt = t2;
-                uint16_t* t3 = curh; curh = nxth; nxth = t3;
-            };
-            for (int l = 0; l < a.n_layers; l += 2) {
-                blk(l, wfA, wgA, wdA);
-                if (l + 1 < a.n_layers) blk(l + 1, wfB, wgB, wdB);
-            }
-            DCLK(c2);
-            for (int i = tid; i < a.n_layers * R; i += 256) {
-                const int l = i / R, r = i - l * R;
-                u_queues[a.q_off[l] + (size_t)slots[l] * R + r] = pushb[i];
-            }
-            dec_sync();                            // every thread has used slots[] for its stores
-            if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
-            dec_sync();
-            if (step + 1 < a.n_steps) load_queues();
-            DCLK(c3);
-            if (tid == 0) {
-                float cv = 0.f;
-                dec_poll(cg, tag, cv, err);
-                s_arg = (int)cv;
-            }
-            DCLK(c4);
-            __syncthreads();
-            DCLK(c5);
-            DACC(0, c1 - c0); DACC(1, c2 - c1); DACC(2, c3 - c2); DACC(3, c4 - c3); DACC(4, c5 - c4);
-            const int nextc = u_forced ? u_forced[step] : s_arg;
-            for (int i = tid; i < Q; i += 256) prev[i] = note[i];
-            pcode = ncode;
-            ncode = nextc;
-            dec_sync();
-            for (int i = tid; i < Q; i += 256) note[i] = (i == nextc) ? 1.0f : 0.0f;
-            dec_sync();
-        }
-        for (int i = tid; i < Q; i += 256) { u_prev_out[i] = prev[i]; u_note_out[i] = note[i]; }
-        DFLUSH;
-    } else {
-        // ------------------------------------------------------------------ skip + post-processing, matrix-core form
-        // (D = 64, S = Q = 256): four waves, wave w owns rows 64w..64w+63 of the skip sum and of both post-processing
-        // products (4 row tiles); one 4-wave barrier per block publishes the z the chain handed over.
-        if (tid >= 256) return;
-        const int lane = tid & 63, w = tid >> 6, c = lane & 15, q = lane >> 4;
-        uint16_t* zz0 = reinterpret_cast<uint16_t*>(sm);   // [2][hi D | lo D] split halfs (2D floats)
-        uint16_t* skip = zz0 + 4 * D;          // [hi S | lo S]
-        uint16_t* h1 = skip + 2 * S;           // [hi S | lo S]
-        float* logit = sm + 2 * D + 2 * S;     // [Q]
-        float* bsk = logit + Q;                // [S] sum of the blocks' skip biases, [S] post_process_1 bias, [Q] post_process_2 bias
-        if (BIAS && a.b_layers) {
-            float t = 0.f;
-            for (int l = 0; l < a.n_layers; ++l) t += a.b_layers[(size_t)l * (2 * D + R + S) + 2 * D + R + tid];
-            bsk[tid] = t;
-        }
-        if (BIAS && a.b_p1) bsk[S + tid] = a.b_p1[tid];
-        if (BIAS && a.b_p2) bsk[2 * S + tid] = a.b_p2[tid];
-        dec_sync();
-        const int KSS = a.n_layers * D / 32;   // k-steps of the skip product
-        const uint16_t* skb = a.pk + a.pk_skip;
-        const uint16_t* p1b = a.pk + a.pk_p1;
-        const uint16_t* p2b = a.pk + a.pk_p2;
-        // out[64w + 16m + 4q + i] = sum_k W[row][k] in[k] for the 256 x 256 post-processing products (8 k-steps)
-        auto post = [&](const uint16_t* wb, const uint16_t* in, uint16_t* outh, float* outf, const float* bvec) {      // outh: relu + split halfs
-            f32x4 acc[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            Frag<F16> wa[2][4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) load_a<F16, 3>(wa[0][m], wb, (4 * w + m) * 8, lane);
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                if (ks + 1 < 8) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) load_a<F16, 3>(wa[(ks + 1) & 1][m], wb, (4 * w + m) * 8 + ks + 1, lane);
-                }
-                const f16x8 bx = dec_get8c(in, S, 32 * ks + 8 * q, c);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = F16::mfma(wa[ks & 1][m].hi, bx, acc[m]);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = F16::mfma(wa[ks & 1][m].lo, bx, acc[m]);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = dec_pairsum(acc[m]);          // (DPP: outside the divergent store below)
-            if (c == 0) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    f32x4 v = acc[m];
-                    if (bvec) v += *reinterpret_cast<const f32x4*>(bvec + 64 * w + 16 * m + 4 * q);
-                    if (outh) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-                        dec_put4(outh, S, 64 * w + 16 * m + 4 * q, v);
-                    } else {
-                        *reinterpret_cast<f32x4*>(outf + 64 * w + 16 * m + 4 * q) = v;
-                    }
-                }
-            }
-        };
-        for (int step = 0; step < a.n_steps; ++step) {
-            const unsigned tag = (unsigned)step + 1u;
-            f32x4 acc2[2][4];                                     // [k-step of the block][row tile]: 8 independent accumulators
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc2[s2][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            Frag<F16> ws[2][4];                                   // [k-step of the block][row tile]
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) load_a<F16, 3>(ws[s2][m], skb, (4 * w + m) * KSS + s2, lane);
-            for (int l = 0; l < a.n_layers; ++l) {
-                uint16_t* zz = zz0 + (l & 1) * 2 * D;
-                if (tid < D) {
-                    float z;
-                    dec_poll(zg + (size_t)l * D + tid, tag, z, err);
-                    dec_put(zz, D, tid, z);
-                }
-                dec_sync();
-                const int ln = l + 1 < a.n_layers ? l + 1 : l;
-                const f16x8 bz[2] = {dec_get8c(zz, D, 8 * q, c), dec_get8c(zz, D, 32 + 8 * q, c)};
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) acc2[s2][m] = F16::mfma(ws[s2][m].hi, bz[s2], acc2[s2][m]);
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) acc2[s2][m] = F16::mfma(ws[s2][m].lo, bz[s2], acc2[s2][m]);
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) load_a<F16, 3>(ws[s2][m], skb, (4 * w + m) * KSS + 2 * ln + s2, lane);      // next block (unconditional)
-            }
-            f32x4 ssum[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) ssum[m] = dec_pairsum(acc2[0][m] + acc2[1][m]);
-            if (c == 0) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    f32x4 v = ssum[m];
-                    if (BIAS && a.b_layers) v += *reinterpret_cast<const f32x4*>(bsk + 64 * w + 16 * m + 4 * q);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-                    dec_put4(skip, S, 64 * w + 16 * m + 4 * q, v);
-                }
-            }
-            dec_sync();
-            post(p1b, skip, h1, nullptr, BIAS && a.b_p1 ? bsk + S : nullptr);
-            dec_sync();
-            post(p2b, h1, nullptr, logit, BIAS && a.b_p2 ? bsk + 2 * S : nullptr);
-            dec_sync();
-            if (tid < 64) {
-                const float ur = a.sample ? dec_uniform(a.seed, (unsigned long long)(a.step0 + step), utt) : 0.f;
-                const int bi = dec_choose(logit, tid, u_probs_out ? u_probs_out + (size_t)step * Q : nullptr, a.inv_temp, a.sample != 0, ur);
-                if (tid == 0) {
-                    u_codes_out[step] = bi;
-                    __hip_atomic_store(cg, dec_pack((float)bi, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            dec_sync();
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1299,385 +619,30 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Pipelined decoder for 1..8 utterances (R = D = 64, S = Q = 256, no biases): THE WEIGHTS NEVER MOVE.
-//
-// The two-workgroup kernels above stream every block's weights from L2 for every sample (2.4 MB through one CU for the
-// chain alone) and that stream - ~50 GB/s into a single CU - is what bounds them at ~2 us per block.  Here an utterance
-// is served by  ceil(n_layers / 2) + 2  workgroups that each load their weight fragments into registers ONCE:
-//   stage k   blocks 2k and 2k+1: the f / g and dense fragments (160 registers per lane) and the two blocks' columns of the
-//             skip product (128 more); stage 0 also runs the causal layer.  Per sample: take x from stage k-1, run the two
-//             blocks, hand x to stage k+1, then - off the critical path - add the two blocks' skip contributions to the
-//             partial skip sum received from stage k-1 and pass that on as well;
-//   post 1    relu(skip) -> post_process_1 -> relu        (256 registers of fragments)
-//   post 2    post_process_2 -> softmax / choice -> code  (256 registers), the code goes back to stage 0.
-// Hand-offs are the tagged 8-byte granules of the two-workgroup kernel (value | sample tag, one relaxed agent-scope
-// store, polled by the consumer); every buffer is written once per sample, and sample t+1 cannot start before post 2
-// has consumed all of sample t, so no buffer needs a second slot.  Each lane stores / polls ONE element (all 16 columns
-// of these matrix-vector products are equal, so lane c picks row element c of the 16 its quad-row holds).
-// Workgroup i runs on XCD i % 8: the launch is 8 x (stages + 2) workgroups and utterance u uses those with i % 8 == u,
-// so that all hand-offs of an utterance stay inside one XCD's L2; the others exit at once.
-#ifdef DEC_TL
-__device__ unsigned long long dec_tl[32 * 8];
-extern "C" int wn_dec_tl_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dec_tl), sizeof(unsigned long long) * 256); }
-#define DTL(j) do { if (step == 1000 && tid == 0) dec_tl[idx * 8 + (j)] = wall_clock64(); if ((j) == 0 && tid == 0 && (step == 2000 || step == 12000)) { dec_tl[idx * 8 + 6 + (step == 12000)] = wall_clock64(); dec_tl[(17 + idx % 8) * 8 + (step == 12000) + 2 * (idx / 8)] = clock64(); } } while (0)
-#else
-#define DTL(j)
-#endif
-constexpr int DP_XCDS = 8;
-__attribute__((visibility("hidden"))) long wn_decode_pipe_granules(int n_layers, int D, int S) {
-    const long nc = (n_layers + 1) / 2;
-    return nc * (D + S) + S + 2;          // x hand-offs, partial skip sums, h1, code, error flag
-}
-// Poll this lane's granule, lane 0 of the wave first: while a hand-off has not arrived only ONE lane per wave keeps
-// asking (up to 17 workgroups x 256 lanes spinning on agent-scope loads slow every hand-off down several times over -
-// two idle workgroups ping-pong a flag in ~0.5 us one way, tools/micro/handoff.hip); once lane 0 has its value the others'
-// are there or a poll away (the stores were issued together).
-__device__ __forceinline__ void dec_poll_w(const unsigned long long* p, unsigned tag, float& v, unsigned long long* err, int lane) {
-    if (lane == 0) dec_poll(p, tag, v, err);
-    dec_poll(p, tag, v, err);
-}
-// element (m = c >> 2, i = c & 3) of four accumulators
-__device__ __forceinline__ float dec_pick16(const f32x4 (&v)[4], int c) {
-    const int m = c >> 2, i = c & 3;
-    const f32x4 r = m == 0 ? v[0] : m == 1 ? v[1] : m == 2 ? v[2] : v[3];
-    return i == 0 ? r[0] : i == 1 ? r[1] : i == 2 ? r[2] : r[3];
-}
-__device__ __forceinline__ void dec_send(unsigned long long* p, float v, unsigned tag) {
-    __hip_atomic_store(p, dec_pack(v, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(DEC_MT) void decode_pipe_k(WnDecodeArgs a) {
-    const int xcd = blockIdx.x % DP_XCDS, idx = blockIdx.x / DP_XCDS;
-    if (xcd >= (a.n_utt > 0 ? a.n_utt : 1)) return;
-    const size_t utt = xcd;
-    constexpr int R = 64, D = 64, S = 256, Q = 256;
-    float* const u_queues = a.queues + utt * a.queues_ustride;
-    const int32_t* const u_forced = a.forced ? a.forced + utt * a.n_steps : nullptr;
-    int32_t* const u_codes_out = a.codes_out + utt * a.n_steps;
-    float* const u_probs_out = a.probs_out ? a.probs_out + utt * (size_t)a.n_steps * Q : nullptr;
-    unsigned long long* const u_sync = a.sync + utt * (size_t)a.sync_ustride;
-    const int NC = (a.n_layers + 1) >> 1;
-    unsigned long long* const xg = u_sync;                       // [NC][D]  x leaving stage k
-    unsigned long long* const sg = xg + (size_t)NC * D;          // [NC][S]  partial skip sum after stage k
-    unsigned long long* const hg = sg + (size_t)NC * S;          // [S]      relu(post_process_1)
-    unsigned long long* const cg = u_sync + (size_t)a.sync_ustride - 2;
-    unsigned long long* const err = cg + 1;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ int s_arg;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, q = lane >> 4;
-
-    if (idx < NC) {
-        // ------------------------------------------------------------------ stage k: blocks l0 (set A) and l0 + 1 (set B)
-        const int k = idx, l0 = 2 * k;
-        const bool two = l0 + 1 < a.n_layers, more = k + 1 < NC;
-        const int l1 = two ? l0 + 1 : l0;
-        float* prev = sm;                         // [Q]   (stage 0)
-        float* note = prev + Q;                   // [Q]
-        float* xa = note + Q;                     // [R]   block A input (the residual term)
-        float* xb = xa + R;                       // [R]   block B input
-        float* oldb1 = xb + R;                    // [R]   queue column of block B
-        float* pushb = oldb1 + R;                 // [2][R] what the two queues take in
-        uint16_t* cha = reinterpret_cast<uint16_t*>(pushb + 2 * R);   // [hi 2R | lo 2R]: x | queue column, block A
-        uint16_t* chb = cha + 4 * R;              //                       block B
-        uint16_t* zd = chb + 4 * R;               // [2][hi D | lo D] z in the chained k order of the dense fragments
-        uint16_t* zn = zd + 4 * D;                // [2][hi D | lo D] z in natural order (skip fragments)
-        const int KSS = a.n_layers * D / 32;
-        Frag<F16> wfA[4], wgA[4], wdA[2], wfB[4], wgB[4], wdB[2], wsA[2][4], wsB[2][4];
-        {
-            const uint16_t* fa = a.pk + a.pk_fg0 + (size_t)l0 * a.pk_lstride;
-            const uint16_t* fb = a.pk + a.pk_fg0 + (size_t)l1 * a.pk_lstride;
-            const uint16_t* da = a.pk + a.pk_d0 + (size_t)l0 * a.pk_lstride;
-            const uint16_t* db = a.pk + a.pk_d0 + (size_t)l1 * a.pk_lstride;
-            const uint16_t* skb = a.pk + a.pk_skip;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                load_a<F16, 3>(wfA[s2], fa, w * 4 + s2, lane);
-                load_a<F16, 3>(wgA[s2], fa, (4 + w) * 4 + s2, lane);
-                load_a<F16, 3>(wfB[s2], fb, w * 4 + s2, lane);
-                load_a<F16, 3>(wgB[s2], fb, (4 + w) * 4 + s2, lane);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                load_a<F16, 3>(wdA[s2], da, w * 2 + s2, lane);
-                load_a<F16, 3>(wdB[s2], db, w * 2 + s2, lane);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    load_a<F16, 3>(wsA[s2][m], skb, (4 * w + m) * KSS + 2 * l0 + s2, lane);
-                    load_a<F16, 3>(wsB[s2][m], skb, (4 * w + m) * KSS + 2 * l1 + s2, lane);
-                }
-            }
-        }
-        if (k == 0) {
-            const float* u_note0 = a.note0 + utt * Q;
-            const float* u_prev0 = a.prev0 + utt * Q;
-            note[tid] = u_note0[tid]; prev[tid] = u_prev0[tid];
-        }
-        const int dilA = a.dil[l0], dilB = a.dil[l1];
-        int slotA = (int)(a.step0 % dilA), slotB = (int)(a.step0 % dilB);
-        int pcode = -1, ncode = -1;
-        const int qb = tid >> 6, r = tid & 63;                  // queue element this thread loads and stores (tid < 2R)
-        const bool qmine = qb == 0 || (qb == 1 && two);
-        float* const qbase = u_queues + a.q_off[qb == 1 ? l1 : l0] + r;
-        dec_sync();
-
-        // one block: B operands = [queue column | x] halfs in `ch`, gate, dense + residual; returns the new x (rows
-        // 16w + 4q .. +3 in every lane) and leaves z of the block in zd / zn
-        auto blk = [&](const uint16_t* ch, uint16_t* zdb, uint16_t* znb, const float* xin, const Frag<F16> (&wf)[4],
-                       const Frag<F16> (&wg)[4], const Frag<F16> (&wd2)[2]) -> f32x4 {
-            Frag<F16> bx[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dec_get8(ch, 2 * R, (ks < 2 ? R + 32 * ks : 32 * (ks - 2)) + 8 * q, bx[ks]);
-            f32x4 pf[4], pg[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { pf[ks] = f32x4{0.f, 0.f, 0.f, 0.f}; pg[ks] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    dec_term(pf[ks], wf[ks], bx[ks], t);
-                    dec_term(pg[ks], wg[ks], bx[ks], t);
-                }
-            const f32x4 af = (pf[0] + pf[1]) + (pf[2] + pf[3]), ag = (pg[0] + pg[1]) + (pg[2] + pg[3]);
-            const float z1 = wn_tanh(dec_pick4(af, c & 3)) * wn_sigmoid(dec_pick4(ag, c & 3));
-            if (c < 4) {          // z[16w + 4q + c]
-                dec_put(zdb, D, 32 * (w >> 1) + 8 * q + 4 * (w & 1) + c, z1);
-                dec_put(znb, D, 16 * w + 4 * q + c, z1);
-            }
-            dec_sync();
-            Frag<F16> bz[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) dec_get8(zdb, D, 32 * s2 + 8 * q, bz[s2]);
-            f32x4 pd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int t = 0; t < 3; ++t) { dec_term(pd[0], wd2[0], bz[0], t); dec_term(pd[1], wd2[1], bz[1], t); }
-            const f32x4 xc = *reinterpret_cast<const f32x4*>(xin + 16 * w + 4 * q);
-            return (pd[0] + pd[1]) + xc;
-        };
-
-        for (int step = 0; step < a.n_steps; ++step) {
-            const unsigned tag = (unsigned)step + 1u;
-            DTL(0);
-            float qv = 0.f;
-            if (qmine) qv = __hip_atomic_load(qbase + (size_t)(qb == 1 ? slotB : slotA) * R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k == 0) {     // causal layer: x0 = Wc[:, tap0] prev + Wc[:, tap1] note ; a one-hot column is a gather
-                const int o = tid >> 2, p4 = tid & 3;
-                const float* wrow = a.w_causal + (size_t)o * 2 * Q;
-                float s = 0.f;
-                if (pcode >= 0) { if (p4 == 0) s += wrow[pcode]; }
-                else for (int kk = p4 * (Q / 4); kk < (p4 + 1) * (Q / 4); ++kk) s = fmaf(wrow[kk], prev[kk], s);
-                if (ncode >= 0) { if (p4 == 0) s += wrow[Q + ncode]; }
-                else for (int kk = p4 * (Q / 4); kk < (p4 + 1) * (Q / 4); ++kk) s = fmaf(wrow[Q + kk], note[kk], s);
-                s += __shfl_xor(s, 1, 64);
-                s += __shfl_xor(s, 2, 64);
-                if (p4 == 0) { xa[o] = s; dec_put(cha, 2 * R, o, s); }
-            } else if (tid < R) {
-                float v;
-                dec_poll_w(xg + (size_t)(k - 1) * D + tid, tag, v, err, lane);
-                xa[tid] = v;
-                dec_put(cha, 2 * R, tid, v);
-            }
-            if (qb == 0) dec_put(cha, 2 * R, R + r, qv);
-            else if (qb == 1) oldb1[r] = qv;
-            DTL(1);
-            dec_sync();
-            const f32x4 va = blk(cha, zd, zn, xa, wfA, wgA, wdA);
-            DTL(2);
-            if (c == 0) {
-                const f32x4 xc = *reinterpret_cast<const f32x4*>(xa + 16 * w + 4 * q);
-                *reinterpret_cast<f32x4*>(pushb + 16 * w + 4 * q) = a.push_input ? xc : va;       // Q5: output by default
-                if (two) {
-                    *reinterpret_cast<f32x4*>(xb + 16 * w + 4 * q) = va;
-                    dec_put4(chb, 2 * R, 16 * w + 4 * q, va);
-                }
-            }
-            f32x4 acc2[2][4];
-            if (two) {
-                if (tid < R) dec_put(chb, 2 * R, R + tid, oldb1[tid]);
-                dec_sync();
-                const f32x4 vb = blk(chb, zd + 2 * D, zn + 2 * D, xb, wfB, wgB, wdB);
-                if (more && c < 4) dec_send(xg + (size_t)k * D + 16 * w + 4 * q + c, dec_pick4(vb, c), tag);
-                DTL(3);
-                if (c == 0) {
-                    const f32x4 xc = *reinterpret_cast<const f32x4*>(xb + 16 * w + 4 * q);
-                    *reinterpret_cast<f32x4*>(pushb + R + 16 * w + 4 * q) = a.push_input ? xc : vb;
-                }
-            }
-            // ---- off the critical path: the two blocks' part of the skip sum, added to what the earlier stages sent
-            {
-                Frag<F16> bzA[2], bzB[2];
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) { dec_get8(zn, D, 32 * s2 + 8 * q, bzA[s2]); dec_get8(zn + 2 * D, D, 32 * s2 + 8 * q, bzB[s2]); }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) acc2[s2][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) dec_term(acc2[s2][m], wsA[s2][m], bzA[s2], t);
-                if (two) {
-#pragma unroll
-                    for (int t = 0; t < 3; ++t)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) dec_term(acc2[s2][m], wsB[s2][m], bzB[s2], t);
-                }
-                f32x4 sum[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) sum[m] = acc2[0][m] + acc2[1][m];
-                float v = dec_pick16(sum, c);
-                const int row = 64 * w + 16 * (c >> 2) + 4 * q + (c & 3);
-                if (k > 0) {
-                    float pv;
-                    dec_poll_w(sg + (size_t)(k - 1) * S + row, tag, pv, err, lane);
-                    v = pv + v;
-                }
-                DTL(4);
-                dec_send(sg + (size_t)k * S + row, v, tag);
-            }
-            DTL(5);
-            dec_sync();                             // pushb complete
-            if (qmine) qbase[(size_t)(qb == 1 ? slotB : slotA) * R] = pushb[qb * R + r];
-            slotA = slotA + 1 == dilA ? 0 : slotA + 1;
-            slotB = slotB + 1 == dilB ? 0 : slotB + 1;
-            if (k == 0) {
-                if (tid == 0) {
-                    float cv = 0.f;
-                    dec_poll(cg, tag, cv, err);
-                    s_arg = (int)cv;
-                }
-                __syncthreads();
-                const int nextc = u_forced ? u_forced[step] : s_arg;
-                prev[tid] = note[tid];
-                pcode = ncode;
-                ncode = nextc;
-                dec_sync();
-                note[tid] = (tid == nextc) ? 1.0f : 0.0f;
-            }
-            dec_sync();
-        }
-        if (k == 0) { a.prev_out[utt * Q + tid] = prev[tid]; a.note_out[utt * Q + tid] = note[tid]; }
-    } else {
-        // ------------------------------------------------------------------ post 1 (idx == NC) and post 2 (idx == NC + 1)
-        const bool last = idx == NC + 1;
-        uint16_t* sv = reinterpret_cast<uint16_t*>(sm);     // [hi S | lo S] input vector halfs
-        float* logit = sm + S;                              // [Q]
-        const uint16_t* wb = a.pk + (last ? a.pk_p2 : a.pk_p1);
-        const unsigned long long* in = last ? hg : sg + (size_t)(NC - 1) * S;
-        Frag<F16> wa[8][4];
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) load_a<F16, 3>(wa[ks][m], wb, (4 * w + m) * 8 + ks, lane);
-        for (int step = 0; step < a.n_steps; ++step) {
-            const unsigned tag = (unsigned)step + 1u;
-            {
-                float v;
-                dec_poll_w(in + tid, tag, v, err, lane);
-                dec_put(sv, S, tid, fmaxf(v, 0.f));          // relu(skip) ; h1 arrives >= 0 already
-            }
-            DTL(1);
-            dec_sync();
-            f32x4 acc[2][4];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[s2][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                Frag<F16> bx;
-                dec_get8(sv, S, 32 * ks + 8 * q, bx);
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) dec_term(acc[ks & 1][m], wa[ks][m], bx, t);
-            }
-            f32x4 sum[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) sum[m] = acc[0][m] + acc[1][m];
-            const float v = dec_pick16(sum, c);
-            const int row = 64 * w + 16 * (c >> 2) + 4 * q + (c & 3);
-            DTL(3);
-            if (!last) {
-                dec_send(hg + row, fmaxf(v, 0.f), tag);
-            } else {
-                logit[row] = v;
-                dec_sync();
-                if (tid < 64) {
-                    const float ur = a.sample ? dec_uniform(a.seed, (unsigned long long)(a.step0 + step), utt) : 0.f;
-                    const int bi = dec_choose(logit, tid, u_probs_out ? u_probs_out + (size_t)step * Q : nullptr, a.inv_temp, a.sample != 0, ur);
-                    if (tid == 0) {
-                        u_codes_out[step] = bi;
-                        dec_send(cg, (float)bi, tag);
-                    }
-                }
-            }
-            DTL(5);
-            dec_sync();
-        }
-    }
-}
-
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
     if (a.n_steps <= 0) return 0;
     if (a.n_layers > WN_DEC_MAX_LAYERS) return wn_set_error_msg(-4, "decode: too many layers");
     const int nu = a.n_utt > 0 ? a.n_utt : 1;
-    // the two workgroups of an utterance spin on each other's hand-offs, so every pair must be resident
-    // at once: one workgroup per CU -> at most 128 utterances per launch on this part
-    // (the matrix-core form puts eight utterances on a pair when their number is a multiple of 8: at most 1024 then)
-    // WN_DEC_U8: 1 (default) = the eight-per-pair kernel for every launch of the matrix-core path (a single utterance too: the spare
-    // columns mirror it - 21.9 k samples/s against 20.8 k for the one-per-pair kernel; 2.78 M against 2.55 M at 128), 0 = one per pair
-    const char* u8_env = getenv("WN_DEC_U8");
-    const int u8_on = u8_env ? atoi(u8_env) : 1;
+    // Matrix-core pair of workgroups (64 / 64 / 256 / 256 channels, with or without biases; the API layer only hands `pk`
+    // over at those shapes): eight utterances per pair, a launch with fewer mirrors the last one into the spare columns.
+    // The two workgroups of a pair spin on each other's hand-offs, so every pair must be resident at once: 128 pairs =
+    // 1024 utterances per launch.  Everything else (other channel counts, fewer than 4 steps) runs on decode_k: one
+    // workgroup per utterance, fp32 FMA.
     const bool any_bias = a.b_layers || a.b_causal || a.b_p1 || a.b_p2;
-    const bool u8 = u8_on && a.pk && a.pk_skip >= 0 && nu <= 1024 && a.sync && a.n_steps >= 4 && !(a.dbg & 31);
-    if (nu > 128 && !u8) return wn_set_error_msg(-4, "decode: at most 128 utterances per launch (1024 on the matrix-core path)");
-    // the float4 kernel needs: no biases, one pass per product, exactly 16 / 4 / 16 weights per thread for
-    // the per-block products and a multiple of 16 for the streamed ones
-    auto nw = [](int M, int K) {
-        int parts = DEC_THREADS / M; if (parts < 1) parts = 1; if (parts > 64) parts = 64;
-        while (parts & (parts - 1)) parts &= parts - 1;
-        return (K % parts) ? -1 : K / parts;
-    };
-    const bool v4 = !a.b_layers && !a.b_causal && !a.b_p1 && !a.b_p2 &&
-                    2 * a.D <= DEC_THREADS && a.S <= DEC_THREADS && a.Q <= DEC_THREADS && a.R <= DEC_THREADS &&
-                    nw(2 * a.D, 2 * a.R) == 16 && nw(a.R, a.D) == 4 && nw(a.S, a.D) == 16 &&
-                    nw(a.R, 2 * a.Q) > 0 && nw(a.R, 2 * a.Q) % 16 == 0 && nw(a.S, a.S) > 0 && nw(a.S, a.S) % 16 == 0 &&
-                    nw(a.Q, a.S) > 0 && nw(a.Q, a.S) % 16 == 0 && (a.layer_stride % 4) == 0;
-    const bool mf = a.pk && a.pk_skip >= 0;         // matrix-core pair of workgroups (biases allowed)
-    if ((v4 || mf) && a.sync && a.n_steps >= 4 && !(a.dbg & 31)) {
+    const bool mf = a.pk && a.pk_skip >= 0 && a.sync && a.n_steps >= 4 && !(a.dbg & 31);
+    if (nu > (mf ? 1024 : 128)) return wn_set_error_msg(-4, "decode: at most 128 utterances per launch (1024 on the matrix-core path)");
+    if (mf) {
         const size_t nsync = (size_t)a.sync_ustride * sizeof(unsigned long long) * (size_t)nu;
         hipError_t e = hipMemsetAsync(a.sync, 0, nsync, st);              // tags start at 1
         if (e != hipSuccess) return wn_set_error(e, __FILE__, __LINE__);
-        size_t sh0 = sizeof(float) * (size_t)(2 * a.Q + 4 * a.R + 3 * a.D + 2 * a.n_layers * a.R + (a.b_layers ? a.n_layers * (2 * a.D + a.R) : 0)) + sizeof(uint16_t) * (size_t)(8 * a.R + 2 * a.D);
-        size_t sh1 = sizeof(float) * (size_t)(2 * a.D + 2 * a.S + a.Q + 2 * a.S + a.Q);
-        static const int pipe_on = [] { const char* e = getenv("WN_DEC_PIPE"); return e ? atoi(e) : 0; }();
-        const int nc = (a.n_layers + 1) / 2;
-        if (mf && pipe_on && !a.b_layers && !a.b_causal && !a.b_p1 && !a.b_p2 && nu <= DP_XCDS && a.sync_ustride >= wn_decode_pipe_granules(a.n_layers, a.D, a.S)) {
-            const size_t shp = sizeof(float) * (size_t)(2 * a.Q + 5 * a.R) + sizeof(uint16_t) * (size_t)(8 * a.R + 8 * a.D);
-            if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] pipeline: %d utterances x %d workgroups, %d steps\n", nu, nc + 2, a.n_steps);
-            hipLaunchKernelGGL(decode_pipe_k, dim3(DP_XCDS * (nc + 2)), dim3(DEC_MT), shp, st, a);
-        } else if (mf && u8) {
-            // eight utterances per workgroup pair
-            const size_t s80 = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R + (a.b_layers ? a.n_layers * (2 * a.D + a.R) : 0)) +
-                               sizeof(uint16_t) * (size_t)(8 * 136 * (3 + (size_t)a.n_layers));
-            const size_t s81 = sizeof(uint16_t) * (size_t)(2 * 8 * 136 + 2 * 8 * 648) + sizeof(float) * (size_t)(8 * a.Q + 2 * a.S + a.Q);
-            if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pairs x 8 utterances: %d utterances, %d steps, biases %d\n", nu, a.n_steps, any_bias ? 1 : 0);
-            if (any_bias) hipLaunchKernelGGL(decode_duo_mfma8_k<true>, dim3(2 * ((nu + 7) / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
-            else hipLaunchKernelGGL(decode_duo_mfma8_k<false>, dim3(2 * ((nu + 7) / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
-        } else if (mf) {
-            if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pair of workgroups: %d utterances, %d steps, biases %d\n", nu, a.n_steps, a.b_layers ? 1 : 0);
-            if (a.b_layers || a.b_causal || a.b_p1 || a.b_p2) hipLaunchKernelGGL(decode_duo_mfma_k<true>, dim3(2 * nu), dim3(DEC_MT), sh0 > sh1 ? sh0 : sh1, st, a);
-            else hipLaunchKernelGGL(decode_duo_mfma_k<false>, dim3(2 * nu), dim3(DEC_MT), sh0 > sh1 ? sh0 : sh1, st, a);
-        } else hipLaunchKernelGGL(decode_duo_k, dim3(2 * nu), dim3(DEC_THREADS), sh0 > sh1 ? sh0 : sh1, st, a);
-    } else if (v4) {
-        size_t sh = sizeof(float) * (size_t)(3 * a.Q + 4 * a.R + 3 * a.D + 2 * a.S);
-        hipLaunchKernelGGL(decode_v4_k, dim3(nu), dim3(DEC_THREADS), sh, st, a);
+        const size_t s80 = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R + (a.b_layers ? a.n_layers * (2 * a.D + a.R) : 0)) +
+                           sizeof(uint16_t) * (size_t)(8 * 136 * (3 + (size_t)a.n_layers));
+        const size_t s81 = sizeof(uint16_t) * (size_t)(2 * 8 * 136 + 2 * 8 * 648) + sizeof(float) * (size_t)(8 * a.Q + 2 * a.S + a.Q);
+        if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pairs x 8 utterances: %d utterances, %d steps, biases %d\n", nu, a.n_steps, any_bias ? 1 : 0);
+        if (any_bias) hipLaunchKernelGGL(decode_duo_mfma8_k<true>, dim3(2 * ((nu + 7) / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
+        else hipLaunchKernelGGL(decode_duo_mfma8_k<false>, dim3(2 * ((nu + 7) / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
     } else {
+        if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] generic fp32 kernel: %d utterances, %d steps\n", nu, a.n_steps);
         size_t sh = sizeof(float) * (size_t)(3 * a.Q + 3 * a.R + 3 * a.D + 2 * a.S + 64);
         hipLaunchKernelGGL(decode_k, dim3(nu), dim3(DEC_THREADS), sh, st, a);
     }

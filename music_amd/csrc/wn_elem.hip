@@ -288,27 +288,6 @@ int wn_launch_avgpool(const float* in, long in_bstride, int in_pitch, int t0, in
     return 0;
 }
 
-// out[b][r][t] = P[b][r][t] (t >= p_lo) + Q[b][r][t + dn] (t + dn < t_hi)   for t in [t_lo, t_hi):
-// materialises a data gradient that the fused backward keeps as an unshifted (P, Q) pair.
-__global__ void shift_add_k(const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ out,
-                            long bstride, int pitch, int rows, int dn, int p_lo, int t_lo, int t_hi) {
-    const int t = t_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y, b = blockIdx.z;
-    if (t >= t_hi) return;
-    const size_t o = (size_t)b * bstride + (size_t)r * pitch;
-    float v = (t >= p_lo) ? p[o + t] : 0.f;
-    if (t + dn < t_hi) v += q[o + t + dn];
-    out[o + t] = v;
-}
-int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride, int pitch, int rows, int dn,
-                        int p_lo, int t_lo, int t_hi, int batch, hipStream_t st) {
-    if (t_hi <= t_lo || rows <= 0 || batch <= 0) return 0;
-    hipLaunchKernelGGL(shift_add_k, dim3((t_hi - t_lo + 255) / 256, rows, batch), dim3(256), 0, st, p, q, out, bstride,
-                       pitch, rows, dn, p_lo, t_lo, t_hi);
-    WN_CHECK_LAUNCH();
-    return 0;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Gradient w.r.t. the autoencoder's conditioning table (model1.py:227-247): bucket sums of a row
 // over time.  One workgroup (4 waves) per (row, clip).  No float atomics: every partial sum has a

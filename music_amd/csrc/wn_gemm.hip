@@ -218,154 +218,6 @@ __global__ __launch_bounds__(512) void chan_gemm_k(WnGemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wide variant with the packed weights of each k-step staged through LDS: the 16 row tiles of a
-// k-step (32 KB in the x3 modes) are fetched from L2 ONCE per workgroup (cooperatively, one k-step
-// ahead, double-buffered) instead of once per wave, and every wave reads its 8 fragments with
-// ds_read_b128.  256 rows x 256 columns per workgroup, 8 waves = 2 (rows) x 4 (columns).
-// ---------------------------------------------------------------------------------------------
-template <class T, int NS>
-__global__ __launch_bounds__(512) void chan_gemm_wide_lds_k(WnGemmArgs a) {
-    constexpr int MTW = 8, WM = 2, WN = 4;
-    constexpr int FR = (NS == 3 ? 1024 : 512);               // halfs per fragment
-    constexpr int STEP_VEC = 16 * FR / 8;                     // u32x4 per k-step (16 row tiles)
-    __shared__ __attribute__((aligned(16))) uint16_t l_a[2][16 * FR];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, q = lane >> 4;
-    // row groups that read the same 256 columns run next to each other on one XCD
-    const WnBlock blk = wn_block<true>(a.swz);
-    const int b = blk.z;
-    const int wm = wave / WN, wn = wave % WN;
-    const int t0 = a.t_base + (blk.x * WN + wn) * 64;
-    const int tl = t0 + 4 * c;
-    const int mg0 = blk.y * 16;                                // first M-tile of the workgroup
-    const int m0 = mg0 + wm * MTW;                             // first M-tile of this wave
-    const int KS = a.ks0 + a.ks1;
-
-    f32x4 acc[MTW][4];
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) {
-        f32x4 init = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias != nullptr) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int row = (m0 + m) * 16 + 4 * q + i;
-                init[i] = row < a.m_valid ? a.bias[row] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = init;
-    }
-    const float* in0 = a.in0 + (size_t)b * a.in_bstride;
-    const float* in1 = a.in1 ? a.in1 + (size_t)b * a.in_bstride : nullptr;
-    const int col0 = tl + a.shift0, col1 = tl + a.shift1;
-    f32x4 raw[8];
-    auto issue = [&](int s) {
-        const float* base; int col; int ch;
-        if (s < a.ks0) { base = in0; col = col0; ch = s * 32; }
-        else { base = in1; col = col1; ch = (s - a.ks0) * 32; }
-        const float* p = base + (size_t)(ch + 8 * q) * a.in_pitch + col;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = ld4g(p + (size_t)j * a.in_pitch, col, a.in_lo, a.in_hi);
-    };
-    // weight staging: tile (mg0 + mt) of k-step s lives at fragment index (mg0 + mt) * KS + s
-    constexpr int PER_THREAD = (STEP_VEC + 511) / 512;
-    u32x4 wreg[PER_THREAD];
-    auto wload = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            int v = threadIdx.x + i * 512;                     // u32x4 index inside the k-step image
-            int mt = v / (FR / 8), r = v % (FR / 8);
-            u32x4 z = {0u, 0u, 0u, 0u};
-            if (v < STEP_VEC && mg0 + mt < a.mt)
-                z = reinterpret_cast<const u32x4*>(a.wpack)[((size_t)(mg0 + mt) * KS + s) * (FR / 8) + r];
-            wreg[i] = z;
-        }
-    };
-    auto wstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            int v = threadIdx.x + i * 512;
-            if (v < STEP_VEC) reinterpret_cast<u32x4*>(l_a[buf])[v] = wreg[i];
-        }
-    };
-    issue(0);
-    wload(0);
-    wstore(0);
-    __syncthreads();
-    for (int s = 0; s < KS; ++s) {
-        Frag<T> bf[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float x = raw[j][n];
-                v[j] = a.relu_in ? fmaxf(x, 0.f) : x;
-            }
-            split8<T, NS>(bf[n], v);
-        }
-        if (s + 1 < KS) { issue(s + 1); wload(s + 1); }
-        const uint16_t* la = l_a[s & 1];
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            Frag<T> af;
-            load_a<T, NS>(af, la, wm * MTW + m, lane);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
-        }
-        if (s + 1 < KS) wstore((s + 1) & 1);
-        __syncthreads();
-    }
-    if (t0 >= a.t_hi || m0 >= a.mt) return;
-
-    float* out = a.out + (size_t)b * a.out_bstride;
-    const float* resid = a.resid ? a.resid + (size_t)b * a.resid_bstride : nullptr;
-    const float* mask = a.mask ? a.mask + (size_t)b * a.mask_bstride : nullptr;
-    const bool full = tl >= a.t_lo && tl + 3 < a.t_hi;
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) {
-        if (m0 + m >= a.mt) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int row = (m0 + m) * 16 + 4 * q + i;
-            if (row >= a.m_valid) continue;
-            f32x4 v = {acc[m][0][i], acc[m][1][i], acc[m][2][i], acc[m][3][i]};
-            if (mask) {
-                const float* mp = mask + (size_t)row * a.mask_pitch + tl;
-                if (full) {
-                    f32x4 mv = ld4u(mp);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (tl + e >= a.t_lo && tl + e < a.t_hi) v[e] = mp[e] > 0.f ? v[e] : 0.f;
-                }
-            }
-            if (resid) {
-                const float* rp = resid + (size_t)row * a.resid_pitch + tl;
-                if (full && tl >= a.resid_lo) {
-                    v += ld4u(rp);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (tl + e >= a.resid_lo && tl + e >= a.t_lo && tl + e < a.t_hi) v[e] += rp[e];
-                }
-            }
-            float* op = out + (size_t)row * a.out_pitch + tl + a.out_shift;
-            if (full) {
-                F4U u = {{v[0], v[1], v[2], v[3]}};
-                *reinterpret_cast<F4U*>(op) = u;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (tl + e >= a.t_lo && tl + e < a.t_hi) op[e] = v[e];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Wide variant 2: BOTH operands of a k-step are shared through LDS as ready-to-use 16-bit hi/lo
 // fragments.  Each activation element is fetched from HBM and split ONCE per workgroup (every wave
 // converts 1/8 of the 32 x 256 k-step slab: 4 float4 per lane) instead of once per row-half wave,
@@ -564,206 +416,6 @@ __global__ __launch_bounds__(512) void chan_gemm_wide2_k(WnGemmArgs a) {
 // 32 x 32, 48 MFMAs per k-step instead of 96.
 // ---------------------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(4))) G2U { float v[2]; };   // 8-B load / store, 4-B aligned
-template <class T>
-__global__ __launch_bounds__(512) void chan_gemm_wide3_k(WnGemmArgs a) {
-    constexpr int NS = 3;
-    constexpr int MTW = 8, WN = 4;
-    constexpr int FR = (NS == 3 ? 1024 : 512);               // halfs per fragment
-    constexpr int FRV = FR / 8;                               // u32x4 per fragment
-    constexpr int STAGE = 32 * FR;                            // halfs per stage: 16 A then 16 B fragments
-    constexpr int PER_A = 16 * FRV / 512;                     // u32x4 of the A image per thread
-    extern __shared__ __attribute__((aligned(16))) uint16_t l_s[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, q = lane >> 4;
-    const WnBlock blk = wn_block<true>(a.swz);
-    const int b = blk.z;
-    const int wm = wave / WN, wn = wave % WN;
-    const int tile0 = a.t_base + blk.x * 256;
-    const int t0 = tile0 + wn * 64;
-    const int tl = t0 + 4 * c;
-    const int mg0 = blk.y * 16;
-    const int m0 = mg0 + wm * MTW;
-    const int KS = a.ks0 + a.ks1;
-
-    // 32x32x16 view of the same LDS fragments: lane = (c3, h3, kh) -> row / column c3 + 16 h3 of a 32-tile, k half kh.
-    // Row tile M of the wave = the 16-row fragments 2M and 2M + 1 (h3 picks one); column tile v = the wave's B fragments
-    // 2 h3 + v, i.e. the lane's two ADJACENT columns tl2, tl2 + 1; result register i: row 8 (i / 4) + 4 kh + i % 4.
-    const int c3 = lane & 15, h3 = (lane >> 4) & 1, kh = lane >> 5;
-    const int tl2 = t0 + 4 * c3 + 2 * h3;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int M = 0; M < 4; ++M) {
-        f32x16 init;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (m0 + 2 * M) * 16 + 8 * (i >> 2) + 4 * kh + (i & 3);
-            init[i] = (a.bias != nullptr && row < a.m_valid) ? a.bias[row] : 0.f;
-        }
-        acc[M][0] = init;
-        acc[M][1] = init;
-    }
-    // loader role of this wave for the activations: column group lg, row half lh of every k-step
-    const int lg = wave & 3, lh = wave >> 2;
-    const int ltl = tile0 + lg * 64 + 4 * c;
-    const float* in0 = a.in0 + (size_t)b * a.in_bstride;
-    const float* in1 = a.in1 ? a.in1 + (size_t)b * a.in_bstride : nullptr;
-    const int tg0 = tile0 + lg * 64;
-    const bool inner0 = tg0 + a.shift0 >= a.in_lo && tg0 + 64 + a.shift0 <= a.in_hi;
-    const bool inner1 = tg0 + a.shift1 >= a.in_lo && tg0 + 64 + a.shift1 <= a.in_hi;
-    auto load_b = [&](f32x4* raw, int s) {
-        const float* base; int col; int ch; bool inner;
-        if (s < a.ks0) { base = in0; col = ltl + a.shift0; ch = s * 32; inner = inner0; }
-        else { base = in1; col = ltl + a.shift1; ch = (s - a.ks0) * 32; inner = inner1; }
-        const float* p = base + (size_t)(ch + 8 * q + 4 * lh) * a.in_pitch + col;
-        if (inner) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) raw[j] = ld4u(p + (size_t)j * a.in_pitch);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) raw[j] = ld4g(p + (size_t)j * a.in_pitch, col, a.in_lo, a.in_hi);
-        }
-    };
-    // split 4 rows x 4 columns and write the 8-byte hi / lo pieces of the 4 B fragments of group lg
-    auto store_b = [&](const f32x4* raw, int st) {
-        uint16_t* bb = l_s + (size_t)st * STAGE + (size_t)(16 + lg * 4) * FR + lane * 8 + lh * 4;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            typedef typename T::elem elem;
-            elem h[4], l[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x = raw[j][n];
-                if (a.relu_in) x = fmaxf(x, 0.f);
-                h[j] = T::cvt(x);
-                if (NS == 3) l[j] = T::cvt(x - T::back(h[j]));
-            }
-            uint2 hv = {(uint32_t)__builtin_bit_cast(uint16_t, h[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[1]) << 16),
-                        (uint32_t)__builtin_bit_cast(uint16_t, h[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[3]) << 16)};
-            *reinterpret_cast<uint2*>(bb + (size_t)n * FR) = hv;
-            if (NS == 3) {
-                uint2 lv = {(uint32_t)__builtin_bit_cast(uint16_t, l[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, l[1]) << 16),
-                            (uint32_t)__builtin_bit_cast(uint16_t, l[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, l[3]) << 16)};
-                *reinterpret_cast<uint2*>(bb + (size_t)n * FR + 512) = lv;
-            }
-        }
-    };
-    u32x4 wreg[PER_A];
-    auto load_w = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < PER_A; ++i) {
-            int v = threadIdx.x + i * 512;
-            int mt = v / FRV, r = v % FRV;
-            u32x4 z = {0u, 0u, 0u, 0u};
-            if (mg0 + mt < a.mt) z = reinterpret_cast<const u32x4*>(a.wpack)[((size_t)(mg0 + mt) * KS + s) * FRV + r];
-            wreg[i] = z;
-        }
-    };
-    auto store_w = [&](int st) {
-        u32x4* d = reinterpret_cast<u32x4*>(l_s + (size_t)st * STAGE);
-#pragma unroll
-        for (int i = 0; i < PER_A; ++i) d[threadIdx.x + i * 512] = wreg[i];
-    };
-    f32x4 raw0[4], raw1[4];
-    load_w(0);
-    load_b(raw0, 0);
-    if (KS > 1) load_b(raw1, 1);
-    store_w(0);
-    store_b(raw0, 0);
-    if (KS > 1) load_w(1);
-    if (KS > 2) load_b(raw0, 2);
-    __syncthreads();
-    // one k-step: MFMAs on stage s & 1, meanwhile the next stage is filled from the registers whose
-    // loads were issued two k-steps ago, and those registers are re-armed two (A: one) k-steps ahead.
-    // (Tidier forms of this loop - branch-free k-steps, the fill spread over the row tiles, a
-    // duplicated loop for edge waves - all measured SLOWER: 405-418 us against 355 us for the skip
-    // product)
-    auto step = [&](int s, f32x4* rnext) {
-        const uint16_t* la = l_s + (size_t)(s & 1) * STAGE;
-        const uint16_t* lb = la + (size_t)(16 + wn * 4) * FR;
-        typedef typename T::vec8 vec8;
-        const int lo3 = (c3 + 16 * kh) * 8;                  // this lane's 16 bytes inside a fragment for k half 0; k half 1: + 32 lanes
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {                       // k half by k half: 16 registers of B, 8 of A live at a time
-            vec8 bh[2], bl[2];                                 // [column tile v]
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const uint16_t* pb = lb + (size_t)(2 * h3 + v) * FR + lo3 + kk * 256;
-                bh[v] = *reinterpret_cast<const vec8*>(pb);
-                bl[v] = *reinterpret_cast<const vec8*>(pb + 512);
-            }
-#pragma unroll
-            for (int M = 0; M < 4; ++M) {
-                const uint16_t* pa = la + (size_t)(wm * MTW + 2 * M + h3) * FR + lo3 + kk * 256;
-                const vec8 ah = *reinterpret_cast<const vec8*>(pa), al = *reinterpret_cast<const vec8*>(pa + 512);
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    acc[M][v] = T::mfma32(al, bh[v], acc[M][v]);
-                    acc[M][v] = T::mfma32(ah, bl[v], acc[M][v]);
-                    acc[M][v] = T::mfma32(ah, bh[v], acc[M][v]);
-                }
-                if (kk == 0 && M == 3 && s + 1 < KS) {
-                    store_b(rnext, (s + 1) & 1);
-                    store_w((s + 1) & 1);
-                    if (s + 3 < KS) load_b(rnext, s + 3);
-                    if (s + 2 < KS) load_w(s + 2);
-                }
-            }
-        }
-        __syncthreads();
-    };
-    for (int s = 0; s < KS; s += 2) {
-        step(s, raw1);
-        if (s + 1 < KS) step(s + 1, raw0);
-    }
-    if (t0 >= a.t_hi || m0 >= a.mt) return;
-
-    float* out = a.out + (size_t)b * a.out_bstride;
-    const float* resid = a.resid ? a.resid + (size_t)b * a.resid_bstride : nullptr;
-    const float* mask = a.mask ? a.mask + (size_t)b * a.mask_bstride : nullptr;
-    const bool full = tl2 >= a.t_lo && tl2 + 1 < a.t_hi;
-#pragma unroll
-    for (int M = 0; M < 4; ++M) {
-        if (m0 + 2 * M >= a.mt) continue;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (m0 + 2 * M) * 16 + 8 * (i >> 2) + 4 * kh + (i & 3);
-            if (row >= a.m_valid) continue;
-            float v[2] = {acc[M][0][i], acc[M][1][i]};
-            if (mask) {
-                const float* mp = mask + (size_t)row * a.mask_pitch + tl2;
-                if (full) {
-                    const G2U mv = *reinterpret_cast<const G2U*>(mp);
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) v[e] = mv.v[e] > 0.f ? v[e] : 0.f;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        if (tl2 + e >= a.t_lo && tl2 + e < a.t_hi) v[e] = mp[e] > 0.f ? v[e] : 0.f;
-                }
-            }
-            if (resid) {
-                const float* rp = resid + (size_t)row * a.resid_pitch + tl2;
-                if (full && tl2 >= a.resid_lo) {
-                    const G2U rv = *reinterpret_cast<const G2U*>(rp);
-                    v[0] += rv.v[0]; v[1] += rv.v[1];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        if (tl2 + e >= a.resid_lo && tl2 + e >= a.t_lo && tl2 + e < a.t_hi) v[e] += rp[e];
-                }
-            }
-            float* op = out + (size_t)row * a.out_pitch + tl2 + a.out_shift;
-            if (full) {
-                G2U u = {{v[0], v[1]}};
-                *reinterpret_cast<G2U*>(op) = u;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    if (tl2 + e >= a.t_lo && tl2 + e < a.t_hi) op[e] = v[e];
-            }
-        }
-    }
-}
 
 template <class T, int NS>
 static int launch_gemm(const WnGemmArgs& k, int batch, hipStream_t st) {
@@ -773,33 +425,16 @@ static int launch_gemm(const WnGemmArgs& k, int batch, hipStream_t st) {
         hipLaunchKernelGGL((chan_gemm_k<T, NS, 4, 1>), g, b, 0, st, k);
     } else {                             // wide: 256 rows x 256 columns per workgroup
         dim3 g((ncol + 255) / 256, (k.mt + 15) / 16, batch), b(512);
-        static int ver = -1;
-        if (ver < 0) { const char* e = getenv("WN_GEMM_WIDE"); ver = e ? atoi(e) : 2; }
-        if (ver == 3 && NS == 3) {
-            const size_t sh = (size_t)2 * 32 * 1024 * sizeof(uint16_t);
-            static unsigned long long done3 = 0;
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (!((done3 >> dev) & 1ull)) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_gemm_wide3_k<T>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-                done3 |= 1ull << dev;
-            }
-            hipLaunchKernelGGL((chan_gemm_wide3_k<T>), g, b, sh, st, k);
-        } else if (ver == 2 || ver == 3) {
-            const size_t sh = (size_t)2 * 32 * (NS == 3 ? 1024 : 512) * sizeof(uint16_t);
-            static unsigned long long done = 0;
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (!((done >> dev) & 1ull)) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_gemm_wide2_k<T, NS>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-                done |= 1ull << dev;
-            }
-            hipLaunchKernelGGL((chan_gemm_wide2_k<T, NS>), g, b, sh, st, k);
-        } else {
-            hipLaunchKernelGGL((chan_gemm_wide_lds_k<T, NS>), g, b, 0, st, k);
+        const size_t sh = (size_t)2 * 32 * (NS == 3 ? 1024 : 512) * sizeof(uint16_t);
+        static unsigned long long done = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!((done >> dev) & 1ull)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_gemm_wide2_k<T, NS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            done |= 1ull << dev;
         }
+        hipLaunchKernelGGL((chan_gemm_wide2_k<T, NS>), g, b, sh, st, k);
     }
     return 0;
 }
@@ -809,7 +444,7 @@ int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st) {
     WnGemmArgs k = a;
     k.t_base = wn_tile_origin(a.t_lo);
     k.swz = wn_xcd_swizzle_enabled();
-    if (wn_launch_gemm_rw(k, batch, mode, st) || wn_launch_gemm_wide_rw(k, batch, mode, st)) {
+    if (wn_launch_gemm_rw(k, batch, mode, st)) {
         WN_CHECK_LAUNCH();
         return 0;
     }

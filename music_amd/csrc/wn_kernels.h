@@ -27,10 +27,7 @@ struct WnGemmArgs {
 int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 // two-role persistent form of the narrow product (wn_gemm_rw.hip); 1 = launched, 0 = arguments not covered
 int wn_launch_gemm_rw(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
-int wn_launch_gemm_wide_rw(const WnGemmArgs& a, int batch, int mode, hipStream_t st);   // wn_gemm_wide_rw.hip, same convention
 struct WnResArgs;
-// two-role persistent forward block (wn_resfwd_rw.hip); 1 = launched, 0 = arguments not covered
-int wn_launch_resblock_fwd_rw(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);
 int wn_launch_enc_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);   // wn_resblock2.hip (ENC)
 int wn_launch_pack(const float* flat, const int32_t* idx, uint16_t* out, int n, int is_bf16, int ns,
                    hipStream_t st);
@@ -49,8 +46,7 @@ struct WnResArgs {
     int swz;
 };
 int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);
-int wn_launch_resblock_fwd_nt(const WnResArgs& a, int ch, int batch, int mode, int nt, hipStream_t st);
-int wn_launch_resblock_fwd_cs(const WnResArgs& a, int batch, hipStream_t st);      // channel-split form: 64 channels, f16x3
+int wn_launch_resblock_fwd_nt(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);
 
 struct WnResBwdArgs {
     const float* x_in;          // x_i          [B][CH][pitch]
@@ -89,7 +85,6 @@ int wn_resms_slabs(int t_lo, int t_hi, int batch);
 // two-role form of the same block (wn_resrw.hip): 8 waves, 32-column items; same arguments and slab format
 int wn_launch_resblock_bwd_rw(const WnResMsArgs& a, int batch, hipStream_t st);
 void wn_resrw_plan(int t_lo, int t_hi, int batch, int& t_base, int& steps, int& ipw, int& nwg);
-int wn_ms_two_role();              // host: env WN_MS_RW (default 1)
 // backward of an autoencoder ENCODER block with both weight gradients (wn_encrw.hip); WnResMsArgs fields as documented there
 int wn_launch_enc_bwd_rw(const WnResMsArgs& a, int ch, int batch, int mode_bwd, hipStream_t st);
 int wn_enc_bwd_slabs(int t_lo, int t_hi, int batch);
@@ -123,23 +118,6 @@ int wn_launch_mulaw_encode(const float* audio, const float* thr, uint8_t* codes,
 int wn_launch_mulaw_decode(const uint8_t* codes, const float* table, float* audio, long n, hipStream_t st);
 int wn_launch_bias_grad(const float* a, long a_bstride, int a_pitch, int a_shift, int rows, int t_lo,
                         int t_hi, int batch, float* out, hipStream_t st);
-
-struct WnResFusedArgs {
-    const float* x_in; long x_bstride; int pitch;          // x_i
-    const float* dP_in; const float* dQ_in; int dn, p_lo;  // dx_{i+1}[t] = P[t](t>=p_lo) + Q[t+dn](t+dn<t_hi); null for the last block
-    const float* dz; long dz_bstride; int z_lo;            // d z-crop (layer slice)
-    float* dP_out; float* dQ_out;                          // dx_i as the pair (P, Q) with shift d
-    float* scratch;                                        // [B * tiles][4*CH][512] floats
-    const uint16_t* wfg; const uint16_t* wdT; const uint16_t* wpq;
-    const float* bias_f; const float* bias_g; int n_f;
-    float* slab_fg; float* slab_d; int has_d;              // one slab per workgroup (clip-major)
-    int d, t_lo, t_hi, t_base;
-    int dbg_skip;                                          // timing diagnostics only (WN_FUSED_SKIP): bit0 skip P/Q, bit1 skip wgrad
-};
-int wn_launch_resblock_bwd_fused(const WnResFusedArgs& a, int ch, int batch, int mode_fwd, int mode_bwd, hipStream_t st);
-int wn_resfused_tiles(int t_lo, int t_hi);
-int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride, int pitch, int rows, int dn,
-                        int p_lo, int t_lo, int t_hi, int batch, hipStream_t st);
 
 int wn_launch_cond_grad(const float* in, long in_bstride, int in_pitch, int rows, int t_lo, int t_hi, int mode, int le,
                         int q, float* out, long out_bstride, int out_pitch, int batch, hipStream_t st);
@@ -178,4 +156,3 @@ struct WnDecodeArgs {
     long pk_skip, pk_p1, pk_p2;          // "skip" ([S/16][n_layers*D/32]), "p1" ([S/16][S/32]), "p2" ([Q/16][S/32]) fragment bases, natural k order (S = Q = 256)
 };
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st);
-long wn_decode_pipe_granules(int n_layers, int D, int S);   // hand-off granules per utterance of the pipelined decoder

@@ -575,3 +575,18 @@ int wn_launch_resblock_bwd_rw(const WnResMsArgs& a, int batch, hipStream_t st) {
     WN_CHECK_LAUNCH();
     return 0;
 }
+
+int wn_resms_slabs(int t_lo, int t_hi, int batch) {
+    if (t_hi <= t_lo || batch <= 0) return 0;
+    int tb, steps, ipw, nwg;
+    wn_resrw_plan(t_lo, t_hi, batch, tb, steps, ipw, nwg);
+    return nwg;
+}
+
+int wn_launch_resblock_bwd_ms(const WnResMsArgs& a, int ch, int batch, int mode_fwd, int mode_bwd, hipStream_t st) {
+    if (a.t_hi <= a.t_lo || batch <= 0) return 0;
+    if (ch != RW_CH) return wn_set_error_msg(-3, "resblock_bwd_ms: 64 padded channels only");
+    if (mode_fwd != WN_MODE_F16X3 || mode_bwd != WN_MODE_BF16X3)
+        return wn_set_error_msg(-2, "resblock_bwd_ms: (f16x3, bf16x3) only");
+    return wn_launch_resblock_bwd_rw(a, batch, st);
+}

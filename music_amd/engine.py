@@ -96,16 +96,10 @@ class WaveNetEngine:
         self._gen = 0
         self.adam_state = None
         self.marks = None            # list of (name, torch.cuda.Event) when profiling is on
-        self.pair_wgrad = False      # both per-layer weight-gradient products in one launch
         # weight-gradient launches that only feed the final slab reduction run on a second HIP stream: the
         # epilogue's three (2 rounds of workgroups at 80 % fill each) then pack into the data-gradient GEMMs'
         # idle CUs (epilogue backward 1.25 -> 1.00 ms)
         self.overlap_wgrad = True
-        # One launch per residual block for the whole backward (wn_resblock_bwd_fused).  Correct and
-        # tested, but SLOWER than the unfused kernels at config 2 (6.0 vs 4.5 ms for the stack): its
-        # 512 KB-per-workgroup scratch tile does not fit the 128 KB-per-CU share of the XCD's L2, so the
-        # re-reads come from the Infinity Cache.  Kept opt-in ("what did not work").
-        self.fused_bwd = False
         # Channel-split backward block with both weight gradients in the launch (wn_resblock_bwd_ms):
         # 64 padded channels, (f16x3, bf16x3) only; None = whenever it applies (WN_MS_BWD=0 turns it off)
         self.ms_bwd = None
@@ -203,13 +197,6 @@ class WaveNetEngine:
                 w[:R, h * CH:h * CH + D] = src[:, :, 1].T
                 w[:R, 2 * CH + h * CH:2 * CH + h * CH + D] = src[:, :, 0].T
             bwd.append(("fgT%d" % i, pack_index(w)))
-            # 11b. the same weights as two UNSHIFTED row blocks for the fused backward:
-            #      rows [0,CH) = W1^T (-> P), rows [CH,2CH) = W0^T (-> Q), K = (df | dg)
-            w = full(2 * CH, 2 * CH)
-            for h, src in enumerate((wf, wg)):
-                w[:R, h * CH:h * CH + D] = src[:, :, 1].T
-                w[CH:CH + R, h * CH:h * CH + D] = src[:, :, 0].T
-            bwd.append(("pq%d" % i, pack_index(w)))
         # 4. skip over the concatenated z-crops: rows S, K = N*CH
         w = full(SP, N * CH)
         for i in range(N):
@@ -337,30 +324,22 @@ class WaveNetEngine:
         # weight-gradient slabs: every wgrad workgroup writes its partial C with plain stores,
         # one batched kernel then sums the slabs of all ops in a fixed order (deterministic)
         T, lo = ws["T"], self.rf - 1
-        fused = self.fused_bwd
-        ms = self._use_ms() and not fused
+        ms = self._use_ms()
         bw["ms"] = ms
         ops = [("p2", lo, T, 1024), ("p1", lo, T, 1024), ("skip", lo, T, 2048)]
         for i in range(self.N):
-            ops.append(("fg%d" % i, self.off[i + 1], T, 0 if fused else (-1 if ms else 512)))
+            ops.append(("fg%d" % i, self.off[i + 1], T, -1 if ms else 512))
             if i < self.N - 1:
-                ops.append(("d%d" % i, self.off[i + 1], T, 0 if fused else (-1 if ms else 512)))
+                ops.append(("d%d" % i, self.off[i + 1], T, -1 if ms else 512))
         ops.append(("causal", 1, T, 512))
-        if fused:
-            tiles = max(_lib.fused_tiles(self.off[i + 1], T) for i in range(self.N))
-            bw["PQ"] = [(buf(self.CH), buf(self.CH)), (buf(self.CH), buf(self.CH))]
-            bw["scratch"] = torch.zeros(B * tiles * 4 * self.CH * 512, dtype=torch.float32, device=dev)
         plan, desc, so, vs = {}, [], 0, 0
         for name, t_lo, t_hi, chunk in ops:
             go, r, c = self.gp_off[name]
             n = r * c
-            # chunk 0: the fused backward writes one slab per 512-column workgroup tile
             if chunk > 0:
                 ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B)
-            elif chunk < 0:                                   # channel-split block: one slab per workgroup
+            else:                                             # channel-split block: one slab per workgroup
                 ns = _lib.ms_slabs(t_lo, t_hi, B)
-            else:
-                ns = _lib.fused_tiles(t_lo, t_hi) * B
             plan[name] = (so, n, chunk)
             desc.append([vs, so, ns, n, go, n])
             so += ns * n
@@ -513,16 +492,6 @@ class WaveNetEngine:
                 call("wn_bias_grad", dU, sb, pitch, 0, self.S, lo, T, B,
                      ptr(self.gpack, bo["dilation_layer_stack.%d.bias" % (4 * i + 3)]), st)
         self.mark("epilogue_bwd")
-        if self.fused_bwd:
-            self._stack_bwd_fused(ws, bw, plan, st)
-            self.mark("stack_bwd")
-            x = ws["x_in"]
-            dx0 = ptr(bw["dX"][0], SLACK)
-            wgrad("causal", dx0, xb, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CH // 16, 0, 2 * Q, 1, T)
-            call("wn_reduce_slabs", ptr(bw["slab_desc"]), bw["slab_nops"], bw["slab_vec"], ptr(bw["slab"]), ptr(self.gpack), st)
-            call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
-            self.mark("causal_bwd")
-            return
         # The per-layer weight-gradient products only feed the slab reduction at the very end, so
         # they run on a second HIP stream next to the data-gradient chain
         # (resblock_bwd -> dx product -> next block); dfg / z scratch is double-buffered for that.
@@ -613,33 +582,6 @@ class WaveNetEngine:
         call("wn_reduce_slabs", ptr(bw["slab_desc"]), bw["slab_nops"], bw["slab_vec"], ptr(bw["slab"]), ptr(self.gpack), st)
         call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
         self.mark("causal_bwd")
-
-    def _stack_bwd_fused(self, ws, bw, plan, st):
-        """One wn_resblock_bwd_fused launch per block, top to bottom; dx between blocks travels as
-        the unshifted (P, Q) pair.  Leaves dx_0 in bw['dX'][0] for the causal weight gradient."""
-        B, T, pitch = ws["B"], ws["T"], ws["pitch"]
-        CH, N, lo = self.CH, self.N, self.rf - 1
-        xb, zb = CH * pitch, N * CH * pitch
-        fr = lambda name: ptr(self.pk_f, self.pk_f_off[name])
-        br = lambda name: ptr(self.pk_b, self.pk_b_off[name])
-        for i in range(N - 1, -1, -1):
-            p_out, q_out = bw["PQ"][i % 2]
-            if i < N - 1:
-                p_in, q_in = (ptr(t, SLACK) for t in bw["PQ"][(i + 1) % 2])
-                dn, p_lo = self.dil[i + 1], self.off[i + 2]
-            else:
-                p_in = q_in = None
-                dn = p_lo = 0
-            bn = "dilation_layer_stack.%d.bias"
-            call("wn_resblock_bwd_fused", self._x(ws, i), p_in, q_in, ptr(bw["dZ"], SLACK + i * CH * pitch),
-                 ptr(p_out, SLACK), ptr(q_out, SLACK), ptr(bw["scratch"]), xb, zb, pitch,
-                 fr("fg%d" % i), br("dT%d" % i), br("pq%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),
-                 self.D, CH, self.dil[i], dn, p_lo, self.off[i + 1], T, lo,
-                 ptr(bw["slab"], plan["fg%d" % i][0]), ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None,
-                 1 if i < N - 1 else 0, B, self.mode_fwd, self.mode_bwd, st)
-        p0, q0 = bw["PQ"][0]
-        call("wn_shift_add", ptr(p0, SLACK), ptr(q0, SLACK), ptr(bw["dX"][0], SLACK), xb, pitch, self.R, self.dil[0],
-             self.off[1], 1, T, B, st)
 
     def backward(self, ws, dprobs):
         """dprobs: (B*W, Q) gradient w.r.t. the probabilities returned by forward()."""

@@ -142,7 +142,7 @@ def _packed_chain(eng):
         if off["fg%d" % i] != fg0 + i * stride or off["d%d" % i] != d0 + i * stride:
             return None, 0, 0, 0, -1, -1, -1
     eng.pack_weights()
-    post = (off["skip"], off["p1"], off["p2"]) if (eng.S == 256 and eng.Q == 256 and os.environ.get("WN_DEC_MFMA_POST", "1") == "1") else (-1, -1, -1)
+    post = (off["skip"], off["p1"], off["p2"]) if (eng.S == 256 and eng.Q == 256) else (-1, -1, -1)
     return (ptr(eng.pk_f), fg0, d0, stride) + post
 
 

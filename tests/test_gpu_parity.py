@@ -294,11 +294,9 @@ def test_g8_autoencoder_forward():
         net(torch.zeros(1, 256, net.receptive_field - 1, device="cuda"))
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_grads_64_channels_vs_oracle(fused):
+def test_grads_64_channels_vs_oracle():
     """The 64-channel kernel instantiations (BASELINE config-2 width) on a 7-block stack with
-    tiles that straddle the 512-column workgroup boundary: loss and every gradient vs the oracle,
-    through the fully fused per-block backward and through the unfused kernels."""
+    tiles that straddle the 512-column workgroup boundary: loss and every gradient vs the oracle."""
     from music_amd.model import wavenet
     cfg = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 512, 3], dilation_channels=64, residual_channels=64,
                skip_channels=96, quantization_channels=256, use_bias=False)
@@ -315,8 +313,6 @@ def test_grads_64_channels_vs_oracle(fused):
     target = torch.from_numpy(rng.integers(0, 256, size=(2 * 1101,)).astype(np.int64))
     net(x[:, :, :net.receptive_field].cuda())
     eng = net._engine
-    eng.fused_bwd = fused
-    eng._ws.clear()                      # the backward workspace plan depends on the flag
     loss = eng.loss_and_grad(x.cuda(), target.cuda())
     l_ref, p_ref, g_ref = wo.loss_and_grads(params, cfg["dilations"], x, target)
     assert abs(loss.item() - l_ref.item()) < 1e-4
@@ -326,7 +322,7 @@ def test_grads_64_channels_vs_oracle(fused):
         err = (eng.param_view(name, grad=True).cpu() - g).abs().max().item() / max(g.abs().max().item(), 1e-12)
         worst = max(worst, err)
         assert err <= GRAD_RTOL, (name, err)
-    print("64-channel grads (fused=%s): worst relative err %.2e" % (fused, worst))
+    print("64-channel grads: worst relative err %.2e" % worst)
     # weight gradients are bit-reproducible (slab reduction, no float atomics)
     g1 = eng.flat_grad.clone()
     eng.loss_and_grad(x.cuda(), target.cuda())
@@ -488,11 +484,10 @@ def test_batched_decode_equals_single_utterances():
 
 
 @pytest.mark.parametrize("bias", [False, True], ids=["nobias", "bias"])
-def test_batched_decode_eight_per_pair_equals_single_utterances(bias, monkeypatch):
-    """More than 128 utterances (a multiple of 8; here forced from 16 on with WN_DEC_U8=2) run eight to a workgroup
-    pair, one pair of MFMA result columns per utterance (decode_duo_mfma8_k): every row must still equal the
-    single-utterance launch exactly, for both queue recurrences, with and without biases, greedy and sampled."""
-    monkeypatch.setenv("WN_DEC_U8", "2")
+def test_batched_decode_eight_per_pair_equals_single_utterances(bias):
+    """Utterances run eight to a workgroup pair, one pair of MFMA result columns per utterance (decode_duo_mfma8_k):
+    every row must equal the single-utterance launch (the utterance mirrored into all eight column pairs) exactly, for
+    both queue recurrences, with and without biases, greedy and sampled."""
     from music_amd.model import wavenet
     from music_amd import fast_generate as fg
     cfg = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 32, 1, 2, 4, 8, 3], dilation_channels=64, residual_channels=64,

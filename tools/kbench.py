@@ -23,9 +23,7 @@ def main():
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--precision", default="f16x3,bf16x3")
-    ap.add_argument("--pair", type=int, default=0)
     ap.add_argument("--overlap", type=int, default=1)
-    ap.add_argument("--fused", type=int, default=0)
     args = ap.parse_args()
     from music_amd.model import wavenet
     from music_amd import _lib
@@ -36,9 +34,7 @@ def main():
     net.precision = tuple(args.precision.split(","))
     net = net.cuda()
     eng = net._engine_for(torch.device("cuda", 0))
-    eng.pair_wgrad = bool(args.pair)
     eng.overlap_wgrad = bool(args.overlap)
-    eng.fused_bwd = bool(args.fused)
     rng = np.random.default_rng(0)
     codes = torch.from_numpy(rng.integers(0, 256, size=(B_LOCAL, T)).astype(np.int32)).cuda()
     target = torch.from_numpy(rng.integers(0, 256, size=(B_LOCAL * (T - 3070),)).astype(np.int64)).cuda()
