@@ -1,8 +1,14 @@
 """Counterpart of the reference's ``wavenet_autoencoder/generate.py``: naive generation by a full
-forward on a sliding window of ``receptive_field + 512`` samples per generated sample
-(generate.py:13-65).  The reference version cannot run as shipped (``librosa`` used without import
-:65, tensors instead of ints appended :48, ``.cuda()`` hard-wired :55); the algorithm is kept, the
-output is written with scipy.  It is O(T * rf): a harness, not a kernel.
+forward per generated sample (generate.py:13-65).  The reference version cannot run as shipped (``librosa`` used
+without import :65, the start tensor instead of the predicted int appended :48, ``.cuda()`` hard-wired :53); the
+algorithm is kept, the output is written with scipy.  It is a harness, not a kernel.
+
+As written, the window update ``input_wav[:,-net.receptive_field-511:]`` (generate.py:55) slices dimension 1 - the
+256 CHANNELS - so it is a no-op and the window GROWS by one sample per step (the pooled encoding gains a frame
+every ``pool`` steps and the ``_conditon`` branches change with it; cost O(T^2)).  ``generate`` reproduces that by
+default, like ``fast_generate`` reproduces the as-written queue recurrence; ``sliding_window=True`` is the evident
+intent (the last ``receptive_field + 511`` samples along TIME plus the new one, O(T * rf)) and NOT the reference's
+behaviour.  Both are pinned by tests/golden/g9_ae_harness.json (outputs of the reference's own ``predict_next``).
 
 ``generate_cached`` / ``cached_decoder`` are the SURVEY 8f3 replacement: encoder ONCE on the start window,
 conditioning projections drawn ONCE, then the persistent cached-queue decode kernel (wn_decode).  That is a
@@ -96,7 +102,28 @@ def generate_cached(net, start_piece, note_num, cond=None, temperature=None, see
     return codes, wnet, enc
 
 
-def generate(model_path, model_name, generate_path, generate_name, start_piece=None, sr=16000, duration=10):
+def generate_codes_naive(net, start_piece, note_num, sliding_window=False, window=None, seed=None):
+    """The loop of generate.py:44-55: one full forward (encoder + conditioned decoder, fresh random conditioning
+    projections) per generated code.  ``sliding_window`` False = as written (growing window), True = the last
+    ``window - 1`` samples + the new one (``window`` defaults to receptive_field + 512).  ``seed``: torch.manual_seed(seed + i)
+    before step i (the projections are drawn from the global RNG), for reproducible runs and the golden tests."""
+    win = window if window is not None else net.receptive_field + 512
+    input_wav = start_piece.cuda()
+    generated = []
+    for i in range(note_num):
+        if seed is not None:
+            torch.manual_seed(int(seed) + i)
+        code = predict_next(net, input_wav, net.quantization_channel)
+        generated.append(code)
+        note = torch.zeros(1, net.quantization_channel, 1, device=input_wav.device)
+        note[0, code, 0] = 1.0
+        keep = input_wav[:, :, -(win - 1):] if sliding_window else input_wav
+        input_wav = torch.cat((keep, note), 2)
+    return generated
+
+
+def generate(model_path, model_name, generate_path, generate_name, start_piece=None, sr=16000, duration=10,
+             sliding_window=False, seed=None):
     if os.path.exists(generate_path) is False:
         os.makedirs(generate_path)
     with open('./params/model_params.json') as f:
@@ -106,18 +133,11 @@ def generate(model_path, model_name, generate_path, generate_name, start_piece=N
     if net is None:
         raise FileNotFoundError(model_path + model_name)
     net = net.cuda()
-    win = net.receptive_field + 512
     if start_piece is None:
-        start_piece = torch.zeros(1, 256, win)
+        start_piece = torch.zeros(1, 256, net.receptive_field + 512)
         start_piece[:, 128, :] = 1.0
-    input_wav = start_piece.cuda()
-    generated = []
-    for i in range(duration * sr):
-        code = predict_next(net, input_wav)
-        generated.append(code)
-        note = torch.zeros(1, net.quantization_channel, 1, device=input_wav.device)
-        note[0, code, 0] = 1.0
-        input_wav = torch.cat((input_wav[:, :, -(win - 1):], note), 2)
+    generated = generate_codes_naive(net, start_piece, int(duration * sr), sliding_window=sliding_window,
+                                     window=start_piece.size(2), seed=seed)
     audio = mu_law_decode(torch.tensor(generated, dtype=torch.int64), net.quantization_channel).cpu().numpy()
     from scipy.io import wavfile
     wavfile.write(generate_path + generate_name, sr, audio.astype(np.float32))

@@ -5,7 +5,10 @@ The reference file is a tab-indented copy of ``wavenet/train.py`` that cannot ru
 imports ``faster_audio_data`` and reads ``./params/train_params.json`` / ``dataset_params.json`` that
 only exist in ``wavenet/``, its ``model_params.json`` is invalid JSON, ``optim.sgd`` is a
 typo (:28), ``sorted(keys=...)`` raises (:159) and ``int(name[7:])`` raises for its own checkpoint
-names (:77-78).  This module keeps its surface and file formats and fixes only what cannot work:
+names (:77-78).  This module keeps its surface and file formats - the reference's own line formats
+``"Average loss is X\\n"`` (:144-146) and ``"Epoch{N}model saved!"`` (:164-166, no separators), checkpoints
+``wavenet_autoencoder{N}.model`` - and fixes only what cannot work (the resume counter, which the reference parses out
+of a loss line that does not contain it (:110-116: ``int("is")``), is the number of logged lines x print_every):
 
     get_optimizer(model, optimizer_type in {'sgd','RMSprop','Adam','lbfgs'}, learning_rate, momentum1)
     save_model(model, num_epoch, path)   -> path + "wavenet_autoencoder{N}.model"
@@ -26,12 +29,12 @@ try:
     from . import dist as wdist
     from .faster_audio_data import audio_data_loader
     from .model1 import wavenet_autoencoder
-    from .train import get_params, load_model, _resume_counter
+    from .train import get_params, load_model
 except ImportError:
     from music_amd import dist as wdist
     from music_amd.faster_audio_data import audio_data_loader
     from music_amd.model1 import wavenet_autoencoder
-    from music_amd.train import get_params, load_model, _resume_counter
+    from music_amd.train import get_params, load_model
 
 PREFIX = "wavenet_autoencoder"
 
@@ -58,6 +61,23 @@ def save_model(model, num_epoch, path):
     print('Storing checkpoint to {}...'.format(path))
     torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, checkpoint_path)
     print('done')
+
+
+def _resume_counter(log_dir, print_every):
+    """Batches trained so far.  The reference reads word 2 of the last loss line (:110-116), but its own lines are
+    "Average loss is X" (word 2 = "is"), so a second run on the same log directory dies there; one line is written
+    every print_every batches, so the count is recovered from the number of lines (a line in the wavenet/train.py
+    format "Trained over N pieces,..." - written by round-1 versions of this module - is honoured too)."""
+    try:
+        with open(log_dir + 'loss_log.log', 'r') as f:
+            lines = [l for l in f.readlines() if l.strip()]
+    except FileNotFoundError:
+        return 0
+    if not lines:
+        return 0
+    if lines[-1].startswith("Trained over "):
+        return int(lines[-1].split(' ')[2])
+    return len(lines) * print_every
 
 
 def _epoch_of(name):
@@ -101,7 +121,7 @@ def train():
         store_log_file = open(train_params["log_dir"] + 'store_log.log', 'a')
     if world > 1:
         torch.distributed.barrier()
-    num_trained = _resume_counter(train_params["log_dir"])
+    num_trained = _resume_counter(train_params["log_dir"], train_params["print_every"])
     device = next(net.parameters()).device
     total_loss = torch.zeros((), dtype=torch.float64, device=device)
     step_seed = int(train_params.get("seed") or 0)
@@ -149,8 +169,7 @@ def train():
                     torch.distributed.all_reduce(total_loss)
                     total_loss /= world
                 if is_writer:
-                    loss_log_file.writelines("Trained over " + str(num_trained) + " pieces," + "Average loss is " +
-                                             str(total_loss.item() / train_params["print_every"]) + "\n")
+                    loss_log_file.writelines('Average loss is ' + str(total_loss.item() / train_params["print_every"]) + '\n')
                     loss_log_file.flush()
                 total_loss.zero_()
         if (epoch + 1) % train_params["check_point_every"] == 0 and is_writer:
@@ -158,7 +177,7 @@ def train():
             if len(stored) == train_params["max_check_points"]:
                 os.remove(sorted(stored, key=_epoch_of)[0])
             save_model(net, epoch_trained + epoch + 1, train_params["restore_dir"])
-            store_log_file.writelines("Epoch " + str(epoch_trained + epoch + 1) + ", model saved!\n")
+            store_log_file.writelines('Epoch' + str(epoch_trained + epoch + 1) + 'model saved!')
             store_log_file.flush()
     if is_writer:
         loss_log_file.close()

@@ -1,0 +1,284 @@
+"""Full-size parity (VERDICT r1 "next" #2): the BASELINE configurations at the sizes the benchmark runs them, not
+at the few-thousand-column sizes of tests/test_gpu_parity.py.  The persistent backward kernels walk item ranges,
+per-XCD interleaved orders and slab counts that depend on the size, so gradients are compared at T = 16000 too.
+
+  (a) config 2   30 blocks, 64/64/256, B = 2, T = 16000        loss + every gradient vs the oracle's autograd
+  (b) config 4   autoencoder 30 + 30 blocks, 64 ch, pool 512   probabilities + every gradient vs the oracle
+                 (Le = 25: the stretch / tile mix of SURVEY Q9)
+  (c) config 5   30-block decoder                               1100+ teacher-forced steps (the d = 512 rings wrap
+                 twice) vs the oracle's cached-queue recurrence, both recurrences; a 16 000-step free run whose
+                 first 1100 codes are what the oracle predicts from the same history
+  (d) the reference's shipped wavenet_params.json (40 blocks, 32/32/512, rf 4094): forward + gradients at
+      window 4000, and the shipped batch (4 x 44093, window 40000) against an oracle window
+
+Run with -m gpu.  Tolerances as tests/test_gpu_parity.py: probabilities 1e-3 absolute on gain-scaled weights,
+gradients 2e-3 of the tensor's max-abs, integers exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import intops
+from oracle import wavenet_oracle as wo
+from tests.helpers import scrambled_input
+
+import os
+
+LOGIT_TOL = 1e-3
+GRAD_RTOL = 2e-3
+ORACLE_THREADS = min(32, os.cpu_count() or 1)      # ATen's CPU convs stop scaling (then collapse) beyond that
+C2 = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 3, dilation_channels=64, residual_channels=64,
+          skip_channels=256, quantization_channels=256, use_bias=False)
+# /root/reference/wavenet/params/wavenet_params.json (values restated here: the file does not travel to the GPU box)
+SHIPPED = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 4, dilation_channels=32, residual_channels=32,
+               skip_channels=512, quantization_channels=256, use_bias=False)
+
+
+def _scaled(net, gain):
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(gain)
+    return {k: v.clone() for k, v in net.state_dict().items()}
+
+
+def _check_grads(eng, g_ref, skip=()):
+    worst, worst_name = 0.0, None
+    for name in eng.param_names:
+        if name in skip:
+            continue
+        g = g_ref[name]
+        err = (eng.param_view(name, grad=True).cpu() - g).abs().max().item() / max(g.abs().max().item(), 1e-12)
+        if err > worst:
+            worst, worst_name = err, name
+        assert err <= GRAD_RTOL, (name, err)
+    return worst, worst_name
+
+
+def test_c2_full_length_loss_and_gradients_vs_oracle():
+    """(a) config 2 at B = 2, T = 16000 through eng.loss_and_grad on the default kernels."""
+    from music_amd.model import wavenet
+    torch.manual_seed(3)
+    net = wavenet(**C2)
+    params = _scaled(net, 2.5)
+    net = net.cuda()
+    rng = np.random.default_rng(31)
+    B, T = 2, 16000
+    rf = net.receptive_field
+    W = T - rf + 1
+    codes = rng.integers(0, 256, size=(B, T))
+    x = scrambled_input(codes)
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64))
+    eng = net._engine_for(torch.device("cuda", 0))
+    xd = eng.onehot(torch.from_numpy(codes.astype(np.int32)).cuda(), scrambled=True)
+    assert torch.equal(xd.cpu(), x)
+    loss = eng.loss_and_grad(xd, target.cuda(), want_probs=True)
+    probs = eng.workspace(B, T)["probs"].cpu()
+    torch.set_num_threads(ORACLE_THREADS)
+    l_ref, p_ref, g_ref = wo.loss_and_grads(params, C2["dilations"], x, target)
+    e_p = (probs - p_ref).abs().max().item()
+    assert probs.shape == (B * W, 256) and e_p <= LOGIT_TOL, e_p
+    assert p_ref.max().item() > 0.5                       # non-vacuous
+    assert abs(loss.item() - l_ref.item()) < 1e-4
+    worst, name = _check_grads(eng, g_ref)
+    print("c2 full length (2 x 16000): probs err %.2e, loss %.6f (oracle %.6f), worst rel grad err %.2e (%s)" %
+          (e_p, loss.item(), l_ref.item(), worst, name))
+    # the same step again: weight gradients are bit-reproducible (slab sums in a fixed order, no float atomics)
+    g1 = eng.flat_grad.clone()
+    eng.loss_and_grad(xd, target.cuda())
+    assert torch.equal(g1, eng.flat_grad)
+
+
+def test_c4_full_size_autoencoder_vs_oracle():
+    """(b) config 4: 30 + 30 blocks, 64 channels, bottleneck 64, pool 512 => Le = 25 pooled frames at T = 16000:
+    decoder layers whose length is a multiple of 25 take the stretch branch of _conditon, the others the tile branch."""
+    from music_amd.model1 import wavenet_autoencoder
+    cfg = dict(filter_width=2, quantization_channel=256, dilations=C2["dilations"], en_residual_channel=64,
+               en_dilation_channel=64, en_bottleneck_width=64, en_pool_kernel_size=512, de_residual_channel=64,
+               de_dilation_channel=64, de_skip_channel=256, use_bias=False)
+    torch.manual_seed(5)
+    net = wavenet_autoencoder(**cfg)
+    params = _scaled(net, 1.6)
+    net = net.cuda()
+    rng = np.random.default_rng(51)
+    B, T = 2, 16000
+    rf = net.receptive_field
+    W = T - rf + 1
+    assert rf == 3071 and W // 512 == 25
+    # which branch each decoder layer's conditioning takes: both must occur
+    L, stretch = T - 1, []
+    for d in cfg["dilations"]:
+        L -= d
+        stretch.append(L % 25 == 0)
+    assert any(stretch) and not all(stretch), stretch
+    idx = rng.integers(0, 256, size=(B, T))
+    x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx]))
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64))
+    torch.manual_seed(77)
+    net.zero_grad()
+    probs = net(x.cuda())
+    loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
+    loss.backward()
+    torch.set_num_threads(ORACLE_THREADS)
+    torch.manual_seed(77)
+    cond = wo.draw_conditioning(len(cfg["dilations"]), cfg["en_bottleneck_width"], cfg["de_dilation_channel"],
+                                cfg["de_skip_channel"])
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    p_ref, enc_ref = wo.autoencoder_forward(leaf, cfg["dilations"], x, cfg["en_pool_kernel_size"], cond)
+    assert enc_ref.shape == (B, 64, 25)
+    l_ref = torch.nn.functional.cross_entropy(p_ref, target)
+    g_ref = torch.autograd.grad(l_ref, list(leaf.values()), allow_unused=True)
+    e_enc = (net.last_encoding.cpu() - enc_ref.detach()).abs().max().item()
+    e_p = (probs.detach().cpu() - p_ref.detach()).abs().max().item()
+    assert e_enc < 1e-4 and e_p <= LOGIT_TOL, (e_enc, e_p)
+    assert abs(loss.item() - l_ref.item()) < 1e-4
+    worst, worst_name = 0.0, None
+    for (name, p), g in zip(net.named_parameters(), g_ref):
+        assert name in leaf
+        if g is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, name
+            continue
+        err = (p.grad.cpu() - g).abs().max().item() / max(g.abs().max().item(), 1e-12)
+        if err > worst:
+            worst, worst_name = err, name
+        assert err <= GRAD_RTOL, (name, err)
+    print("c4 full size (2 x 16000, Le 25, %d stretch / %d tile layers): enc err %.2e probs err %.2e (max p %.3f) "
+          "worst rel grad err %.2e (%s)" % (sum(stretch), len(stretch) - sum(stretch), e_enc, e_p,
+                                            p_ref.max().item(), worst, worst_name))
+
+
+def _onehot(ix):
+    return torch.from_numpy(intops.one_hot_proper(np.atleast_1d(ix)))[None]
+
+
+@pytest.mark.parametrize("correct", [False, True], ids=["as_written", "corrected"])
+def test_c5_full_size_decode_rings_wrap_vs_oracle(correct):
+    """(c) config 5: 1100 teacher-forced steps on the matrix-core decoder vs the oracle's cached-queue recurrence
+    (every ring, the three d = 512 ones included, wraps at least twice): argmax ids exact, probabilities 1e-4."""
+    from music_amd import fast_generate as fg
+    from music_amd.model import wavenet
+    torch.manual_seed(21)
+    net = wavenet(**C2)
+    params = _scaled(net, 2.2)
+    net = net.cuda()
+    rng = np.random.default_rng(22)
+    n = 1100
+    start = rng.integers(0, 256, size=(net.receptive_field,))
+    forced = rng.integers(0, 256, size=(n,))
+    torch.set_num_threads(4)
+    pred_o, q_o = wo.fast_predict_next(params, C2["dilations"], _onehot(start), None)
+    want, want_p = [int(pred_o[0])], []
+    for s in forced:
+        pred_o, q_o, pr = wo.fast_predict_next(params, C2["dilations"], _onehot(s), q_o, correct_queue=correct, return_probs=True)
+        want.append(int(pred_o[0]))
+        want_p.append(pr.numpy())
+    want_p = np.stack(want_p)
+    pred, st = fg.predict_next(net, _onehot(start).cuda(), None)
+    got = [int(pred[0])]
+    nxt = torch.from_numpy(np.concatenate([forced[1:], [0]]).astype(np.int32))
+    codes, probs, _ = fg._decode(net, st, _onehot(forced[0]).reshape(-1).cuda(), n, forced=nxt, want_probs=True,
+                                 correct_queue=correct)
+    got += codes.cpu().tolist()
+    probs = probs.cpu().numpy()
+    err = np.abs(probs - want_p).max()
+    # an argmax may only differ where the oracle's own top two are closer than the tolerance
+    for k, (a, b) in enumerate(zip(got[1:], want[1:])):
+        if a != b:
+            assert abs(want_p[k][a] - want_p[k][b]) < 1e-5, (k, a, b)
+    print("config-5 decode, %d teacher-forced steps (correct_queue=%s): probs err %.2e, %d/%d ids equal" %
+          (n, correct, err, sum(a == b for a, b in zip(got, want)), len(want)))
+    assert err < 1e-4
+    for i in (9, 19, 29):                                  # the d = 512 rings after two wraps
+        np.testing.assert_allclose(st["block_%d" % (i + 1)].cpu().numpy(), q_o["block_%d" % (i + 1)].numpy(), atol=2e-4, rtol=0)
+
+
+def test_c5_16000_step_free_run_first_codes_vs_oracle():
+    """(c) one 16 000-sample greedy free run (1 s of audio, BASELINE config 5) in one launch: deterministic, and its
+    first 1100 codes are what the oracle's recurrence predicts when it is fed the same history."""
+    from music_amd import fast_generate as fg
+    from music_amd.model import wavenet
+    torch.manual_seed(23)
+    net = wavenet(**C2)
+    params = _scaled(net, 2.2)
+    net = net.cuda()
+    start = np.full((net.receptive_field,), 128)           # fast_generate.py:159-160: class-128 start piece
+    codes = fg.generate_codes(net, _onehot(start).cuda(), 16000).cpu().view(-1)
+    again = fg.generate_codes(net, _onehot(start).cuda(), 16000).cpu().view(-1)
+    assert codes.shape == (16000,) and torch.equal(codes, again)
+    assert int(codes.min()) >= 0 and int(codes.max()) < 256 and len(torch.unique(codes)) > 4
+    torch.set_num_threads(4)
+    n = 1100
+    pred_o, q_o = wo.fast_predict_next(params, C2["dilations"], _onehot(start), None)
+    assert int(pred_o[0]) == int(codes[0])
+    mism = 0
+    for k in range(n - 1):
+        pred_o, q_o, pr = wo.fast_predict_next(params, C2["dilations"], _onehot(int(codes[k])), q_o, return_probs=True)
+        if int(pred_o[0]) != int(codes[k + 1]):
+            assert abs(pr[int(pred_o[0])] - pr[int(codes[k + 1])]).item() < 1e-5, k
+            mism += 1
+    print("config-5 free run: 16000 codes, %d distinct; first %d agree with the oracle (%d near-ties)" %
+          (len(torch.unique(codes)), n, mism))
+    assert mism <= 2
+
+
+def test_shipped_config_forward_and_gradients_vs_oracle():
+    """(d) the reference's own wavenet_params.json: 40 blocks, 32 residual / dilation channels, 512 skip channels
+    (rf 4094) at window 4000, B = 2: probabilities, loss and every gradient."""
+    from music_amd.model import wavenet
+    torch.manual_seed(7)
+    net = wavenet(**SHIPPED)
+    params = _scaled(net, 3.0)
+    net = net.cuda()
+    assert net.receptive_field == 4094
+    rng = np.random.default_rng(71)
+    B, W = 2, 4000
+    T = net.receptive_field + W - 1
+    codes = rng.integers(0, 256, size=(B, T))
+    x = scrambled_input(codes)
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64))
+    eng = net._engine_for(torch.device("cuda", 0))
+    loss = eng.loss_and_grad(x.cuda(), target.cuda(), want_probs=True)
+    probs = eng.workspace(B, T)["probs"].cpu()
+    torch.set_num_threads(ORACLE_THREADS)
+    l_ref, p_ref, g_ref = wo.loss_and_grads(params, SHIPPED["dilations"], x, target)
+    e_p = (probs - p_ref).abs().max().item()
+    assert e_p <= LOGIT_TOL and p_ref.max().item() > 0.3, (e_p, p_ref.max().item())
+    assert abs(loss.item() - l_ref.item()) < 1e-4
+    worst, name = _check_grads(eng, g_ref)
+    print("shipped config (40 blocks, 32/32/512, 2 x %d): probs err %.2e (max p %.3f), worst rel grad err %.2e (%s)" %
+          (T, e_p, p_ref.max().item(), worst, name))
+
+
+def test_shipped_config_shipped_batch_window_vs_oracle():
+    """(d) the shipped dataset_params.json shape: batch 4, window 40000 (T = 44093).  Size-independent properties of
+    the full batch plus one oracle window of 700 outputs cut from the middle of a clip."""
+    from music_amd.model import wavenet
+    torch.manual_seed(8)
+    net = wavenet(**SHIPPED)
+    _scaled(net, 3.0)
+    net = net.cuda()
+    rf, B, W = net.receptive_field, 4, 40000
+    T = rf + W - 1
+    rng = np.random.default_rng(81)
+    codes = torch.from_numpy(rng.integers(0, 256, size=(B, T)).astype(np.int32)).cuda()
+    eng = net._engine_for(torch.device("cuda", 0))
+    x = eng.onehot(codes, scrambled=True)
+    with torch.no_grad():
+        p = net(x)
+        assert p.shape == (B * W, 256) and torch.isfinite(p).all()
+        assert (p.sum(1) - 1).abs().max().item() < 1e-5 and p.min().item() >= 0
+        assert torch.equal(p, net(x))
+        assert torch.equal(net(x[1:3].contiguous()), p[W:3 * W])
+        xs = x[2:3, :, 20000:20000 + rf + 699].contiguous()
+        got = net(xs).cpu()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    want = wo.wavenet_forward(sd, SHIPPED["dilations"], xs.cpu())
+    err = (got - want).abs().max().item()
+    print("shipped config at 4 x %d: window probs err %.2e" % (T, err))
+    assert err <= LOGIT_TOL
+    # a full training step at this shape runs and is bit-reproducible
+    target = codes[:, rf:rf + W].to(torch.int64).contiguous().view(-1)
+    l1 = eng.loss_and_grad(x, target).item()
+    g1 = eng.flat_grad.clone()
+    l2 = eng.loss_and_grad(x, target).item()
+    assert l1 == l2 and torch.equal(g1, eng.flat_grad) and np.isfinite(l1)

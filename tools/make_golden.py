@@ -466,6 +466,110 @@ def g8_autoencoder():
     torch.nn.Module.cuda = old_cuda
 
 
+def g9_autoencoder_harness():
+    """Row a14.  (1) exec wavenet_autoencoder/train.py (Appendix A.2 style): async=True -> non_blocking=True,
+    loss.data[0] -> loss.item(), the one space-indented line of get_optimizer re-indented with tabs (TabError
+    otherwise), nn.Module.cuda = identity (A.4), valid ./params/*.json, gain-scaled constructor, ONE torch seed at
+    the start (constructor, DataLoader iterators and the per-forward conditioning convs then draw from one stream).
+    (2) generate.py:13-19 `predict_next` + the window update of generate.py:55 on a growing window, the global RNG
+    seeded before every forward (the conditioning convs are redrawn per forward)."""
+    ae_dir = os.path.join(REF, "wavenet_autoencoder")
+    if ae_dir not in sys.path:
+        sys.path.insert(0, ae_dir)
+    old_cuda = torch.nn.Module.cuda
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    import model1
+    model1.print = lambda *a, **k: None
+    src = open(os.path.join(ae_dir, "train.py")).read()
+    src = src.replace("async=True", "non_blocking=True").replace("loss.data[0]", "loss.item()")
+    src = src.replace("                return optim.LBFGS", "\t\treturn optim.LBFGS")
+    cfg = dict(filter_width=2, quantization_channel=256, dilations=[1, 2, 4, 8, 1, 2, 4, 8],
+               en_residual_channel=16, en_dilation_channel=16, en_bottleneck_width=8,
+               en_pool_kernel_size=10, de_residual_channel=16, de_dilation_channel=16,
+               de_skip_channel=32, use_bias=False)
+    out = {"model_params": cfg, "gain": 3.0, "data_seed": 99, "data_lens": [900, 640]}
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "params"))
+    rng = np.random.default_rng(out["data_seed"])
+    data = [rng.integers(0, 256, size=(l,)).astype(np.int32) for l in out["data_lens"]]
+    with open(os.path.join(tmp, "np_audio.pkl"), "wb") as f:
+        pickle.dump(data, f)
+    dp = dict(batch_size=2, shuffle=True, num_workers=0, pin_memory=False, audio_path=os.path.join(tmp, "np_audio.pkl"),
+              receptive_field=32, window_length=120, cuda_available=False, quantization_channels=256)
+    tp = dict(log_dir="./log/", restore_dir="./restore/", restore_model="", check_point_every=1, print_every=2,
+              num_epochs=2, optimizer_type="Adam", max_check_points=10, learning_rate=1e-3, momentum=0.9, device_ids=None)
+    for n, p in (("model", cfg), ("dataset", dp), ("train", tp)):
+        json.dump(p, open(os.path.join(tmp, "params", n + "_params.json"), "w"))
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        ns = {"__name__": "ref_ae_train"}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            exec(compile(src, "train.py", "exec"), ns)
+            orig = ns["wavenet_autoencoder"]
+            ns["wavenet_autoencoder"] = lambda **kw: scaled(orig(**kw), out["gain"])
+            torch.manual_seed(0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ns["train"]()
+        out["loss_log"] = open("log/loss_log.log").read()
+        out["store_log"] = open("log/store_log.log").read()
+        out["files"] = sorted(os.listdir("restore"))
+        ck = torch.load("restore/wavenet_autoencoder2.model")
+        out["ckpt_keys"] = list(ck.keys())
+        out["ckpt_shapes"] = [list(v.shape) for v in ck.values()]
+        out["ckpt_abs_sum"] = [float(v.double().abs().sum()) for v in ck.values()]
+    finally:
+        os.chdir(cwd)
+    out["dataset_params"], out["train_params"] = dict(dp, audio_path="np_audio.pkl"), tp
+
+    # (2) naive generation, as written: predict_next (generate.py:13-19) and the window update of generate.py:55
+    gsrc = open(os.path.join(ae_dir, "generate.py")).read()
+    tree = ast.parse(gsrc)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "predict_next"]
+    gns = {"torch": torch}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "generate.py", "exec"), gns)
+    torch.manual_seed(9)
+    net = scaled(model1.wavenet_autoencoder(**cfg), 3.0)
+    rf, pool = net.receptive_field, cfg["en_pool_kernel_size"]
+    rng = np.random.default_rng(909)
+    start = rng.integers(0, 256, size=(rf + pool,))
+    x = torch.zeros(1, 256, rf + pool)
+    x[0, torch.from_numpy(start), torch.arange(rf + pool)] = 1.0
+    n_steps, seed0 = 26, 4000
+    codes, lens, margins = [], [], []
+    input_wav = x
+    with torch.no_grad():
+        for i in range(n_steps):
+            torch.manual_seed(seed0 + i)
+            c = gns["predict_next"](net, input_wav)
+            codes.append(int(c))
+            lens.append(int(input_wav.size(2)))
+            torch.manual_seed(seed0 + i)
+            top2 = torch.topk(net(input_wav).view(-1, 256)[-1], 2)[0]
+            margins.append(float(top2[0] - top2[1]))          # how decided each argmax is (near-ties may flip in fp32)
+            note = torch.zeros(1, 256, 1)
+            note[0, c, 0] = 1.0
+            # generate.py:55 slices DIMENSION 1 (channels) with -rf-511: a no-op for 256 channels, so the window GROWS
+            input_wav = torch.cat((input_wav[:, -net.receptive_field - 511:], note), 2)
+    # the same with the window the line evidently meant (last rf + pool samples along time)
+    slid = []
+    input_wav = x
+    with torch.no_grad():
+        for i in range(n_steps):
+            torch.manual_seed(seed0 + i)
+            c = gns["predict_next"](net, input_wav)
+            slid.append(int(c))
+            note = torch.zeros(1, 256, 1)
+            note[0, c, 0] = 1.0
+            input_wav = torch.cat((input_wav[:, :, -(rf + pool - 1):], note), 2)
+    out["gen"] = {"start": [int(v) for v in start], "seed0": seed0, "codes_as_written": codes, "window_lens": lens, "margins_as_written": margins,
+                  "codes_sliding": slid, "ctor_seed": 9}
+    np.savez_compressed(os.path.join(OUT, "g9_gen_weights.npz"), **{"w:" + k: v for k, v in sd_np(net).items()})
+    json.dump(out, open(os.path.join(OUT, "g9_ae_harness.json"), "w"), indent=1)
+    torch.nn.Module.cuda = old_cuda
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     model, af, fad = ref_modules()
@@ -477,6 +581,7 @@ def main():
     g6_fastgen(model)
     g7_train()
     g8_autoencoder()
+    g9_autoencoder_harness()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", os.path.normpath(OUT), "total %.2f MB" % (tot / 1e6))
 
