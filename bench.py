@@ -53,6 +53,9 @@ CFG = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 3, dilation_c
            residual_channels=64, skip_channels=256, quantization_channels=256, use_bias=False)
 B_LOCAL, T = 8, 16000
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec); 6.29e12 measured copy
+MFMA_PEAK = 2.5e15         # FLOP/s, dense bf16 / f16 MFMA (same guide)
+BWD_KERNELS = "resblock_bwd_rw_k + chan_gemm_rw_k"
+BWD_PMC = ("resblock_bwd_rw_k<true>", "chan_gemm_rw_k")
 
 
 def synth_codes(rank, b, t):
@@ -80,9 +83,44 @@ def stack_bytes(dil, r, d, b, t):
     return fwd * b, bwd * b
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The CPU oracle (== the reference's ATen-CPU op sequence, pinned by tests/golden) timed on
-    this host: full training step (forward + CE + backward + Adam) on ONE clip of 16000 samples."""
+def host_cores():
+    """(logical CPUs, physical cores) of this host, from /proc/cpuinfo where it says."""
+    logical = os.cpu_count() or 1
+    phys = set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return logical, (len(phys) if phys else logical)
+
+
+def flops_per_clip(dil, r, d, s, q, t):
+    """SURVEY 8(d) algorithmic FLOPs per clip: (stack forward: f/g products, dense; skip; post-processing; causal)."""
+    L = [t - 1]
+    for x in dil:
+        L.append(L[-1] - x)
+    w, lout = L[-1], sum(L[1:])
+    fg = 2 * (2 * 2 * r * d) * lout
+    dense = 2 * d * r * lout
+    skip = 2 * d * s * w * len(dil)
+    post = 2 * s * s * w + 2 * s * q * w
+    causal = 2 * (2 * q * r) * L[0]
+    return dict(fg=fg, dense=dense, skip=skip, post=post, causal=causal)
+
+
+def cpu_baseline():
+    """the CPU oracle (== the reference's ATen-CPU op sequence, pinned by tests/golden) timed on this
+    host on the SAME workload shape - full training step (forward + CE + backward + Adam) on 8 clips x 16000 samples,
+    2 warm-up + 5 timed steps - plus a one-thread figure on one clip.  Bounded: about 30 s of CPU work."""
     from oracle import wavenet_oracle as wo
     from oracle import intops
     torch.manual_seed(0)
@@ -91,29 +129,100 @@ def cpu_baseline(seconds_budget=25.0):
     params = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
     opt = torch.optim.Adam(list(params.values()), lr=1e-4)
     rng = np.random.default_rng(1234)
-    codes = rng.integers(0, 256, size=(T + 1,))
-    x = torch.from_numpy(intops.one_hot_scrambled(codes[:T]))[None]
+    codes = rng.integers(0, 256, size=(B_LOCAL, T + 1))
+    x = torch.from_numpy(np.stack([intops.one_hot_scrambled(c[:T]) for c in codes]))
     rf = 3071
-    target = torch.from_numpy(codes[rf:rf + T - rf + 1].astype(np.int64))
-    # ATen's CPU conv kernels stop scaling (and then collapse) long before a 256-core host is
-    # full: use at most 32 threads and say so in `cores`
-    cores = min(32, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    times = []
-    t_start = time.time()
-    for it in range(4):
+    W = T - rf + 1
+    target = torch.from_numpy(codes[:, rf:rf + W].astype(np.int64)).reshape(-1)
+    logical, physical = host_cores()
+
+    def step(xb, tb):
         t0 = time.time()
         opt.zero_grad()
-        loss = wo.ce_on_probs(wo.wavenet_forward(params, CFG["dilations"], x), target)
+        loss = wo.ce_on_probs(wo.wavenet_forward(params, CFG["dilations"], xb), tb)
         loss.backward()
         opt.step()
-        times.append(time.time() - t0)
-        if time.time() - t_start > seconds_budget:
-            break
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": T / best, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d full training steps (fwd+CE+bwd+Adam) of the 30-layer config on 1 clip x 16000 samples, "
-                      "torch CPU threads=%d, best of %d after 1 warm-up" % (len(times), cores, max(1, len(times) - 1))}
+        return time.time() - t0
+
+    # ATen's CPU conv kernels stop scaling (and then collapse) long before a 256-core host is full: one probe step
+    # each at all physical cores and at 32 threads, the timed steps run at the faster setting
+    cand = sorted({min(physical, 256), min(32, physical)}, reverse=True)
+    probe = {}
+    for n in cand:
+        torch.set_num_threads(n)
+        probe[n] = step(x, target)
+    cores = min(probe, key=probe.get)
+    torch.set_num_threads(cores)
+    step(x, target)                                   # second warm-up at the chosen setting
+    times = [step(x, target) for _ in range(5)]
+    best = min(times)
+    torch.set_num_threads(1)
+    t1 = step(x[:1], target[:W])
+    return {"value": B_LOCAL * T / best, "unit": "samples/s", "cores": cores, "kind": "port",
+            "host_logical_cpus": logical, "host_physical_cores": physical,
+            "probe_s_per_step": {str(k): round(v, 3) for k, v in probe.items()},
+            "mean_value": B_LOCAL * T * len(times) / sum(times),
+            "one_thread": {"value": T / t1, "unit": "samples/s", "sample": "1 step on 1 clip x 16000, 1 thread"},
+            "sample": "full training steps (fwd+CE+bwd+Adam) of the 30-layer config on %d clips x %d samples: 1 probe step per "
+                      "thread setting %s, 1 more warm-up, 5 timed at torch CPU threads=%d (best; mean in mean_value)" %
+                      (B_LOCAL, T, cand, cores)}
+
+
+def sub_benchmarks(net, x, target):
+    """Driver-timed figures for BASELINE configs[3] and [4] (extra keys of the JSON line): the autoencoder's fused
+    training step at 8 x 16000 and the cached-queue decoder on 16 000 greedy samples, one stream and 128 utterances."""
+    out = {}
+    dev = x.device
+    from music_amd.model1 import wavenet_autoencoder
+    torch.manual_seed(0)
+    ae = wavenet_autoencoder(filter_width=2, quantization_channel=256, dilations=CFG["dilations"], en_residual_channel=64,
+                             en_dilation_channel=64, en_bottleneck_width=64, en_pool_kernel_size=512,
+                             de_residual_channel=64, de_dilation_channel=64, de_skip_channel=256, use_bias=False).cuda()
+    aeng = ae._engine_for(dev)
+    aeng.adam_init(lr=1e-4)
+
+    def ae_step():
+        loss = aeng.loss_and_grad(x, target, ae._draw_conditioning())      # fresh conditioning projections per forward
+        aeng.adam_step()
+        return loss
+    for _ in range(2):
+        ae_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        loss = ae_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    out["c4_autoencoder"] = {"workload": "BASELINE configs[3]: autoencoder 30+30 blocks, 64 ch, 256 skip, bottleneck 64, pool 512, "
+                                         "batch 8x16000, fused step (fwd + CE + bwd + Adam), 5 steps after 2 warm-up",
+                             "ms_per_step": dt * 1e3, "samples_per_s": B_LOCAL * T / dt, "final_loss": float(loss.item())}
+    del ae, aeng
+    from music_amd import fast_generate as fg
+    start = torch.zeros(1, 256, net.receptive_field, device=dev)
+    start[:, 128, :] = 1.0
+    fg.generate_codes(net, start, 200)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    codes = fg.generate_codes(net, start, 16000)
+    torch.cuda.synchronize()
+    dt1 = time.perf_counter() - t0
+    U = 128
+    starts = torch.zeros(U, 256, net.receptive_field, device=dev)
+    for u in range(U):
+        starts[u, (128 + u) % 256, :] = 1.0
+    fg.generate_codes_batch(net, starts, 50)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fg.generate_codes_batch(net, starts, 16000)
+    torch.cuda.synchronize()
+    dtu = time.perf_counter() - t0
+    out["c5_decode"] = {"workload": "BASELINE configs[4]: cached-queue greedy decode, 30-layer model, 16000 samples (1 s @16 kHz) "
+                                    "from the class-128 start piece, one persistent launch (queue fill included)",
+                        "single_stream_samples_per_s": 16000 / dt1, "single_stream_s": dt1,
+                        "real_time_factor": 16000 / dt1 / 16000.0,
+                        "batch128_samples_per_s": U * 16000 / dtu, "batch128_s": dtu,
+                        "distinct_codes": int(torch.unique(codes).numel())}
+    return out
 
 
 def measured_copy_gbs():
@@ -143,6 +252,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="f16x3,bf16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config-4 / config-5 sub-benchmarks")
     ap.add_argument("--phases", action="store_true", help="print the per-phase GPU time table to stderr")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch plumbing only (CPU, gloo): every rank joins the group, rank 0 prints the world size")
@@ -180,15 +290,24 @@ def main():
     net = wavenet(**CFG)
     net.precision = tuple(args.precision.split(","))
     net = net.cuda()
-    eng = net._engine_for(torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    eng = net._engine_for(dev)
     eng.adam_init(lr=1e-4)
     codes = synth_codes(rank, B_LOCAL, T)
     rf = net.receptive_field
     W = T - rf + 1
-    piece = codes[:, :T].contiguous()
-    target = codes[:, rf:rf + W].to(torch.int64).contiguous().view(-1)
+    # what a loader hands over per step: int32 sample codes and int64 targets in pinned host memory (1.3 MB); the
+    # H2D copies are part of the step, the one-hot is built in HBM
+    piece_h = codes[:, :T].contiguous().cpu().pin_memory()
+    target_h = codes[:, rf:rf + W].to(torch.int64).contiguous().view(-1).cpu().pin_memory()
+    piece = torch.empty(B_LOCAL, T, dtype=torch.int32, device=dev)
+    target = torch.empty(B_LOCAL * W, dtype=torch.int64, device=dev)
 
     def step():
+        eng.mark("step_begin")
+        piece.copy_(piece_h, non_blocking=True)
+        target.copy_(target_h, non_blocking=True)
+        eng.mark("h2d")
         x = eng.onehot(piece, scrambled=True)
         loss = eng.loss_and_grad(x, target)
         if use_dist:
@@ -220,34 +339,51 @@ def main():
     # per-phase GPU time from the HIP events recorded on the launch stream inside the timed region
     phase = {}
     for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
-        phase[n1] = phase.get(n1, 0.0) + e0.elapsed_time(e1)
+        if n1 != "step_begin":
+            phase[n1] = phase.get(n1, 0.0) + e0.elapsed_time(e1)
     phase = {k: v / args.steps for k, v in phase.items()}       # ms per step
     if args.phases and rank == 0:
         print(json.dumps({"phase_ms_per_step": phase}), file=sys.stderr)
 
-    fwd_b, bwd_b = stack_bytes(CFG["dilations"], 64, 64, B_LOCAL, T)
-    n_layers = len(CFG["dilations"])
+    dil = CFG["dilations"]
+    fwd_b, bwd_b = stack_bytes(dil, 64, 64, B_LOCAL, T)
+    n_layers = len(dil)
     nan = float("nan")
     fwd_ms, bwd_ms = phase.get("stack_fwd", nan), phase.get("stack_bwd", nan)
 
     def gbs(nbytes, ms):
         return nbytes / (ms * 1e-3) / 1e9 if ms == ms and ms > 0 else None
 
-    # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes (tools/gpu_check.sh
-    # prof; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), if a summary is committed
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_resblock_fwd.json")
+    def roof(nbytes, ms, **extra):
+        g = gbs(nbytes, ms)
+        r = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (g * 1e9 / HBM_PEAK) if g else None}
+        r.update(extra)
+        return r
+
+    # HBM traffic per launch from the separate rocprofv3 --pmc passes of the same command (tools/gpu_check.sh prof ->
+    # profiles/pmc_kernels.json; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), when a summary is committed
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_kernels.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_path))
         except Exception:
-            traffic = None
-    ach = gbs(fwd_b, fwd_ms)
+            pmc = {}
+
+    def traffic_of(*prefixes):
+        tot = 0.0
+        for pre in prefixes:
+            hit = [v["hbm_bytes_per_launch"] for k, v in pmc.items() if k.startswith(pre)]
+            if not hit:
+                return None
+            tot += max(hit)
+        return tot
+
     copy_gbs = measured_copy_gbs() if rank == 0 else None
     # Per-kernel split of the backward stack, from 3 extra (untimed) steps with one HIP event per launch
-    # (the events would cost ~1 % inside the timed region): the block kernel and the data-gradient product.
-    bwd_kernels = None
-    if rank == 0 and world == 1 and getattr(eng, "_use_ms", lambda: False)():
+    # (the events would cost ~1 % inside the timed region)
+    kern = None
+    if rank == 0 and world == 1:
         eng.fine_marks, eng.marks = True, []
         for _ in range(3):
             x = eng.onehot(piece, scrambled=True)
@@ -256,25 +392,38 @@ def main():
         m2, eng.marks, eng.fine_marks = eng.marks, None, False
         tot, cnt = {}, {}
         for (n0, e0), (n1, e1) in zip(m2[:-1], m2[1:]):
-            if n1 in ("b_block", "b_dx"):
-                tot[n1] = tot.get(n1, 0.0) + e0.elapsed_time(e1)
-                cnt[n1] = cnt.get(n1, 0) + 1
-        dil, off = CFG["dilations"], [1]
+            tot[n1] = tot.get(n1, 0.0) + e0.elapsed_time(e1)
+            cnt[n1] = cnt.get(n1, 0) + 1
+        off = [1]
         for d in dil:
             off.append(off[-1] + d)
-        Wc = T - off[-1]                                          # columns of the skip crop
-        ch = 64
-        blk_b = sum(4 * B_LOCAL * ch * ((T - off[i]) + (T - off[i + 1]) + Wc + 2 * (T - off[i + 1])) for i in range(len(dil))) / len(dil)
-        dx_b = sum(4 * B_LOCAL * ch * (2 * (T - off[i + 1]) + (T - off[i + 1]) + (T - off[i])) for i in range(len(dil))) / len(dil)
-        bwd_kernels = []
-        for key, name, nbytes, what in (("b_block", "resblock_bwd_rw_k", blk_b, "x, dy, dz-crop in; [df;dg] out (+ 20 MB of weight-gradient slabs, not counted)"),
-                                        ("b_dx", "chan_gemm_rw_k", dx_b, "[df;dg], dy in; dx out")):
-            if cnt.get(key):
-                ms = tot[key] / cnt[key]
-                bwd_kernels.append({"kernel": name, "avg_launch_ms": ms, "bytes_per_launch": nbytes, "bytes": what,
-                                    "achieved": gbs(nbytes, ms), "unit": "GB/s",
-                                    "frac": gbs(nbytes, ms) * 1e9 / HBM_PEAK,
-                                    "frac_of_measured_copy": (gbs(nbytes, ms) / copy_gbs) if copy_gbs else None})
+        Wc, ch = T - off[-1], 64
+        per = {k: tot[k] / cnt[k] for k in tot}
+        kern = {"fine_ms_per_launch": {k: round(v, 5) for k, v in per.items() if k.startswith(("b_", "f_"))}}
+
+    fl = flops_per_clip(dil, 64, 64, 256, 256, T)
+    B = B_LOCAL
+    issued = {      # x3: every product is hi*hi + lo*hi + hi*lo on the 16-bit matrix cores
+        "stack_fwd": 3 * B * (fl["fg"] + fl["dense"]),
+        "stack_bwd": 3 * B * (3 * fl["fg"] + 2 * fl["dense"]),          # recompute, dz, dx, dWfg, dWd
+        "epilogue_fwd": 3 * B * (fl["skip"] + fl["post"]),
+        "epilogue_bwd": 3 * B * 2 * (fl["skip"] + fl["post"]),
+        "causal_fwd": 3 * B * fl["causal"],
+    }
+    x3 = args.precision == "f16x3,bf16x3"
+    mfma = {"peak_TFLOPs": MFMA_PEAK / 1e12, "unit": "fraction of the dense 16-bit MFMA peak",
+            "note": "issued MFMA FLOPs = 3 x algorithmic (2-term operand split) / phase time / peak" if x3 else
+                    "issued MFMA FLOPs = algorithmic / phase time / peak"}
+    tot_fl = 0.0
+    for k, v in issued.items():
+        v = v if x3 else v / 3
+        tot_fl += v
+        if phase.get(k):
+            mfma[k] = v / (phase[k] * 1e-3) / MFMA_PEAK
+    mfma["step"] = tot_fl / (dt / args.steps) / MFMA_PEAK
+    mfma["issued_TFLOP_per_step"] = tot_fl / 1e12
+
+    bwd_launch_ms = bwd_ms / n_layers
     out = {
         "metric": "audio samples/sec trained (whole node), 30-layer WaveNet @16kHz",
         "value": world * B_LOCAL * T * args.steps / dt,
@@ -282,38 +431,34 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (f16/bf16 2-term split operands, 3 MFMA per product, f32 accumulate)"
-                 if args.precision == "f16x3,bf16x3" else args.precision,
+        "dtype": "f32 (f16/bf16 2-term split operands, 3 MFMA per product, f32 accumulate)" if x3 else args.precision,
         "data": "synthetic",
+        "rccl_ranks": world if use_dist else 0, "backend": (dist.get_backend() if use_dist else "none"),
         "config": {"workload": "BASELINE configs[1]: 30-layer (3x dilations 1..512) WaveNet, 64 res/dil, 256 skip, "
-                               "batch 8x16000 per GPU, full train step (one-hot + fwd + CE + bwd + all-reduce + Adam)",
+                               "batch 8x16000 per GPU, full train step (H2D of codes + one-hot + fwd + CE + bwd + all-reduce + Adam)",
                    "global_batch": world * B_LOCAL, "seq_len": T, "parallelism": "dp%d" % world,
                    "precision": args.precision, "final_loss": float(loss.item())},
-        # dominant kernel family = the dilated-conv stack: forward kernel, one launch per block
-        "roofline": {"bound": "hbm", "kernel": "resblock_fwd_nt_k (dilated-conv stack forward, %d launches/step)" % n_layers,
-                     "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": (ach * 1e9 / HBM_PEAK) if ach else None, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": fwd_b / n_layers,
-                     "avg_launch_ms": fwd_ms / n_layers,
-                     # the nominal peak next to what a plain device copy reaches on this box
-                     # (read + write bytes of a 1 GiB float4 copy / its time)
-                     "measured_copy_GBs": copy_gbs,
-                     "frac_of_measured_copy": (ach / copy_gbs) if (ach and copy_gbs) else None},
-        # the same stack, backward (resblock_bwd_rw_k + chan_gemm_rw_k per block) and forward+backward
-        "roofline_stack_bwd": {"bound": "hbm", "achieved": gbs(bwd_b, bwd_ms), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": (gbs(bwd_b, bwd_ms) * 1e9 / HBM_PEAK) if gbs(bwd_b, bwd_ms) else None,
-                               "algorithmic_bytes_per_step": bwd_b},
-        "roofline_stack_fwd_bwd": {"bound": "hbm", "achieved": gbs(fwd_b + bwd_b, fwd_ms + bwd_ms), "peak": HBM_PEAK / 1e9,
-                                   "unit": "GB/s",
-                                   "frac": (gbs(fwd_b + bwd_b, fwd_ms + bwd_ms) * 1e9 / HBM_PEAK)
-                                   if gbs(fwd_b + bwd_b, fwd_ms + bwd_ms) else None,
-                                   "algorithmic_bytes_per_step": fwd_b + bwd_b},
+        # the time-dominant kernels: one residual block's backward (SURVEY 8d A_b per block; duration = the HIP-event
+        # time of the backward stack inside the timed region / its 30 blocks)
+        "roofline": roof(bwd_b / n_layers, bwd_launch_ms,
+                         kernel="%s: backward of one residual block, %d per step" % (BWD_KERNELS, n_layers),
+                         traffic=traffic_of(*BWD_PMC), algorithmic_bytes_per_launch=bwd_b / n_layers,
+                         avg_launch_ms=bwd_launch_ms, measured_copy_GBs=copy_gbs,
+                         frac_of_measured_copy=(gbs(bwd_b / n_layers, bwd_launch_ms) / copy_gbs) if copy_gbs and bwd_ms == bwd_ms else None),
+        # the dilated-conv stack of the north star, forward / backward / both (SURVEY 8d A_f, A_b)
+        "roofline_stack_fwd": roof(fwd_b, fwd_ms, kernel="resblock_fwd_nt_k x %d" % n_layers, traffic=traffic_of("resblock_fwd_nt_k"),
+                                   algorithmic_bytes_per_launch=fwd_b / n_layers, avg_launch_ms=fwd_ms / n_layers,
+                                   algorithmic_bytes_per_step=fwd_b),
+        "roofline_stack_bwd": roof(bwd_b, bwd_ms, algorithmic_bytes_per_step=bwd_b),
+        "roofline_stack_fwd_bwd": roof(fwd_b + bwd_b, fwd_ms + bwd_ms, algorithmic_bytes_per_step=fwd_b + bwd_b),
+        "mfma_util": mfma,
         "phase_ms_per_step": {k: round(v, 4) for k, v in phase.items()},
     }
-    if bwd_kernels:
-        # per launch, kernel-level bytes ([df;dg] goes through HBM); avg_launch_ms is the time between two HIP events
-        # around the lone launch (3 untimed steps), ~10 % above its back-to-back time inside the timed region
-        out["roofline_bwd_kernels"] = bwd_kernels
+    if kern:
+        out["kernels"] = kern
+    if rank == 0 and world == 1 and not args.no_extras:
+        x = eng.onehot(piece, scrambled=True)
+        out["extra"] = sub_benchmarks(net, x, target)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -151,6 +151,15 @@ int wn_resblock_wgrad(const float* dfg, const float* x_in, const float* dy, cons
                       int64_t dfg_bstride, int64_t x_bstride, int64_t z_bstride, int pitch, int ch, int d,
                       int t_lo, int t_hi, float* slab_fg, float* slab_d, int chunk, int batch, int mode,
                       wn_stream_t stream);
+/* Weight gradient of the causal layer (autograd of wavenet/model.py:104) when the layer's input is the ONE-HOT tensor
+ * wn_onehot built from `codes` (int32 [batch][t]; scrambled as there): dW[r][q][tap] = sum_{b,s} dx[b][r][s] *
+ * in[b][q][s-1+tap] becomes a scatter of dx columns - dx (ch rows) is read once, the 4*q*t bytes per clip of dense
+ * one-hot are not read at all.  Writes wn_causal_wgrad_codes_slabs(t, batch) slabs [ch][2q] (columns = tap 0 rows |
+ * tap 1 rows, the layout wn_wgrad gives the same product); sum them with wn_reduce_slabs.  Bit-reproducible.
+ * Arbitrary float inputs (faster_audio_data.py hands the model a dense tensor) keep using wn_wgrad. */
+int wn_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, int64_t dx_bstride, int pitch, int ch, int q,
+                          int t, int batch, float* slab, wn_stream_t stream);
+int wn_causal_wgrad_codes_slabs(int t, int batch);
 /* desc[op] = {vec_start, slab_off, n_slabs, stride, out_off, n} (int64, device memory):
  * out[out_off+e] = sum_s slab[slab_off + s*stride + e] for e < n; work item v covers 4 floats and
  * belongs to the op with vec_start <= v. */
@@ -167,7 +176,8 @@ int wn_chunk_softmax256_fwd(const float* x, float* y, int64_t nrows, wn_stream_t
 int wn_chunk_softmax256_bwd(const float* y, const float* dy, float* dx, int64_t nrows, wn_stream_t stream);
 /* Fused chunk softmax + nn.CrossEntropyLoss applied to the PROBABILITIES (wavenet/train.py:146,179;
  * SURVEY Q1) + both backward steps.  probs/dx may be NULL.  loss_part: WN_CE_NUM_PARTIALS floats,
- * their sum is the mean loss. */
+ * their sum is the mean loss.  A target outside [0, 256) - nn.CrossEntropyLoss raises for it - turns the loss and
+ * that row's dx into NaN (no silent wrong value, no host round trip). */
 int wn_chunk_softmax256_ce(const float* x, const int64_t* target, float* probs, float* dx,
                            float* loss_part, int64_t nrows, float inv_n, wn_stream_t stream);
 

@@ -45,6 +45,8 @@ SIGNATURES = {
                            _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_bwd_ms_slabs": [_i, _i, _i],
     "wn_resblock_wgrad": [_p, _p, _p, _p, _l, _l, _l, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p],
+    "wn_causal_wgrad_codes": [_p, _i, _p, _l, _i, _i, _i, _i, _i, _p, _p],
+    "wn_causal_wgrad_codes_slabs": [_i, _i],
     "wn_reduce_slabs": [_p, _i, _l, _p, _p, _p],
     "wn_bias_grad": [_p, _l, _i, _i, _i, _i, _i, _i, _p, _p],
     "wn_chunk_softmax256_fwd": [_p, _p, _l, _p],
@@ -100,6 +102,11 @@ def load():
 def wgrad_slabs(t_lo, t_hi, chunk, batch):
     """Number of slabs one wn_wgrad call writes (plain int return, not a status)."""
     return load().wn_wgrad_slabs(t_lo, t_hi, chunk, batch)
+
+
+def causal_codes_slabs(t, batch):
+    """Number of slabs one wn_causal_wgrad_codes call writes (plain int return, not a status)."""
+    return load().wn_causal_wgrad_codes_slabs(t, batch)
 
 
 def ms_slabs(t_lo, t_hi, batch):

@@ -222,6 +222,14 @@ int wn_enc_resblock_bwd(const float* x_in, const float* dy, const float* h, floa
 int wn_enc_resblock_bwd_slabs(int t_lo, int t_hi, int batch) { return wn_enc_bwd_slabs(t_lo, t_hi, batch); }
 int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch) { return wn_resms_slabs(t_lo, t_hi, batch); }
 
+int wn_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, int64_t dx_bstride, int pitch, int ch, int q,
+                          int t, int batch, float* slab, wn_stream_t stream) {
+    if (q != 256) return wn_set_error_msg(-4, "wn_causal_wgrad_codes: 256 quantisation channels only");
+    if (!codes || !dx || !slab) return wn_set_error_msg(-4, "wn_causal_wgrad_codes: null argument");
+    return wn_launch_causal_wgrad_codes(codes, scrambled, dx, dx_bstride, pitch, ch, t, batch, slab, (hipStream_t)stream);
+}
+int wn_causal_wgrad_codes_slabs(int t, int batch) { return wn_causal_codes_slabs(t, batch); }
+
 int wn_cond_grad(const float* in, int64_t in_bstride, int in_pitch, int rows, int t_lo, int t_hi, int mode, int le,
                  int q, float* out, int64_t out_bstride, int out_pitch, int batch, wn_stream_t stream) {
     return wn_launch_cond_grad(in, in_bstride, in_pitch, rows, t_lo, t_hi, mode, le, q, out, out_bstride, out_pitch, batch,

@@ -63,11 +63,11 @@ __global__ __launch_bounds__(64 * CE_WAVES) void softmax256_ce_k(const float* __
     // clamped row index: a load under a run-time condition would not be a prefetch)
     long rc = row < nrows ? row : nrows - 1;
     f32x4 v = ld4(x + rc * 256 + lane * 4);
-    int y = (int)target[rc];
+    long y = target[rc];
     for (; row < nrows; row += stride) {
         const long rn = row + stride < nrows ? row + stride : nrows - 1;
         const f32x4 vn = ld4(x + rn * 256 + lane * 4);
-        const int yn = (int)target[rn];
+        const long yn = target[rn];
         float m = wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
         f32x4 e = {expf(v[0] - m), expf(v[1] - m), expf(v[2] - m), expf(v[3] - m)};
         float inv = 1.0f / wave_sum((e[0] + e[1]) + (e[2] + e[3]));
@@ -76,15 +76,20 @@ __global__ __launch_bounds__(64 * CE_WAVES) void softmax256_ce_k(const float* __
         // second (log-)softmax over the probabilities: p in [0,1] so no max shift is needed
         f32x4 e2 = {expf(p[0]), expf(p[1]), expf(p[2]), expf(p[3])};
         float s2 = wave_sum((e2[0] + e2[1]) + (e2[2] + e2[3]));
-        int yl = y >> 2, ye = y & 3;
+        // a target outside [0, 256) (nn.CrossEntropyLoss raises "Target out of bounds" for it) poisons the loss and this
+        // row's gradient with NaN instead of silently reading another lane's probability: corrupt data stays visible
+        // in the loss log without a device -> host check per step
+        const bool bad = (unsigned long)y > 255ul;
+        const int yl = (int)(y >> 2) & 63, ye = (int)y & 3;
         float py = __shfl(ye == 0 ? p[0] : ye == 1 ? p[1] : ye == 2 ? p[2] : p[3], yl, 64);
-        lacc += logf(s2) - py;
+        lacc += bad ? __builtin_nanf("") : logf(s2) - py;
         if (dx) {
             float is2 = inv_n / s2;
             f32x4 dp = {e2[0] * is2, e2[1] * is2, e2[2] * is2, e2[3] * is2};
             if (lane == yl) dp[ye] -= inv_n;
             float dot = wave_sum((p[0] * dp[0] + p[1] * dp[1]) + (p[2] * dp[2] + p[3] * dp[3]));
             f32x4 r = {p[0] * (dp[0] - dot), p[1] * (dp[1] - dot), p[2] * (dp[2] - dot), p[3] * (dp[3] - dot)};
+            if (bad) r = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
             *reinterpret_cast<f32x4*>(dx + row * 256 + lane * 4) = r;
         }
         v = vn;

@@ -105,6 +105,11 @@ int wn_launch_wgrad2(const WnWgradArgs* a1, const WnWgradArgs* a2, int batch, in
 int wn_wgrad_num_slabs(int t_lo, int t_hi, int chunk, int batch);
 int wn_launch_reduce_slabs(const long* desc, int n_ops, long total_vec, const float* slab, float* out, hipStream_t st);
 
+// causal-layer weight gradient from integer codes (wn_causal.hip); one slab [ch][2*256] per workgroup
+int wn_launch_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, long dx_bstride, int pitch, int ch,
+                                 int T, int batch, float* slab, hipStream_t st);
+int wn_causal_codes_slabs(int T, int batch);
+
 int wn_launch_softmax_fwd(const float* x, float* y, long nrows, hipStream_t st);
 int wn_launch_softmax_bwd(const float* y, const float* dy, float* dx, long nrows, hipStream_t st);
 #define WN_CE_PARTIALS 1024

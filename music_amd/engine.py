@@ -332,21 +332,30 @@ class WaveNetEngine:
             if i < self.N - 1:
                 ops.append(("d%d" % i, self.off[i + 1], T, -1 if ms else 512))
         ops.append(("causal", 1, T, 512))
+        # the same gradient from integer codes (wn_causal_wgrad_codes) when the input is a one-hot this engine / the
+        # loader built: its own slab region and its own reduction table (only the last row differs)
+        ops.append(("causal_codes", 1, T, None))
         plan, desc, so, vs = {}, [], 0, 0
         for name, t_lo, t_hi, chunk in ops:
-            go, r, c = self.gp_off[name]
+            go, r, c = self.gp_off["causal" if name == "causal_codes" else name]
             n = r * c
-            if chunk > 0:
+            if chunk is None:
+                ns = _lib.causal_codes_slabs(T, B)
+            elif chunk > 0:
                 ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B)
             else:                                             # channel-split block: one slab per workgroup
                 ns = _lib.ms_slabs(t_lo, t_hi, B)
             plan[name] = (so, n, chunk)
-            desc.append([vs, so, ns, n, go, n])
+            if name == "causal_codes":
+                desc_codes = desc[:-1] + [[desc[-1][0], so, ns, n, go, n]]
+            else:
+                desc.append([vs, so, ns, n, go, n])
+                vs += (n + 3) // 4
             so += ns * n
-            vs += (n + 3) // 4
         bw["slab"] = torch.empty(so, dtype=torch.float32, device=dev)
         bw["slab_plan"], bw["slab_vec"], bw["slab_nops"] = plan, vs, len(desc)
         bw["slab_desc"] = torch.tensor(desc, dtype=torch.int64, device=dev)
+        bw["slab_desc_codes"] = torch.tensor(desc_codes, dtype=torch.int64, device=dev)
         ws["bwd"] = bw
         return bw
 
@@ -378,6 +387,16 @@ class WaveNetEngine:
         self._gen += 1
         ws["gen"] = self._gen
         ws["x_in"] = x
+        # a one-hot built from integer codes by onehot() / the loader carries them along: the backward then forms the
+        # causal layer's weight gradient by scatter instead of streaming the dense tensor (still valid only while the
+        # tensor has not been written to since)
+        tag = getattr(x, "_wn_codes", None)
+        ws["x_codes"] = None
+        if tag is not None and os.environ.get("WN_CAUSAL_CODES", "1") == "1":
+            codes, scrambled, version = tag
+            if (x._version == version and codes.is_cuda and codes.dtype == torch.int32 and codes.is_contiguous() and
+                    tuple(codes.shape) == (B, T)):
+                ws["x_codes"] = (codes, scrambled)
         # causal conv (wavenet/model.py:104): x0[t] = W0 in[t-1] + W1 in[t], t in [1,T)
         call("wn_chan_gemm", ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, fr("causal"), CH // 16, self.R,
              self._x(ws, 0), xb, pitch, 0, self._bias_ptr("causal_layer.bias"),
@@ -576,10 +595,17 @@ class WaveNetEngine:
         # causal weight gradient: dWc[r][q][tap] = sum dx0[r][t] in[q][t-1+tap]
         x = ws["x_in"]
         dx0 = ptr(bw["dX"][0], SLACK)
-        wgrad("causal", dx0, xb, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CH // 16, 0, 2 * Q, 1, T)
+        desc = bw["slab_desc"]
+        if ws.get("x_codes") is not None:
+            codes, scrambled = ws["x_codes"]
+            call("wn_causal_wgrad_codes", ptr(codes), 1 if scrambled else 0, dx0, xb, pitch, CH, Q, T, B,
+                 ptr(bw["slab"], plan["causal_codes"][0]), st)
+            desc = bw["slab_desc_codes"]
+        else:
+            wgrad("causal", dx0, xb, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CH // 16, 0, 2 * Q, 1, T)
         if self.use_bias:
             call("wn_bias_grad", dx0, xb, pitch, 0, self.R, 1, T, B, ptr(self.gpack, self.gp_bias_off["causal_layer.bias"]), st)
-        call("wn_reduce_slabs", ptr(bw["slab_desc"]), bw["slab_nops"], bw["slab_vec"], ptr(bw["slab"]), ptr(self.gpack), st)
+        call("wn_reduce_slabs", ptr(desc), bw["slab_nops"], bw["slab_vec"], ptr(bw["slab"]), ptr(self.gpack), st)
         call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
         self.mark("causal_bwd")
 
@@ -634,4 +660,6 @@ class WaveNetEngine:
         out = torch.empty(B, self.Q, T, dtype=torch.float32, device=self.device)
         call("wn_onehot", ptr(codes), ptr(out), B, self.Q, T, 1 if scrambled else 0, _lib.stream())
         self.mark("onehot")
+        if codes.is_contiguous() and codes.dtype == torch.int32:
+            out._wn_codes = (codes, bool(scrambled), out._version)      # see forward_logits
         return out

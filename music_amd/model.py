@@ -25,6 +25,10 @@ class _WaveNetFunction(torch.autograd.Function):
         x = wave_sample.detach()
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
+        else:
+            tag = getattr(wave_sample, "_wn_codes", None)        # one-hot built from codes (engine.forward_logits)
+            if tag is not None and wave_sample._version == tag[2]:
+                x._wn_codes = (tag[0], tag[1], x._version)
         probs, ws = eng.forward(x)
         ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
         return probs

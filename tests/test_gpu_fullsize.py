@@ -11,8 +11,18 @@ per-XCD interleaved orders and slab counts that depend on the size, so gradients
   (d) the reference's shipped wavenet_params.json (40 blocks, 32/32/512, rf 4094): forward + gradients at
       window 4000, and the shipped batch (4 x 44093, window 40000) against an oracle window
 
-Run with -m gpu.  Tolerances as tests/test_gpu_parity.py: probabilities 1e-3 absolute on gain-scaled weights,
-gradients 2e-3 of the tensor's max-abs, integers exact."""
+Run with -m gpu.  Probabilities: 1e-3 absolute on gain-scaled weights, integers exact, as tests/test_gpu_parity.py.
+
+Gradients at these sizes are sums over 26 k - 160 k columns of terms that mostly cancel, and the REFERENCE's own float32
+arithmetic is not reproducible to 2e-3 there: evaluated in float64, the same algorithm moves every gradient tensor by
+2e-3 ... 5e-2 of its max-abs (tools/diag_fullsize.py: config 2 at 2 x 16000, gain 2.5: float32 CPU 3.7e-2, this path
+1.2e-2).  So the yardstick here is the float64 oracle: a gradient passes when its error against float64 is within
+FULL_GRAD_RTOL = 1e-2 of the tensor's max-abs (the bf16 hi/lo operands of the backward products carry 2^-17 per
+element: 2.5e-3 measured on well-conditioned config-2 sums, 5e-3 on the autoencoder's encoder weights, whose gradient
+arrives through the bucket sums of the conditioning tables) or within 3x the error the float32 CPU path itself makes on
+that tensor.  What that bar cannot see - a dropped tile at a clip or workgroup boundary moves a sum by ~1e-3 - is caught by a
+property with no conditioning in it: the batch gradient must equal the mean of the single-clip gradients, which the
+persistent kernels compute with a different partition of items, slabs and XCD walks (1e-4)."""
 import numpy as np
 import pytest
 import torch
@@ -26,7 +36,7 @@ from tests.helpers import scrambled_input
 import os
 
 LOGIT_TOL = 1e-3
-GRAD_RTOL = 2e-3
+FULL_GRAD_RTOL = 1e-2
 ORACLE_THREADS = min(32, os.cpu_count() or 1)      # ATen's CPU convs stop scaling (then collapse) beyond that
 C2 = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 3, dilation_channels=64, residual_channels=64,
           skip_channels=256, quantization_channels=256, use_bias=False)
@@ -42,17 +52,28 @@ def _scaled(net, gain):
     return {k: v.clone() for k, v in net.state_dict().items()}
 
 
-def _check_grads(eng, g_ref, skip=()):
-    worst, worst_name = 0.0, None
-    for name in eng.param_names:
-        if name in skip:
+def _check_grads(got, g64, g32):
+    """got / g64 / g32: name -> gradient (this path, float64 oracle, float32 oracle).  Returns the worst (error vs f64,
+    name, the float32 path's error on that tensor)."""
+    worst = (0.0, None, 0.0)
+    for name, ref in g64.items():
+        if ref is None:
+            assert got[name] is None or got[name].abs().max().item() == 0.0, name
             continue
-        g = g_ref[name]
-        err = (eng.param_view(name, grad=True).cpu() - g).abs().max().item() / max(g.abs().max().item(), 1e-12)
-        if err > worst:
-            worst, worst_name = err, name
-        assert err <= GRAD_RTOL, (name, err)
-    return worst, worst_name
+        scale = max(ref.abs().max().item(), 1e-30)
+        e_gpu = (got[name].detach().cpu().double() - ref).abs().max().item() / scale
+        e_cpu = (g32[name].double() - ref).abs().max().item() / scale
+        if e_gpu > worst[0]:
+            worst = (e_gpu, name, e_cpu)
+        assert e_gpu <= max(FULL_GRAD_RTOL, 3.0 * e_cpu), (name, e_gpu, e_cpu)
+    return worst
+
+
+def _oracle_grads_f32_f64(params, dilations, x, target):
+    torch.set_num_threads(ORACLE_THREADS)
+    l32, p32, g32 = wo.loss_and_grads(params, dilations, x, target)
+    l64, p64, g64 = wo.loss_and_grads({k: v.double() for k, v in params.items()}, dilations, x.double(), target)
+    return l32, p32, g32, l64, g64
 
 
 def test_c2_full_length_loss_and_gradients_vs_oracle():
@@ -74,19 +95,30 @@ def test_c2_full_length_loss_and_gradients_vs_oracle():
     assert torch.equal(xd.cpu(), x)
     loss = eng.loss_and_grad(xd, target.cuda(), want_probs=True)
     probs = eng.workspace(B, T)["probs"].cpu()
-    torch.set_num_threads(ORACLE_THREADS)
-    l_ref, p_ref, g_ref = wo.loss_and_grads(params, C2["dilations"], x, target)
+    got = {n: eng.param_view(n, grad=True).clone() for n in eng.param_names}
+    l_ref, p_ref, g32, l64, g64 = _oracle_grads_f32_f64(params, C2["dilations"], x, target)
     e_p = (probs - p_ref).abs().max().item()
     assert probs.shape == (B * W, 256) and e_p <= LOGIT_TOL, e_p
     assert p_ref.max().item() > 0.5                       # non-vacuous
-    assert abs(loss.item() - l_ref.item()) < 1e-4
-    worst, name = _check_grads(eng, g_ref)
-    print("c2 full length (2 x 16000): probs err %.2e, loss %.6f (oracle %.6f), worst rel grad err %.2e (%s)" %
-          (e_p, loss.item(), l_ref.item(), worst, name))
+    assert abs(loss.item() - l_ref.item()) < 1e-4 and abs(loss.item() - l64.item()) < 1e-4
+    worst, name, cpu = _check_grads(got, g64, g32)
+    print("c2 full length (2 x 16000): probs err %.2e, loss %.7f (oracle f32 %.7f, f64 %.7f), worst grad err vs f64 %.2e "
+          "(%s; the float32 CPU path: %.2e)" % (e_p, loss.item(), l_ref.item(), l64.item(), worst, name, cpu))
     # the same step again: weight gradients are bit-reproducible (slab sums in a fixed order, no float atomics)
     g1 = eng.flat_grad.clone()
     eng.loss_and_grad(xd, target.cuda())
     assert torch.equal(g1, eng.flat_grad)
+    # partition independence: batch gradient == mean of the single-clip gradients (other item / slab / XCD partitions)
+    acc = torch.zeros_like(g1)
+    for b in range(B):
+        eng.loss_and_grad(xd[b:b + 1].contiguous(), target.view(B, W)[b].contiguous().cuda())
+        acc += eng.flat_grad
+    acc /= B
+    for n in eng.param_names:
+        o, shp = eng.spec.off[n], eng.spec.shape[n]
+        k = int(np.prod(shp))
+        a1, a2 = g1[o:o + k], acc[o:o + k]
+        assert (a1 - a2).abs().max().item() <= 1e-4 * max(a1.abs().max().item(), 1e-30), n
 
 
 def test_c4_full_size_autoencoder_vs_oracle():
@@ -127,24 +159,36 @@ def test_c4_full_size_autoencoder_vs_oracle():
     p_ref, enc_ref = wo.autoencoder_forward(leaf, cfg["dilations"], x, cfg["en_pool_kernel_size"], cond)
     assert enc_ref.shape == (B, 64, 25)
     l_ref = torch.nn.functional.cross_entropy(p_ref, target)
-    g_ref = torch.autograd.grad(l_ref, list(leaf.values()), allow_unused=True)
+    g32 = dict(zip(leaf.keys(), torch.autograd.grad(l_ref, list(leaf.values()), allow_unused=True)))
+    leaf64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    p64, _ = wo.autoencoder_forward(leaf64, cfg["dilations"], x.double(), cfg["en_pool_kernel_size"],
+                                    [(w.double(), b.double()) for w, b in cond])
+    l64 = torch.nn.functional.cross_entropy(p64, target)
+    g64 = dict(zip(leaf64.keys(), torch.autograd.grad(l64, list(leaf64.values()), allow_unused=True)))
     e_enc = (net.last_encoding.cpu() - enc_ref.detach()).abs().max().item()
     e_p = (probs.detach().cpu() - p_ref.detach()).abs().max().item()
     assert e_enc < 1e-4 and e_p <= LOGIT_TOL, (e_enc, e_p)
     assert abs(loss.item() - l_ref.item()) < 1e-4
-    worst, worst_name = 0.0, None
-    for (name, p), g in zip(net.named_parameters(), g_ref):
-        assert name in leaf
-        if g is None:
-            assert p.grad is None or p.grad.abs().max().item() == 0.0, name
-            continue
-        err = (p.grad.cpu() - g).abs().max().item() / max(g.abs().max().item(), 1e-12)
-        if err > worst:
-            worst, worst_name = err, name
-        assert err <= GRAD_RTOL, (name, err)
+    got = {name: p.grad for name, p in net.named_parameters()}
+    assert list(got.keys()) == list(g64.keys())
+    worst, worst_name, cpu = _check_grads(got, g64, {k: (torch.zeros_like(params[k]) if v is None else v) for k, v in g32.items()})
     print("c4 full size (2 x 16000, Le 25, %d stretch / %d tile layers): enc err %.2e probs err %.2e (max p %.3f) "
-          "worst rel grad err %.2e (%s)" % (sum(stretch), len(stretch) - sum(stretch), e_enc, e_p,
-                                            p_ref.max().item(), worst, worst_name))
+          "worst grad err vs f64 %.2e (%s; the float32 CPU path: %.2e)" %
+          (sum(stretch), len(stretch) - sum(stretch), e_enc, e_p, p_ref.max().item(), worst, worst_name, cpu))
+    # partition independence with the SAME conditioning projections: batch gradient == mean of single-clip gradients
+    aeng = net._engine_for(torch.device("cuda", 0))
+    xd, td = x.cuda(), target.cuda()
+    aeng.loss_and_grad(xd, td, cond)
+    g_batch = aeng.flat_grad.clone()
+    acc = torch.zeros_like(g_batch)
+    for b in range(B):
+        aeng.loss_and_grad(xd[b:b + 1].contiguous(), td.view(B, W)[b].contiguous(), cond)
+        acc += aeng.flat_grad
+    acc /= B
+    for name, p in net.named_parameters():
+        o = aeng.spec.off[name]
+        a1, a2 = g_batch[o:o + p.numel()], acc[o:o + p.numel()]
+        assert (a1 - a2).abs().max().item() <= 1e-4 * max(a1.abs().max().item(), 1e-30), name
 
 
 def _onehot(ix):
@@ -239,14 +283,14 @@ def test_shipped_config_forward_and_gradients_vs_oracle():
     eng = net._engine_for(torch.device("cuda", 0))
     loss = eng.loss_and_grad(x.cuda(), target.cuda(), want_probs=True)
     probs = eng.workspace(B, T)["probs"].cpu()
-    torch.set_num_threads(ORACLE_THREADS)
-    l_ref, p_ref, g_ref = wo.loss_and_grads(params, SHIPPED["dilations"], x, target)
+    got = {n: eng.param_view(n, grad=True).clone() for n in eng.param_names}
+    l_ref, p_ref, g32, l64, g64 = _oracle_grads_f32_f64(params, SHIPPED["dilations"], x, target)
     e_p = (probs - p_ref).abs().max().item()
     assert e_p <= LOGIT_TOL and p_ref.max().item() > 0.3, (e_p, p_ref.max().item())
     assert abs(loss.item() - l_ref.item()) < 1e-4
-    worst, name = _check_grads(eng, g_ref)
-    print("shipped config (40 blocks, 32/32/512, 2 x %d): probs err %.2e (max p %.3f), worst rel grad err %.2e (%s)" %
-          (T, e_p, p_ref.max().item(), worst, name))
+    worst, name, cpu = _check_grads(got, g64, g32)
+    print("shipped config (40 blocks, 32/32/512, 2 x %d): probs err %.2e (max p %.3f), worst grad err vs f64 %.2e "
+          "(%s; the float32 CPU path: %.2e)" % (T, e_p, p_ref.max().item(), worst, name, cpu))
 
 
 def test_shipped_config_shipped_batch_window_vs_oracle():
@@ -277,7 +321,7 @@ def test_shipped_config_shipped_batch_window_vs_oracle():
     print("shipped config at 4 x %d: window probs err %.2e" % (T, err))
     assert err <= LOGIT_TOL
     # a full training step at this shape runs and is bit-reproducible
-    target = codes[:, rf:rf + W].to(torch.int64).contiguous().view(-1)
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).cuda()
     l1 = eng.loss_and_grad(x, target).item()
     g1 = eng.flat_grad.clone()
     l2 = eng.loss_and_grad(x, target).item()

@@ -373,6 +373,17 @@ def test_chunk_softmax_fwd_bwd_ce():
     pr = p.detach()
     ref = pr * (dy.cpu().double() - (dy.cpu().double() * pr).sum(1, keepdim=True))
     assert (dx2.cpu().double() - ref).abs().max().item() < 1e-5
+    # a target outside [0, 256) (nn.CrossEntropyLoss raises for it) must not pass silently: NaN loss, NaN row gradient,
+    # the other rows untouched
+    for bad in (256, -1, 1 << 40):
+        tb = tgt.clone()
+        tb[17] = bad
+        dxb = torch.empty(n, 256, device=DEV)
+        call("wn_chunk_softmax256_ce", ptr(xd), ptr(tb.to(DEV)), None, ptr(dxb), ptr(part), n, 1.0 / n, _lib.stream())
+        assert torch.isnan(part.sum()).item() and torch.isnan(dxb[17]).all().item()
+        keep = torch.ones(n, dtype=torch.bool)
+        keep[17] = False
+        assert torch.equal(dxb.cpu()[keep], dx.cpu()[keep])
 
 
 def test_onehot_and_mulaw():
@@ -476,3 +487,36 @@ def test_cond_grad_bucket_sums(mode, le, q):
     err = np.abs(out.cpu().numpy() - ref).max()
     print("cond_grad mode %d le %d: max err %.2e" % (mode, le, err))
     assert err < 2e-4
+
+
+@pytest.mark.parametrize("scrambled", [True, False], ids=["scrambled", "proper"])
+@pytest.mark.parametrize("ch,T,B", [(64, 1000, 3), (32, 517, 2), (64, 16000, 2)])
+def test_causal_wgrad_from_codes_equals_dense_product(scrambled, ch, T, B):
+    """wn_causal_wgrad_codes (scatter of dx columns selected by the integer codes) against the definition
+    dW[r][q][tap] = sum_{b,t in [1,T)} dx[b][r][t] * in[b][q][t-1+tap] evaluated in float64 on the dense one-hot the
+    same codes give, both layouts; repeated codes (silence), the first / last columns and stale data outside [1, T)."""
+    from oracle import intops
+    rng = np.random.default_rng(T + ch)
+    codes = rng.integers(0, 256, size=(B, T)).astype(np.int32)
+    codes[0, : T // 3] = 128                                  # a run of one class: many ones in one row
+    codes[-1, -5:] = [0, 255, 255, 0, 7]
+    fn = intops.one_hot_scrambled if scrambled else intops.one_hot_proper
+    dense = torch.from_numpy(np.stack([fn(r) for r in codes])).double()          # (B, 256, T)
+    pitch = ((T + 255) // 256) * 256 + 512
+    dx = torch.from_numpy(rng.standard_normal((B, ch, pitch)).astype(np.float32))     # garbage outside [1, T) on purpose
+    want = torch.zeros(ch, 512, dtype=torch.float64)
+    d = dx.double()
+    for b in range(B):
+        want[:, :256] += d[b, :, 1:T] @ dense[b, :, 0:T - 1].t()                 # tap 0: in[t-1]
+        want[:, 256:] += d[b, :, 1:T] @ dense[b, :, 1:T].t()                     # tap 1: in[t]
+    ns = _lib.causal_codes_slabs(T, B)
+    slab = torch.full((ns, ch, 512), float("nan"), device=DEV)
+    cd, dxd = torch.from_numpy(codes).to(DEV), dx.to(DEV)
+    call("wn_causal_wgrad_codes", ptr(cd), 1 if scrambled else 0, ptr(dxd), ch * pitch, pitch, ch, 256, T, B, ptr(slab), _lib.stream())
+    got = slab.double().sum(0).cpu()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    assert err < 1e-5, err
+    slab2 = torch.empty_like(slab)
+    call("wn_causal_wgrad_codes", ptr(cd), 1 if scrambled else 0, ptr(dxd), ch * pitch, pitch, ch, 256, T, B, ptr(slab2), _lib.stream())
+    assert torch.equal(slab, slab2)                           # bit-reproducible

@@ -953,3 +953,54 @@ def test_autoencoder_train_harness_on_gpu(tmp_path, monkeypatch, fused):
     losses = [float(l.split(' ')[-1]) for l in lines]
     assert len(losses) >= 4 and all(np.isfinite(losses)) and all(5.0 < v < 6.0 for v in losses)
     assert sorted(os.listdir(tmp_path / "restore")) == ["wavenet_autoencoder1.model", "wavenet_autoencoder2.model"]
+
+
+@pytest.mark.parametrize("scrambled", [True, False], ids=["scrambled", "proper"])
+def test_code_aware_causal_gradient_equals_dense_path(scrambled, monkeypatch):
+    """A one-hot built by eng.onehot / the loader carries its codes: the causal layer's weight gradient is then a
+    scatter (wn_causal_wgrad_codes).  Same gradients as the dense product on the same tensor; a tensor that was
+    modified after it was built, or any other float input, takes the dense path."""
+    from music_amd.model import wavenet
+    cfg = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 32, 64], dilation_channels=64, residual_channels=64,
+               skip_channels=64, quantization_channels=256, use_bias=True)
+    torch.manual_seed(5)
+    net = wavenet(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.5)
+    net = net.cuda()
+    eng = net._engine_for(torch.device("cuda", 0))
+    rng = np.random.default_rng(6)
+    B, T = 3, net.receptive_field + 900
+    W = T - net.receptive_field + 1
+    codes = torch.from_numpy(rng.integers(0, 256, size=(B, T)).astype(np.int32)).cuda()
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).cuda()
+    x = eng.onehot(codes, scrambled=scrambled)
+    assert x._wn_codes[0] is codes
+    eng.loss_and_grad(x, target)
+    assert eng.workspace(B, T)["x_codes"] is not None
+    g_codes = eng.flat_grad.clone()
+    monkeypatch.setenv("WN_CAUSAL_CODES", "0")
+    eng.loss_and_grad(x, target)
+    assert eng.workspace(B, T)["x_codes"] is None
+    g_dense = eng.flat_grad.clone()
+    monkeypatch.delenv("WN_CAUSAL_CODES")
+    o = eng.spec.off["causal_layer.weight"]
+    n = 64 * 256 * 2
+    a, b = g_codes[o:o + n], g_dense[o:o + n]
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    rest = torch.ones_like(g_codes, dtype=torch.bool)
+    rest[o:o + n] = False
+    assert torch.equal(g_codes[rest], g_dense[rest])           # nothing else changes
+    # through the nn.Module + autograd surface the tag survives detach()
+    net.zero_grad()
+    torch.nn.CrossEntropyLoss()(net(x), target).backward()
+    assert eng.workspace(B, T)["x_codes"] is not None
+    assert (net.causal_layer.weight.grad.reshape(-1) - a).abs().max().item() <= 1e-4 * a.abs().max().item()
+    # a modified tensor is no longer the one-hot of its codes: dense path, and the gradient follows the data
+    x[0, :, 100] = 0.5
+    eng.loss_and_grad(x, target)
+    assert eng.workspace(B, T)["x_codes"] is None
+    # plain float input (no codes at all)
+    eng.loss_and_grad(torch.rand(B, 256, T, device="cuda"), target)
+    assert eng.workspace(B, T)["x_codes"] is None

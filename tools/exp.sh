@@ -2,7 +2,7 @@ mkdir -p gpurun_out
 REPO=$(pwd)
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/prof.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $REPO/gpurun_out/prof.log 2>&1)
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/prof/**/*kernel_trace.csv", recursive=True)[0]

@@ -57,6 +57,13 @@ def main():
         print()
     # HBM bytes per launch of the dominant kernel, corrected as MI355X_MICROARCH.md prescribes for gfx950:
     # FETCH_SIZE (KiB) counts 128-B wide reads at 64 B -> x2; WRITE_SIZE (KiB) is exact.
+    import json
+    allk = {k: {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"],
+                "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024}
+            for k, v in pmc.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    if allk:
+        # bench.py reads this one (copied to profiles/pmc_kernels.json): HBM bytes per launch of every kernel
+        json.dump(allk, open(os.path.join(root, "pmc_kernels.json"), "w"), indent=1)
     for k, v in pmc.items():
         if k.startswith("resblock_fwd") and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             import json
