@@ -54,8 +54,8 @@ CFG = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 3, dilation_c
 B_LOCAL, T = 8, 16000
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec); 6.29e12 measured copy
 MFMA_PEAK = 2.5e15         # FLOP/s, dense bf16 / f16 MFMA (same guide)
-BWD_KERNELS = "resblock_bwd_rw_k + chan_gemm_rw_k"
-BWD_PMC = ("resblock_bwd_rw_k<true>", "chan_gemm_rw_k")
+BWD_KERNELS = "resblock_bwd_pq_k"
+BWD_PMC = ("resblock_bwd_pq_k<true>",)
 
 
 def synth_codes(rank, b, t):
@@ -145,15 +145,18 @@ def cpu_baseline():
         return time.time() - t0
 
     # ATen's CPU conv kernels stop scaling (and then collapse) long before a 256-core host is full: one probe step
-    # each at all physical cores and at 32 threads, the timed steps run at the faster setting
+    # on ONE clip each at all physical cores and at 32 threads (the second of two, the first warms the allocator up),
+    # the timed steps run at the faster setting
     cand = sorted({min(physical, 256), min(32, physical)}, reverse=True)
     probe = {}
     for n in cand:
         torch.set_num_threads(n)
-        probe[n] = step(x, target)
+        step(x[:1], target[:W])
+        probe[n] = step(x[:1], target[:W])
     cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
-    step(x, target)                                   # second warm-up at the chosen setting
+    for _ in range(2):
+        step(x, target)                               # 2 warm-up steps at the workload's batch
     times = [step(x, target) for _ in range(5)]
     best = min(times)
     torch.set_num_threads(1)
@@ -163,8 +166,8 @@ def cpu_baseline():
             "probe_s_per_step": {str(k): round(v, 3) for k, v in probe.items()},
             "mean_value": B_LOCAL * T * len(times) / sum(times),
             "one_thread": {"value": T / t1, "unit": "samples/s", "sample": "1 step on 1 clip x 16000, 1 thread"},
-            "sample": "full training steps (fwd+CE+bwd+Adam) of the 30-layer config on %d clips x %d samples: 1 probe step per "
-                      "thread setting %s, 1 more warm-up, 5 timed at torch CPU threads=%d (best; mean in mean_value)" %
+            "sample": "full training steps (fwd+CE+bwd+Adam) of the 30-layer config on %d clips x %d samples: thread setting picked "
+                      "by a one-clip probe step at each of %s, then 2 warm-up + 5 timed steps at torch CPU threads=%d (best; mean in mean_value)" %
                       (B_LOCAL, T, cand, cores)}
 
 
@@ -300,16 +303,37 @@ def main():
     # H2D copies are part of the step, the one-hot is built in HBM
     piece_h = codes[:, :T].contiguous().cpu().pin_memory()
     target_h = codes[:, rf:rf + W].to(torch.int64).contiguous().view(-1).cpu().pin_memory()
-    piece = torch.empty(B_LOCAL, T, dtype=torch.int32, device=dev)
-    target = torch.empty(B_LOCAL * W, dtype=torch.int64, device=dev)
+    # double-buffered device copies, filled one step ahead on a copy stream (what a prefetching loader does): the
+    # copies of step k+1 run beside the kernels of step k, the step waits for its own batch's event
+    main = torch.cuda.current_stream()
+    copy_stream = torch.cuda.Stream(device=dev)
+    bufs = [(torch.empty(B_LOCAL, T, dtype=torch.int32, device=dev), torch.empty(B_LOCAL * W, dtype=torch.int64, device=dev),
+             torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
+    state = {"k": 0}
+
+    def prefetch(k):
+        p, t, ready, free = bufs[k & 1]
+        copy_stream.wait_event(free)                   # the step that last used this pair is done with it
+        with torch.cuda.stream(copy_stream):
+            p.copy_(piece_h, non_blocking=True)
+            t.copy_(target_h, non_blocking=True)
+            ready.record(copy_stream)
+
+    for b in bufs:
+        b[3].record(main)
+    prefetch(0)
 
     def step():
+        k = state["k"]
+        state["k"] = k + 1
+        piece, target, ready, free = bufs[k & 1]
+        prefetch(k + 1)
         eng.mark("step_begin")
-        piece.copy_(piece_h, non_blocking=True)
-        target.copy_(target_h, non_blocking=True)
-        eng.mark("h2d")
+        main.wait_event(ready)
+        eng.mark("h2d_wait")
         x = eng.onehot(piece, scrambled=True)
         loss = eng.loss_and_grad(x, target)
+        free.record(main)
         if use_dist:
             dist.all_reduce(eng.flat_grad)          # ONE flat fp32 bucket (5.08 MB), RCCL over xGMI
             eng.mark("allreduce")
@@ -385,6 +409,8 @@ def main():
     kern = None
     if rank == 0 and world == 1:
         eng.fine_marks, eng.marks = True, []
+        torch.cuda.synchronize()
+        piece, target = bufs[0][0], bufs[0][1]
         for _ in range(3):
             x = eng.onehot(piece, scrambled=True)
             eng.loss_and_grad(x, target)
@@ -435,7 +461,7 @@ def main():
         "data": "synthetic",
         "rccl_ranks": world if use_dist else 0, "backend": (dist.get_backend() if use_dist else "none"),
         "config": {"workload": "BASELINE configs[1]: 30-layer (3x dilations 1..512) WaveNet, 64 res/dil, 256 skip, "
-                               "batch 8x16000 per GPU, full train step (H2D of codes + one-hot + fwd + CE + bwd + all-reduce + Adam)",
+                               "batch 8x16000 per GPU, full train step (H2D of codes and targets, prefetched one step ahead on a copy stream, + one-hot + fwd + CE + bwd + all-reduce + Adam)",
                    "global_batch": world * B_LOCAL, "seq_len": T, "parallelism": "dp%d" % world,
                    "precision": args.precision, "final_loss": float(loss.item())},
         # the time-dominant kernels: one residual block's backward (SURVEY 8d A_b per block; duration = the HIP-event
@@ -457,8 +483,8 @@ def main():
     if kern:
         out["kernels"] = kern
     if rank == 0 and world == 1 and not args.no_extras:
-        x = eng.onehot(piece, scrambled=True)
-        out["extra"] = sub_benchmarks(net, x, target)
+        x = eng.onehot(bufs[0][0], scrambled=True)
+        out["extra"] = sub_benchmarks(net, x, bufs[0][1])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -131,6 +131,24 @@ int wn_resblock_bwd_ms(const float* x_in, const float* dy, const float* dz, floa
                        wn_stream_t stream);
 int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch);
 
+/* The whole backward of one residual block in ONE launch, data gradient of the dilated convs included (64 padded
+ * channels, modes (f16x3, bf16x3), no biases, no conditioning table): what wn_resblock_bwd_ms + the wn_chan_gemm launch
+ * on its dfg compute, without [df;dg] ever reaching HBM.  The data gradient travels between blocks as an UNSHIFTED pair:
+ *   in : dx_{i+1}[t] = p_in[t] (t >= p_lo) + q_in[t + dn]   (the pair the block above wrote; dn = ITS dilation, p_lo =
+ *        ITS t_lo; both NULL for the last block: no dz product, no dWd);
+ *   out: p_out[t] = W1^T [df;dg][t] + dx_{i+1}[t],  q_out[t] = W0^T [df;dg][t]  on [t_lo, t_hi), so that
+ *        dx_i[t] = p_out[t] + q_out[t + d] (wn_shift_add makes it whole where a plain tensor is needed).
+ * x / P / Q share x_bstride and pitch; q buffers must read as zero beyond t_hi (never written there).  wpq: packed
+ * [W1^T; W0^T] ([2ch rows][K = df | dg], bf16x3).  Slabs as wn_resblock_bwd_ms (same count: wn_resblock_bwd_ms_slabs).
+ * Autograd of wavenet/model.py:111-129 for one layer. */
+int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, int dn, int p_lo, const float* dz,
+                       float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
+                       const uint16_t* wdT, const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, int z_lo,
+                       float* slab_fg, float* slab_d, int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
+/* out[b][r][t] = p[b][r][t] (t >= p_lo) + q[b][r][t+dn] (t+dn < t_hi), t in [t_lo,t_hi) */
+int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,
+                 int t_lo, int t_hi, int batch, wn_stream_t stream);
+
 /* Weight gradient: C[m][n] = sum_{b, t in [t_lo,t_hi)} A[b][m][t+a_shift] * B_tap[b][n][t+b_shift_tap]
  * C columns [0, 16*nt_per_tap) come from b0, the next 16*nt_per_tap from b1 (if not NULL).
  * The time axis is cut into chunks; workgroup (clip b, chunk j) writes its partial C (leading

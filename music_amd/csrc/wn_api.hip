@@ -222,6 +222,27 @@ int wn_enc_resblock_bwd(const float* x_in, const float* dy, const float* h, floa
 int wn_enc_resblock_bwd_slabs(int t_lo, int t_hi, int batch) { return wn_enc_bwd_slabs(t_lo, t_hi, batch); }
 int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch) { return wn_resms_slabs(t_lo, t_hi, batch); }
 
+int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, int dn, int p_lo, const float* dz,
+                       float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
+                       const uint16_t* wdT, const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, int z_lo,
+                       float* slab_fg, float* slab_d, int batch, int mode_fwd, int mode_bwd, wn_stream_t stream) {
+    if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: pitch must be a multiple of 4");
+    if (ch != 64) return wn_set_error_msg(-3, "wn_resblock_bwd_pq: 64 padded channels only");
+    if (mode_fwd != WN_MODE_F16X3 || mode_bwd != WN_MODE_BF16X3) return wn_set_error_msg(-2, "wn_resblock_bwd_pq: (f16x3, bf16x3) only");
+    if (!x_in || !dz || !p_out || !q_out || !wfg || !wpq || !slab_fg) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: null argument");
+    if ((p_in && (!q_in || !wdT)) || (!p_in && q_in)) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: p_in, q_in and wdT go together");
+    WnResPqArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x_in = x_in; a.p_in = p_in; a.q_in = q_in; a.dn = dn; a.p_lo = p_lo; a.dz = dz; a.p_out = p_out; a.q_out = q_out;
+    a.x_bstride = x_bstride; a.dz_bstride = dz_bstride; a.pitch = pitch; a.wfg = wfg; a.wdT = wdT; a.wpq = wpq;
+    a.slab_fg = slab_fg; a.slab_d = p_in ? slab_d : nullptr; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = z_lo;
+    return wn_launch_resblock_bwd_pq(a, batch, (hipStream_t)stream);
+}
+int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,
+                 int t_lo, int t_hi, int batch, wn_stream_t stream) {
+    return wn_launch_shift_add(p, q, out, bstride, pitch, rows, dn, p_lo, t_lo, t_hi, batch, (hipStream_t)stream);
+}
+
 int wn_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, int64_t dx_bstride, int pitch, int ch, int q,
                           int t, int batch, float* slab, wn_stream_t stream) {
     if (q != 256) return wn_set_error_msg(-4, "wn_causal_wgrad_codes: 256 quantisation channels only");

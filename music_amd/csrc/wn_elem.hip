@@ -131,6 +131,26 @@ int wn_launch_softmax_ce(const float* x, const int64_t* target, float* probs, fl
     return 0;
 }
 
+// out[b][r][t] = p[b][r][t] (t >= p_lo) + q[b][r][t + dn] (t + dn < t_hi), t in [t_lo, t_hi): materialises a data
+// gradient that the one-launch backward block (wn_respq.hip) hands on as an unshifted (P, Q) pair.
+__global__ void shift_add_k(const float* __restrict__ p, const float* __restrict__ q, float* __restrict__ out,
+                            long bstride, int pitch, int dn, int p_lo, int t_lo, int t_hi) {
+    const int t = t_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= t_hi) return;
+    const size_t o = (size_t)blockIdx.z * bstride + (size_t)blockIdx.y * pitch + t;
+    const float a = t >= p_lo ? p[o] : 0.f;
+    const float b = t + dn < t_hi ? q[o + dn] : 0.f;
+    out[o] = a + b;
+}
+int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride, int pitch, int rows, int dn,
+                        int p_lo, int t_lo, int t_hi, int batch, hipStream_t st) {
+    if (t_hi <= t_lo || rows <= 0 || batch <= 0) return 0;
+    hipLaunchKernelGGL(shift_add_k, dim3((t_hi - t_lo + 255) / 256, rows, batch), dim3(256), 0, st, p, q, out, bstride,
+                       pitch, dn, p_lo, t_lo, t_hi);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Flat Adam (torch.optim.Adam semantics, wavenet/train.py:39-42): g is pre-scaled by gscale
 // (1/world_size after the all-reduce); bc1 = 1 - b1^t, bc2 = 1 - b2^t are supplied by the host.

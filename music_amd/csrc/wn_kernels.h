@@ -85,6 +85,22 @@ int wn_resms_slabs(int t_lo, int t_hi, int batch);
 // two-role form of the same block (wn_resrw.hip): 8 waves, 32-column items; same arguments and slab format
 int wn_launch_resblock_bwd_rw(const WnResMsArgs& a, int batch, hipStream_t st);
 void wn_resrw_plan(int t_lo, int t_hi, int batch, int& t_base, int& steps, int& ipw, int& nwg);
+// backward of one block with the data gradient inside, handed on as the unshifted (P, Q) pair (wn_respq.hip)
+struct WnResPqArgs {
+    const float* x_in;                                     // x_i
+    const float* p_in; const float* q_in; int dn, p_lo;    // dx_{i+1}[t] = p_in[t] (t >= p_lo) + q_in[t + dn]; null for the last block
+    const float* dz;                                       // d z-crop slice (valid t >= z_lo)
+    float* p_out; float* q_out;                            // dx_i[t] = p_out[t] + q_out[t + d], both written on [t_lo, t_hi)
+    long x_bstride, dz_bstride; int pitch;                 // x / P / Q share x_bstride and pitch
+    const uint16_t* wfg; const uint16_t* wdT; const uint16_t* wpq;   // fg pack (f16x3), Wd^T and [W1^T; W0^T] packs (bf16x3)
+    float* slab_fg; float* slab_d;                         // one slab per workgroup: [2CH][2CH] and [CH][CH]
+    int d, t_lo, t_hi, z_lo, t_base;
+    int steps_per_clip, items_per_wg, batch;               // set by the launcher
+    int swz;
+};
+int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st);
+int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride, int pitch, int rows, int dn,
+                        int p_lo, int t_lo, int t_hi, int batch, hipStream_t st);
 // backward of an autoencoder ENCODER block with both weight gradients (wn_encrw.hip); WnResMsArgs fields as documented there
 int wn_launch_enc_bwd_rw(const WnResMsArgs& a, int ch, int batch, int mode_bwd, hipStream_t st);
 int wn_enc_bwd_slabs(int t_lo, int t_hi, int batch);

@@ -1,0 +1,524 @@
+// Backward of one gated residual block in ONE launch, data gradient included (CH = 64, recompute in F16x3,
+// gradient products in BF16x3; no biases, no conditioning table: those configurations keep
+// resblock_bwd_rw_k + chan_gemm_rw_k).
+//
+// What resblock_bwd_rw_k (wn_resrw.hip) leaves to a second launch is the data gradient of the dilated convs,
+//     dx_i[t] = W1^T [df;dg][t] + W0^T [df;dg][t + d] + dx_{i+1}[t],
+// which made [df;dg] (2 activation tensors) travel to HBM and back twice.  Here the block hands its data gradient on as
+// the UNSHIFTED pair
+//     P[t] = W1^T [df;dg][t] + dx_{i+1}[t]        Q[t] = W0^T [df;dg][t]            (dx_i[t] = P[t] + Q[t + d])
+// and takes dx_{i+1} from the block above in the same form (P_in[t] for t >= p_lo, + Q_in[t + dn]); [df;dg] never
+// leaves the CU.  Per block: x, P_in, Q_in, dz-crop in; P, Q out = 5.9 activation tensors against 9.8.
+//
+// Division of labour (8 waves, two per SIMD, 32-column items, two LDS stages, one barrier per item, as wn_resrw.hip):
+//   * R waves (0..3; wave g = dilation channels 16g..): recompute f, g from x fragments, dz = Wd^T dy, gate, and leave
+//     df, dg, z in LDS as 16-bit hi/lo tiles [channel][time].  They no longer store anything to HBM.
+//   * W waves (4..7; wave g = ROW tile g of x(t-d), x(t), dy): weight gradients and the (P, Q) product of the PREVIOUS
+//     item.  A W wave now owns the COLUMNS of the weight-gradient results that belong to its 16 x rows
+//     (all 128 [df;dg] rows x its 32 columns, all 64 z rows x its 16 dy columns), so its own raw rows - 8 samples of one
+//     row per lane - ARE the MFMA B operands: no [row][time] operand tiles in LDS (48 KB freed), and the packed
+//     [W1^T; W0^T] weights (64 KB) take their place.  The (P, Q) product runs TRANSPOSED, out[time][row] =
+//     [df;dg]^T W^T: its A operand ([time][channel]) comes out of the result tiles with ds_read_b64_tr_b16, its result
+//     lands as 4 consecutive samples of one row per lane - the layout of the raw dy rows the lane already holds (exact
+//     fp32 residual add) and a 16-byte store.
+// The time axis inside a tile is permuted (position 8q+j holds sample 4q+j for j < 4, 16+4q+j-4 otherwise) so that one
+// 16-byte row read gives the samples of the lane's two 4-sample groups; the R waves' pair writes, the row reads and the
+// transposed reads are all conflict free / 2-way with the chunk swizzle K[] below (MI355X_MICROARCH.md LDS table).
+//
+// PQ_T_* macros are timing-build switches (remove one ingredient; results are then wrong) used to see what a launch is
+// made of: -DPQ_T_NOREC / NOGATE / NOWG / NOPQ / NOSTORE / NOFILLDY / NOCONV via `make EXTRA=...` (tools/pq_phases.sh).
+#include <stdlib.h>
+#include "wn_common.h"
+#include "wn_kernels.h"
+
+#define PQ_THREADS 512
+#define PQ_CH 64
+#define PQ_COLS 32
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+struct __attribute__((packed, aligned(4))) PqF2U { float v[2]; };
+__device__ __forceinline__ f32x2 pq_ld2u(const float* p) {
+    PqF2U u = *reinterpret_cast<const PqF2U*>(p);
+    f32x2 r = {u.v[0], u.v[1]};
+    return r;
+}
+// (a, b) -> packed bf16 pairs hi = (bf16(a), bf16(b)) and lo = (bf16(a - hi_a), bf16(b - hi_b))
+__device__ __forceinline__ void pq_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f32x2 v = {a, b};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+}
+
+// LDS map, in halfs (uint16): per stage 8 x fragments | 4 dy fragments | 12 result tiles; then the packed (P, Q) weights
+#define PQ_XF 0
+#define PQ_DYF 8192
+#define PQ_T 12288
+#define PQ_STAGE 24576
+#define PQ_W (2 * PQ_STAGE)
+#define PQ_LDS_HALFS (PQ_W + 32768)
+
+// chunk swizzle of the result tiles: 16-byte chunk `ch` (8 positions) of row `r` sits at slot 16*ch + (r ^ K[ch])
+__device__ __forceinline__ int pq_k(int ch) { return ch == 0 ? 0 : ch == 1 ? 13 : ch == 2 ? 6 : 11; }
+
+template <class T>
+__device__ __forceinline__ void pq_store_frag(uint16_t* base, int idx, int lane, const Frag<T>& f) {
+    u32x4* p = reinterpret_cast<u32x4*>(base) + (size_t)idx * 128 + lane;
+    p[0] = __builtin_bit_cast(u32x4, f.hi);
+    p[64] = __builtin_bit_cast(u32x4, f.lo);
+}
+
+template <bool HAS_DY>
+__global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
+    constexpr int CH = PQ_CH;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = wv & 3;
+    const int c = lane & 15, q = lane >> 4;
+    const int tile_rd = (16 * q + (c ^ pq_k(q))) * 8;            // halfs; chunk q of row c (a 16-byte row read)
+
+    // items of this workgroup: the workgroups of an XCD walk one contiguous item range interleaved (wn_resrw.hip)
+    int first, cnt, j;
+    if (a.swz) {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int qn = nwg >> 3, rn = nwg & 7, xcd = id & 7;
+        first = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+        cnt = xcd < rn ? qn + 1 : qn;
+        j = id >> 3;
+    } else {
+        first = 0; cnt = gridDim.x; j = blockIdx.x;
+    }
+    const int wgid = first + j;
+    const int total = a.steps_per_clip * a.batch;
+    const int i_lo = first * a.items_per_wg + j;
+    int i_hi = (first + cnt) * a.items_per_wg;
+    if (i_hi > total) i_hi = total;
+    const int n_items = i_lo < i_hi ? (i_hi - i_lo + cnt - 1) / cnt : 0;
+
+    struct Pos { int b, t0; bool live; };
+    auto pos_k = [&](int k) {                                  // position of this workgroup's k-th item, clamped
+        const bool live = k >= 0 && k < n_items;
+        k = k < n_items ? k : n_items - 1;
+        int it = i_lo + (k < 0 ? 0 : k) * cnt;
+        it = it < total ? it : total - 1;
+        Pos p;
+        p.b = it / a.steps_per_clip;
+        p.t0 = a.t_base + PQ_COLS * (it - p.b * a.steps_per_clip);
+        p.live = live;
+        return p;
+    };
+
+    // the packed [W1^T; W0^T] weights (32 fragments x 2 KB) and zeros in the result tiles of stage 1 (multiplied once
+    // before anything was written to them)
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.wpq);
+        u32x4* dst = reinterpret_cast<u32x4*>(lds + PQ_W);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k * PQ_THREADS + threadIdx.x] = src[k * PQ_THREADS + threadIdx.x];
+        u32x4* z = reinterpret_cast<u32x4*>(lds + PQ_STAGE + PQ_T);
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) z[k * PQ_THREADS + threadIdx.x] = zero;       // 12 tiles x 2 KB = 24 KB
+    }
+
+    if (wv < 4) {
+        // =========================== R waves: recompute, dz, gate ===========================
+        struct RawX { f32x2 x[8]; };
+        // recompute operands ("time on lanes"; lane (c, q) of N-tile n holds sample t0 + 2c + n): wave g converts
+        // k-step g = (tap g>>1, channel half g&1) of x, both N-tiles
+        auto load_x = [&](RawX& r, Pos ps) {
+            const int tl = ps.t0 + 2 * c;
+            const float* xin = a.x_in + (size_t)ps.b * a.x_bstride;
+            const float* p = ps.live ? xin + (size_t)(32 * (g & 1) + 8 * q) * a.pitch + ((g >> 1) == 0 ? tl - a.d : tl) : a.x_in;
+            const size_t rp = ps.live ? (size_t)a.pitch : 0;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) r.x[jj] = pq_ld2u(p + jj * rp);
+        };
+        auto fill_x = [&](const RawX& r, int stage) {
+            uint16_t* xf = lds + (size_t)stage * PQ_STAGE + PQ_XF;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float v[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = r.x[jj][n];
+                Frag<F16> f;
+                split8<F16, 3>(f, v);
+                pq_store_frag<F16>(xf, g * 2 + n, lane, f);
+            }
+        };
+        Frag<F16> wf[4], wg[4];
+        Frag<BF16> wd[2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            load_a<F16, 3>(wf[s], a.wfg, g * 4 + s, lane);
+            load_a<F16, 3>(wg[s], a.wfg, (4 + g) * 4 + s, lane);
+        }
+        if (HAS_DY) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) load_a<BF16, 3>(wd[s], a.wdT, g * 2 + s, lane);
+        }
+        // this lane's dwords in the result tiles: row 4q + i, samples 2c, 2c+1 -> position 8*((2c & 15) >> 2) + 4*(c >> 3) +
+        // (2c & 3): chunk (c & 7) >> 1, dword 2*(c >> 3) + (c & 1)
+        int t_wr[4];
+        {
+            const int chk = (c & 7) >> 1, dw = 2 * (c >> 3) + (c & 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t_wr[i] = (16 * chk + ((4 * q + i) ^ pq_k(chk))) * 8 + dw * 2;
+        }
+        auto load_cr = [&](f32x2* cr, Pos ps) {
+            const float* dzc = ps.live ? a.dz + (size_t)ps.b * a.dz_bstride + (size_t)(16 * g + 4 * q) * a.pitch + ps.t0 + 2 * c : a.dz;
+            const size_t rp = ps.live ? (size_t)a.pitch : 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cr[i] = pq_ld2u(dzc + i * rp);
+        };
+
+        f32x2 crA[4], crB[4];
+        load_cr(crA, pos_k(0));
+        load_cr(crB, pos_k(1));
+        RawX x0, x1;                                        // x1 / x0 hold the raw rows of items it+1 / it+2
+        load_x(x0, pos_k(0));
+        load_x(x1, pos_k(1));
+        fill_x(x0, 0);
+        load_x(x0, pos_k(2));
+        __syncthreads();                                    // stage 0 operands of the first item, the weights, the zeros
+        auto r_body = [&](const int it, f32x2* cr, RawX& rx) {
+            fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
+            load_x(rx, pos_k(it + 3));
+            const Pos p_cur = pos_k(it);
+            const bool live = it < n_items;
+            const int tl = p_cur.t0 + 2 * c;
+            uint16_t* st = lds + (size_t)(it & 1) * PQ_STAGE;
+            const uint16_t* xf = st + PQ_XF;
+            const uint16_t* dyf = st + PQ_DYF;
+
+            f32x4 af[2], ag[2], dz[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                af[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ag[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dz[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#ifndef PQ_T_NOREC
+            {
+                // the three products of an x3 term and the f / g / N-tile accumulators are walked in rotation, the dz
+                // products woven in: no MFMA waits for the result of the one in front of it
+                auto term = [](auto tr, f32x4& acc, const auto& wa, const auto& xb, int t) {
+                    typedef decltype(tr) TT;
+                    acc = t == 0 ? TT::mfma(wa.lo, xb.hi, acc) : t == 1 ? TT::mfma(wa.hi, xb.lo, acc) : TT::mfma(wa.hi, xb.hi, acc);
+                };
+                Frag<F16> bx[2][2];
+                Frag<BF16> by[2];
+                load_a<F16, 3>(bx[0][0], xf, 0, lane);
+                load_a<F16, 3>(bx[0][1], xf, 1, lane);
+                if (HAS_DY) load_a<BF16, 3>(by[0], dyf, 0, lane);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks + 1 < 4) {
+                        load_a<F16, 3>(bx[(ks + 1) & 1][0], xf, 2 * ks + 2, lane);
+                        load_a<F16, 3>(bx[(ks + 1) & 1][1], xf, 2 * ks + 3, lane);
+                        if (HAS_DY) load_a<BF16, 3>(by[(ks + 1) & 1], dyf, ks + 1, lane);      // dy fragment (k-step (ks+1)>>1, N-tile (ks+1)&1)
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        term(F16(), af[0], wf[ks], bx[ks & 1][0], t);
+                        term(F16(), ag[0], wg[ks], bx[ks & 1][0], t);
+                        term(F16(), af[1], wf[ks], bx[ks & 1][1], t);
+                        term(F16(), ag[1], wg[ks], bx[ks & 1][1], t);
+                        if (HAS_DY) term(BF16(), dz[ks & 1], wd[ks >> 1], by[ks & 1], t);
+                    }
+                }
+            }
+#endif
+            uint16_t* tt = st + PQ_T;
+            const bool ok0 = live && tl >= a.t_lo && tl < a.t_hi, ok1 = live && tl + 1 >= a.t_lo && tl + 1 < a.t_hi;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float vz[2], vf[2], vg[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const bool ok = n ? ok1 : ok0;
+                    float gz = dz[n][i];
+                    if (tl + n >= a.z_lo && tl + n < a.t_hi) gz += cr[i][n];
+#ifdef PQ_T_NOGATE
+                    const float th = af[n][i], sg = ag[n][i];
+#else
+                    const float th = wn_tanh(af[n][i]);
+                    const float sg = wn_sigmoid(ag[n][i]);
+#endif
+                    vz[n] = ok ? th * sg : 0.f;
+                    vf[n] = ok ? gz * sg * (1.0f - th * th) : 0.f;
+                    vg[n] = ok ? gz * th * sg * (1.0f - sg) : 0.f;
+                }
+                // 16-bit hi/lo pairs of (sample 2c, sample 2c+1) -> one dword each in the [channel][time] tiles
+                auto put = [&](int kind, const float* v) {
+                    uint32_t hi, lo;
+                    pq_split2(v[0], v[1], hi, lo);
+                    uint16_t* p = tt + (kind * 4 + g) * 1024 + t_wr[i];
+                    *reinterpret_cast<uint32_t*>(p) = hi;
+                    *reinterpret_cast<uint32_t*>(p + 512) = lo;
+                };
+                put(0, vf);
+                put(1, vg);
+                if (HAS_DY) put(2, vz);
+            }
+            load_cr(cr, pos_k(it + 2));
+            __syncthreads();
+        };
+        for (int it = 0; it < n_items; it += 2) {
+            r_body(it, crA, x1);
+            r_body(it + 1, crB, x0);
+        }
+        __syncthreads();                                    // the W waves' extra round (products of the last item)
+        return;
+    }
+
+    // =========================== W waves: weight gradients and the (P, Q) product ===========================
+    f32x4 cfg[8][2], cd[4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { cfg[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; cfg[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) cd[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float* p_or_x = HAS_DY ? a.p_in : a.x_in;         // loads stay unconditional
+    const float* q_or_x = HAS_DY ? a.q_in : a.x_in;
+    // raw rows of this wave's row tile: lane (row c, q) holds samples t0 + 4q .. + 3 and t0 + 16 + 4q .. + 3
+    struct RawRows { f32x4 x0[2], x1[2], p[2], qq[2]; };
+    auto load_rows = [&](RawRows& r, Pos ps) {
+        const size_t ro = ps.live ? (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q : 0;
+        const int dd = ps.live ? a.d : 0, dn = ps.live ? a.dn : 0, h = ps.live ? 16 : 0;
+        const float* xr = a.x_in + ro;
+        r.x0[0] = ld4u(xr - dd); r.x0[1] = ld4u(xr - dd + h);
+        r.x1[0] = ld4u(xr); r.x1[1] = ld4u(xr + h);
+        if (HAS_DY) {
+            const float* pr = p_or_x + ro;
+            const float* qr = q_or_x + ro + dn;
+            r.p[0] = ld4u(pr); r.p[1] = ld4u(pr + h);
+            r.qq[0] = ld4u(qr); r.qq[1] = ld4u(qr + h);
+        }
+    };
+    // dy rows for the R waves' dz product, as recompute-style fragments: wave g converts rows 4(g&1).. of k-step g>>1
+    struct RawD { f32x2 p[4], qq[4]; };
+    auto load_dy = [&](RawD& r, Pos ps) {
+        if (HAS_DY) {
+            const size_t ro = ps.live ? (size_t)ps.b * a.x_bstride + (size_t)(32 * (g >> 1) + 8 * q + 4 * (g & 1)) * a.pitch + ps.t0 + 2 * c : 0;
+            const size_t rp = ps.live ? (size_t)a.pitch : 0;
+            const int dn = ps.live ? a.dn : 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                r.p[jj] = pq_ld2u(p_or_x + ro + jj * rp);
+                r.qq[jj] = pq_ld2u(q_or_x + ro + dn + jj * rp);
+            }
+        }
+    };
+    // dx_{i+1}[t] = P_in[t] (t >= p_lo) + Q_in[t + dn], on [t_lo, t_hi) only (Q_in is never written beyond t_hi)
+    auto dyv = [&](float p, float qv, int t) {
+        const float pv = t >= a.p_lo ? p : 0.f;
+        return (t >= a.t_lo && t < a.t_hi) ? pv + qv : 0.f;
+    };
+    auto fill_dy = [&](const RawD& r, Pos ps, int stage) {
+        if (HAS_DY) {
+            const int tl = ps.t0 + 2 * c;
+            uint16_t* dyf = lds + (size_t)stage * PQ_STAGE + PQ_DYF;
+            const int ks = g >> 1, h = g & 1;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                uint32_t hh[2], ll[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    pq_split2(dyv(r.p[2 * jj][n], r.qq[2 * jj][n], tl + n), dyv(r.p[2 * jj + 1][n], r.qq[2 * jj + 1][n], tl + n), hh[jj], ll[jj]);
+                uint16_t* fb = dyf + (size_t)(ks * 2 + n) * 1024 + lane * 8 + h * 4;
+                *reinterpret_cast<uint2*>(fb) = uint2{hh[0], hh[1]};
+                *reinterpret_cast<uint2*>(fb + 512) = uint2{ll[0], ll[1]};
+            }
+        }
+    };
+    // this wave's B operands of the weight-gradient products (k = the 8 positions of the lane's chunk) and its dy rows
+    // in fp32 (the residual term of P)
+    struct Ops { Frag<BF16> x0, x1, dy; float dy32[8]; };
+    auto to_frag = [&](Frag<BF16>& f, const float* w) {
+        u32x4 fh, fl;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            uint32_t hi, lo;
+            pq_split2(w[2 * jj], w[2 * jj + 1], hi, lo);
+            fh[jj] = hi;
+            fl[jj] = lo;
+        }
+        f.hi = __builtin_bit_cast(bf16x8, fh);
+        f.lo = __builtin_bit_cast(bf16x8, fl);
+    };
+    auto convert = [&](Ops& o, const RawRows& r, Pos ps) {
+        float w[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) w[jj] = ps.live ? r.x0[jj >> 2][jj & 3] : 0.f;
+        to_frag(o.x0, w);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) w[jj] = ps.live ? r.x1[jj >> 2][jj & 3] : 0.f;
+        to_frag(o.x1, w);
+        if (HAS_DY) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int t = ps.t0 + 16 * (jj >> 2) + 4 * q + (jj & 3);
+                o.dy32[jj] = ps.live ? dyv(r.p[jj >> 2][jj & 3], r.qq[jj >> 2][jj & 3], t) : 0.f;
+            }
+            to_frag(o.dy, o.dy32);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) o.dy32[jj] = 0.f;
+        }
+    };
+    auto load_tile = [&](Frag<BF16>& f, const uint16_t* base, int tile) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(base + tile * 1024 + tile_rd);
+        f.hi = __builtin_bit_cast(bf16x8, p[0]);
+        f.lo = __builtin_bit_cast(bf16x8, p[64]);
+    };
+    // transposed-read addresses (halfs) of this lane inside a tile plane: lane c = 4q' + p of its 16-lane group supplies
+    // row (r0 + q'), piece p (positions 8p + 4m' .. + 3 = samples 16m' + 4p .. + 3); r0 = 8(q&1) + 4h
+    int tr_off[2];
+    {
+        const int qp = c >> 2, p = c & 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) tr_off[h] = (16 * p + ((8 * (q & 1) + 4 * h + qp) ^ pq_k(p))) * 8;
+    }
+    float* p_out_b = a.p_out;
+    float* q_out_b = a.q_out;
+    auto products = [&](int stage, const Ops& o, Pos ps) {
+        const uint16_t* tt = lds + (size_t)stage * PQ_STAGE + PQ_T;
+        // ---- weight gradients: rows = all [df;dg] / z tiles, columns = this wave's x / dy rows
+#ifndef PQ_T_NOWG
+        {
+            Frag<BF16> am[2];
+            load_tile(am[0], tt, 0);
+#pragma unroll
+            for (int m = 0; m < (HAS_DY ? 12 : 8); ++m) {
+                if (m + 1 < (HAS_DY ? 12 : 8)) load_tile(am[(m + 1) & 1], tt, m + 1);
+                if (m < 8) {
+                    mma<BF16, 3>(cfg[m][0], am[m & 1], o.x0);
+                    mma<BF16, 3>(cfg[m][1], am[m & 1], o.x1);
+                } else {
+                    mma<BF16, 3>(cd[m - 8], am[m & 1], o.dy);
+                }
+            }
+        }
+#endif
+        // ---- (P, Q)^T = [df;dg]^T [W1 | W0]: rows = time (two 16-sample tiles), columns = this wave's 16 P / Q rows
+        f32x4 ap[2], aq[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { ap[m] = f32x4{0.f, 0.f, 0.f, 0.f}; aq[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const uint16_t* pw = lds + PQ_W;
+#ifndef PQ_T_NOPQ
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Frag<BF16> wp, wq;
+            load_a<BF16, 3>(wp, pw, g * 4 + s, lane);
+            load_a<BF16, 3>(wq, pw, (4 + g) * 4 + s, lane);
+            const uint16_t* tb = tt + ((s >> 1) * 4 + 2 * (s & 1) + (q >> 1)) * 1024;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                Frag<BF16> ad;
+                s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[0] + 4 * m));
+                s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[1] + 4 * m));
+                s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[0] + 4 * m));
+                s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[1] + 4 * m));
+                s16x8 hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                s16x8 ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                ad.hi = __builtin_bit_cast(bf16x8, hh);
+                ad.lo = __builtin_bit_cast(bf16x8, ll);
+                mma<BF16, 3>(ap[m], ad, wp);
+                mma<BF16, 3>(aq[m], ad, wq);
+            }
+        }
+#endif
+#ifndef PQ_T_NOSTORE
+        if (ps.live) {
+            const size_t ro = (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int t = ps.t0 + 16 * m + 4 * q;
+                f32x4 pv = ap[m];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pv[i] += o.dy32[4 * m + i];
+                st4m(p_out_b + ro + 16 * m, pv, t, a.t_lo, a.t_hi);
+                st4m(q_out_b + ro + 16 * m, aq[m], t, a.t_lo, a.t_hi);
+            }
+        }
+#endif
+    };
+
+    {
+        RawD rd;
+        RawRows rr;
+        Ops ops;
+        load_dy(rd, pos_k(0));
+        load_rows(rr, pos_k(0));
+        fill_dy(rd, pos_k(0), 0);
+        load_dy(rd, pos_k(1));
+        convert(ops, rr, pos_k(-1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
+        __syncthreads();
+        // iteration it: dy fragments of item it+1 -> LDS; products of item it-1 (result tiles of stage (it-1)&1, operands
+        // in `ops`); then the raw rows of item it become `ops` and the rows of item it+1 are requested
+        auto w_body = [&](const int it) {
+#ifndef PQ_T_NOFILLDY
+            fill_dy(rd, pos_k(it + 1), (it + 1) & 1);
+            load_dy(rd, pos_k(it + 2));
+#endif
+            products((it + 1) & 1, ops, pos_k(it - 1));
+#ifndef PQ_T_NOCONV
+            convert(ops, rr, pos_k(it));
+            load_rows(rr, pos_k(it + 1));
+#endif
+            __syncthreads();
+        };
+        const int n_even = (n_items + 1) & ~1;
+        for (int it = 0; it < n_even; ++it) w_body(it);
+        products((n_even - 1) & 1, ops, pos_k(n_even - 1)); // the last item (a void one if the count was padded)
+        __syncthreads();
+    }
+
+    // ---- slab of this workgroup (every workgroup writes one, also an idle one: zeros)
+    float* sfg = a.slab_fg + (size_t)wgid * (4 * CH * CH);
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int tap = 0; tap < 2; ++tap)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_nontemporal_store(cfg[m][tap][i], &sfg[(size_t)(16 * m + 4 * q + i) * (2 * CH) + tap * CH + 16 * g + c]);
+    if (HAS_DY && a.slab_d) {
+        float* sd = a.slab_d + (size_t)wgid * (CH * CH);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_nontemporal_store(cd[m][i], &sd[(size_t)(16 * g + c) * CH + 16 * m + 4 * q + i]);
+    }
+}
+
+int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
+    if (a.t_hi <= a.t_lo || batch <= 0) return 0;
+    WnResPqArgs k = a;
+    int nwg;
+    wn_resrw_plan(a.t_lo, a.t_hi, batch, k.t_base, k.steps_per_clip, k.items_per_wg, nwg);      // same items and slabs as wn_resrw.hip
+    k.batch = batch;
+    k.swz = wn_xcd_swizzle_enabled();
+    const size_t sh = (size_t)PQ_LDS_HALFS * sizeof(uint16_t);
+    static unsigned long long done = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((done >> dev) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        done |= 1ull << dev;
+    }
+    if (k.p_in && k.q_in) hipLaunchKernelGGL(resblock_bwd_pq_k<true>, dim3(nwg), dim3(PQ_THREADS), sh, st, k);
+    else hipLaunchKernelGGL(resblock_bwd_pq_k<false>, dim3(nwg), dim3(PQ_THREADS), sh, st, k);
+    WN_CHECK_LAUNCH();
+    return 0;
+}

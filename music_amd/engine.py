@@ -197,6 +197,13 @@ class WaveNetEngine:
                 w[:R, h * CH:h * CH + D] = src[:, :, 1].T
                 w[:R, 2 * CH + h * CH:2 * CH + h * CH + D] = src[:, :, 0].T
             bwd.append(("fgT%d" % i, pack_index(w)))
+            # 11b. the same weights as two UNSHIFTED row blocks for the one-launch backward block (wn_resblock_bwd_pq):
+            #      rows [0,CH) = W1^T (-> P), rows [CH,2CH) = W0^T (-> Q), K = (df | dg)
+            w = full(2 * CH, 2 * CH)
+            for h, src in enumerate((wf, wg)):
+                w[:R, h * CH:h * CH + D] = src[:, :, 1].T
+                w[CH:CH + R, h * CH:h * CH + D] = src[:, :, 0].T
+            bwd.append(("pq%d" % i, pack_index(w)))
         # 4. skip over the concatenated z-crops: rows S, K = N*CH
         w = full(SP, N * CH)
         for i in range(N):
@@ -326,6 +333,9 @@ class WaveNetEngine:
         T, lo = ws["T"], self.rf - 1
         ms = self._use_ms()
         bw["ms"] = ms
+        bw["pq"] = self._use_pq()
+        if bw["pq"]:
+            bw["PQ"] = [(buf(self.CH), buf(self.CH)), (buf(self.CH), buf(self.CH))]
         ops = [("p2", lo, T, 1024), ("p1", lo, T, 1024), ("skip", lo, T, 2048)]
         for i in range(self.N):
             ops.append(("fg%d" % i, self.off[i + 1], T, -1 if ms else 512))
@@ -366,6 +376,12 @@ class WaveNetEngine:
         if self.ms_bwd and not ok:
             raise NotImplementedError("ms_bwd needs 64 padded channels and precision (f16x3, bf16x3)")
         return bool(self.ms_bwd)
+
+    def _use_pq(self):
+        """The whole per-block backward, data gradient included, in one launch (wn_resblock_bwd_pq): wherever the
+        two-role block applies and there are no biases (their gradients are sums over [df;dg], which that kernel
+        never writes out).  WN_PQ_BWD=0: resblock_bwd_rw_k + chan_gemm_rw_k."""
+        return self._use_ms() and not self.use_bias and os.environ.get("WN_PQ_BWD", "1") == "1"
 
     def _x(self, ws, i):
         return ptr(ws["X"], SLACK + i * ws["B"] * self.CH * ws["pitch"])
@@ -525,6 +541,23 @@ class WaveNetEngine:
             bn = "dilation_layer_stack.%d.bias"
             if overlap and ev_w[k] is not None:
                 main.wait_event(ev_w[k])
+            if bw["pq"]:
+                p_out, q_out = (ptr(t, SLACK) for t in bw["PQ"][i % 2])
+                if i < N - 1:
+                    p_in, q_in = (ptr(t, SLACK) for t in bw["PQ"][(i + 1) % 2])
+                    dn, p_lo = self.dil[i + 1], self.off[i + 2]
+                else:
+                    p_in = q_in = None
+                    dn = p_lo = 0
+                call("wn_resblock_bwd_pq", self._x(ws, i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CH * pitch),
+                     p_out, q_out, xb, zb, pitch, fr("fg%d" % i), br("dT%d" % i), br("pq%d" % i), CH, d, t_lo, T, lo,
+                     ptr(bw["slab"], plan["fg%d" % i][0]), ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None,
+                     B, mf, mb, st)
+                self.fmark("b_block")
+                if i == 0:
+                    # dx_0 for the causal layer: the pair made whole once
+                    call("wn_shift_add", p_out, q_out, ptr(bw["dX"][0], SLACK), xb, pitch, CH, d, t_lo, self.off[0], T, B, st)
+                continue
             if bw["ms"]:
                 call("wn_resblock_bwd_ms", self._x(ws, i), dy, ptr(bw["dZ"], SLACK + i * CH * pitch), dfg, xb, zb, 2 * CH * pitch,
                      pitch, fr("fg%d" % i), br("dT%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SWITCHES = [
+    {"WN_PQ_BWD": "0"},            # resblock_bwd_rw_k + chan_gemm_rw_k instead of the one-launch block (what biased / conditioned blocks run)
     {"WN_MS_BWD": "0"},            # resblock_bwd_k + 2 x wgrad_k instead of the two-role block (what 32 padded channels / x1 modes run)
     {"WN_GEMM_RW": "0"},           # one-pass narrow product (chan_gemm_k) for the per-layer data gradient (what other shapes run)
     {"WN_TALIGN": "4"},            # tile origins at t_lo & ~3 instead of 64-sample lines (also disables the two-role narrow product)
