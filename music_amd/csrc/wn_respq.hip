@@ -61,6 +61,26 @@ __device__ __forceinline__ void pq_split2(float a, float b, uint32_t& hi, uint32
 #define PQ_W (2 * PQ_STAGE)
 #define PQ_LDS_HALFS (PQ_W + 32768)
 
+#ifdef PQ_DBG
+// phase clock sums (developer build, tools/pq_clocks.py): [R: fill_x, recompute, gate+put, barrier | W: fill_dy, wgrad, pq, store, convert, barrier]
+__device__ unsigned long long pq_dbg[16];
+#define PQ_TICK(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+#define PQ_ACC(slot, dt) dbg_acc[(slot)] += (unsigned long long)(dt)
+#define PQ_FLUSH(base, n) do { if (lane == 0) for (int z_ = 0; z_ < (n); ++z_) atomicAdd(&pq_dbg[(base) + z_], dbg_acc[(base) + z_]); } while (0)
+extern "C" int wn_pq_dbg_read(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pq_dbg), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(pq_dbg), z, sizeof(z));
+    }
+    return (int)e;
+}
+#else
+#define PQ_TICK(var)
+#define PQ_ACC(slot, dt)
+#define PQ_FLUSH(base, n)
+#endif
+
 // chunk swizzle of the result tiles: 16-byte chunk `ch` (8 positions) of row `r` sits at slot 16*ch + (r ^ K[ch])
 __device__ __forceinline__ int pq_k(int ch) { return ch == 0 ? 0 : ch == 1 ? 13 : ch == 2 ? 6 : 11; }
 
@@ -80,6 +100,9 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     const int g = wv & 3;
     const int c = lane & 15, q = lane >> 4;
     const int tile_rd = (16 * q + (c ^ pq_k(q))) * 8;            // halfs; chunk q of row c (a 16-byte row read)
+#ifdef PQ_DBG
+    unsigned long long dbg_acc[16] = {};
+#endif
 
     // items of this workgroup: the workgroups of an XCD walk one contiguous item range interleaved (wn_resrw.hip)
     int first, cnt, j;
@@ -124,6 +147,114 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) z[k * PQ_THREADS + threadIdx.x] = zero;       // 12 tiles x 2 KB = 24 KB
     }
+
+    const float* p_or_x = HAS_DY ? a.p_in : a.x_in;         // loads stay unconditional
+    const float* q_or_x = HAS_DY ? a.q_in : a.x_in;
+    // dy rows for the R waves' dz product, as recompute-style fragments: wave g converts rows 4(g&1).. of k-step g>>1
+    struct RawD { f32x2 p[4], qq[4]; };
+    auto load_dy = [&](RawD& r, Pos ps) {
+        if (HAS_DY) {
+            const size_t ro = ps.live ? (size_t)ps.b * a.x_bstride + (size_t)(32 * (g >> 1) + 8 * q + 4 * (g & 1)) * a.pitch + ps.t0 + 2 * c : 0;
+            const size_t rp = ps.live ? (size_t)a.pitch : 0;
+            const int dn = ps.live ? a.dn : 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                r.p[jj] = pq_ld2u(p_or_x + ro + jj * rp);
+                r.qq[jj] = pq_ld2u(q_or_x + ro + dn + jj * rp);
+            }
+        }
+    };
+    // dx_{i+1}[t] = P_in[t] (t >= p_lo) + Q_in[t + dn], on [t_lo, t_hi) only (Q_in is never written beyond t_hi)
+    auto dyv = [&](float p, float qv, int t) {
+        const float pv = t >= a.p_lo ? p : 0.f;
+        return (t >= a.t_lo && t < a.t_hi) ? pv + qv : 0.f;
+    };
+    // an item whose 32 columns all lie inside [max(p_lo, t_lo), t_hi) needs none of these masks (wave-uniform)
+    auto interior = [&](Pos ps) { return ps.live && ps.t0 >= a.p_lo && ps.t0 >= a.t_lo && ps.t0 + PQ_COLS <= a.t_hi; };
+    auto fill_dy = [&](const RawD& r, Pos ps, int stage) {
+        if (HAS_DY) {
+            const int tl = ps.t0 + 2 * c;
+            uint16_t* dyf = lds + (size_t)stage * PQ_STAGE + PQ_DYF;
+            const int ks = g >> 1, h = g & 1;
+            const bool fast = interior(ps);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                uint32_t hh[2], ll[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float v0 = fast ? r.p[2 * jj][n] + r.qq[2 * jj][n] : dyv(r.p[2 * jj][n], r.qq[2 * jj][n], tl + n);
+                    const float v1 = fast ? r.p[2 * jj + 1][n] + r.qq[2 * jj + 1][n] : dyv(r.p[2 * jj + 1][n], r.qq[2 * jj + 1][n], tl + n);
+                    pq_split2(v0, v1, hh[jj], ll[jj]);
+                }
+                uint16_t* fb = dyf + (size_t)(ks * 2 + n) * 1024 + lane * 8 + h * 4;
+                *reinterpret_cast<uint2*>(fb) = uint2{hh[0], hh[1]};
+                *reinterpret_cast<uint2*>(fb + 512) = uint2{ll[0], ll[1]};
+            }
+        }
+    };
+    // ---- one half of (P, Q)^T = [df;dg]^T [W1 | W0] for the item whose result tiles sit in `stage`: rows = time (two
+    // 16-sample tiles), columns = the 16 P (sel 0) or Q (sel 1) rows of wave g.  The W waves take P (+ their fp32 dy rows),
+    // the R waves Q, so that both roles issue 84 MFMAs per item.
+    // transposed-read addresses (halfs) of this lane inside a tile plane: lane c = 4q' + p of its 16-lane group supplies
+    // row (r0 + q'), piece p (positions 8p + 4m' .. + 3 = samples 16m' + 4p .. + 3); r0 = 8(q&1) + 4h
+    int tr_off[2];
+    {
+        const int qp = c >> 2, p = c & 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) tr_off[h] = (16 * p + ((8 * (q & 1) + 4 * h + qp) ^ pq_k(p))) * 8;
+    }
+    auto pq_half = [&](int stage, int sel, Pos ps, const float* dy32) {
+        const uint16_t* tt = lds + (size_t)stage * PQ_STAGE + PQ_T;
+        const uint16_t* pw = lds + PQ_W;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 acb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // odd k-steps: four chains in flight
+#ifndef PQ_T_NOPQ
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Frag<BF16> w;
+            load_a<BF16, 3>(w, pw, (sel * 4 + g) * 4 + s, lane);
+            const uint16_t* tb = tt + ((s >> 1) * 4 + 2 * (s & 1) + (q >> 1)) * 1024;
+            Frag<BF16> ad[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[0] + 4 * m));
+                s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[1] + 4 * m));
+                s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[0] + 4 * m));
+                s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[1] + 4 * m));
+                s16x8 hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                s16x8 ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                ad[m].hi = __builtin_bit_cast(bf16x8, hh);
+                ad[m].lo = __builtin_bit_cast(bf16x8, ll);
+            }
+            f32x4* ac = (s & 1) ? acb : acc;
+            ac[0] = BF16::mfma(ad[0].lo, w.hi, ac[0]);
+            ac[1] = BF16::mfma(ad[1].lo, w.hi, ac[1]);
+            ac[0] = BF16::mfma(ad[0].hi, w.lo, ac[0]);
+            ac[1] = BF16::mfma(ad[1].hi, w.lo, ac[1]);
+            ac[0] = BF16::mfma(ad[0].hi, w.hi, ac[0]);
+            ac[1] = BF16::mfma(ad[1].hi, w.hi, ac[1]);
+        }
+        acc[0] += acb[0];
+        acc[1] += acb[1];
+#endif
+#ifndef PQ_T_NOSTORE
+        if (ps.live) {
+            float* out = (sel ? a.q_out : a.p_out) + (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q;
+            const bool whole = ps.t0 >= a.t_lo && ps.t0 + PQ_COLS <= a.t_hi;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x4 v = acc[m];
+                if (dy32 != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += dy32[4 * m + i];
+                }
+                if (whole) *reinterpret_cast<f32x4*>(out + 16 * m) = v;
+                else st4m(out + 16 * m, v, ps.t0 + 16 * m + 4 * q, a.t_lo, a.t_hi);
+            }
+        }
+#endif
+    };
 
     if (wv < 4) {
         // =========================== R waves: recompute, dz, gate ===========================
@@ -180,14 +311,25 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         load_cr(crA, pos_k(0));
         load_cr(crB, pos_k(1));
         RawX x0, x1;                                        // x1 / x0 hold the raw rows of items it+1 / it+2
+        RawD rd;                                            // dy rows (as the pair) of item it+1
         load_x(x0, pos_k(0));
+        load_dy(rd, pos_k(0));
         load_x(x1, pos_k(1));
         fill_x(x0, 0);
+        fill_dy(rd, pos_k(0), 0);
         load_x(x0, pos_k(2));
+        load_dy(rd, pos_k(1));
         __syncthreads();                                    // stage 0 operands of the first item, the weights, the zeros
         auto r_body = [&](const int it, f32x2* cr, RawX& rx) {
+            PQ_TICK(k0);
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
             load_x(rx, pos_k(it + 3));
+#ifndef PQ_T_NOFILLDY
+            fill_dy(rd, pos_k(it + 1), (it + 1) & 1);        // (the R waves wait at the barrier otherwise: the W waves are the pole)
+            load_dy(rd, pos_k(it + 2));
+#endif
+            pq_half((it + 1) & 1, 1, pos_k(it - 1), nullptr);       // Q rows of the previous item
+            PQ_TICK(k1);
             const Pos p_cur = pos_k(it);
             const bool live = it < n_items;
             const int tl = p_cur.t0 + 2 * c;
@@ -233,6 +375,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 }
             }
 #endif
+            PQ_TICK(k2);
             uint16_t* tt = st + PQ_T;
             const bool ok0 = live && tl >= a.t_lo && tl < a.t_hi, ok1 = live && tl + 1 >= a.t_lo && tl + 1 < a.t_hi;
 #pragma unroll
@@ -246,8 +389,13 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #ifdef PQ_T_NOGATE
                     const float th = af[n][i], sg = ag[n][i];
 #else
-                    const float th = wn_tanh(af[n][i]);
-                    const float sg = wn_sigmoid(ag[n][i]);
+                    // th = (1 - e1) / (1 + e1), sg = 1 / (1 + e2) with ONE reciprocal (e1 = exp(-2f), e2 = exp(-g)); the same
+                    // values as wn_tanh / wn_sigmoid to ~1e-7 absolute
+                    const float fc = fminf(fmaxf(af[n][i], -15.f), 15.f);
+                    const float e1 = __expf(-2.0f * fc), e2 = fminf(__expf(-ag[n][i]), 1e30f);
+                    const float rr = __builtin_amdgcn_rcpf((1.0f + e1) * (1.0f + e2));
+                    const float th = (1.0f - e1) * (1.0f + e2) * rr;
+                    const float sg = (1.0f + e1) * rr;
 #endif
                     vz[n] = ok ? th * sg : 0.f;
                     vf[n] = ok ? gz * sg * (1.0f - th * th) : 0.f;
@@ -266,13 +414,21 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 if (HAS_DY) put(2, vz);
             }
             load_cr(cr, pos_k(it + 2));
+            PQ_TICK(k3);
             __syncthreads();
+            PQ_TICK(k4);
+            PQ_ACC(0, k1 - k0); PQ_ACC(1, k2 - k1); PQ_ACC(2, k3 - k2); PQ_ACC(3, k4 - k3);
         };
         for (int it = 0; it < n_items; it += 2) {
             r_body(it, crA, x1);
             r_body(it + 1, crB, x0);
         }
+        {
+            const int n_even = (n_items + 1) & ~1;
+            pq_half((n_even - 1) & 1, 1, pos_k(n_even - 1), nullptr);      // Q rows of the last item
+        }
         __syncthreads();                                    // the W waves' extra round (products of the last item)
+        PQ_FLUSH(0, 4);
         return;
     }
 
@@ -283,8 +439,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) cd[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const float* p_or_x = HAS_DY ? a.p_in : a.x_in;         // loads stay unconditional
-    const float* q_or_x = HAS_DY ? a.q_in : a.x_in;
     // raw rows of this wave's row tile: lane (row c, q) holds samples t0 + 4q .. + 3 and t0 + 16 + 4q .. + 3
     struct RawRows { f32x4 x0[2], x1[2], p[2], qq[2]; };
     auto load_rows = [&](RawRows& r, Pos ps) {
@@ -298,42 +452,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             const float* qr = q_or_x + ro + dn;
             r.p[0] = ld4u(pr); r.p[1] = ld4u(pr + h);
             r.qq[0] = ld4u(qr); r.qq[1] = ld4u(qr + h);
-        }
-    };
-    // dy rows for the R waves' dz product, as recompute-style fragments: wave g converts rows 4(g&1).. of k-step g>>1
-    struct RawD { f32x2 p[4], qq[4]; };
-    auto load_dy = [&](RawD& r, Pos ps) {
-        if (HAS_DY) {
-            const size_t ro = ps.live ? (size_t)ps.b * a.x_bstride + (size_t)(32 * (g >> 1) + 8 * q + 4 * (g & 1)) * a.pitch + ps.t0 + 2 * c : 0;
-            const size_t rp = ps.live ? (size_t)a.pitch : 0;
-            const int dn = ps.live ? a.dn : 0;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                r.p[jj] = pq_ld2u(p_or_x + ro + jj * rp);
-                r.qq[jj] = pq_ld2u(q_or_x + ro + dn + jj * rp);
-            }
-        }
-    };
-    // dx_{i+1}[t] = P_in[t] (t >= p_lo) + Q_in[t + dn], on [t_lo, t_hi) only (Q_in is never written beyond t_hi)
-    auto dyv = [&](float p, float qv, int t) {
-        const float pv = t >= a.p_lo ? p : 0.f;
-        return (t >= a.t_lo && t < a.t_hi) ? pv + qv : 0.f;
-    };
-    auto fill_dy = [&](const RawD& r, Pos ps, int stage) {
-        if (HAS_DY) {
-            const int tl = ps.t0 + 2 * c;
-            uint16_t* dyf = lds + (size_t)stage * PQ_STAGE + PQ_DYF;
-            const int ks = g >> 1, h = g & 1;
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                uint32_t hh[2], ll[2];
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-                    pq_split2(dyv(r.p[2 * jj][n], r.qq[2 * jj][n], tl + n), dyv(r.p[2 * jj + 1][n], r.qq[2 * jj + 1][n], tl + n), hh[jj], ll[jj]);
-                uint16_t* fb = dyf + (size_t)(ks * 2 + n) * 1024 + lane * 8 + h * 4;
-                *reinterpret_cast<uint2*>(fb) = uint2{hh[0], hh[1]};
-                *reinterpret_cast<uint2*>(fb + 512) = uint2{ll[0], ll[1]};
-            }
         }
     };
     // this wave's B operands of the weight-gradient products (k = the 8 positions of the lane's chunk) and its dy rows
@@ -360,10 +478,15 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         for (int jj = 0; jj < 8; ++jj) w[jj] = ps.live ? r.x1[jj >> 2][jj & 3] : 0.f;
         to_frag(o.x1, w);
         if (HAS_DY) {
+            if (interior(ps)) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int t = ps.t0 + 16 * (jj >> 2) + 4 * q + (jj & 3);
-                o.dy32[jj] = ps.live ? dyv(r.p[jj >> 2][jj & 3], r.qq[jj >> 2][jj & 3], t) : 0.f;
+                for (int jj = 0; jj < 8; ++jj) o.dy32[jj] = r.p[jj >> 2][jj & 3] + r.qq[jj >> 2][jj & 3];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int t = ps.t0 + 16 * (jj >> 2) + 4 * q + (jj & 3);
+                    o.dy32[jj] = ps.live ? dyv(r.p[jj >> 2][jj & 3], r.qq[jj >> 2][jj & 3], t) : 0.f;
+                }
             }
             to_frag(o.dy, o.dy32);
         } else {
@@ -376,108 +499,79 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         f.hi = __builtin_bit_cast(bf16x8, p[0]);
         f.lo = __builtin_bit_cast(bf16x8, p[64]);
     };
-    // transposed-read addresses (halfs) of this lane inside a tile plane: lane c = 4q' + p of its 16-lane group supplies
-    // row (r0 + q'), piece p (positions 8p + 4m' .. + 3 = samples 16m' + 4p .. + 3); r0 = 8(q&1) + 4h
-    int tr_off[2];
-    {
-        const int qp = c >> 2, p = c & 3;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) tr_off[h] = (16 * p + ((8 * (q & 1) + 4 * h + qp) ^ pq_k(p))) * 8;
-    }
-    float* p_out_b = a.p_out;
-    float* q_out_b = a.q_out;
     auto products = [&](int stage, const Ops& o, Pos ps) {
+        PQ_TICK(p0);
         const uint16_t* tt = lds + (size_t)stage * PQ_STAGE + PQ_T;
         // ---- weight gradients: rows = all [df;dg] / z tiles, columns = this wave's x / dy rows
 #ifndef PQ_T_NOWG
         {
-            Frag<BF16> am[2];
-            load_tile(am[0], tt, 0);
+            // the three products of an x3 term are walked across FOUR accumulators (two tiles x two column blocks), so
+            // no MFMA waits for the one in front of it; the next pair of tiles is read meanwhile
+            auto term = [](f32x4& acc, const Frag<BF16>& wa, const Frag<BF16>& xb, int t) {
+                acc = t == 0 ? BF16::mfma(wa.lo, xb.hi, acc) : t == 1 ? BF16::mfma(wa.hi, xb.lo, acc) : BF16::mfma(wa.hi, xb.hi, acc);
+            };
+            Frag<BF16> am[2][2];
+            load_tile(am[0][0], tt, 0);
+            load_tile(am[0][1], tt, 1);
 #pragma unroll
-            for (int m = 0; m < (HAS_DY ? 12 : 8); ++m) {
-                if (m + 1 < (HAS_DY ? 12 : 8)) load_tile(am[(m + 1) & 1], tt, m + 1);
-                if (m < 8) {
-                    mma<BF16, 3>(cfg[m][0], am[m & 1], o.x0);
-                    mma<BF16, 3>(cfg[m][1], am[m & 1], o.x1);
+            for (int mm = 0; mm < (HAS_DY ? 12 : 8); mm += 2) {
+                const int cur = (mm >> 1) & 1;
+                if (mm + 2 < (HAS_DY ? 12 : 8)) {
+                    load_tile(am[cur ^ 1][0], tt, mm + 2);
+                    load_tile(am[cur ^ 1][1], tt, mm + 3);
+                }
+                if (mm < 8) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        term(cfg[mm][0], am[cur][0], o.x0, t);
+                        term(cfg[mm][1], am[cur][0], o.x1, t);
+                        term(cfg[mm + 1][0], am[cur][1], o.x0, t);
+                        term(cfg[mm + 1][1], am[cur][1], o.x1, t);
+                    }
                 } else {
-                    mma<BF16, 3>(cd[m - 8], am[m & 1], o.dy);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        term(cd[mm - 8], am[cur][0], o.dy, t);
+                        term(cd[mm - 7], am[cur][1], o.dy, t);
+                    }
                 }
             }
         }
 #endif
-        // ---- (P, Q)^T = [df;dg]^T [W1 | W0]: rows = time (two 16-sample tiles), columns = this wave's 16 P / Q rows
-        f32x4 ap[2], aq[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) { ap[m] = f32x4{0.f, 0.f, 0.f, 0.f}; aq[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        const uint16_t* pw = lds + PQ_W;
-#ifndef PQ_T_NOPQ
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            Frag<BF16> wp, wq;
-            load_a<BF16, 3>(wp, pw, g * 4 + s, lane);
-            load_a<BF16, 3>(wq, pw, (4 + g) * 4 + s, lane);
-            const uint16_t* tb = tt + ((s >> 1) * 4 + 2 * (s & 1) + (q >> 1)) * 1024;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                Frag<BF16> ad;
-                s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[0] + 4 * m));
-                s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[1] + 4 * m));
-                s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[0] + 4 * m));
-                s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[1] + 4 * m));
-                s16x8 hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                s16x8 ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-                ad.hi = __builtin_bit_cast(bf16x8, hh);
-                ad.lo = __builtin_bit_cast(bf16x8, ll);
-                mma<BF16, 3>(ap[m], ad, wp);
-                mma<BF16, 3>(aq[m], ad, wq);
-            }
-        }
-#endif
-#ifndef PQ_T_NOSTORE
-        if (ps.live) {
-            const size_t ro = (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int t = ps.t0 + 16 * m + 4 * q;
-                f32x4 pv = ap[m];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pv[i] += o.dy32[4 * m + i];
-                st4m(p_out_b + ro + 16 * m, pv, t, a.t_lo, a.t_hi);
-                st4m(q_out_b + ro + 16 * m, aq[m], t, a.t_lo, a.t_hi);
-            }
-        }
-#endif
+        PQ_TICK(p1);
+        pq_half(stage, 0, ps, o.dy32);
+        PQ_TICK(p2);
+        PQ_TICK(p3);
+        PQ_ACC(5, p1 - p0); PQ_ACC(6, p2 - p1); PQ_ACC(7, p3 - p2);
     };
 
     {
-        RawD rd;
         RawRows rr;
         Ops ops;
-        load_dy(rd, pos_k(0));
         load_rows(rr, pos_k(0));
-        fill_dy(rd, pos_k(0), 0);
-        load_dy(rd, pos_k(1));
         convert(ops, rr, pos_k(-1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
         __syncthreads();
-        // iteration it: dy fragments of item it+1 -> LDS; products of item it-1 (result tiles of stage (it-1)&1, operands
-        // in `ops`); then the raw rows of item it become `ops` and the rows of item it+1 are requested
+        // iteration it: products of item it-1 (result tiles of stage (it-1)&1, operands in `ops`); then the raw rows of
+        // item it become `ops` and the rows of item it+1 are requested
         auto w_body = [&](const int it) {
-#ifndef PQ_T_NOFILLDY
-            fill_dy(rd, pos_k(it + 1), (it + 1) & 1);
-            load_dy(rd, pos_k(it + 2));
-#endif
+            PQ_TICK(k0);
+            PQ_TICK(k1);
             products((it + 1) & 1, ops, pos_k(it - 1));
+            PQ_TICK(k2);
 #ifndef PQ_T_NOCONV
             convert(ops, rr, pos_k(it));
             load_rows(rr, pos_k(it + 1));
 #endif
+            PQ_TICK(k3);
             __syncthreads();
+            PQ_TICK(k4);
+            PQ_ACC(4, k1 - k0); PQ_ACC(8, k3 - k2); PQ_ACC(9, k4 - k3);
         };
         const int n_even = (n_items + 1) & ~1;
         for (int it = 0; it < n_even; ++it) w_body(it);
         products((n_even - 1) & 1, ops, pos_k(n_even - 1)); // the last item (a void one if the count was padded)
         __syncthreads();
+        PQ_FLUSH(4, 6);
     }
 
     // ---- slab of this workgroup (every workgroup writes one, also an idle one: zeros)
