@@ -279,6 +279,8 @@ def main():
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": t.item()}))
         return
+    backend = os.environ.get("WN_DIST_BACKEND", "nccl")       # gloo: several ranks on one GPU (tests on a 1-GPU box)
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
     # under torchrun (RANK/MASTER_ADDR set) the process group is always created, also for 1 rank,
@@ -286,7 +288,10 @@ def main():
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from music_amd.model import wavenet
     torch.manual_seed(0)                               # identical replicas on every rank

@@ -2,6 +2,7 @@
 // 16-column N-tiles a wave owns.  NT = 4 is what runs: 8 waves x 64 columns (float4 per lane), 512 columns per
 // workgroup, one copy of the packed weights in LDS.  (NT = 2, 16 waves x 32 columns, measured 33 vs 26.6 us per
 // config-2 block and is not instantiated.)
+#include <stdlib.h>
 #include "wn_common.h"
 #include "wn_kernels.h"
 
@@ -44,11 +45,11 @@ template <int NT> struct NtCfg { static constexpr int WAVES = NT == 4 ? 8 : 16; 
 // ENC = the autoencoder's ENCODER block (wavenet_autoencoder/model1.py:137-152) on the same skeleton:
 //   h = Wdil [relu x(t-d); relu x(t)] (+ bias) ; x_out = Wd relu(h) (+ bias) + x(t) ; h (pre-activation) is stored where
 //   the decoder block stores z.  One row group (no gate), ReLU on load and in front of the dense product.
-template <class T, int NS, int CH, int NT, bool ENC = false>
-__global__ __launch_bounds__(64 * NtCfg<NT>::WAVES) void resblock_fwd_nt_k(WnResArgs a) {
+template <class T, int NS, int CH, int NT, bool ENC = false, int WV = NtCfg<NT>::WAVES>
+__global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
     typedef typename VecN<NT>::t fvec;
-    constexpr int THREADS = 64 * NtCfg<NT>::WAVES;
-    constexpr int COLS = NtCfg<NT>::WAVES * 16 * NT;
+    constexpr int THREADS = 64 * WV;
+    constexpr int COLS = WV * 16 * NT;
     constexpr int MT = (ENC ? 1 : 2) * CH / 16;        // fg row tiles (f rows then g rows); encoder: h rows only
     constexpr int KS = 2 * CH / 32;        // fg k-steps (tap 0 channels then tap 1 channels)
     constexpr int KT = CH / 32;            // k-steps per tap

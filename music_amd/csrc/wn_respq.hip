@@ -323,7 +323,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         auto r_body = [&](const int it, f32x2* cr, RawX& rx) {
             PQ_TICK(k0);
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
-            load_x(rx, pos_k(it + 3));
+            load_x(rx, pos_k(it + 3));                       // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
 #ifndef PQ_T_NOFILLDY
             fill_dy(rd, pos_k(it + 1), (it + 1) & 1);        // (the R waves wait at the barrier otherwise: the W waves are the pole)
             load_dy(rd, pos_k(it + 2));

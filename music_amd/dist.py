@@ -29,9 +29,13 @@ def init_from_env(backend=None, force=False):
     lr = int(os.environ.get("LOCAL_RANK", "0"))
     if (w > 1 or (force and "MASTER_ADDR" in os.environ)) and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            # WN_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate devices) - used by the GPU tests
+            # to run the N-rank code path on a 1-GPU box; production is nccl (= RCCL), one rank per GPU
+            backend = os.environ.get("WN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            lr = lr % max(1, torch.cuda.device_count())
             torch.cuda.set_device(lr)
+        if backend == "nccl":
             dist.init_process_group(backend, device_id=torch.device("cuda", lr))
         else:
             dist.init_process_group(backend)

@@ -25,8 +25,11 @@ def _free_port():
     return p
 
 
-def _run(nproc, tmp_path, with_launcher=True, shards=1):
+def _run(nproc, tmp_path, with_launcher=True, shards=1, backend=None):
     env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("WN_DIST_BACKEND", None)
+    if backend:
+        env["WN_DIST_BACKEND"] = backend
     worker = os.path.join(ROOT, "tests", "dist_worker_gpu.py")
     if with_launcher:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
@@ -61,3 +64,40 @@ def test_rccl_path_one_rank_per_gpu(tmp_path):
             assert abs(a - b) < 2e-5, (many["losses"], whole["losses"])
         assert abs(many["gsum"] - whole["gsum"]) < 1e-3 * whole["gsum"]
         assert abs(many["psum"] - whole["psum"]) < 1e-5 * whole["psum"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_n_ranks_equal_one_rank_with_n_times_the_batch(tmp_path, world):
+    """The N-rank code path on whatever the box has: N processes, each with its own engine and its contiguous chunk of
+    one global batch, one flat all-reduce per step, 1/N inside Adam - against ONE process on the same 2N clips
+    (DataParallel's global-batch-mean gradient): losses, the reduced gradient and the parameters after 3 Adam steps
+    agree to fp32 reduction-order noise.  With fewer GPUs than ranks the ranks share a device and the collective runs on
+    gloo (RCCL refuses duplicate devices); with enough GPUs it is RCCL."""
+    n = torch.cuda.device_count()
+    backend = None if n >= world else "gloo"
+    whole = _run(1, tmp_path, with_launcher=False, shards=world)
+    many = _run(world, tmp_path, shards=world, backend=backend)
+    assert many["world"] == world and many["backend"] == ("nccl" if backend is None else "gloo")
+    for a, b in zip(many["losses"], whole["losses"]):
+        assert abs(a - b) < 2e-5, (many["losses"], whole["losses"])
+    assert abs(many["gsum"] - whole["gsum"]) < 1e-3 * whole["gsum"]
+    assert abs(many["psum"] - whole["psum"]) < 1e-5 * whole["psum"]
+
+
+def test_bench_two_ranks_on_this_box(tmp_path):
+    """`python bench.py --gpus 2` end to end: the parent starts two ranks, they train in lock step (barrier, max-over-ranks
+    time, one all-reduce per step) and rank 0 prints ONE line for the whole job.  On a 1-GPU box the two ranks share the
+    device over gloo; the line then says so in `backend`."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.device_count() < 2:
+        env["WN_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    assert "allreduce" in out["phase_ms_per_step"] and out["value"] > 0
+    assert abs(out["value"] - 2 * 8 * 16000 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
