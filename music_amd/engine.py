@@ -419,14 +419,17 @@ class WaveNetEngine:
              None, 0, 0, 0, None, 0, 0, 1, T, 0, B, mf, st)
         zb = N * CH * pitch
         self.mark("causal_fwd")
-        # z is stored on the block's WHOLE valid range [off_{i+1}, T), not only on the skip crop
-        # [rf-1, T): the backward's dWd product reads it from here instead of having the recompute
-        # kernel write a second copy (-1 activation-sized write per block and step, +19 % of z here)
+        # z: the skip product needs it on the crop [rf-1, T) only, and the two-role / one-launch backward blocks recompute
+        # it on the CU.  Only the fallback backward (resblock_bwd_k + wgrad_k: 32 padded channels, x1 modes) reads the
+        # forward's z for dWd on the block's whole valid range [off_{i+1}, T) (19 % more z; it saves that path a second
+        # copy written by its recompute kernel).
+        z_whole = self.z_from_fwd and not self._use_ms()
         for i, d in enumerate(self.dil):
             bn = "dilation_layer_stack.%d.bias"
             call("wn_resblock_fwd", self._x(ws, i), self._x(ws, i + 1), ptr(ws["Z"], SLACK + i * CH * pitch), xb, zb, pitch,
                  fr("fg%d" % i), fr("d%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),
-                 self._bias_ptr(bn % (4 * i + 2)), self.D, self.R, CH, d, self.off[i + 1], T, self.off[i + 1],
+                 self._bias_ptr(bn % (4 * i + 2)), self.D, self.R, CH, d, self.off[i + 1], T,
+                 self.off[i + 1] if z_whole else self.rf - 1,
                  1 if i < N - 1 else 0, None, 0, 0, 0, 0, 0, B, mf, st)
         self.mark("stack_fwd")
         lo = self.rf - 1
@@ -638,9 +641,10 @@ class WaveNetEngine:
             wgrad("causal", dx0, xb, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CH // 16, 0, 2 * Q, 1, T)
         if self.use_bias:
             call("wn_bias_grad", dx0, xb, pitch, 0, self.R, 1, T, B, ptr(self.gpack, self.gp_bias_off["causal_layer.bias"]), st)
+        self.mark("causal_bwd")
         call("wn_reduce_slabs", ptr(desc), bw["slab_nops"], bw["slab_vec"], ptr(bw["slab"]), ptr(self.gpack), st)
         call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
-        self.mark("causal_bwd")
+        self.mark("slab_reduce")
 
     def backward(self, ws, dprobs):
         """dprobs: (B*W, Q) gradient w.r.t. the probabilities returned by forward()."""
