@@ -546,21 +546,22 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     };
 
     {
-        RawRows rr;
-        Ops ops;
+        RawRows rr, rr2;                                    // raw rows of items it / it+1: requested two items ahead
+        Ops ops;                                            // (one item ahead: 1.968 vs 1.941 ms for the stack)
         load_rows(rr, pos_k(0));
+        load_rows(rr2, pos_k(1));
         convert(ops, rr, pos_k(-1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
         __syncthreads();
         // iteration it: products of item it-1 (result tiles of stage (it-1)&1, operands in `ops`); then the raw rows of
-        // item it become `ops` and the rows of item it+1 are requested
-        auto w_body = [&](const int it) {
+        // item it become `ops` and the rows of item it+2 are requested (loop unrolled by two: no register copies)
+        auto w_body = [&](const int it, RawRows& rr) {
             PQ_TICK(k0);
             PQ_TICK(k1);
             products((it + 1) & 1, ops, pos_k(it - 1));
             PQ_TICK(k2);
 #ifndef PQ_T_NOCONV
             convert(ops, rr, pos_k(it));
-            load_rows(rr, pos_k(it + 1));
+            load_rows(rr, pos_k(it + 2));
 #endif
             PQ_TICK(k3);
             __syncthreads();
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             PQ_ACC(4, k1 - k0); PQ_ACC(8, k3 - k2); PQ_ACC(9, k4 - k3);
         };
         const int n_even = (n_items + 1) & ~1;
-        for (int it = 0; it < n_even; ++it) w_body(it);
+        for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, rr2); }
         products((n_even - 1) & 1, ops, pos_k(n_even - 1)); // the last item (a void one if the count was padded)
         __syncthreads();
         PQ_FLUSH(4, 6);
