@@ -132,8 +132,10 @@ int wn_resblock_bwd_ms(const float* x_in, const float* dy, const float* dz, floa
 int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch);
 
 /* The whole backward of one residual block in ONE launch, data gradient of the dilated convs included (64 padded
- * channels, modes (f16x3, bf16x3), no biases, no conditioning table): what wn_resblock_bwd_ms + the wn_chan_gemm launch
- * on its dfg compute, without [df;dg] ever reaching HBM.  The data gradient travels between blocks as an UNSHIFTED pair:
+ * channels, modes (f16x3, bf16x3), no biases): what wn_resblock_bwd_ms + the wn_chan_gemm launch on its dfg compute,
+ * without [df;dg] ever reaching HBM (unless asked for: dfg != NULL writes it as wn_resblock_bwd_ms does - the
+ * autoencoder's conditioned decoder blocks need it for wn_cond_grad; cond* = the conditioning table of wn_resblock_fwd,
+ * NULL = none).  The data gradient travels between blocks as an UNSHIFTED pair:
  *   in : dx_{i+1}[t] = p_in[t] (t >= p_lo) + q_in[t + dn]   (the pair the block above wrote; dn = ITS dilation, p_lo =
  *        ITS t_lo; both NULL for the last block: no dz product, no dWd);
  *   out: p_out[t] = W1^T [df;dg][t] + dx_{i+1}[t],  q_out[t] = W0^T [df;dg][t]  on [t_lo, t_hi), so that
@@ -144,7 +146,9 @@ int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch);
 int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, int dn, int p_lo, const float* dz,
                        float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
                        const uint16_t* wdT, const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, int z_lo,
-                       float* slab_fg, float* slab_d, int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
+                       float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode,
+                       int cond_le, int cond_q, float* dfg, int64_t dfg_bstride, int batch, int mode_fwd, int mode_bwd,
+                       wn_stream_t stream);
 /* out[b][r][t] = p[b][r][t] (t >= p_lo) + q[b][r][t+dn] (t+dn < t_hi), t in [t_lo,t_hi) */
 int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,
                  int t_lo, int t_hi, int batch, wn_stream_t stream);

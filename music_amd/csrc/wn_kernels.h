@@ -97,6 +97,9 @@ struct WnResPqArgs {
     int d, t_lo, t_hi, z_lo, t_base;
     int steps_per_clip, items_per_wg, batch;               // set by the launcher
     int swz;
+    const float* cond; long cond_bstride; int cond_pitch;  // conditioning table as in WnResArgs (null: none)
+    int cond_mode, cond_le, cond_q;
+    float* dfg; long dfg_bstride;                          // optional: [df;dg] written out as well ([B][2CH][pitch]); null: not
 };
 int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st);
 int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride, int pitch, int rows, int dn,

@@ -1,6 +1,8 @@
 // Backward of one gated residual block in ONE launch, data gradient included (CH = 64, recompute in F16x3,
-// gradient products in BF16x3; no biases, no conditioning table: those configurations keep
-// resblock_bwd_rw_k + chan_gemm_rw_k).
+// gradient products in BF16x3; no biases: biased blocks keep resblock_bwd_rw_k + chan_gemm_rw_k).  The autoencoder's
+// conditioned decoder blocks run it too: the conditioning table is added in the recompute as in the forward, and since
+// its gradient is a bucket sum over [df;dg] (wn_cond_grad) the R waves then ALSO write [df;dg] out (dfg != NULL) -
+// 2 more tensors of stores, still one launch less and no [df;dg] re-read by a data-gradient product.
 //
 // What resblock_bwd_rw_k (wn_resrw.hip) leaves to a second launch is the data gradient of the dilated convs,
 //     dx_i[t] = W1^T [df;dg][t] + W0^T [df;dg][t + d] + dx_{i+1}[t],
@@ -91,7 +93,9 @@ __device__ __forceinline__ void pq_store_frag(uint16_t* base, int idx, int lane,
     p[64] = __builtin_bit_cast(u32x4, f.lo);
 }
 
-template <bool HAS_DY>
+// COND: the conditioned form (conditioning table in the recompute, [df;dg] also written out); compiled apart so that the
+// plain form keeps its register budget (240, no spills; the conditioned one spills 14)
+template <bool HAS_DY, bool COND>
 __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     constexpr int CH = PQ_CH;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -375,6 +379,24 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 }
             }
 #endif
+            if (COND && a.cond) {       // same conditioning bias as the forward (wavenet_autoencoder/model1.py:183)
+                const float* cb = a.cond + (size_t)p_cur.b * a.cond_bstride;
+                int idx[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    int tr = tl + n - a.t_lo;
+                    tr = tr < 0 ? 0 : tr;
+                    const int ix = a.cond_mode == 1 ? tr / a.cond_q : tr % a.cond_le;
+                    idx[n] = ix < a.cond_le ? ix : a.cond_le - 1;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* rf = cb + (size_t)(16 * g + 4 * q + i) * a.cond_pitch;
+                    const float* rg = cb + (size_t)(CH + 16 * g + 4 * q + i) * a.cond_pitch;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) { af[n][i] += rf[idx[n]]; ag[n][i] += rg[idx[n]]; }
+                }
+            }
             PQ_TICK(k2);
             uint16_t* tt = st + PQ_T;
             const bool ok0 = live && tl >= a.t_lo && tl < a.t_hi, ok1 = live && tl + 1 >= a.t_lo && tl + 1 < a.t_hi;
@@ -400,6 +422,17 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                     vz[n] = ok ? th * sg : 0.f;
                     vf[n] = ok ? gz * sg * (1.0f - th * th) : 0.f;
                     vg[n] = ok ? gz * th * sg * (1.0f - sg) : 0.f;
+                }
+                if (COND && a.dfg != nullptr) {      // conditioned blocks: [df;dg] is also wanted in HBM (wn_cond_grad sums it by bucket)
+                    float* pf = a.dfg + (size_t)p_cur.b * a.dfg_bstride + (size_t)(16 * g + 4 * q + i) * a.pitch + tl;
+                    float* pg = pf + (size_t)CH * a.pitch;
+                    if (ok0 && ok1) {
+                        *reinterpret_cast<PqF2U*>(pf) = PqF2U{{vf[0], vf[1]}};
+                        *reinterpret_cast<PqF2U*>(pg) = PqF2U{{vg[0], vg[1]}};
+                    } else {
+                        if (ok0) { pf[0] = vf[0]; pg[0] = vg[0]; }
+                        if (ok1) { pf[1] = vf[1]; pg[1] = vg[1]; }
+                    }
                 }
                 // 16-bit hi/lo pairs of (sample 2c, sample 2c+1) -> one dword each in the [channel][time] tiles
                 auto put = [&](int kind, const float* v) {
@@ -606,14 +639,21 @@ int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((done >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         done |= 1ull << dev;
     }
-    if (k.p_in && k.q_in) hipLaunchKernelGGL(resblock_bwd_pq_k<true>, dim3(nwg), dim3(PQ_THREADS), sh, st, k);
-    else hipLaunchKernelGGL(resblock_bwd_pq_k<false>, dim3(nwg), dim3(PQ_THREADS), sh, st, k);
+    const bool has_dy = k.p_in && k.q_in, cnd = k.cond != nullptr || k.dfg != nullptr;
+    if (has_dy && cnd) hipLaunchKernelGGL((resblock_bwd_pq_k<true, true>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
+    else if (has_dy) hipLaunchKernelGGL((resblock_bwd_pq_k<true, false>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
+    else if (cnd) hipLaunchKernelGGL((resblock_bwd_pq_k<false, true>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
+    else hipLaunchKernelGGL((resblock_bwd_pq_k<false, false>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
     WN_CHECK_LAUNCH();
     return 0;
 }

@@ -130,6 +130,9 @@ class _AutoencoderEngine:
                 wx[:Rd, 2 * CHd + h * CHd:2 * CHd + h * CHd + Dd] = wfg[rows, :, 0].T
             add("de_fg%d" % i, w)
             bwd.append(("de_fgT%d" % i, pack_index(wx)))
+            wq = full(2 * CHd, 2 * CHd)                 # [W1^T; W0^T] over (df | dg): the one-launch backward block
+            wq[:CHd], wq[CHd:] = wx[:, :2 * CHd], wx[:, 2 * CHd:]
+            bwd.append(("de_pq%d" % i, pack_index(wq)))
             w = full(CHd, CHd)
             w[:Rd, :Dd] = sp.conv("de_dilation_layer_stack.%d.weight" % (3 * i + 1))[:, :, 0]
             add("de_d%d" % i, w, chained=True)
@@ -316,6 +319,10 @@ class _AutoencoderEngine:
         ms = (self.CHd == 64 and self.mode == _lib.F16X3 and self.mode_b == _lib.BF16X3
               and os.environ.get("WN_MS_BWD", "1") == "1")
         bw["ms"] = ms
+        # ... and the data gradient inside the same launch, as the (P, Q) pair (wn_resblock_bwd_pq), without biases
+        bw["pq"] = ms and not self.use_bias and os.environ.get("WN_PQ_BWD", "1") == "1"
+        if bw["pq"]:
+            bw["PQ"] = [(buf(self.CHd), buf(self.CHd)), (buf(self.CHd), buf(self.CHd))]
         # encoder blocks: wn_enc_resblock_bwd (dh + both weight gradients in one launch) where it applies
         enc_fused = (self.CHe == 64 and self.mode_b == _lib.BF16X3 and os.environ.get("WN_AE_FUSED_ENC_BWD", "1") == "1")
         bw["enc_fused"] = enc_fused
@@ -451,6 +458,23 @@ class _AutoencoderEngine:
                 bias_grad(nm, dfg, 2 * CHd * pitch, pitch, 0, Dd, t_lo, T, dst=Dd)                    # filter rows = df
                 if dy is not None:
                     bias_grad("de_dilation_layer_stack.%d" % (3 * i + 1), dy, db, pitch, 0, Rd, t_lo, T)
+            if bw["pq"]:
+                p_out, q_out = (ptr(t, SLACK) for t in bw["PQ"][i % 2])
+                if i < N - 1:
+                    p_in, q_in = (ptr(t, SLACK) for t in bw["PQ"][(i + 1) % 2])
+                    dn, p_lo = self.dil[i + 1], self.off[i + 2]
+                else:
+                    p_in = q_in = None
+                    dn = p_lo = 0
+                call("wn_resblock_bwd_pq", xd(i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CHd * pitch), p_out, q_out,
+                     db, zb, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), br("de_pq%d" % i), CHd, d, t_lo, T, lo,
+                     ptr(bw["slab"], plan["de_fg%d" % i][0]), ptr(bw["slab"], plan["de_d%d" % i][0]) if i < N - 1 else None,
+                     ptr(ws["tab"][i]), 2 * CHd * Le, Le, mode_c, Le, max(q, 1), dfg, 2 * CHd * pitch, B, mf, mb, st)
+                call("wn_cond_grad", dfg, 2 * CHd * pitch, pitch, 2 * CHd, t_lo, T, mode_c, Le, max(q, 1),
+                     ptr(d_tab[i]), 2 * CHd * Le, Le, B, st)
+                if i == 0:
+                    call("wn_shift_add", p_out, q_out, ptr(bw["dXd"][0], SLACK), db, pitch, CHd, d, t_lo, self.off[0], T, B, st)
+                continue
             if bw["ms"]:
                 call("wn_resblock_bwd_ms", xd(i), dy, ptr(bw["dZ"], SLACK + i * CHd * pitch), dfg, db, zb, 2 * CHd * pitch, pitch,
                      fr("de_fg%d" % i), br("de_dT%d" % i), bf, bias_fg, Dd, CHd, d, t_lo, T, lo,
