@@ -4,9 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
 
 One process per GPU (torch.distributed, backend nccl = RCCL); weak scaling, 8 clips x 16000 samples
-per GPU.  One "step" = on-device one-hot build + forward + CrossEntropy-on-probabilities +
-backward + gradient all-reduce (N > 1) + Adam, i.e. wavenet/train.py:171-182 of the reference, with
-the int32 sample codes already resident in HBM.  Prints ONE JSON line on rank 0.
+per GPU.  One "step" = H2D of the int32 codes + int64 targets (prefetched) + forward on the loader-layout one-hot of
+those codes (not materialised: gather / scatter in the causal layer) + CrossEntropy-on-probabilities + backward +
+gradient all-reduce (N > 1) + Adam, i.e. wavenet/train.py:171-182 of the reference.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -336,8 +336,9 @@ def main():
         eng.mark("step_begin")
         main.wait_event(ready)
         eng.mark("h2d_wait")
-        x = eng.onehot(piece, scrambled=True)
-        loss = eng.loss_and_grad(x, target)
+        # the loader-faithful (scrambled) one-hot of these codes is what the model sees; it is never
+        # materialised: the causal layer runs as a gather / scatter on the codes (engine.loss_and_grad_codes)
+        loss = eng.loss_and_grad_codes(piece, target, scrambled=True)
         free.record(main)
         if use_dist:
             dist.all_reduce(eng.flat_grad)          # ONE flat fp32 bucket (5.08 MB), RCCL over xGMI
@@ -417,8 +418,7 @@ def main():
         torch.cuda.synchronize()
         piece, target = bufs[0][0], bufs[0][1]
         for _ in range(3):
-            x = eng.onehot(piece, scrambled=True)
-            eng.loss_and_grad(x, target)
+            eng.loss_and_grad_codes(piece, target, scrambled=True)
         torch.cuda.synchronize()
         m2, eng.marks, eng.fine_marks = eng.marks, None, False
         tot, cnt = {}, {}
@@ -466,7 +466,7 @@ def main():
         "data": "synthetic",
         "rccl_ranks": world if use_dist else 0, "backend": (dist.get_backend() if use_dist else "none"),
         "config": {"workload": "BASELINE configs[1]: 30-layer (3x dilations 1..512) WaveNet, 64 res/dil, 256 skip, "
-                               "batch 8x16000 per GPU, full train step (H2D of codes and targets, prefetched one step ahead on a copy stream, + one-hot + fwd + CE + bwd + all-reduce + Adam)",
+                               "batch 8x16000 per GPU, full train step (H2D of codes and targets, prefetched one step ahead on a copy stream, + fwd on the loader-layout one-hot of the codes (never materialised) + CE + bwd + all-reduce + Adam)",
                    "global_batch": world * B_LOCAL, "seq_len": T, "parallelism": "dp%d" % world,
                    "precision": args.precision, "final_loss": float(loss.item())},
         # the time-dominant kernels: one residual block's backward (SURVEY 8d A_b per block; duration = the HIP-event

@@ -182,6 +182,12 @@ int wn_resblock_wgrad(const float* dfg, const float* x_in, const float* dy, cons
 int wn_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, int64_t dx_bstride, int pitch, int ch, int q,
                           int t, int batch, float* slab, wn_stream_t stream);
 int wn_causal_wgrad_codes_slabs(int t, int batch);
+/* Forward of the causal layer (wavenet/model.py:104) from the same codes, without the one-hot tensor:
+ * x0[b][r][s] = bias[r] + sum over the ones (q, s-1) of W[r][q][0] + sum over the ones (q, s) of W[r][q][1], s in [1, t).
+ * wt = the layer's weight re-laid as [tap][q][ch] floats (ch contiguous, zero-padded to ch); n_rows = real channel count;
+ * bias may be NULL.  Sums of exact fp32 weights in a fixed order (bit-reproducible). */
+int wn_causal_fwd_codes(const int32_t* codes, int scrambled, const float* wt, const float* bias, int n_rows, float* x0,
+                        int64_t x_bstride, int pitch, int ch, int q, int t, int batch, wn_stream_t stream);
 /* desc[op] = {vec_start, slab_off, n_slabs, stride, out_off, n} (int64, device memory):
  * out[out_off+e] = sum_s slab[slab_off + s*stride + e] for e < n; work item v covers 4 floats and
  * belongs to the op with vec_start <= v. */

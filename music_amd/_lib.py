@@ -50,6 +50,7 @@ SIGNATURES = {
     "wn_resblock_wgrad": [_p, _p, _p, _p, _l, _l, _l, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p],
     "wn_causal_wgrad_codes": [_p, _i, _p, _l, _i, _i, _i, _i, _i, _p, _p],
     "wn_causal_wgrad_codes_slabs": [_i, _i],
+    "wn_causal_fwd_codes": [_p, _i, _p, _p, _i, _p, _l, _i, _i, _i, _i, _i, _p],
     "wn_reduce_slabs": [_p, _i, _l, _p, _p, _p],
     "wn_bias_grad": [_p, _l, _i, _i, _i, _i, _i, _i, _p, _p],
     "wn_chunk_softmax256_fwd": [_p, _p, _l, _p],

@@ -256,6 +256,12 @@ int wn_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, 
     return wn_launch_causal_wgrad_codes(codes, scrambled, dx, dx_bstride, pitch, ch, t, batch, slab, (hipStream_t)stream);
 }
 int wn_causal_wgrad_codes_slabs(int t, int batch) { return wn_causal_codes_slabs(t, batch); }
+int wn_causal_fwd_codes(const int32_t* codes, int scrambled, const float* wt, const float* bias, int n_rows, float* x0,
+                        int64_t x_bstride, int pitch, int ch, int q, int t, int batch, wn_stream_t stream) {
+    if (q != 256) return wn_set_error_msg(-4, "wn_causal_fwd_codes: 256 quantisation channels only");
+    if (!codes || !wt || !x0) return wn_set_error_msg(-4, "wn_causal_fwd_codes: null argument");
+    return wn_launch_causal_fwd_codes(codes, scrambled, wt, bias, n_rows, x0, x_bstride, pitch, ch, t, batch, (hipStream_t)stream);
+}
 
 int wn_cond_grad(const float* in, int64_t in_bstride, int in_pitch, int rows, int t_lo, int t_hi, int mode, int le,
                  int q, float* out, int64_t out_bstride, int out_pitch, int batch, wn_stream_t stream) {

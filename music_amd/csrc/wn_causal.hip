@@ -151,3 +151,88 @@ int wn_launch_causal_wgrad_codes(const int32_t* codes, int scrambled, const floa
     WN_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward of the causal layer from the same codes:  x0[r][t] = bias[r] + sum_{ones (q, t-1)} W[r][q][0] + sum_{ones (q, t)}
+// W[r][q][1],  t in [1, T) - a GATHER of weight columns instead of a (R x 2Q) x (2Q x T) product over a 131 MB tensor of
+// zeros and ones (which then need not exist at all).  wt = the weight as [tap][q][ch] (ch contiguous, padded to CH).
+// One workgroup per tile of 64 output columns; the ones of input columns t0-1 .. t0+63 are listed as in the backward;
+// output column j of the tile is owned by wave j % 8, which adds its contributions in slot order, tap 1 before tap 0 of
+// the same slot: deterministic.  Sums of exact fp32 weights: closer to the reference's fp32 conv than the split product.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(CW_THREADS) void causal_fwd_codes_k(const int32_t* __restrict__ codes, int scrambled,
+                                                                 const float* __restrict__ wt, const float* __restrict__ bias,
+                                                                 int n_rows, float* __restrict__ x0, long x_bstride, int pitch, int T) {
+    __shared__ float tile[CH * (CW_TC + 1)];
+    __shared__ int list[2 * CW_Q];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, t0 = blockIdx.x * CW_TC;              // output columns t0 .. t0 + 63
+    const int32_t* cb = codes + (size_t)b * T;
+    const int c_lo = t0 > 0 ? t0 - 1 : 0;                           // first input column of interest
+    int c_hi = t0 + CW_TC;                                          // one past the last
+    if (c_hi > T) c_hi = T;
+    for (int i = tid; i < CH * (CW_TC + 1); i += CW_THREADS) {
+        const int r = i / (CW_TC + 1);
+        tile[i] = (bias != nullptr && r < n_rows) ? bias[r] : 0.f;
+    }
+    // entries (q << 8 | j), j = input column - (t0 - 1) in [0, 64]
+    if (scrambled) {
+        if (tid < CW_Q) {
+            const long rowbase = (long)tid * T;
+            const long F = rowbase + c_lo, hi = rowbase + c_hi;
+            int e0 = -1, e1 = -1;
+            if (hi > F) {
+                const long s0 = F >> 8, s1 = (hi - 1) >> 8;
+                const int k0 = cb[s0], k1 = cb[s1];
+                const long f0 = (s0 << 8) + k0, f1 = (s1 << 8) + k1;
+                if (k0 >= 0 && k0 < CW_Q && f0 >= F && f0 < hi) e0 = (tid << 8) | (int)(f0 - rowbase - (t0 - 1));
+                if (s1 != s0 && k1 >= 0 && k1 < CW_Q && f1 >= F && f1 < hi) e1 = (tid << 8) | (int)(f1 - rowbase - (t0 - 1));
+            }
+            list[2 * tid] = e0;
+            list[2 * tid + 1] = e1;
+        }
+    } else {
+        int e = -1;
+        const int col = t0 - 1 + tid;
+        if (tid <= CW_TC && col >= 0 && col < T) {
+            const int k = cb[col];
+            if (k >= 0 && k < CW_Q) e = (k << 8) | tid;
+        }
+        list[tid] = e;
+    }
+    __syncthreads();
+    for (int base = 0; base < 2 * CW_Q; base += 64) {
+        const int e = list[base + lane];
+        const int j = e & 255;
+        // tap 1 lands on tile column j - 1, tap 0 on tile column j
+        unsigned long long m = __ballot(e >= 0 && ((j >= 1 && ((j - 1) & 7) == wv) || (j < CW_TC && (j & 7) == wv)));
+        while (m) {
+            const int src_lane = __builtin_ctzll(m);
+            m &= m - 1;
+            const int ee = __builtin_amdgcn_readlane(e, src_lane);
+            const int q = ee >> 8, jj = ee & 255;
+            if (lane < CH) {
+                if (jj >= 1 && ((jj - 1) & 7) == wv) tile[lane * (CW_TC + 1) + jj - 1] += wt[(size_t)(CW_Q + q) * CH + lane];
+                if (jj < CW_TC && (jj & 7) == wv) tile[lane * (CW_TC + 1) + jj] += wt[(size_t)q * CH + lane];
+            }
+        }
+    }
+    __syncthreads();
+    float* out = x0 + (size_t)b * x_bstride;
+    for (int i = tid; i < CH * CW_TC; i += CW_THREADS) {
+        const int r = i >> 6, jo = i & 63, t = t0 + jo;
+        if (t >= 1 && t < T && r < n_rows) out[(size_t)r * pitch + t] = tile[r * (CW_TC + 1) + jo];
+    }
+}
+
+int wn_launch_causal_fwd_codes(const int32_t* codes, int scrambled, const float* wt, const float* bias, int n_rows, float* x0,
+                               long x_bstride, int pitch, int ch, int T, int batch, hipStream_t st) {
+    if (T <= 1 || batch <= 0) return 0;
+    if (ch != 32 && ch != 64) return wn_set_error_msg(-3, "causal_fwd_codes: padded channel count must be 32 or 64");
+    dim3 g((T + CW_TC - 1) / CW_TC, batch);
+    if (ch == 32) hipLaunchKernelGGL(causal_fwd_codes_k<32>, g, dim3(CW_THREADS), 0, st, codes, scrambled, wt, bias, n_rows, x0, x_bstride, pitch, T);
+    else hipLaunchKernelGGL(causal_fwd_codes_k<64>, g, dim3(CW_THREADS), 0, st, codes, scrambled, wt, bias, n_rows, x0, x_bstride, pitch, T);
+    WN_CHECK_LAUNCH();
+    return 0;
+}

@@ -128,6 +128,8 @@ int wn_launch_reduce_slabs(const long* desc, int n_ops, long total_vec, const fl
 int wn_launch_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, long dx_bstride, int pitch, int ch,
                                  int T, int batch, float* slab, hipStream_t st);
 int wn_causal_codes_slabs(int T, int batch);
+int wn_launch_causal_fwd_codes(const int32_t* codes, int scrambled, const float* wt, const float* bias, int n_rows, float* x0,
+                               long x_bstride, int pitch, int ch, int T, int batch, hipStream_t st);
 
 int wn_launch_softmax_fwd(const float* x, float* y, long nrows, hipStream_t st);
 int wn_launch_softmax_bwd(const float* y, const float* dy, float* dx, long nrows, hipStream_t st);

@@ -284,6 +284,12 @@ class WaveNetEngine:
             put(name, bo + np.arange(self.spec.shape[name][0]))
         assert (gidx >= 0).all()
         self.gidx = torch.from_numpy(gidx.astype(np.int32)).to(dev)
+        # causal weight re-laid as [tap][q][ch] for the forward from codes (wn_causal_fwd_codes): a gather map over the
+        # flat parameter buffer (-1 = padded channel, reads as 0)
+        wt = np.full((2, Q, CH), -1, dtype=np.int64)
+        wt[:, :, :R] = wc.transpose(2, 1, 0)
+        self.wt_idx = torch.from_numpy(wt.reshape(-1).astype(np.int32)).to(dev)
+        self.wt = torch.zeros(2 * Q * CH, dtype=torch.float32, device=dev)
 
     def pack_weights(self):
         st = _lib.stream()
@@ -387,11 +393,17 @@ class WaveNetEngine:
         return ptr(ws["X"], SLACK + i * ws["B"] * self.CH * ws["pitch"])
 
     # ------------------------------------------------------------------ forward
-    def forward_logits(self, x, ws=None):
+    def forward_logits(self, x, ws=None, codes=None):
         """x: (B,Q,T) float32 contiguous on the device.  Runs causal conv, the residual stack, the
-        skip product and both post-process convs; leaves the pre-softmax (B,Q,W) in ws['O']."""
-        B, Q, T = x.shape
-        assert Q == self.Q and x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda
+        skip product and both post-process convs; leaves the pre-softmax (B,Q,W) in ws['O'].
+        codes = (int32 (B,T) device tensor, scrambled) instead of x: the one-hot is never built."""
+        if x is None:
+            B, T = codes[0].shape
+            Q = self.Q
+            assert codes[0].is_cuda and codes[0].dtype == torch.int32 and codes[0].is_contiguous()
+        else:
+            B, Q, T = x.shape
+            assert Q == self.Q and x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda
         W = T - self.rf + 1
         if W <= 0:
             raise ValueError("wave sample not long enough")          # wavenet/model.py:100-101
@@ -406,17 +418,24 @@ class WaveNetEngine:
         # a one-hot built from integer codes by onehot() / the loader carries them along: the backward then forms the
         # causal layer's weight gradient by scatter instead of streaming the dense tensor (still valid only while the
         # tensor has not been written to since)
-        tag = getattr(x, "_wn_codes", None)
-        ws["x_codes"] = None
+        tag = getattr(x, "_wn_codes", None) if x is not None else None
+        ws["x_codes"] = (codes[0], bool(codes[1])) if x is None else None
         if tag is not None and os.environ.get("WN_CAUSAL_CODES", "1") == "1":
             codes, scrambled, version = tag
             if (x._version == version and codes.is_cuda and codes.dtype == torch.int32 and codes.is_contiguous() and
                     tuple(codes.shape) == (B, T)):
                 ws["x_codes"] = (codes, scrambled)
         # causal conv (wavenet/model.py:104): x0[t] = W0 in[t-1] + W1 in[t], t in [1,T)
-        call("wn_chan_gemm", ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, fr("causal"), CH // 16, self.R,
-             self._x(ws, 0), xb, pitch, 0, self._bias_ptr("causal_layer.bias"),
-             None, 0, 0, 0, None, 0, 0, 1, T, 0, B, mf, st)
+        if ws["x_codes"] is not None:
+            # the input is the one-hot of known codes: a gather of weight columns (the dense tensor is not read)
+            codes, scrambled = ws["x_codes"]
+            call("wn_gather_grads", ptr(self.flat), ptr(self.wt_idx), ptr(self.wt), self.wt.numel(), st)
+            call("wn_causal_fwd_codes", ptr(codes), 1 if scrambled else 0, ptr(self.wt), self._bias_ptr("causal_layer.bias"),
+                 self.R, self._x(ws, 0), xb, pitch, CH, Q, T, B, st)
+        else:
+            call("wn_chan_gemm", ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, fr("causal"), CH // 16, self.R,
+                 self._x(ws, 0), xb, pitch, 0, self._bias_ptr("causal_layer.bias"),
+                 None, 0, 0, 0, None, 0, 0, 1, T, 0, B, mf, st)
         zb = N * CH * pitch
         self.mark("causal_fwd")
         # z: the skip product needs it on the crop [rf-1, T) only, and the two-role / one-launch backward blocks recompute
@@ -654,13 +673,20 @@ class WaveNetEngine:
         self.backward_from_dlogits(ws)
 
     # ------------------------------------------------------------------ fused training step
-    def loss_and_grad(self, x, target, want_probs=False):
+    def loss_and_grad_codes(self, codes, target, scrambled=True, want_probs=False):
+        """loss_and_grad on the integer codes themselves (int32 (B,T) on the device; `scrambled` = the loader's one-hot
+        layout, faster_audio_data.py:77-81): same result as loss_and_grad(self.onehot(codes, scrambled), target), but the
+        (B,256,T) float tensor is never built, written or read - the causal layer is a gather forward and
+        a scatter backward."""
+        return self.loss_and_grad(None, target, want_probs, codes=(codes, scrambled))
+
+    def loss_and_grad(self, x, target, want_probs=False, codes=None):
         """forward + CrossEntropyLoss(probs, target) + backward (wavenet/train.py:178-181).
         Returns the loss as a 0-d device tensor; gradients land in self.flat_grad."""
         self.mark("begin")
         self.pack_weights()
         self.mark("pack")
-        ws = self.forward_logits(x)
+        ws = self.forward_logits(x, codes=codes)
         bw = self._bwd_workspace(ws)
         B, W = ws["B"], ws["W"]
         n = B * W

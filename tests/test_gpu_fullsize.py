@@ -112,8 +112,9 @@ def test_c2_full_length_loss_and_gradients_vs_oracle():
     assert torch.equal(g1, eng.flat_grad)
     # partition independence: batch gradient == mean of the single-clip gradients (other item / slab / XCD partitions)
     acc = torch.zeros_like(g1)
-    for b in range(B):
-        eng.loss_and_grad(xd[b:b + 1].contiguous(), target.view(B, W)[b].contiguous().cuda())
+    cdev = torch.from_numpy(codes.astype(np.int32)).cuda()
+    for b in range(B):             # (through the codes, as the batch above: the tagged one-hot takes the code-aware causal layer)
+        eng.loss_and_grad_codes(cdev[b:b + 1].contiguous(), target.view(B, W)[b].contiguous().cuda(), scrambled=True)
         acc += eng.flat_grad
     acc /= B
     for n in eng.param_names:
@@ -314,7 +315,8 @@ def test_shipped_config_shipped_batch_window_vs_oracle():
         assert p.shape == (B * W, 256) and torch.isfinite(p).all()
         assert (p.sum(1) - 1).abs().max().item() < 1e-5 and p.min().item() >= 0
         assert torch.equal(p, net(x))
-        assert torch.equal(net(x[1:3].contiguous()), p[W:3 * W])
+        assert torch.equal(net(eng.onehot(codes[1:3].contiguous(), scrambled=True)), p[W:3 * W])   # same code-aware path
+        assert (net(x[1:3].contiguous()) - p[W:3 * W]).abs().max().item() < 2 * LOGIT_TOL          # the dense path (each within 1e-3 of the oracle)
         xs = x[2:3, :, 20000:20000 + rf + 699].contiguous()
         got = net(xs).cpu()
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}

@@ -520,3 +520,31 @@ def test_causal_wgrad_from_codes_equals_dense_product(scrambled, ch, T, B):
     slab2 = torch.empty_like(slab)
     call("wn_causal_wgrad_codes", ptr(cd), 1 if scrambled else 0, ptr(dxd), ch * pitch, pitch, ch, 256, T, B, ptr(slab2), _lib.stream())
     assert torch.equal(slab, slab2)                           # bit-reproducible
+
+
+@pytest.mark.parametrize("scrambled", [True, False], ids=["scrambled", "proper"])
+@pytest.mark.parametrize("ch,R,T,B,bias", [(64, 64, 1000, 3, False), (32, 20, 517, 2, True), (64, 48, 16000, 2, True)])
+def test_causal_forward_from_codes_equals_conv(scrambled, ch, R, T, B, bias):
+    """wn_causal_fwd_codes (gather of weight columns selected by the codes) against F.conv1d in float64 on the dense
+    one-hot the same codes give: x0 on [1, T), both layouts, runs of one class, padded channels, bias."""
+    from oracle import intops
+    rng = np.random.default_rng(T + R)
+    codes = rng.integers(0, 256, size=(B, T)).astype(np.int32)
+    codes[0, : T // 3] = 128
+    codes[-1, -5:] = [0, 255, 255, 0, 7]
+    fn = intops.one_hot_scrambled if scrambled else intops.one_hot_proper
+    dense = torch.from_numpy(np.stack([fn(r) for r in codes])).double()
+    w = torch.from_numpy(rng.standard_normal((R, 256, 2)).astype(np.float32))
+    bvec = torch.from_numpy(rng.standard_normal(R).astype(np.float32)) if bias else None
+    want = F.conv1d(dense, w.double(), bvec.double() if bias else None)              # (B, R, T-1): column j = time j+1
+    wt = torch.zeros(2, 256, ch)
+    wt[:, :, :R] = w.permute(2, 1, 0)
+    pitch = ((T + 255) // 256) * 256 + 512
+    x0 = torch.full((B, ch, pitch), 7.0, device=DEV)                                 # canary outside [1, T) x real rows
+    cd, wtd, bd = torch.from_numpy(codes).to(DEV), wt.to(DEV), (bvec.to(DEV) if bias else None)     # (kept alive past the call)
+    call("wn_causal_fwd_codes", ptr(cd), 1 if scrambled else 0, ptr(wtd), ptr(bd), R, ptr(x0), ch * pitch, pitch, ch, 256, T, B,
+         _lib.stream())
+    got = x0.cpu()
+    err = (got[:, :R, 1:T].double() - want).abs().max().item()
+    assert err < 1e-5, err
+    assert (got[:, :, 0] == 7.0).all() and (got[:, :, T:] == 7.0).all() and (got[:, R:] == 7.0).all()
