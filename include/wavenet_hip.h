@@ -178,9 +178,10 @@ int wn_resblock_wgrad(const float* dfg, const float* x_in, const float* dy, cons
  * in[b][q][s-1+tap] becomes a scatter of dx columns - dx (ch rows) is read once, the 4*q*t bytes per clip of dense
  * one-hot are not read at all.  Writes wn_causal_wgrad_codes_slabs(t, batch) slabs [ch][2q] (columns = tap 0 rows |
  * tap 1 rows, the layout wn_wgrad gives the same product); sum them with wn_reduce_slabs.  Bit-reproducible.
+ * dx_q != NULL: the data gradient comes as the unshifted pair wn_resblock_bwd_pq writes, dx[s] (s >= p_lo) + dx_q[s + dn].
  * Arbitrary float inputs (faster_audio_data.py hands the model a dense tensor) keep using wn_wgrad. */
-int wn_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, int64_t dx_bstride, int pitch, int ch, int q,
-                          int t, int batch, float* slab, wn_stream_t stream);
+int wn_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, const float* dx_q, int dn, int p_lo,
+                          int64_t dx_bstride, int pitch, int ch, int q, int t, int batch, float* slab, wn_stream_t stream);
 int wn_causal_wgrad_codes_slabs(int t, int batch);
 /* Forward of the causal layer (wavenet/model.py:104) from the same codes, without the one-hot tensor:
  * x0[b][r][s] = bias[r] + sum over the ones (q, s-1) of W[r][q][0] + sum over the ones (q, s) of W[r][q][1], s in [1, t).

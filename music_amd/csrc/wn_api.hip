@@ -249,11 +249,11 @@ int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, in
     return wn_launch_shift_add(p, q, out, bstride, pitch, rows, dn, p_lo, t_lo, t_hi, batch, (hipStream_t)stream);
 }
 
-int wn_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, int64_t dx_bstride, int pitch, int ch, int q,
-                          int t, int batch, float* slab, wn_stream_t stream) {
+int wn_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, const float* dx_q, int dn, int p_lo,
+                          int64_t dx_bstride, int pitch, int ch, int q, int t, int batch, float* slab, wn_stream_t stream) {
     if (q != 256) return wn_set_error_msg(-4, "wn_causal_wgrad_codes: 256 quantisation channels only");
     if (!codes || !dx || !slab) return wn_set_error_msg(-4, "wn_causal_wgrad_codes: null argument");
-    return wn_launch_causal_wgrad_codes(codes, scrambled, dx, dx_bstride, pitch, ch, t, batch, slab, (hipStream_t)stream);
+    return wn_launch_causal_wgrad_codes(codes, scrambled, dx, dx_q, dn, p_lo, dx_bstride, pitch, ch, t, batch, slab, (hipStream_t)stream);
 }
 int wn_causal_wgrad_codes_slabs(int t, int batch) { return wn_causal_codes_slabs(t, batch); }
 int wn_causal_fwd_codes(const int32_t* codes, int scrambled, const float* wt, const float* bias, int n_rows, float* x0,

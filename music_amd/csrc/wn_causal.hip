@@ -28,7 +28,8 @@
 
 template <int CH>
 __global__ __launch_bounds__(CW_THREADS) void causal_wgrad_codes_k(const int32_t* __restrict__ codes, int scrambled,
-                                                                   const float* __restrict__ dx, long dx_bstride, int pitch,
+                                                                   const float* __restrict__ dx, const float* __restrict__ dxq,
+                                                                   int dn, int p_lo, long dx_bstride, int pitch,
                                                                    int T, int batch, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) float cw_lds[];
     float* acc = cw_lds;                                   // [2Q][CW_ACC_LD]
@@ -51,7 +52,15 @@ __global__ __launch_bounds__(CW_THREADS) void causal_wgrad_codes_k(const int32_t
         for (int k = 0; k < NV; ++k) {
             const int i = tid + k * CW_THREADS;
             const int r = i / (CW_TC + 1), j = i - r * (CW_TC + 1), t = t0 + j;
-            nxt[k] = (live && i < CH * (CW_TC + 1) && t >= 1 && t < T) ? src[(size_t)r * pitch + t] : 0.f;
+            const bool ok = live && i < CH * (CW_TC + 1) && t >= 1 && t < T;
+            if (dxq == nullptr) {
+                nxt[k] = ok ? src[(size_t)r * pitch + t] : 0.f;
+            } else {
+                // the first block handed its data gradient on as the unshifted pair: dx0[t] = P[t] (t >= p_lo) + Q[t + dn]
+                const float pv = (ok && t >= p_lo) ? src[(size_t)r * pitch + t] : 0.f;
+                const float qv = (ok && t + dn < T) ? dxq[(size_t)b * dx_bstride + (size_t)r * pitch + t + dn] : 0.f;
+                nxt[k] = pv + qv;
+            }
         }
     };
     // the ones of a tile, one list slot per possible position; also computed one tile ahead (the code look-ups are
@@ -130,8 +139,8 @@ int wn_causal_codes_slabs(int T, int batch) {
     return tiles < 256 ? tiles : 256;
 }
 
-int wn_launch_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, long dx_bstride, int pitch, int ch,
-                                 int T, int batch, float* slab, hipStream_t st) {
+int wn_launch_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, const float* dxq, int dn, int p_lo,
+                                 long dx_bstride, int pitch, int ch, int T, int batch, float* slab, hipStream_t st) {
     const int nwg = wn_causal_codes_slabs(T, batch);
     if (nwg <= 0) return 0;
     if (ch != 32 && ch != 64) return wn_set_error_msg(-3, "causal_wgrad_codes: padded channel count must be 32 or 64");
@@ -146,8 +155,8 @@ int wn_launch_causal_wgrad_codes(const int32_t* codes, int scrambled, const floa
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&causal_wgrad_codes_k<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max);
         done |= 1ull << dev;
     }
-    if (ch == 32) hipLaunchKernelGGL(causal_wgrad_codes_k<32>, dim3(nwg), dim3(CW_THREADS), sh, st, codes, scrambled, dx, dx_bstride, pitch, T, batch, slab);
-    else hipLaunchKernelGGL(causal_wgrad_codes_k<64>, dim3(nwg), dim3(CW_THREADS), sh, st, codes, scrambled, dx, dx_bstride, pitch, T, batch, slab);
+    if (ch == 32) hipLaunchKernelGGL(causal_wgrad_codes_k<32>, dim3(nwg), dim3(CW_THREADS), sh, st, codes, scrambled, dx, dxq, dn, p_lo, dx_bstride, pitch, T, batch, slab);
+    else hipLaunchKernelGGL(causal_wgrad_codes_k<64>, dim3(nwg), dim3(CW_THREADS), sh, st, codes, scrambled, dx, dxq, dn, p_lo, dx_bstride, pitch, T, batch, slab);
     WN_CHECK_LAUNCH();
     return 0;
 }

@@ -125,8 +125,8 @@ int wn_wgrad_num_slabs(int t_lo, int t_hi, int chunk, int batch);
 int wn_launch_reduce_slabs(const long* desc, int n_ops, long total_vec, const float* slab, float* out, hipStream_t st);
 
 // causal-layer weight gradient from integer codes (wn_causal.hip); one slab [ch][2*256] per workgroup
-int wn_launch_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, long dx_bstride, int pitch, int ch,
-                                 int T, int batch, float* slab, hipStream_t st);
+int wn_launch_causal_wgrad_codes(const int32_t* codes, int scrambled, const float* dx, const float* dxq, int dn, int p_lo,
+                                 long dx_bstride, int pitch, int ch, int T, int batch, float* slab, hipStream_t st);
 int wn_causal_codes_slabs(int T, int batch);
 int wn_launch_causal_fwd_codes(const int32_t* codes, int scrambled, const float* wt, const float* bias, int n_rows, float* x0,
                                long x_bstride, int pitch, int ch, int T, int batch, hipStream_t st);

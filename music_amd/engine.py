@@ -577,7 +577,8 @@ class WaveNetEngine:
                      None, 0, 0, 0, 0, 0, None, 0, B, mf, mb, st)
                 self.fmark("b_block")
                 if i == 0:
-                    # dx_0 for the causal layer: the pair made whole once
+                    # dx_0 for the causal layer: the pair made whole once (19 us; the scatter from codes can also take the
+                    # pair as it is - wn_causal_wgrad_codes(dx_q) - but its doubled, masked tile loads cost the same 20 us)
                     call("wn_shift_add", p_out, q_out, ptr(bw["dX"][0], SLACK), xb, pitch, CH, d, t_lo, self.off[0], T, B, st)
                 continue
             if bw["ms"]:
@@ -653,7 +654,7 @@ class WaveNetEngine:
         desc = bw["slab_desc"]
         if ws.get("x_codes") is not None:
             codes, scrambled = ws["x_codes"]
-            call("wn_causal_wgrad_codes", ptr(codes), 1 if scrambled else 0, dx0, xb, pitch, CH, Q, T, B,
+            call("wn_causal_wgrad_codes", ptr(codes), 1 if scrambled else 0, dx0, None, 0, 0, xb, pitch, CH, Q, T, B,
                  ptr(bw["slab"], plan["causal_codes"][0]), st)
             desc = bw["slab_desc_codes"]
         else:

@@ -512,14 +512,25 @@ def test_causal_wgrad_from_codes_equals_dense_product(scrambled, ch, T, B):
     ns = _lib.causal_codes_slabs(T, B)
     slab = torch.full((ns, ch, 512), float("nan"), device=DEV)
     cd, dxd = torch.from_numpy(codes).to(DEV), dx.to(DEV)
-    call("wn_causal_wgrad_codes", ptr(cd), 1 if scrambled else 0, ptr(dxd), ch * pitch, pitch, ch, 256, T, B, ptr(slab), _lib.stream())
+    call("wn_causal_wgrad_codes", ptr(cd), 1 if scrambled else 0, ptr(dxd), None, 0, 0, ch * pitch, pitch, ch, 256, T, B, ptr(slab), _lib.stream())
     got = slab.double().sum(0).cpu()
     assert torch.isfinite(got).all()
     err = (got - want).abs().max().item() / want.abs().max().item()
     assert err < 1e-5, err
     slab2 = torch.empty_like(slab)
-    call("wn_causal_wgrad_codes", ptr(cd), 1 if scrambled else 0, ptr(dxd), ch * pitch, pitch, ch, 256, T, B, ptr(slab2), _lib.stream())
+    call("wn_causal_wgrad_codes", ptr(cd), 1 if scrambled else 0, ptr(dxd), None, 0, 0, ch * pitch, pitch, ch, 256, T, B, ptr(slab2), _lib.stream())
     assert torch.equal(slab, slab2)                           # bit-reproducible
+    # the data gradient as an unshifted pair (what wn_resblock_bwd_pq hands on): dx[s] = P[s] (s >= p_lo) + Q[s + dn]
+    dn, p_lo = 3, 5
+    P = torch.from_numpy(rng.standard_normal((B, ch, pitch)).astype(np.float32))
+    Qv = torch.from_numpy(rng.standard_normal((B, ch, pitch)).astype(np.float32))
+    whole = torch.zeros(B, ch, pitch)
+    whole[:, :, p_lo:T] = P[:, :, p_lo:T]
+    whole[:, :, 1:T - dn] += Qv[:, :, 1 + dn:T]
+    Pd, Qd, wd = P.to(DEV), Qv.to(DEV), whole.to(DEV)
+    call("wn_causal_wgrad_codes", ptr(cd), 1 if scrambled else 0, ptr(wd), None, 0, 0, ch * pitch, pitch, ch, 256, T, B, ptr(slab), _lib.stream())
+    call("wn_causal_wgrad_codes", ptr(cd), 1 if scrambled else 0, ptr(Pd), ptr(Qd), dn, p_lo, ch * pitch, pitch, ch, 256, T, B, ptr(slab2), _lib.stream())
+    assert torch.equal(slab, slab2)
 
 
 @pytest.mark.parametrize("scrambled", [True, False], ids=["scrambled", "proper"])
