@@ -251,8 +251,8 @@ def measured_copy_gbs():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)          # discard 10 warm-up steps, time >= 50
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", default="f16x3,bf16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-4 / config-5 sub-benchmarks")
