@@ -421,8 +421,8 @@ class WaveNetEngine:
         tag = getattr(x, "_wn_codes", None) if x is not None else None
         ws["x_codes"] = (codes[0], bool(codes[1])) if x is None else None
         if tag is not None and os.environ.get("WN_CAUSAL_CODES", "1") == "1":
-            codes, scrambled, version = tag
-            if (x._version == version and codes.is_cuda and codes.dtype == torch.int32 and codes.is_contiguous() and
+            codes, scrambled, version, cversion = tag
+            if (x._version == version and codes._version == cversion and codes.is_cuda and codes.dtype == torch.int32 and codes.is_contiguous() and
                     tuple(codes.shape) == (B, T)):
                 ws["x_codes"] = (codes, scrambled)
         # causal conv (wavenet/model.py:104): x0[t] = W0 in[t-1] + W1 in[t], t in [1,T)
@@ -725,5 +725,5 @@ class WaveNetEngine:
         call("wn_onehot", ptr(codes), ptr(out), B, self.Q, T, 1 if scrambled else 0, _lib.stream())
         self.mark("onehot")
         if codes.is_contiguous() and codes.dtype == torch.int32:
-            out._wn_codes = (codes, bool(scrambled), out._version)      # see forward_logits
+            out._wn_codes = (codes, bool(scrambled), out._version, codes._version)      # see forward_logits
         return out

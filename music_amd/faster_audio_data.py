@@ -70,7 +70,7 @@ def onehot_device(codes, quantization_channels=256, scrambled=True):
     _lib.call("wn_onehot", _lib.ptr(c), _lib.ptr(out), b, quantization_channels, t, 1 if scrambled else 0, _lib.stream())
     # the codes ride along with the tensor: the engine forms the causal layer's weight gradient from them (a scatter)
     # as long as the tensor has not been modified since (music_amd/engine.py: forward_logits)
-    out._wn_codes = (c, bool(scrambled), out._version)
+    out._wn_codes = (c, bool(scrambled), out._version, c._version)
     return out
 
 

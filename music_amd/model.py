@@ -28,7 +28,7 @@ class _WaveNetFunction(torch.autograd.Function):
         else:
             tag = getattr(wave_sample, "_wn_codes", None)        # one-hot built from codes (engine.forward_logits)
             if tag is not None and wave_sample._version == tag[2]:
-                x._wn_codes = (tag[0], tag[1], x._version)
+                x._wn_codes = (tag[0], tag[1], x._version, tag[3])
         probs, ws = eng.forward(x)
         ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
         return probs

@@ -1004,6 +1004,13 @@ def test_code_aware_causal_gradient_equals_dense_path(scrambled, monkeypatch):
     x[0, :, 100] = 0.5
     eng.loss_and_grad(x, target)
     assert eng.workspace(B, T)["x_codes"] is None
+    # ... and so is one whose CODES were overwritten after it was built (a reused staging buffer)
+    x2 = eng.onehot(codes, scrambled=scrambled)
+    saved = codes.clone()
+    codes.add_(1).remainder_(256)
+    eng.loss_and_grad(x2, target)
+    assert eng.workspace(B, T)["x_codes"] is None
+    codes.copy_(saved)
     # plain float input (no codes at all)
     eng.loss_and_grad(torch.rand(B, 256, T, device="cuda"), target)
     assert eng.workspace(B, T)["x_codes"] is None
