@@ -483,6 +483,11 @@ def main():
         "roofline_stack_bwd": roof(bwd_b, bwd_ms, algorithmic_bytes_per_step=bwd_b),
         "roofline_stack_fwd_bwd": roof(fwd_b + bwd_b, fwd_ms + bwd_ms, algorithmic_bytes_per_step=fwd_b + bwd_b),
         "mfma_util": mfma,
+        # the same run as predicted samples/s (x W/T), and the dilated-conv stack alone (forward, forward + backward)
+        "predicted_samples_per_s": world * B_LOCAL * W * args.steps / dt,
+        "stack_only": {"fwd_ms": fwd_ms, "fwd_bwd_ms": fwd_ms + bwd_ms,
+                       "fwd_bwd_input_samples_per_s_per_gpu": B_LOCAL * T / ((fwd_ms + bwd_ms) * 1e-3) if fwd_ms == fwd_ms else None,
+                       "target_fwd_bwd_ms_at_40pct_of_hbm": (fwd_b + bwd_b) / (0.4 * HBM_PEAK) * 1e3},
         "phase_ms_per_step": {k: round(v, 4) for k, v in phase.items()},
     }
     if kern:
