@@ -264,6 +264,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to fd 1 when the process group comes
+    # up (and libraries may print more), so fd 1 points at stderr until the line is written
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, which launches the "
                          "N ranks itself, or under `python -m torch.distributed.run --nproc-per-node N`)" % (args.gpus, world))
@@ -276,8 +281,11 @@ def main():
             dist.destroy_process_group()
         else:
             t = torch.tensor([1.0])
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        os.close(stdout_fd)
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": t.item()}))
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": t.item()}), flush=True)
         return
     backend = os.environ.get("WN_DIST_BACKEND", "nccl")       # gloo: several ranks on one GPU (tests on a 1-GPU box)
     local = local % max(1, torch.cuda.device_count())
@@ -497,10 +505,13 @@ def main():
         out["extra"] = sub_benchmarks(net, x, bufs[0][1])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
-    if rank == 0:
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    os.close(stdout_fd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -94,10 +94,27 @@ def test_bench_two_ranks_on_this_box(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = r.stdout.strip().split("\n")
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout          # ONE JSON line on stdout, nothing else
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
     assert "allreduce" in out["phase_ms_per_step"] and out["value"] > 0
     assert abs(out["value"] - 2 * 8 * 16000 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+
+
+def test_bench_under_launcher_prints_one_json_line_with_rccl():
+    """The driver's launch form: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (here N = 1, the
+    collective really is RCCL).  RCCL prints a version banner to fd 1 when the process group comes up: stdout must
+    still carry exactly ONE line, the JSON."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "WN_DIST_BACKEND")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = r.stdout.strip().split("\n")
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["backend"] == "nccl" and "allreduce" in out["phase_ms_per_step"]
