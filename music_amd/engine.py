@@ -96,6 +96,7 @@ class WaveNetEngine:
         self._gen = 0
         self.adam_state = None
         self.marks = None            # list of (name, torch.cuda.Event) when profiling is on
+        self.mark_only = None        # optional set of mark names to keep
         # weight-gradient launches that only feed the final slab reduction run on a second HIP stream: the
         # epilogue's three (2 rounds of workgroups at 80 % fill each) then pack into the data-gradient GEMMs'
         # idle CUs (epilogue backward 1.25 -> 1.00 ms)
@@ -109,8 +110,9 @@ class WaveNetEngine:
         self.z_from_fwd = True
 
     def mark(self, name):
-        """Record a timing event on the current stream (only when self.marks is a list)."""
-        if self.marks is not None:
+        """Record a timing event on the current stream (only when self.marks is a list; self.mark_only, if set, limits
+        the events to those names - every event costs a marker packet between two kernels)."""
+        if self.marks is not None and (self.mark_only is None or name in self.mark_only):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.marks.append((name, ev))
