@@ -102,11 +102,17 @@ class _AutoencoderEngine:
                 gidx[w[r, c]] = o + r * w.shape[1] + c
                 gsize[0] += w.size
 
+        self.wt_idx, self.wt = {}, {}
         for name, ch, r in (("en_causal", CHe, Re), ("de_causal", CHd, Rd)):
             wc = sp.conv(name + "_layer.weight")
             w = full(ch, 2 * Q)
             w[:r, :Q], w[:r, Q:] = wc[:, :, 0], wc[:, :, 1]
             add(name, w)
+            # the same weight as [tap][q][ch] for the forward from codes (wn_causal_fwd_codes), a gather map
+            wt = np.full((2, Q, ch), -1, dtype=np.int64)
+            wt[:, :, :r] = wc.transpose(2, 1, 0)
+            self.wt_idx[name] = torch.from_numpy(wt.reshape(-1).astype(np.int32)).to(self.device)
+            self.wt[name] = torch.zeros(2 * Q * ch, dtype=torch.float32, device=self.device)
         for i in range(N):
             wd = sp.conv("en_dilation_layer_stack.%d.weight" % i)              # [De,Re,2]
             w = full(CHe, 2 * CHe)
@@ -210,6 +216,15 @@ class _AutoencoderEngine:
         ws = self.workspace(B, T)
         self._gen += 1
         ws["gen"], ws["x_in"], ws["Le"] = self._gen, x, Le
+        # a one-hot built from integer codes (engine.onehot / the loader) carries them: both causal layers then run on the
+        # codes (gather forward, scatter backward), as in music_amd/engine.py
+        ws["x_codes"] = None
+        tag = getattr(x, "_wn_codes", None)
+        if tag is not None and os.environ.get("WN_CAUSAL_CODES", "1") == "1":
+            codes, scrambled, version, cversion = tag
+            if (x._version == version and codes._version == cversion and codes.is_cuda and codes.dtype == torch.int32 and
+                    codes.is_contiguous() and tuple(codes.shape) == (B, T)):
+                ws["x_codes"] = (codes, scrambled)
         st = _lib.stream()
         m, pitch, N, CHe, CHd, SP, BwP = self.mode, ws["pitch"], self.N, self.CHe, self.CHd, self.SP, self.BwP
         call("wn_pack_weights", ptr(self.flat), ptr(self.pk_idx), ptr(self.pk), self.pk_idx.numel(), m, st)
@@ -223,8 +238,16 @@ class _AutoencoderEngine:
         he = lambda i: self._lay(ws["He"], i, CHe, ws)
         E = ptr(ws["E"], SLACK)
         eb = CHe * pitch
-        gemm("en_causal", ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, CHe // 16, self.Re,
-             xe(0), eb, pitch, 0, self._bias("en_causal_layer"), NONE3, NONE3, 1, T, 0)
+        def causal(name, ch, rows, out, obs, bias):
+            if ws["x_codes"] is None:
+                gemm(name, ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, ch // 16, rows, out, obs, pitch, 0, bias,
+                     NONE3, NONE3, 1, T, 0)
+                return
+            codes, scrambled = ws["x_codes"]
+            call("wn_gather_grads", ptr(self.flat), ptr(self.wt_idx[name]), ptr(self.wt[name]), self.wt[name].numel(), st)
+            call("wn_causal_fwd_codes", ptr(codes), 1 if scrambled else 0, ptr(self.wt[name]), bias, rows, out, obs, pitch, ch, Q, T,
+                 B, st)
+        causal("en_causal", CHe, self.Re, xe(0), eb, self._bias("en_causal_layer"))
         for i, d in enumerate(self.dil):
             t_lo = self.off[i + 1]
             # h = dilated_conv(relu(x));   x' = dense(relu(h)) + x[tail]
@@ -257,8 +280,7 @@ class _AutoencoderEngine:
         # ---------------- decoder (model1.py:158-225)
         xd = lambda i: self._lay(ws["Xd"], i, CHd, ws)
         db, zb = CHd * pitch, N * CHd * pitch
-        gemm("de_causal", ptr(x), ptr(x), Q * T, T, 0, T, -1, 0, Q // 32, Q // 32, CHd // 16, self.Rd,
-             xd(0), db, pitch, 0, self._bias("de_causal_layer"), NONE3, NONE3, 1, T, 0)
+        causal("de_causal", CHd, self.Rd, xd(0), db, self._bias("de_causal_layer"))
         bn = "de_dilation_layer_stack.%d"
         cmodes = []
         for i, d in enumerate(self.dil):
@@ -333,18 +355,30 @@ class _AutoencoderEngine:
             if i < N - 1:
                 ops.append(("de_d%d" % i, self.off[i + 1], T, -1 if ms else 512))
         plan, desc, so, vs = {}, [], 0, 0
+        row_of = {}
         for name, t_lo, t_hi, chunk in ops:
             go, r, c = self.gp_off[name]
             n = r * c
             ns = (_lib.wgrad_slabs(t_lo, t_hi, chunk, B) if chunk > 0 else
                   _lib.ms_slabs(t_lo, t_hi, B) if chunk == -1 else _lib.enc_slabs(t_lo, t_hi, B))
             plan[name] = (so, n, chunk)
+            row_of[name] = len(desc)
             desc.append([vs, so, ns, n, go, n])
             so += ns * n
             vs += (n + 3) // 4
+        # the causal layers' weight gradients from codes (wn_causal_wgrad_codes): their own slab regions, and a second
+        # reduction table in which only those two rows differ
+        desc_codes = [list(r) for r in desc]
+        for name in ("de_causal", "en_causal"):
+            go, r, c = self.gp_off[name]
+            ns = _lib.causal_codes_slabs(T, B)
+            plan[name + "_codes"] = (so, r * c, None)
+            desc_codes[row_of[name]][1:3] = [so, ns]
+            so += ns * r * c
         bw["slab"] = torch.empty(so, dtype=torch.float32, device=dev)
         bw["plan"], bw["vec"], bw["nops"] = plan, vs, len(desc)
         bw["desc"] = torch.tensor(desc, dtype=torch.int64, device=dev)
+        bw["desc_codes"] = torch.tensor(desc_codes, dtype=torch.int64, device=dev)
         ws["bwd"] = bw
         return bw
 
@@ -500,8 +534,16 @@ class _AutoencoderEngine:
             gemm("de_fgT%d" % i, dfg, dfg, 2 * CHd * pitch, pitch, t_lo, T, 0, d, 2 * CHd // 32, 2 * CHd // 32, CHd // 16, Rd,
                  ptr(bw["dXd"][i % 2], SLACK), db, pitch, 0, None, (dy, db, pitch, t_lo) if dy else NONE3, NONE3, self.off[i], T, 0)
         x = ws["x_in"]
-        wgrad("de_causal", ptr(bw["dXd"][0], SLACK), db, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CHd // 16, 0,
-              2 * Q, 1, T)
+        codes_path = ws.get("x_codes") is not None
+
+        def causal_wgrad(name, dx0, bs, ch):
+            if codes_path:
+                codes, scrambled = ws["x_codes"]
+                call("wn_causal_wgrad_codes", ptr(codes), 1 if scrambled else 0, dx0, None, 0, 0, bs, pitch, ch, Q, T, B,
+                     ptr(bw["slab"], plan[name + "_codes"][0]), st)
+            else:
+                wgrad(name, dx0, bs, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, ch // 16, 0, 2 * Q, 1, T)
+        causal_wgrad("de_causal", ptr(bw["dXd"][0], SLACK), db, CHd)
         bias_grad("de_causal_layer", ptr(bw["dXd"][0], SLACK), db, pitch, 0, Rd, 1, T)
         # ---- conditioning: en_i = cw_i enc + b (rows in the reference order: gate first), enf = cfw enc + b
         d_en = torch.cat([d_tab[:, :, CHd:CHd + Dd], d_tab[:, :, :Dd]], 2)            # (N,B,2Dd,Le) reference row order
@@ -542,9 +584,10 @@ class _AutoencoderEngine:
             # dx_i[t] = [x_i > 0] (Wdil1^T dh[t] + Wdil0^T dh[t+d]) + dy[t]
             gemm("en_dilT%d" % i, dHe, dHe, eb, pitch, t_lo, T, 0, d, CHe // 32, CHe // 32, CHe // 16, Re, dxe[i % 2], eb, pitch, 0,
                  None, (dy, eb, pitch, y_lo), (xe(i), eb, pitch), self.off[i], T, 0)
-        wgrad("en_causal", dxe[0], eb, pitch, 0, pitch, ptr(x), ptr(x), Q * T, T, -1, 0, T, Q // 16, CHe // 16, 0, 2 * Q, 1, T)
+        causal_wgrad("en_causal", dxe[0], eb, CHe)
         bias_grad("en_causal_layer", dxe[0], eb, pitch, 0, Re, 1, T)
-        call("wn_reduce_slabs", ptr(bw["desc"]), bw["nops"], bw["vec"], ptr(bw["slab"]), ptr(self.gpack), st)
+        call("wn_reduce_slabs", ptr(bw["desc_codes"] if codes_path else bw["desc"]), bw["nops"], bw["vec"], ptr(bw["slab"]),
+             ptr(self.gpack), st)
         call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
         if self.use_bias:
             self.flat_grad.index_copy_(0, b_idx, b_grad)
@@ -554,7 +597,14 @@ class _AutoencoderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, wave_sample, cond, *params):
         eng = net._engine_for(wave_sample.device)
-        probs, enc, ws = eng.forward(wave_sample.detach().float().contiguous(), cond)
+        x = wave_sample.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        else:
+            tag = getattr(wave_sample, "_wn_codes", None)        # one-hot built from codes (see _AutoencoderEngine.forward)
+            if tag is not None and wave_sample._version == tag[2]:
+                x._wn_codes = (tag[0], tag[1], x._version, tag[3])
+        probs, enc, ws = eng.forward(x, cond)
         net.last_encoding = enc
         ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
         return probs

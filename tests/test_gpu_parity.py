@@ -1029,3 +1029,49 @@ def test_code_aware_causal_gradient_equals_dense_path(scrambled, monkeypatch):
     g_c = eng.flat_grad.clone()
     eng.loss_and_grad(eng.onehot(codes, scrambled=scrambled), target)
     assert torch.equal(g_c, eng.flat_grad)
+
+
+@pytest.mark.parametrize("scrambled", [True, False], ids=["scrambled", "proper"])
+def test_autoencoder_causal_layers_on_codes_equal_dense_path(scrambled, monkeypatch):
+    """The autoencoder's two causal layers (encoder and decoder) on the integer codes of a loader-built one-hot (gather
+    forward, scatter backward) against the dense products on the same tensor, same conditioning projections."""
+    from music_amd.faster_audio_data import onehot_device
+    from music_amd.model1 import wavenet_autoencoder
+    cfg = dict(filter_width=2, quantization_channel=256, dilations=[1, 2, 4, 8, 16, 3], en_residual_channel=64,
+               en_dilation_channel=64, en_bottleneck_width=12, en_pool_kernel_size=50, de_residual_channel=64,
+               de_dilation_channel=64, de_skip_channel=80, use_bias=False)
+    torch.manual_seed(43)
+    net = wavenet_autoencoder(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    net = net.cuda()
+    rng = np.random.default_rng(44)
+    B, W = 2, 500
+    T = net.receptive_field + W - 1
+    codes = torch.from_numpy(rng.integers(0, 256, size=(B, T)).astype(np.int32)).cuda()
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).cuda()
+    eng = net._engine_for(torch.device("cuda", 0))
+    x = onehot_device(codes, 256, scrambled=scrambled)
+    torch.manual_seed(9)
+    cond = net._draw_conditioning()
+    l1 = eng.loss_and_grad(x, target, cond).item()
+    assert eng.workspace(B, T)["x_codes"] is not None
+    g1 = eng.flat_grad.clone()
+    monkeypatch.setenv("WN_CAUSAL_CODES", "0")
+    l0 = eng.loss_and_grad(x, target, cond).item()
+    assert eng.workspace(B, T)["x_codes"] is None
+    g0 = eng.flat_grad.clone()
+    assert abs(l1 - l0) < 1e-6
+    for name, p in net.named_parameters():
+        o = eng.spec.off[name]
+        u, v = g1[o:o + p.numel()], g0[o:o + p.numel()]
+        assert (u - v).abs().max().item() <= 1e-2 * max(v.abs().max().item(), 1e-30), name
+    monkeypatch.delenv("WN_CAUSAL_CODES")
+    # bit-reproducible, and through autograd the tag survives detach()
+    eng.loss_and_grad(x, target, cond)
+    assert torch.equal(g1, eng.flat_grad)
+    torch.manual_seed(9)
+    net.zero_grad()
+    torch.nn.CrossEntropyLoss()(net(x), target).backward()
+    assert eng.workspace(B, T)["x_codes"] is not None
