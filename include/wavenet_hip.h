@@ -165,14 +165,6 @@ int wn_wgrad(const float* a, int64_t a_bstride, int a_pitch, int a_shift, int a_
              int b_shift1, int b_cols, int nt_per_tap, int mt, int relu_b, float* c, int ldc,
              int64_t c_slab_stride, int t_lo, int t_hi, int chunk, int batch, int mode, wn_stream_t stream);
 int wn_wgrad_slabs(int t_lo, int t_hi, int chunk, int batch);
-/* Both weight-gradient products of one residual block in ONE launch:
- *   slab_fg: C[2ch][2ch]  = sum_t dfg[t] [x(t-d) | x(t)]^T   (rows df then dg; cols tap0 then tap1)
- *   slab_d : C[ch][ch]    = sum_t dy[t] z[t]^T               (skipped when dy or slab_d is NULL)
- * slab strides are 4*ch*ch and ch*ch floats; slab counts as wn_wgrad_slabs(t_lo,t_hi,chunk,batch). */
-int wn_resblock_wgrad(const float* dfg, const float* x_in, const float* dy, const float* z,
-                      int64_t dfg_bstride, int64_t x_bstride, int64_t z_bstride, int pitch, int ch, int d,
-                      int t_lo, int t_hi, float* slab_fg, float* slab_d, int chunk, int batch, int mode,
-                      wn_stream_t stream);
 /* Weight gradient of the causal layer (autograd of wavenet/model.py:104) when the layer's input is the ONE-HOT tensor
  * wn_onehot built from `codes` (int32 [batch][t]; scrambled as there): dW[r][q][tap] = sum_{b,s} dx[b][r][s] *
  * in[b][q][s-1+tap] becomes a scatter of dx columns - dx (ch rows) is read once, the 4*q*t bytes per clip of dense

@@ -130,26 +130,6 @@ int wn_wgrad(const float* a_, int64_t a_bstride, int a_pitch, int a_shift, int a
     return wn_launch_wgrad(a, batch, mode, (hipStream_t)stream);
 }
 
-int wn_resblock_wgrad(const float* dfg, const float* x_in, const float* dy, const float* z,
-                      int64_t dfg_bstride, int64_t x_bstride, int64_t z_bstride, int pitch, int ch, int d,
-                      int t_lo, int t_hi, float* slab_fg, float* slab_d, int chunk, int batch, int mode,
-                      wn_stream_t stream) {
-    WnWgradArgs f, g;
-    memset(&f, 0, sizeof(f));
-    memset(&g, 0, sizeof(g));
-    // dWf/dWg: C[2ch][tap0 ch | tap1 ch] = sum_t dfg[t] * [x(t-d) | x(t)]^T
-    f.a = dfg; f.a_bstride = dfg_bstride; f.a_pitch = pitch; f.a_shift = 0; f.a_cols = pitch;
-    f.b0 = x_in; f.b1 = x_in; f.b_bstride = x_bstride; f.b_pitch = pitch; f.b_shift0 = -d; f.b_shift1 = 0; f.b_cols = pitch;
-    f.nt_per_tap = ch / 16; f.mt = 2 * ch / 16; f.relu_b = 0; f.c = slab_fg; f.ldc = 2 * ch;
-    f.c_slab_stride = (int64_t)4 * ch * ch; f.t_lo = t_lo; f.t_hi = t_hi; f.chunk = chunk;
-    // dWd: C[ch][ch] = sum_t dy[t] * z[t]^T
-    g.a = dy; g.a_bstride = x_bstride; g.a_pitch = pitch; g.a_shift = 0; g.a_cols = pitch;
-    g.b0 = z; g.b1 = nullptr; g.b_bstride = z_bstride; g.b_pitch = pitch; g.b_cols = pitch;
-    g.nt_per_tap = ch / 16; g.mt = ch / 16; g.c = slab_d; g.ldc = ch; g.c_slab_stride = (int64_t)ch * ch;
-    g.t_lo = t_lo; g.t_hi = t_hi; g.chunk = chunk;
-    return wn_launch_wgrad2(&f, (dy && slab_d) ? &g : nullptr, batch, mode, (hipStream_t)stream);
-}
-
 int wn_wgrad_slabs(int t_lo, int t_hi, int chunk, int batch) { return wn_wgrad_num_slabs(t_lo, t_hi, chunk, batch); }
 
 int wn_reduce_slabs(const int64_t* desc, int n_ops, int64_t total_vec, const float* slab, float* out, wn_stream_t stream) {
