@@ -55,7 +55,7 @@ B_LOCAL, T = 8, 16000
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec); 6.29e12 measured copy
 MFMA_PEAK = 2.5e15         # FLOP/s, dense bf16 / f16 MFMA (same guide)
 BWD_KERNELS = "resblock_bwd_pq_k"
-BWD_PMC = ("resblock_bwd_pq_k<true>",)
+BWD_PMC = ("resblock_bwd_pq_k<true",)
 
 
 def synth_codes(rank, b, t):
