@@ -325,6 +325,15 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         load_dy(rd, pos_k(1));
         __syncthreads();                                    // stage 0 operands of the first item, the weights, the zeros
         auto r_body = [&](const int it, f32x2* cr, RawX& rx) {
+#ifndef PQ_NO_VOIDSKIP
+            if (it >= n_items) {
+                // the void item that pads an odd count: nothing of its own to do (its result tiles are never multiplied:
+                // the W waves skip a void item's products), only the Q rows of the last real item
+                pq_half((it + 1) & 1, 1, pos_k(it - 1), nullptr);
+                __syncthreads();
+                return;
+            }
+#endif
             PQ_TICK(k0);
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
             load_x(rx, pos_k(it + 3));                       // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         }
         {
             const int n_even = (n_items + 1) & ~1;
-            pq_half((n_even - 1) & 1, 1, pos_k(n_even - 1), nullptr);      // Q rows of the last item
+            if (pos_k(n_even - 1).live) pq_half((n_even - 1) & 1, 1, pos_k(n_even - 1), nullptr);      // Q rows of the last item
         }
         __syncthreads();                                    // the W waves' extra round (products of the last item)
         PQ_FLUSH(0, 4);
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         };
         const int n_even = (n_items + 1) & ~1;
         for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, rr2); }
-        products((n_even - 1) & 1, ops, pos_k(n_even - 1)); // the last item (a void one if the count was padded)
+        if (pos_k(n_even - 1).live) products((n_even - 1) & 1, ops, pos_k(n_even - 1));    // the last item, unless it is the void one
         __syncthreads();
         PQ_FLUSH(4, 6);
     }
