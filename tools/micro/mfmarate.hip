@@ -14,12 +14,12 @@ __global__ __launch_bounds__(256) void rate(float* out, unsigned long long* t, i
     unsigned long long t0 = wall_clock64();
     if (SHAPE == 0) {          // 16x16x32 f16, 8 accumulators
         f32x4 acc[8];
-        for (int j = 0; j < 8; ++j) acc[j] = f32x4{(float)(j + tid), 0.f, 0.f, 0.f};          // distinct: no common-subexpression folding
+        for (int j = 0; j < 8; ++j) acc[j] = f32x4{(float)(j + tid), (float)(2 * j + tid), (float)(3 * j + tid), (float)(5 * j + tid)};   // distinct in every component: no folding, no accumulator shuffles in the loop
         for (int i = 0; i < n / 8; ++i) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[j], 0, 0, 0);
+            for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(a), "v"(b));   // (the builtin form made hipcc shuffle accumulators inside the loop)
         }
-        for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][3];
+        for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
     } else if (SHAPE == 1) {   // 32x32x16 f16, 4 accumulators
         f32x16 acc[4];
         for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) acc[j][e] = (float)(j + e + tid);
@@ -30,12 +30,12 @@ __global__ __launch_bounds__(256) void rate(float* out, unsigned long long* t, i
         for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) s += acc[j][e];
     } else if (SHAPE == 2) {   // 16x16x32 bf16
         f32x4 acc[8];
-        for (int j = 0; j < 8; ++j) acc[j] = f32x4{(float)(j + tid), 0.f, 0.f, 0.f};          // distinct: no common-subexpression folding
+        for (int j = 0; j < 8; ++j) acc[j] = f32x4{(float)(j + tid), (float)(2 * j + tid), (float)(3 * j + tid), (float)(5 * j + tid)};   // distinct in every component: no folding, no accumulator shuffles in the loop
         for (int i = 0; i < n / 8; ++i) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, acc[j], 0, 0, 0);
+            for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(ab), "v"(bb));
         }
-        for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][3];
+        for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
     } else {                   // 32x32x16 bf16
         f32x16 acc[4];
         for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) acc[j][e] = (float)(j + e + tid);
