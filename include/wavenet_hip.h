@@ -149,6 +149,10 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
                        float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode,
                        int cond_le, int cond_q, float* dfg, int64_t dfg_bstride, int batch, int mode_fwd, int mode_bwd,
                        wn_stream_t stream);
+/* The operand format of the "x3" products: hi[i] = round16(x[i]), lo[i] = round16(x[i] - hi[i]),
+ * 16-bit = IEEE half (is_bf16 = 0) or bfloat16 (1), round to nearest even.  The same device function every MFMA operand
+ * of the library is split with; no counterpart in the reference (its products are fp32). */
+int wn_split16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, int is_bf16, wn_stream_t stream);
 /* out[b][r][t] = p[b][r][t] (t >= p_lo) + q[b][r][t+dn] (t+dn < t_hi), t in [t_lo,t_hi) */
 int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,
                  int t_lo, int t_hi, int batch, wn_stream_t stream);

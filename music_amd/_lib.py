@@ -46,6 +46,7 @@ SIGNATURES = {
     "wn_resblock_bwd_ms_slabs": [_i, _i, _i],
     "wn_resblock_bwd_pq": [_p, _p, _p, _i, _i, _p, _p, _p, _l, _l, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p,
                            _p, _l, _i, _i, _i, _i, _p, _l, _i, _i, _i, _p],
+    "wn_split16": [_p, _p, _p, _l, _i, _p],
     "wn_shift_add": [_p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_causal_wgrad_codes": [_p, _i, _p, _p, _i, _i, _l, _i, _i, _i, _i, _i, _p, _p],
     "wn_causal_wgrad_codes_slabs": [_i, _i],

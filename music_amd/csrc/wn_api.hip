@@ -224,6 +224,10 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
     a.cond_le = cond_le; a.cond_q = cond_q; a.dfg = dfg; a.dfg_bstride = dfg_bstride;
     return wn_launch_resblock_bwd_pq(a, batch, (hipStream_t)stream);
 }
+int wn_split16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, int is_bf16, wn_stream_t stream) {
+    if (n > 0 && (!x || !hi || !lo)) return wn_set_error_msg(-4, "wn_split16: null argument");
+    return wn_launch_split16(x, hi, lo, (long)n, is_bf16, (hipStream_t)stream);
+}
 int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,
                  int t_lo, int t_hi, int batch, wn_stream_t stream) {
     return wn_launch_shift_add(p, q, out, bstride, pitch, rows, dn, p_lo, t_lo, t_hi, batch, (hipStream_t)stream);

@@ -410,3 +410,32 @@ int wn_launch_avgpool_bwd(const float* denc, long denc_bstride, int denc_pitch, 
     WN_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The operand format of the x3 products, as a kernel of its own: hi = cvt16(x), lo = cvt16(x - hi) for every element
+// (split2 of wn_common.h - the function every MFMA operand of the library goes through - on pairs).  A utility for
+// hosts that want to pre-split a tensor, and the handle by which tests/test_gpu_kernels.py checks split2 bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ void split16_k(const float* __restrict__ x, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, long n) {
+    const long i = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const float a = x[i], b = i + 1 < n ? x[i + 1] : 0.f;
+    uint32_t h, l;
+    split2<T>(a, b, h, l);
+    hi[i] = (uint16_t)h;
+    lo[i] = (uint16_t)l;
+    if (i + 1 < n) {
+        hi[i + 1] = (uint16_t)(h >> 16);
+        lo[i + 1] = (uint16_t)(l >> 16);
+    }
+}
+int wn_launch_split16(const float* x, uint16_t* hi, uint16_t* lo, long n, int is_bf16, hipStream_t st) {
+    if (n <= 0) return 0;
+    const long pairs = (n + 1) / 2;
+    dim3 g((unsigned)((pairs + 255) / 256)), b(256);
+    if (is_bf16) hipLaunchKernelGGL(split16_k<BF16>, g, b, 0, st, x, hi, lo, n);
+    else hipLaunchKernelGGL(split16_k<F16>, g, b, 0, st, x, hi, lo, n);
+    WN_CHECK_LAUNCH();
+    return 0;
+}

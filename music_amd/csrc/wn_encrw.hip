@@ -29,12 +29,7 @@ __device__ __forceinline__ er_f32x2 er_ld2u(const float* p) {
     er_f32x2 r = {u.v[0], u.v[1]};
     return r;
 }
-__device__ __forceinline__ void er_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const er_f32x2 v = {a, b};
-    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, er_bf16x2));
-    const er_f32x2 r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, er_bf16x2));
-}
+__device__ __forceinline__ void er_split2(float a, float b, uint32_t& hi, uint32_t& lo) { split2<BF16>(a, b, hi, lo); }
 
 // WnResMsArgs fields as used here: x_in = x_i, dy, dz = h (pre-activation, dz_bstride), dfg = dh out (CH rows,
 // dfg_bstride), wdT, slab_fg (CH x 2CH per workgroup), slab_d (CH x CH), d, t_lo, t_hi, z_lo = first column on

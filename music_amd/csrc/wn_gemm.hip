@@ -6,6 +6,7 @@
 // concatenated z-crops and post_process_1/2 (model.py:128-138), and every "weights transposed"
 // data-gradient product of the backward pass.  The fused residual-block kernels live in
 // wn_resblock.hip; this kernel is the unfused workhorse around them.
+#include <type_traits>
 #include "wn_common.h"
 #include "wn_kernels.h"
 
@@ -282,28 +283,28 @@ __global__ __launch_bounds__(512) void chan_gemm_wide2_k(WnGemmArgs a) {
         }
     };
     // split 4 rows x 4 columns and write the 8-byte hi / lo pieces of the 4 B fragments of group lg
-    auto store_b = [&](const f32x4* raw, int st) {
+    auto store_b_as = [&](const f32x4* raw, int st, auto relu) {
         uint16_t* bb = l_s + (size_t)st * STAGE + (size_t)(16 + lg * 4) * FR + lane * 8 + lh * 4;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            typedef typename T::elem elem;
-            elem h[4], l[4];
+            float x[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x = raw[j][n];
-                if (a.relu_in) x = fmaxf(x, 0.f);
-                h[j] = T::cvt(x);
-                if (NS == 3) l[j] = T::cvt(x - T::back(h[j]));
-            }
-            uint2 hv = {(uint32_t)__builtin_bit_cast(uint16_t, h[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[1]) << 16),
-                        (uint32_t)__builtin_bit_cast(uint16_t, h[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[3]) << 16)};
-            *reinterpret_cast<uint2*>(bb + (size_t)n * FR) = hv;
+            for (int j = 0; j < 4; ++j) x[j] = decltype(relu)::value ? fmaxf(raw[j][n], 0.f) : raw[j][n];
+            uint2 hv, lv;
             if (NS == 3) {
-                uint2 lv = {(uint32_t)__builtin_bit_cast(uint16_t, l[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, l[1]) << 16),
-                            (uint32_t)__builtin_bit_cast(uint16_t, l[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, l[3]) << 16)};
-                *reinterpret_cast<uint2*>(bb + (size_t)n * FR + 512) = lv;
+                split2<T>(x[0], x[1], hv.x, lv.x);
+                split2<T>(x[2], x[3], hv.y, lv.y);
+            } else {
+                hv.x = cvt2<T>(x[0], x[1]);
+                hv.y = cvt2<T>(x[2], x[3]);
             }
+            *reinterpret_cast<uint2*>(bb + (size_t)n * FR) = hv;
+            if (NS == 3) *reinterpret_cast<uint2*>(bb + (size_t)n * FR + 512) = lv;
         }
+    };
+    auto store_b = [&](const f32x4* raw, int st) {
+        if (a.relu_in) store_b_as(raw, st, std::true_type());
+        else store_b_as(raw, st, std::false_type());
     };
     u32x4 wreg[PER_A];
     auto load_w = [&](int s) {

@@ -102,6 +102,7 @@ struct WnResPqArgs {
     float* dfg; long dfg_bstride;                          // optional: [df;dg] written out as well ([B][2CH][pitch]); null: not
 };
 int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st);
+int wn_launch_split16(const float* x, uint16_t* hi, uint16_t* lo, long n, int is_bf16, hipStream_t st);
 int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride, int pitch, int rows, int dn,
                         int p_lo, int t_lo, int t_hi, int batch, hipStream_t st);
 // backward of an autoencoder ENCODER block with both weight gradients (wn_encrw.hip); WnResMsArgs fields as documented there

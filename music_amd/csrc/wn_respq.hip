@@ -48,12 +48,7 @@ __device__ __forceinline__ f32x2 pq_ld2u(const float* p) {
     return r;
 }
 // (a, b) -> packed bf16 pairs hi = (bf16(a), bf16(b)) and lo = (bf16(a - hi_a), bf16(b - hi_b))
-__device__ __forceinline__ void pq_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const f32x2 v = {a, b};
-    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-    const f32x2 r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
-}
+__device__ __forceinline__ void pq_split2(float a, float b, uint32_t& hi, uint32_t& lo) { split2<BF16>(a, b, hi, lo); }
 
 // LDS map, in halfs (uint16): per stage 8 x fragments | 4 dy fragments | 12 result tiles; then the packed (P, Q) weights
 #define PQ_XF 0

@@ -44,12 +44,7 @@ __device__ __forceinline__ f32x2 ld2u(const float* p) {
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // (a, b) -> packed bf16 pairs hi = (bf16(a), bf16(b)) and lo = (bf16(a - hi_a), bf16(b - hi_b)): 6 VALU per pair
-__device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const f32x2 v = {a, b};
-    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-    const f32x2 r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
-}
+__device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint32_t& lo) { split2<BF16>(a, b, hi, lo); }
 
 // LDS map of one stage, in halfs (uint16): 8 x fragments | 4 dy fragments | 12 operand tiles | 12 result tiles
 #define RW_XF 0

@@ -559,3 +559,37 @@ def test_causal_forward_from_codes_equals_conv(scrambled, ch, R, T, B, bias):
     err = (got[:, :R, 1:T].double() - want).abs().max().item()
     assert err < 1e-5, err
     assert (got[:, :, 0] == 7.0).all() and (got[:, :, T:] == 7.0).all() and (got[:, R:] == 7.0).all()
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_split16_is_round_to_nearest_hi_and_lo(bf16):
+    """The operand split every MFMA product goes through (wn_common.h split2, hand-written instructions): hi = round16(x),
+    lo = round16(x - hi), bit for bit what torch's conversions give, over normal, tiny (f16-subnormal), huge and special
+    values, odd and even lengths."""
+    g = torch.Generator().manual_seed(5)
+    parts = [torch.randn(4001, generator=g) * s for s in (1.0, 1e-3, 1e-6, 3e-8, 1e3, 6e4)]
+    parts.append(torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, -65504.0, 6.1e-5, 5.96e-8, 2.0 ** -25, 1.0 + 2.0 ** -11,
+                               1.0 + 2.0 ** -12, 1.0 + 3 * 2.0 ** -12, float("inf"), -float("inf"), 1e38, -1e38, 7e4]))
+    x = torch.cat(parts).to(DEV)
+    n = x.numel()
+    assert n % 2 == 1
+    t16 = torch.bfloat16 if bf16 else torch.float16
+    hi = torch.zeros(n, dtype=torch.int16, device=DEV)
+    lo = torch.zeros(n, dtype=torch.int16, device=DEV)
+    call("wn_split16", ptr(x), ptr(hi), ptr(lo), n, bf16, _lib.stream())
+    torch.cuda.synchronize()
+    xr = x.cpu()
+    h_ref = xr.to(t16)
+    l_ref = (xr - h_ref.float()).to(t16)
+    h_got, l_got = hi.cpu().view(t16), lo.cpu().view(t16)
+    assert torch.equal(h_got.view(torch.int16), h_ref.view(torch.int16))
+    fin = torch.isfinite(h_ref.float())
+    assert torch.equal(l_got.view(torch.int16)[fin], l_ref.view(torch.int16)[fin])
+    # x beyond the 16-bit range: hi = +-inf and lo = x - hi = -+inf, or NaN where x itself is infinite - as the reference
+    nan_ref = torch.isnan(l_ref.float())
+    assert torch.equal(torch.isnan(l_got.float()), nan_ref)
+    assert torch.equal(l_got.view(torch.int16)[~nan_ref], l_ref.view(torch.int16)[~nan_ref])
+    # and the pair carries the value to 2^-22 (f16) / 2^-17 (bf16) of its magnitude where nothing underflows
+    ok = fin & (xr.abs() > 0.5)                    # (an f16 lo below 6e-5 is subnormal: absolute, not relative, precision)
+    rel = ((h_got.float() + l_got.float() - xr).abs() / xr.abs())[ok].max().item()
+    assert rel < (2.0 ** -16 if bf16 else 2.0 ** -21), rel
