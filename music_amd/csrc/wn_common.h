@@ -77,29 +77,22 @@ __device__ __forceinline__ void mma(f32x4& acc, const Frag<T>& a, const Frag<T>&
 }
 
 // (a, b) -> packed 16-bit pairs hi = (cvt(a), cvt(b)) and lo = (cvt(a - hi_a), cvt(b - hi_b)), a in the low half.
-// Written as instructions because hipcc's own code for the same arithmetic converts every hi twice (once packed for the
-// fragment, once alone for the subtraction), packs the subtractions into v_pk_add_f32 and shuffles registers into
-// pairs for it: 4-5 VALU per element where 1.5 (f16) / 3 (bf16) do.
-//   f16 : the mixed-precision FMA reads the f16 hi as an f32 operand, subtracts it from the f32 input and rounds the
-//         difference - which is exact in f32 - to f16, all in one instruction per element: the same bits as
-//         cvt(x - float(hi)).
-//   bf16: no mixed form; hi back to f32 by shift / mask.
+// f16 is written as instructions: hipcc's own code for the same arithmetic converts every hi twice (once packed for the
+// fragment, once alone for the subtraction), packs the subtractions into v_pk_add_f32 and shuffles registers into pairs
+// for it - 4-5 VALU per element.  The mixed-precision FMA reads the f16 hi as an f32 operand, subtracts it from the
+// f32 input and rounds the difference - which is exact in f32 - to f16 in one instruction per element: 1.5 per
+// element, the same bits as cvt(x - float(hi)) (tests/test_gpu_kernels.py, wn_split16).  Worth 1 % of the step
+// (-DWN_SPLIT_PLAIN is the compiler's form, for timing): the kernels are not bound by vector issue.
 template <class T> __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo);
-#ifdef WN_SPLIT_PLAIN      // timing builds: the same arithmetic left to the compiler
 typedef _Float16 wn_f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 wn_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float wn_f32x2 __attribute__((ext_vector_type(2)));
+#ifdef WN_SPLIT_PLAIN      // timing builds: the same arithmetic left to the compiler
 template <> __device__ __forceinline__ void split2<F16>(float a, float b, uint32_t& hi, uint32_t& lo) {
     const wn_f16x2 h = {(_Float16)a, (_Float16)b};
     const wn_f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
-}
-template <> __device__ __forceinline__ void split2<BF16>(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const wn_f32x2 v = {a, b};
-    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wn_bf16x2));
-    const wn_f32x2 r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, wn_bf16x2));
 }
 #else
 template <> __device__ __forceinline__ void split2<F16>(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -107,16 +100,15 @@ template <> __device__ __forceinline__ void split2<F16>(float a, float b, uint32
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
 }
-template <> __device__ __forceinline__ void split2<BF16>(float a, float b, uint32_t& hi, uint32_t& lo) {
-    float ra, rb;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-    asm("v_lshlrev_b32 %0, 16, %1" : "=v"(ra) : "v"(hi));
-    asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(rb) : "v"(hi));
-    asm("v_sub_f32 %0, %1, %2" : "=v"(ra) : "v"(a), "v"(ra));
-    asm("v_sub_f32 %0, %1, %2" : "=v"(rb) : "v"(b), "v"(rb));
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(ra), "v"(rb));
-}
 #endif
+// bf16 has no mixed form: hi back to f32 by shift / mask, six instructions per pair, and here the compiler's own code is
+// the faster one (the same six written as instructions: backward stack 1.998 vs 1.963 ms on one box)
+template <> __device__ __forceinline__ void split2<BF16>(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const wn_f32x2 v = {a, b};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wn_bf16x2));
+    const wn_f32x2 r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, wn_bf16x2));
+}
 template <class T> __device__ __forceinline__ uint32_t cvt2(float a, float b);       // hi pair only (x1 modes)
 template <> __device__ __forceinline__ uint32_t cvt2<F16>(float a, float b) {
     uint32_t h;
