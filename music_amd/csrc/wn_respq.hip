@@ -248,7 +248,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] += dy32[4 * m + i];
                 }
-                if (whole) *reinterpret_cast<f32x4*>(out + 16 * m) = v;
+                if (whole) *reinterpret_cast<f32x4*>(out + 16 * m) = v;      // plain: the next launch finds P and Q in L2 (streaming stores: 2.21 vs 2.00 ms for the stack)
                 else st4m(out + 16 * m, v, ps.t0 + 16 * m + 4 * q, a.t_lo, a.t_hi);
             }
         }
