@@ -40,6 +40,9 @@ struct WnResArgs {
     int n_f, n_d;                                       // real dilation / residual channel counts
     int d, t_lo, t_hi, z_lo, t_base;                    // outputs valid on [t_lo,t_hi); z stored for t >= z_lo
     int write_x;                                        // 0 for the last block (its x is unused)
+#ifdef FW_DBG
+    int n_d_dbg;                                        // developer build: slot of this launch in the span log
+#endif
     // optional conditioning (wavenet_autoencoder/model1.py:183,227-247): [f;g] += cond[b][row][idx(t)]
     const float* cond; long cond_bstride; int cond_pitch;   // [B][2CH][cond_pitch]
     int cond_mode, cond_le, cond_q;                     // 1: idx = (t-t_lo)/cond_q (stretch); 2: idx = (t-t_lo) % cond_le (tile)

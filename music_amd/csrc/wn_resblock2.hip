@@ -45,8 +45,20 @@ template <int NT> struct NtCfg { static constexpr int WAVES = NT == 4 ? 8 : 16; 
 // ENC = the autoencoder's ENCODER block (wavenet_autoencoder/model1.py:137-152) on the same skeleton:
 //   h = Wdil [relu x(t-d); relu x(t)] (+ bias) ; x_out = Wd relu(h) (+ bias) + x(t) ; h (pre-activation) is stored where
 //   the decoder block stores z.  One row group (no gate), ReLU on load and in front of the dense product.
+#ifdef FW_DBG
+// developer build (tools/fw_spans.py): start / end of every workgroup of the last 64 launches on the 100 MHz realtime clock
+__device__ unsigned long long fw_dbg[64 * 256 * 8];
+static int fw_dbg_slot = 0;
+extern "C" int wn_fw_dbg_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fw_dbg), sizeof(unsigned long long) * 64 * 256 * 8);
+}
+#endif
 template <class T, int NS, int CH, int NT, bool ENC = false, int WV = NtCfg<NT>::WAVES>
 __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
+#ifdef FW_DBG
+    const int dbg_wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8] = __builtin_amdgcn_s_memrealtime();
+#endif
     typedef typename VecN<NT>::t fvec;
     constexpr int THREADS = 64 * WV;
     constexpr int COLS = WV * 16 * NT;
@@ -91,14 +103,51 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
     };
     issue(0);      // first activation loads are in flight while the weights are staged
 
-    {   // stage the packed weights (contiguous copies, 16 B per thread per step)
-        const u32x4* s0 = reinterpret_cast<const u32x4*>(a.wfg);
-        u32x4* d0 = reinterpret_cast<u32x4*>(l_fg);
-        for (int i = threadIdx.x; i < NFG * FR / 8; i += THREADS) d0[i] = s0[i];
-        const u32x4* s1 = reinterpret_cast<const u32x4*>(a.wd);
-        u32x4* d1 = reinterpret_cast<u32x4*>(l_d);
-        for (int i = threadIdx.x; i < ND * FR / 8; i += THREADS) d1[i] = s1[i];
-    }
+    // The packed weights go to LDS one k-step at a time: only the MT fragments of k-step 0 are waited for before the first
+    // MFMA; the fragments of k-step s + 1 (after the last one: the dense product's) are fetched from L2 while k-step s is
+    // multiplied and written behind it, one workgroup barrier per k-step.  (All 80 KB up front held every wave at the first
+    // barrier for 4 of the launch's 24 us: in-kernel stamps, tools/fw_spans.sh.)
+    constexpr int FRV = FR / 8;                               // u32x4 per fragment
+    constexpr int WPT = (MT * FRV + THREADS - 1) / THREADS;   // u32x4 per thread for one k-step's fg fragments
+    constexpr int DPT = (ND * FRV + THREADS - 1) / THREADS;   // ... for the dense product's fragments
+    constexpr int SPT = WPT > DPT ? WPT : DPT;
+    u32x4 wst[SPT];
+    auto stage_ld = [&](int s) {          // s < KS: fg fragments (m, s), m = 0..MT-1 ; s == KS: the dense fragments
+        if (s < KS) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(a.wfg);
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int v = threadIdx.x + i * THREADS;
+                if (MT * FRV % THREADS == 0 || v < MT * FRV) wst[i] = src[(size_t)((v / FRV) * KS + s) * FRV + v % FRV];
+            }
+        } else {
+            const u32x4* src = reinterpret_cast<const u32x4*>(a.wd);
+#pragma unroll
+            for (int i = 0; i < DPT; ++i) {
+                const int v = threadIdx.x + i * THREADS;
+                if (ND * FRV % THREADS == 0 || v < ND * FRV) wst[i] = src[v];
+            }
+        }
+    };
+    auto stage_st = [&](int s) {
+        if (s < KS) {
+            u32x4* dst = reinterpret_cast<u32x4*>(l_fg);
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int v = threadIdx.x + i * THREADS;
+                if (MT * FRV % THREADS == 0 || v < MT * FRV) dst[(size_t)((v / FRV) * KS + s) * FRV + v % FRV] = wst[i];
+            }
+        } else {
+            u32x4* dst = reinterpret_cast<u32x4*>(l_d);
+#pragma unroll
+            for (int i = 0; i < DPT; ++i) {
+                const int v = threadIdx.x + i * THREADS;
+                if (ND * FRV % THREADS == 0 || v < ND * FRV) dst[v] = wst[i];
+            }
+        }
+    };
+    stage_ld(0);
+    stage_st(0);
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -116,6 +165,11 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
         for (int n = 0; n < NT; ++n) acc[m][n] = init;
     }
     __syncthreads();
+#ifdef FW_DBG
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -128,6 +182,7 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
             split8<T, NS>(bf[n], v);
         }
         if (s + 1 < KS) issue(s + 1);
+        stage_ld(s + 1);
         {   // weight fragment m+1 is on its way from LDS while the matrix core works on fragment m
             Frag<T> af[2];
             load_a<T, NS>(af[0], l_fg, s, lane);
@@ -149,8 +204,15 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
 #endif
         }
+        stage_st(s + 1);
+        __syncthreads();
     }
 
+#ifdef FW_DBG
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (!ENC && a.cond) {       // per-(channel, time-bucket) conditioning bias, gathered from a tiny table
         const float* cb = a.cond + (size_t)b * a.cond_bstride;
         int idx[NT];
@@ -191,6 +253,11 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
             for (int i = 0; i < 4; ++i)
                 z[m][n][i] = ENC ? acc[m][n][i] : wn_gate(acc[m][n][i], acc[ENC ? m : m + MT2][n][i]);
 
+#ifdef FW_DBG
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // z-crop store (rows 16m+4q+i; the lane's 4 N-tiles are 4 consecutive samples)
     {
         float* zo = a.z_out + (size_t)b * a.z_bstride;
@@ -209,6 +276,17 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
                 VecN<NT>::stm(zo + (size_t)(16 * m + 4 * q + i) * a.pitch + tl, v, tl, a.z_lo, a.t_hi);
             }
     }
+#ifdef FW_DBG
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef FW_DBG
+    if (!a.write_x) {
+        if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        return;
+    }
+#endif
     if (!a.write_x) return;
 
     // dense: x' = Wd z + x   (B fragments straight from the z accumulators, chained k order)
@@ -247,6 +325,11 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
             for (int n = 0; n < NT; ++n) mma<T, NS>(acc2[m][n], af, bf[n]);
         }
     }
+#ifdef FW_DBG
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (NT != 4) {                        // 128-VGPR budget: fetch the residual rows only now
 #pragma unroll
         for (int m = 0; m < MT2; ++m)
@@ -272,6 +355,15 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
 #endif
             VecN<NT>::stm(xo + (size_t)(16 * m + 4 * q + i) * a.pitch + tl, v, tl, a.t_lo, a.t_hi);
         }
+#ifdef FW_DBG
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef FW_DBG
+    __syncthreads();            // all waves have issued their stores
+    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 
@@ -280,6 +372,10 @@ static int launch_fwd_nt(const WnResArgs& a, int ch, int batch, hipStream_t st) 
     WnResArgs k = a;
     k.swz = wn_xcd_swizzle_enabled();
     k.t_base = wn_tile_origin(a.t_lo);
+#ifdef FW_DBG
+    k.n_d_dbg = fw_dbg_slot;
+    fw_dbg_slot = (fw_dbg_slot + 1) & 63;
+#endif
     const int ncol = a.t_hi - k.t_base;
     constexpr int COLS = NtCfg<NT>::WAVES * 16 * NT;
     dim3 g((ncol + COLS - 1) / COLS, batch), b(64 * NtCfg<NT>::WAVES);
