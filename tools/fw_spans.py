@@ -34,3 +34,11 @@ for s, live in rows:
     st = v[s][live][:, 0]
     print("slot %2d  wgs %3d  start spread %.2f us | " % (s, live.sum(), (st.max() - st.min()) / 100.0) +
           ", ".join("%s %.2f" % (n, m) for n, m in zip(names, d.mean(axis=0))) + " | slowest workgroup %.2f" % d[:, -1].max())
+clk = (ctypes.c_ulonglong * (64 * 256 * 2))()
+lib.wn_fw_clk_read(clk)
+c = np.array(list(clk), dtype=np.float64).reshape(64, 256, 2)
+for s_, live in rows[-2:]:
+    dt_rt = (v[s_][live][:, 2] - v[s_][live][:, 1]) / 100.0          # us
+    dt_ck = c[s_][live][:, 1] - c[s_][live][:, 0]
+    print("slot %2d  shader clock during the f/g phase: %.0f MHz (mean of %d workgroups; %.0f clocks in %.2f us)" %
+          (s_, (dt_ck / dt_rt).mean(), live.sum(), dt_ck.mean(), dt_rt.mean()))
