@@ -48,7 +48,11 @@ template <int NT> struct NtCfg { static constexpr int WAVES = NT == 4 ? 8 : 16; 
 #ifdef FW_DBG
 // developer build (tools/fw_spans.py): start / end of every workgroup of the last 64 launches on the 100 MHz realtime clock
 __device__ unsigned long long fw_dbg[64 * 256 * 8];
+__device__ unsigned long long fw_clk[64 * 256 * 2];      // shader clock (s_memtime) at the f/g phase's start and end
 static int fw_dbg_slot = 0;
+extern "C" int wn_fw_clk_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fw_clk), sizeof(unsigned long long) * 64 * 256 * 2);
+}
 extern "C" int wn_fw_dbg_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fw_dbg), sizeof(unsigned long long) * 64 * 256 * 8);
 }
@@ -168,6 +172,7 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
 #ifdef FW_DBG
     __builtin_amdgcn_sched_barrier(0);
     if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && dbg_wg < 256) fw_clk[((size_t)a.n_d_dbg * 256 + dbg_wg) * 2] = __builtin_readcyclecounter();
     __builtin_amdgcn_sched_barrier(0);
 #endif
 
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
 #ifdef FW_DBG
     __builtin_amdgcn_sched_barrier(0);
     if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && dbg_wg < 256) fw_clk[((size_t)a.n_d_dbg * 256 + dbg_wg) * 2 + 1] = __builtin_readcyclecounter();
     __builtin_amdgcn_sched_barrier(0);
 #endif
     if (!ENC && a.cond) {       // per-(channel, time-bucket) conditioning bias, gathered from a tiny table
