@@ -103,6 +103,9 @@ struct WnResPqArgs {
     const float* cond; long cond_bstride; int cond_pitch;  // conditioning table as in WnResArgs (null: none)
     int cond_mode, cond_le, cond_q;
     float* dfg; long dfg_bstride;                          // optional: [df;dg] written out as well ([B][2CH][pitch]); null: not
+#ifdef PQ_SPAN
+    int span_slot;                                      // developer build: slot of this launch in the span log
+#endif
 };
 int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st);
 int wn_launch_split16(const float* x, uint16_t* hi, uint16_t* lo, long n, int is_bf16, hipStream_t st);

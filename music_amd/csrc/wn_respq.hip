@@ -58,6 +58,18 @@ __device__ __forceinline__ void pq_split2(float a, float b, uint32_t& hi, uint32
 #define PQ_W (2 * PQ_STAGE)
 #define PQ_LDS_HALFS (PQ_W + 32768)
 
+#ifdef PQ_SPAN
+// developer build (tools/pq_spans.py): realtime-clock (100 MHz) stamps of every workgroup of the last 64 launches:
+// [start, R first barrier, R loop end, W first barrier, W loop end, end (slab stores issued), n_items, -]
+__device__ unsigned long long pq_span[64 * 256 * 8];
+static int pq_span_slot = 0;
+extern "C" int wn_pq_span_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pq_span), sizeof(unsigned long long) * 64 * 256 * 8);
+}
+#define PQ_STAMP(i) do { if (lane == 0 && (wv == 0 || wv == 4) && blockIdx.x < 256) pq_span[((size_t)a.span_slot * 256 + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PQ_STAMP(i)
+#endif
 #ifdef PQ_DBG
 // phase clock sums (developer build, tools/pq_clocks.py): [R: fill_x, recompute, gate+put, barrier | W: fill_dy, wgrad, pq, store, convert, barrier]
 __device__ unsigned long long pq_dbg[16];
@@ -99,6 +111,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     const int g = wv & 3;
     const int c = lane & 15, q = lane >> 4;
     const int tile_rd = (16 * q + (c ^ pq_k(q))) * 8;            // halfs; chunk q of row c (a 16-byte row read)
+    if (wv == 0) PQ_STAMP(0);
 #ifdef PQ_DBG
     unsigned long long dbg_acc[16] = {};
 #endif
@@ -135,7 +148,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     };
 
     // the packed [W1^T; W0^T] weights (32 fragments x 2 KB) and zeros in the result tiles of stage 1 (multiplied once
-    // before anything was written to them)
+    // before anything was written to them).  (Requested by LDS-DMA from the W waves instead and first used in iteration
+    // 1: the first barrier stays 6 us after the workgroup's start - it waits for the first item's rows, not for these.)
     {
         const u32x4* src = reinterpret_cast<const u32x4*>(a.wpq);
         u32x4* dst = reinterpret_cast<u32x4*>(lds + PQ_W);
@@ -319,6 +333,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         load_x(x0, pos_k(2));
         load_dy(rd, pos_k(1));
         __syncthreads();                                    // stage 0 operands of the first item, the weights, the zeros
+        if (wv == 0) PQ_STAMP(1);
         auto r_body = [&](const int it, f32x2* cr, RawX& rx) {
 #ifndef PQ_NO_VOIDSKIP
             if (it >= n_items) {
@@ -464,6 +479,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             const int n_even = (n_items + 1) & ~1;
             if (pos_k(n_even - 1).live) pq_half((n_even - 1) & 1, 1, pos_k(n_even - 1), nullptr);      // Q rows of the last item
         }
+        if (wv == 0) PQ_STAMP(2);
         __syncthreads();                                    // the W waves' extra round (products of the last item)
         PQ_FLUSH(0, 4);
         return;
@@ -589,6 +605,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         load_rows(rr2, pos_k(1));
         convert(ops, rr, pos_k(-1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
         __syncthreads();
+        if (wv == 4) PQ_STAMP(3);
         // iteration it: products of item it-1 (result tiles of stage (it-1)&1, operands in `ops`); then the raw rows of
         // item it become `ops` and the rows of item it+2 are requested (loop unrolled by two: no register copies)
         auto w_body = [&](const int it, RawRows& rr) {
@@ -609,6 +626,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, rr2); }
         if (pos_k(n_even - 1).live) products((n_even - 1) & 1, ops, pos_k(n_even - 1));    // the last item, unless it is the void one
         __syncthreads();
+        if (wv == 4) PQ_STAMP(4);
         PQ_FLUSH(4, 6);
     }
 
@@ -629,6 +647,12 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             for (int i = 0; i < 4; ++i)
                 __builtin_nontemporal_store(cd[m][i], &sd[(size_t)(16 * g + c) * CH + 16 * m + 4 * q + i]);
     }
+    if (wv == 4) {
+        PQ_STAMP(5);
+#ifdef PQ_SPAN
+        if (lane == 0 && blockIdx.x < 256) pq_span[((size_t)a.span_slot * 256 + blockIdx.x) * 8 + 6] = (unsigned long long)n_items;
+#endif
+    }
 }
 
 int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
@@ -638,6 +662,10 @@ int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
     wn_resrw_plan(a.t_lo, a.t_hi, batch, k.t_base, k.steps_per_clip, k.items_per_wg, nwg);      // same items and slabs as wn_resrw.hip
     k.batch = batch;
     k.swz = wn_xcd_swizzle_enabled();
+#ifdef PQ_SPAN
+    k.span_slot = pq_span_slot;
+    pq_span_slot = (pq_span_slot + 1) & 63;
+#endif
     const size_t sh = (size_t)PQ_LDS_HALFS * sizeof(uint16_t);
     static unsigned long long done = 0;
     int dev = 0;
