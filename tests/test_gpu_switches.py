@@ -53,3 +53,33 @@ def test_decode_generic_kernel_stays_correct():
            os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", "(decode or generat) and not eight_per_pair and not full_size"]
     r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_forward_epilogue_chains_give_the_same_bits(bias, monkeypatch):
+    """The skip product and the two post-processing products run as per-clip-group chains on two streams (WN_EPI_SPLIT,
+    default 2; read at every call): every clip goes through the same tiles whatever the grouping, so probabilities, loss
+    and gradients must be bit-identical for 1 chain, 2, and 3 (ragged groups of a batch of 3)."""
+    import numpy as np
+    import torch
+    from music_amd.model import wavenet
+    from tests.helpers import scrambled_input
+    cfg = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 32], dilation_channels=64, residual_channels=64,
+               skip_channels=96, quantization_channels=256, use_bias=bias)
+    torch.manual_seed(21)
+    net = wavenet(**cfg).cuda()
+    rng = np.random.default_rng(22)
+    T = net.receptive_field + 700
+    x = scrambled_input(rng.integers(0, 256, size=(3, T))).cuda()
+    target = torch.from_numpy(rng.integers(0, 256, size=(3 * 701,)).astype(np.int64)).cuda()
+    got = {}
+    for split in ("1", "2", "3"):
+        monkeypatch.setenv("WN_EPI_SPLIT", split)
+        probs = net(x).detach().clone()
+        eng = net._engine
+        loss = eng.loss_and_grad(x, target)
+        torch.cuda.synchronize()
+        got[split] = (probs, loss.clone(), eng.flat_grad.clone())
+    for split in ("2", "3"):
+        for a, b in zip(got["1"], got[split]):
+            assert torch.equal(a, b), split
