@@ -31,3 +31,18 @@ for i, (s, live) in enumerate(rows):
     gap = (v[rows[i + 1][0]][rows[i + 1][1]][:, 0].min() - last_end) / 100.0 if i + 1 < len(rows) else float("nan")
     print("%4d   %4d %5.1f | %5.2f | " % (i, live.sum(), v[s][live][:, 6].mean(), (st.max() - st.min()) / 100.0) +
           " | ".join("%6.2f" % x for x in d.mean(axis=0)) + " | %6.2f | %5.2f" % ((last_end - t0) / 100.0, gap))
+# which workgroups are the slow ones? (last whole launch of the list)
+s, live = rows[-2]
+ids = np.nonzero(live)[0]
+dur = (v[s][live][:, 5] - v[s][live][:, 0]) / 100.0
+loop = (v[s][live][:, 4] - v[s][live][:, 3]) / 100.0
+startd = (v[s][live][:, 0] - v[s][live][:, 0].min()) / 100.0
+print("by XCD (block id mod 8): mean duration / mean loop / mean start delay, us")
+for x in range(8):
+    m = (ids % 8) == x
+    print("  xcd-group %d: n %3d  dur %6.2f  loop %6.2f  start +%4.2f  max dur %6.2f" % (x, m.sum(), dur[m].mean(), loop[m].mean(), startd[m].mean(), dur[m].max()))
+o = np.argsort(-dur)[:12]
+print("slowest workgroups (block id, items, duration, loop, start delay):")
+for k in o:
+    print("  %3d  items %2d  %6.2f  %6.2f  +%4.2f" % (ids[k], int(v[s][live][k, 6]), dur[k], loop[k], startd[k]))
+print("fastest: %.2f  median %.2f  p90 %.2f  max %.2f" % (dur.min(), np.median(dur), np.percentile(dur, 90), dur.max()))
