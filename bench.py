@@ -497,7 +497,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (f16/bf16 2-term split operands, 3 MFMA per product, f32 accumulate)" if x3 else args.precision,
+        "dtype": "f32 (forward + recompute: f16 2-term split operands, 2^-22 per element; backward products: bf16 2-term split, 2^-17 per element, f32 range; 3 MFMA per product, f32 accumulate)" if x3 else args.precision,
         "data": "synthetic",
         "rccl_ranks": world if use_dist else 0, "backend": (dist.get_backend() if use_dist else "none"),
         "config": {"workload": "BASELINE configs[1]: 30-layer (3x dilations 1..512) WaveNet, 64 res/dil, 256 skip, "

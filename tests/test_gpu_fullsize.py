@@ -13,16 +13,22 @@ per-XCD interleaved orders and slab counts that depend on the size, so gradients
 
 Run with -m gpu.  Probabilities: 1e-3 absolute on gain-scaled weights, integers exact, as tests/test_gpu_parity.py.
 
-Gradients at these sizes are sums over 26 k - 160 k columns of terms that mostly cancel, and the REFERENCE's own float32
-arithmetic is not reproducible to 2e-3 there: evaluated in float64, the same algorithm moves every gradient tensor by
-2e-3 ... 5e-2 of its max-abs (tools/diag_fullsize.py: config 2 at 2 x 16000, gain 2.5: float32 CPU 3.7e-2, this path
-1.2e-2).  So the yardstick here is the float64 oracle: a gradient passes when its error against float64 is within
-FULL_GRAD_RTOL = 3e-2 of the tensor's max-abs - the level of the float32 CPU path's own worst tensors above - or
-within 3x the error the float32 CPU path itself makes on that tensor.  (Where this path is LESS accurate than float32:
-the bf16 hi/lo operands of the backward products carry 2^-17 per element, so a gradient whose terms cancel by a factor
-C loses C x 2^-17 of its max-abs.  Measured: 2.5e-3 on well-conditioned config-2 sums, 5e-3 on the autoencoder's
-encoder weights, 1.0e-2 on the autoencoder's skip weights (C ~ 3000: dU is a zero-mean softmax gradient summed over
-26 k columns), where float32 makes 2e-4.  A scaled-f16 split of the gradient operand would give 2^-22; not done.)  What that bar cannot see - a dropped tile at a clip or workgroup boundary moves a sum by ~1e-3 - is caught by a
+Gradients at full size, and what the comparison has to hold fixed (round 3, tools/diag_stage.py + tools/emu_bwd.py).
+Round 2 compared with the float64 oracle at 3e-2 of a tensor's max-abs, because this path sat 2.5e-3 off float64 on a
+well-conditioned ("aligned") batch where the float32 CPU path sits 8e-6 off, and blamed the bf16 hi/lo operands of the
+backward.  That was the wrong culprit.  Measured on the device, every backward kernel reproduces float64 evaluated ON
+ITS OWN INPUTS to 5e-6 ... 1.5e-5 of its output's max-abs, and the operand-rounding emulation of the whole backward in
+float64 puts the bf16 split at 3e-5 (the float32 CPU path: 2.7e-5).  The 2.5e-3 comes from 14 + 16 of the 13 M
+pre-activations of the two post-processing ReLUs (model.py:135,137) that lie within 8e-6 of zero: this path's forward
+and the float64 forward disagree on their SIGN (both are within 1e-5 of each other there - any two correct float32
+forwards do this; the float32 CPU path happened to flip none on that batch and flips plenty on others), and one
+flipped element of dU moves every skip-weight gradient by ~1e-3 of its max-abs.  So the reference gradient is
+evaluated with the subgradient of ReLU at |pre-activation| < RELU_EPS * max-abs chosen the way the device chose it
+(oracle `relu=` hook; a mask that differs anywhere ELSE fails the test), and the bar drops from 3e-2 to 2e-4 of a
+tensor's max-abs (or 3x the float32 CPU path's error on that tensor against float64 with ITS near-zero signs, which
+only the saturated shipped configuration needs: measured 3.4e-5 / 4.0e-5 / 6.8e-5 on aligned config 2 / random config 2 /
+config 4, where the float32 CPU path makes 1.6e-5).  What that bar cannot see - a
+dropped tile at a clip or workgroup boundary moves a sum by ~1e-3 - is also caught by a
 property with no conditioning in it: the batch gradient must equal the mean of the single-clip gradients, which the
 persistent kernels compute with a different partition of items, slabs and XCD walks (1e-4)."""
 import numpy as np
@@ -38,7 +44,9 @@ from tests.helpers import scrambled_input
 import os
 
 LOGIT_TOL = 1e-3
-FULL_GRAD_RTOL = 3e-2
+FULL_GRAD_RTOL = 2e-4           # random-target batches (or 3x the float32 CPU path's own error on that tensor)
+ALIGNED_GRAD_RTOL = 2e-4        # structured clip + constant target: the terms of every gradient sum line up
+RELU_EPS = 2e-4                 # |pre-activation| below this fraction of the tensor's max-abs: the device's sign is taken
 ORACLE_THREADS = min(32, os.cpu_count() or 1)      # ATen's CPU convs stop scaling (then collapse) beyond that
 C2 = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 3, dilation_channels=64, residual_channels=64,
           skip_channels=256, quantization_channels=256, use_bias=False)
@@ -54,9 +62,11 @@ def _scaled(net, gain):
     return {k: v.clone() for k, v in net.state_dict().items()}
 
 
-def _check_grads(got, g64, g32):
-    """got / g64 / g32: name -> gradient (this path, float64 oracle, float32 oracle).  Returns the worst (error vs f64,
-    name, the float32 path's error on that tensor)."""
+def _check_grads(got, g64, e32, rtol=FULL_GRAD_RTOL):
+    """got / g64: name -> gradient (this path, float64 oracle with the device's near-zero ReLU signs); e32: name -> the
+    float32 CPU path's error on that tensor against float64 with ITS OWN near-zero signs (the like-for-like yardstick).
+    A tensor passes within rtol of its max-abs or within 3x the float32 path's error.  Returns the worst (error, name,
+    the float32 path's error on that tensor)."""
     worst = (0.0, None, 0.0)
     for name, ref in g64.items():
         if ref is None:
@@ -64,18 +74,74 @@ def _check_grads(got, g64, g32):
             continue
         scale = max(ref.abs().max().item(), 1e-30)
         e_gpu = (got[name].detach().cpu().double() - ref).abs().max().item() / scale
-        e_cpu = (g32[name].double() - ref).abs().max().item() / scale
+        e_cpu = e32.get(name, 0.0)
         if e_gpu > worst[0]:
             worst = (e_gpu, name, e_cpu)
-        assert e_gpu <= max(FULL_GRAD_RTOL, 3.0 * e_cpu), (name, e_gpu, e_cpu)
+        assert e_gpu <= max(rtol, 3.0 * e_cpu), (name, e_gpu, e_cpu)
     return worst
 
 
-def _oracle_grads_f32_f64(params, dilations, x, target):
+def _device_relu(dev_pre):
+    """Oracle `relu=` hook that follows the DEVICE's sign where the reference pre-activation is within RELU_EPS of zero
+    (relative to the tensor's max-abs) and insists on equal signs everywhere else.  dev_pre: name -> the device's own
+    pre-activation (CPU tensor, the reference's shape).  Returns (hook, stats)."""
+    stats = dict(near=0, flips=0)
+
+    def relu(name, t):
+        d = dev_pre[name]
+        assert d.shape == t.shape, (name, d.shape, t.shape)
+        eps = RELU_EPS * t.detach().abs().max().item()
+        near = t.detach().abs() < eps
+        ref_m, dev_m = t.detach() > 0, d > 0
+        assert not ((ref_m != dev_m) & ~near).any(), "ReLU mask of %s differs outside the tolerance band" % name
+        stats["near"] += int(near.sum())
+        stats["flips"] += int(((ref_m != dev_m) & near).sum())
+        return t * torch.where(near, dev_m, ref_m).to(t.dtype)
+    return relu, stats
+
+
+def _c2_dev_pre(eng, ws):
+    """the device's pre-ReLU skip sum and post_process_1 output, (B, S, W) each"""
+    from music_amd.engine import SLACK
+    B, pitch, T, lo = ws["B"], ws["pitch"], ws["T"], eng.rf - 1
+    v = lambda buf: buf[SLACK:SLACK + B * eng.SP * pitch].view(B, eng.SP, pitch)[:, :eng.S, lo:T].cpu()
+    return {"skip_sum": v(ws["U"]), "post_process_1": v(ws["H"])}
+
+
+def _c4_dev_pre(aeng, B, T):
+    """the autoencoder's pre-ReLU tensors on the device, in the oracle's shapes and names (autoencoder_encode / _decode)"""
+    from music_amd.engine import SLACK
+    ws = aeng.workspace(B, T)
+    pitch, lo, N = ws["pitch"], aeng.rf - 1, aeng.N
+    xe = ws["Xe"][SLACK:SLACK + (N + 1) * B * aeng.CHe * pitch].view(N + 1, B, aeng.CHe, pitch)
+    he = ws["He"][SLACK:SLACK + N * B * aeng.CHe * pitch].view(N, B, aeng.CHe, pitch)
+    pre = {}
+    for i in range(N):
+        pre["en_x%d" % i] = xe[i][:, :aeng.Re, aeng.off[i]:T].cpu()
+        pre["en_h%d" % i] = he[i][:, :aeng.De, aeng.off[i + 1]:T].cpu()
+    v = lambda buf: buf[SLACK:SLACK + B * aeng.SP * pitch].view(B, aeng.SP, pitch)[:, :aeng.Sd, lo:T].cpu()
+    pre["de_skip"], pre["de_conn"] = v(ws["U"]), v(ws["R1"])
+    return pre
+
+
+def _oracle_grads_f32_f64(params, dilations, x, target, dev_pre):
+    """-> (float32 loss, float32 probs, e32, float64 loss, g64): g64 = float64 gradients with the DEVICE's signs at the
+    near-zero ReLU pre-activations; e32[name] = error of the float32 CPU path against float64 with the float32 path's
+    own signs there (two float64 passes)."""
     torch.set_num_threads(ORACLE_THREADS)
-    l32, p32, g32 = wo.loss_and_grads(params, dilations, x, target)
-    l64, p64, g64 = wo.loss_and_grads({k: v.double() for k, v in params.items()}, dilations, x.double(), target)
-    return l32, p32, g32, l64, g64
+    inter = {}
+    l32, p32, g32 = wo.loss_and_grads(params, dilations, x, target, intermediates=inter)
+    cpu_pre = {k: inter[k].detach() for k in ("skip_sum", "post_process_1")}
+    del inter
+    p64 = {k: v.double() for k, v in params.items()}
+    relu, stats = _device_relu(dev_pre)
+    l64, _, g64 = wo.loss_and_grads(p64, dilations, x.double(), target, relu=relu)
+    relu_c, stats_c = _device_relu(cpu_pre)
+    _, _, g64c = wo.loss_and_grads(p64, dilations, x.double(), target, relu=relu_c)
+    e32 = {n: (g32[n].double() - g64c[n]).abs().max().item() / max(g64c[n].abs().max().item(), 1e-30) for n in g64c}
+    print("  ReLU pre-activations inside the tolerance band: %d; sign differs from float64's on the device at %d, in the float32 CPU path at %d" %
+          (stats["near"], stats["flips"], stats_c["flips"]))
+    return l32, p32, e32, l64, g64
 
 
 def test_c2_full_length_loss_and_gradients_vs_oracle():
@@ -98,7 +164,7 @@ def test_c2_full_length_loss_and_gradients_vs_oracle():
     loss = eng.loss_and_grad(xd, target.cuda(), want_probs=True)
     probs = eng.workspace(B, T)["probs"].cpu()
     got = {n: eng.param_view(n, grad=True).clone() for n in eng.param_names}
-    l_ref, p_ref, g32, l64, g64 = _oracle_grads_f32_f64(params, C2["dilations"], x, target)
+    l_ref, p_ref, g32, l64, g64 = _oracle_grads_f32_f64(params, C2["dilations"], x, target, _c2_dev_pre(eng, eng.workspace(B, T)))
     e_p = (probs - p_ref).abs().max().item()
     assert probs.shape == (B * W, 256) and e_p <= LOGIT_TOL, e_p
     assert p_ref.max().item() > 0.5                       # non-vacuous
@@ -122,6 +188,67 @@ def test_c2_full_length_loss_and_gradients_vs_oracle():
         k = int(np.prod(shp))
         a1, a2 = g1[o:o + k], acc[o:o + k]
         assert (a1 - a2).abs().max().item() <= 1e-4 * max(a1.abs().max().item(), 1e-30), n
+
+
+def _aligned_batch(B, T, W):
+    """structured clip (period-7 pattern, a different phase per clip) + constant target: the terms of every gradient
+    sum line up instead of cancelling, so the comparison resolves 2^-17 from 2^-22 arithmetic (tools/diag_fullsize.py)"""
+    codes = (np.arange(T)[None, :] * 37 % 7 * 31 + 11 + np.arange(B)[:, None]) % 256
+    return codes, torch.from_numpy(np.full((B * W,), 7, dtype=np.int64))
+
+
+@pytest.mark.parametrize("case", ["c2", "shipped"])
+def test_aligned_full_length_gradients_vs_oracle(case):
+    """The discriminating gradient test: a well-conditioned full-length batch, every gradient
+    within ALIGNED_GRAD_RTOL = 2e-4 of its tensor's max-abs against the float64 oracle."""
+    from music_amd.model import wavenet
+    cfg, gain, seed, T = (C2, 2.5, 3, 16000) if case == "c2" else (SHIPPED, 3.0, 7, 4094 + 3999)
+    torch.manual_seed(seed)
+    net = wavenet(**cfg)
+    params = _scaled(net, gain)
+    net = net.cuda()
+    B = 2
+    W = T - net.receptive_field + 1
+    codes, target = _aligned_batch(B, T, W)
+    x = scrambled_input(codes)
+    eng = net._engine_for(torch.device("cuda", 0))
+    loss = eng.loss_and_grad(x.cuda(), target.cuda(), want_probs=True)
+    got = {n: eng.param_view(n, grad=True).clone() for n in eng.param_names}
+    l_ref, p_ref, g32, l64, g64 = _oracle_grads_f32_f64(params, cfg["dilations"], x, target, _c2_dev_pre(eng, eng.workspace(B, T)))
+    assert abs(loss.item() - l64.item()) < 1e-5
+    worst, name, cpu = _check_grads(got, g64, g32, ALIGNED_GRAD_RTOL)
+    print("aligned %s (2 x %d): loss %.7f (f64 %.7f), worst grad err vs f64 %.2e (%s; the float32 CPU path on that tensor: %.2e)" %
+          (case, T, loss.item(), l64.item(), worst, name, cpu))
+
+
+def test_gradient_operands_have_no_range_limit():
+    """The gradient operands of the backward are split in bf16, which has float32's exponent range: a loss scaled by
+    2^-32 ... 2^+32 must give the SAME gradient bits times that power of two (an f16 split would underflow / overflow;
+    VERDICT r2 next #1c asks for exactly this guard), on gain-scaled weights whose |d logits| span more than 2^20."""
+    from music_amd.model import wavenet
+    torch.manual_seed(11)
+    net = wavenet(**C2)
+    _scaled(net, 3.0)
+    net = net.cuda()
+    B, T = 1, 4000
+    rng = np.random.default_rng(12)
+    eng = net._engine_for(torch.device("cuda", 0))
+    x = eng.onehot(torch.from_numpy(rng.integers(0, 256, size=(B, T)).astype(np.int32)).cuda(), scrambled=True)
+    W = T - net.receptive_field + 1
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).cuda()
+    probs, ws = eng.forward(x)
+    p = probs.detach().clone().requires_grad_(True)
+    torch.nn.functional.cross_entropy(p, target).backward()
+    dprobs = p.grad
+    eng.backward(ws, dprobs)
+    g0 = eng.flat_grad.clone()
+    dO = ws["bwd"]["dO"][:B * 256 * W].abs()
+    span = (dO.max() / dO[dO > 0].min()).log2().item()
+    assert span >= 20, span
+    for k in (-32, -16, 16, 32):
+        eng.backward(ws, dprobs * 2.0 ** k)
+        assert torch.equal(eng.flat_grad * 2.0 ** (-k), g0), k
+    print("gradient bits invariant under loss scales 2^-32 .. 2^32; |d logits| span 2^%.1f" % span)
 
 
 def test_c4_full_size_autoencoder_vs_oracle():
@@ -154,6 +281,7 @@ def test_c4_full_size_autoencoder_vs_oracle():
     probs = net(x.cuda())
     loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
     loss.backward()
+    dev_pre = _c4_dev_pre(net._engine_for(torch.device("cuda", 0)), B, T)
     torch.set_num_threads(ORACLE_THREADS)
     torch.manual_seed(77)
     cond = wo.draw_conditioning(len(cfg["dilations"]), cfg["en_bottleneck_width"], cfg["de_dilation_channel"],
@@ -164,8 +292,10 @@ def test_c4_full_size_autoencoder_vs_oracle():
     l_ref = torch.nn.functional.cross_entropy(p_ref, target)
     g32 = dict(zip(leaf.keys(), torch.autograd.grad(l_ref, list(leaf.values()), allow_unused=True)))
     leaf64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    relu, stats = _device_relu(dev_pre)
     p64, _ = wo.autoencoder_forward(leaf64, cfg["dilations"], x.double(), cfg["en_pool_kernel_size"],
-                                    [(w.double(), b.double()) for w, b in cond])
+                                    [(w.double(), b.double()) for w, b in cond], relu=relu)
+    print("  ReLU pre-activations inside the tolerance band: %d, of which the device's sign differs: %d" % (stats["near"], stats["flips"]))
     l64 = torch.nn.functional.cross_entropy(p64, target)
     g64 = dict(zip(leaf64.keys(), torch.autograd.grad(l64, list(leaf64.values()), allow_unused=True)))
     e_enc = (net.last_encoding.cpu() - enc_ref.detach()).abs().max().item()
@@ -174,7 +304,7 @@ def test_c4_full_size_autoencoder_vs_oracle():
     assert abs(loss.item() - l_ref.item()) < 1e-4
     got = {name: p.grad for name, p in net.named_parameters()}
     assert list(got.keys()) == list(g64.keys())
-    worst, worst_name, cpu = _check_grads(got, g64, {k: (torch.zeros_like(params[k]) if v is None else v) for k, v in g32.items()})
+    worst, worst_name, cpu = _check_grads(got, g64, {})            # fixed bar (the float32 path is not consulted here)
     print("c4 full size (2 x 16000, Le 25, %d stretch / %d tile layers): enc err %.2e probs err %.2e (max p %.3f) "
           "worst grad err vs f64 %.2e (%s; the float32 CPU path: %.2e)" %
           (sum(stretch), len(stretch) - sum(stretch), e_enc, e_p, p_ref.max().item(), worst, worst_name, cpu))
@@ -287,7 +417,7 @@ def test_shipped_config_forward_and_gradients_vs_oracle():
     loss = eng.loss_and_grad(x.cuda(), target.cuda(), want_probs=True)
     probs = eng.workspace(B, T)["probs"].cpu()
     got = {n: eng.param_view(n, grad=True).clone() for n in eng.param_names}
-    l_ref, p_ref, g32, l64, g64 = _oracle_grads_f32_f64(params, SHIPPED["dilations"], x, target)
+    l_ref, p_ref, g32, l64, g64 = _oracle_grads_f32_f64(params, SHIPPED["dilations"], x, target, _c2_dev_pre(eng, eng.workspace(B, T)))
     e_p = (probs - p_ref).abs().max().item()
     assert e_p <= LOGIT_TOL and p_ref.max().item() > 0.3, (e_p, p_ref.max().item())
     assert abs(loss.item() - l_ref.item()) < 1e-4
