@@ -11,7 +11,6 @@ gradient all-reduce (N > 1) + Adam, i.e. wavenet/train.py:171-182 of the referen
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -31,12 +30,10 @@ def _self_launch():
     known, _ = ap.parse_known_args()
     if known.gpus <= 1:
         return
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(known.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun picks AND holds the rendezvous port itself (a bind / close / hand-over of a "free" port
+    # can lose it to another process in between)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(known.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this host driver)
     env.setdefault("OMP_NUM_THREADS", "8")
@@ -81,6 +78,19 @@ def stack_bytes(dil, r, d, b, t):
     w = L[-1]
     fwd = 4 * sum(r * L[i] + r * L[i + 1] + d * w for i in range(len(dil)))
     bwd = 4 * sum(r * L[i + 1] + r * L[i] + d * w + r * L[i] for i in range(len(dil)))
+    return fwd * b, bwd * b
+
+
+def enc_stack_bytes(dil, r, d, b, t):
+    """Algorithmic bytes of the autoencoder's ENCODER stack (wavenet_autoencoder/model1.py:137-152), fp32, layer at a
+    time, every tensor touched once - the same accounting as SURVEY 8(d) uses for the decoder stack.  Forward per
+    block: read x_i, write x_{i+1}, write the pre-activation h_i (the backward needs it); backward: read dx_{i+1}, x_i
+    (ReLU mask and weight-gradient operand) and h_i, write dx_i."""
+    L = [t - 1]
+    for x in dil:
+        L.append(L[-1] - x)
+    fwd = 4 * sum(r * L[i] + r * L[i + 1] + d * L[i + 1] for i in range(len(dil)))
+    bwd = 4 * sum(r * L[i + 1] + r * L[i] + d * L[i + 1] + r * L[i] for i in range(len(dil)))
     return fwd * b, bwd * b
 
 
@@ -197,9 +207,34 @@ def sub_benchmarks(net, x, target):
         loss = ae_step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
+    # phase table + roofline of its two stacks: 3 more steps with HIP events between the phases
+    aeng.marks = []
+    for _ in range(3):
+        ae_step()
+    torch.cuda.synchronize()
+    m, aeng.marks = aeng.marks, None
+    ph = {}
+    for (n0, e0), (n1, e1) in zip(m[:-1], m[1:]):
+        if n1 != "begin":
+            ph[n1] = ph.get(n1, 0.0) + e0.elapsed_time(e1) / 3
+    df, db_ = stack_bytes(CFG["dilations"], 64, 64, B_LOCAL, T)
+    ef, eb_ = enc_stack_bytes(CFG["dilations"], 64, 64, B_LOCAL, T)
+    st_ms = sum(ph.get(k, float("nan")) for k in ("enc_stack_fwd", "dec_stack_fwd", "dec_stack_bwd", "enc_stack_bwd"))
+    frac = lambda nbytes, ms: nbytes / (ms * 1e-3) / 8e12 if ms == ms and ms > 0 else None
     out["c4_autoencoder"] = {"workload": "BASELINE configs[3]: autoencoder 30+30 blocks, 64 ch, 256 skip, bottleneck 64, pool 512, "
                                          "batch 8x16000, fused step (fwd + CE + bwd + Adam), 5 steps after 2 warm-up",
-                             "ms_per_step": dt * 1e3, "samples_per_s": B_LOCAL * T / dt, "final_loss": float(loss.item())}
+                             "ms_per_step": dt * 1e3, "samples_per_s": B_LOCAL * T / dt, "final_loss": float(loss.item()),
+                             "phase_ms_per_step": {k: round(v, 4) for k, v in ph.items()},
+                             "roofline_stacks": {
+                                 "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+                                 "algorithmic_bytes_per_step": {"decoder_fwd": df, "decoder_bwd": db_, "encoder_fwd": ef, "encoder_bwd": eb_},
+                                 "frac_decoder_fwd": frac(df, ph.get("dec_stack_fwd", float("nan"))),
+                                 "frac_decoder_bwd": frac(db_, ph.get("dec_stack_bwd", float("nan"))),
+                                 "frac_encoder_fwd": frac(ef, ph.get("enc_stack_fwd", float("nan"))),
+                                 "frac_encoder_bwd": frac(eb_, ph.get("enc_stack_bwd", float("nan"))),
+                                 "frac": frac(df + db_ + ef + eb_, st_ms), "stacks_ms": st_ms,
+                                 "note": "decoder stack: SURVEY 8(d) A_f / A_b; encoder stack: the same accounting (enc_stack_bytes); the "
+                                         "decoder backward also stores [df;dg] for the conditioning gradient, not counted"}}
     del ae, aeng
     from music_amd import fast_generate as fg
     start = torch.zeros(1, 256, net.receptive_field, device=dev)
@@ -229,6 +264,77 @@ def sub_benchmarks(net, x, target):
     return out
 
 
+def surface_benchmarks(net, eng, piece, target):
+    """What a caller of the REFERENCE SURFACE gets: the loop of wavenet/train.py:171-182 as written -
+    optimizer.zero_grad(), net(x), nn.CrossEntropyLoss on the probabilities, backward(), torch.optim.Adam.step() - at
+    8 x 16000, on (a) the loader's one-hot (carries its codes: the causal layer runs on them) and (b) a plain dense
+    (B, 256, T) float tensor; and the fused engine step captured in ONE hipGraph next to its eager time."""
+    out = {}
+    B, W = piece.shape[0], target.numel() // piece.shape[0]
+    ce = torch.nn.CrossEntropyLoss()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    x_tag = eng.onehot(piece, scrambled=True)
+    x_plain = x_tag.clone()                                    # a copy loses the tag: the dense path
+
+    def ref_step(x):
+        opt.zero_grad()
+        loss = ce(net(x), target)
+        loss.backward()
+        opt.step()
+        return loss
+    for name, x in (("loader_onehot", x_tag), ("dense_tensor", x_plain)):
+        for _ in range(3):
+            ref_step(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            loss = ref_step(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        out[name] = {"ms_per_step": dt * 1e3, "samples_per_s": B * piece.shape[1] / dt, "loss": float(loss.item())}
+    out["workload"] = ("the reference's own training loop (wavenet/train.py:171-182: zero_grad, net(x), CrossEntropyLoss on the "
+                       "probabilities, backward, torch.optim.Adam) on this nn.Module at 8 x 16000, input resident, 10 steps after 3")
+    del x_tag, x_plain, opt
+
+    def fused():
+        loss = eng.loss_and_grad_codes(piece, target, scrambled=True)
+        eng.adam_step()
+        return loss
+    for _ in range(3):
+        fused()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        fused()
+    torch.cuda.synchronize()
+    eager = (time.perf_counter() - t0) / 20
+    g = torch.cuda.CUDAGraph()
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    try:
+        with torch.cuda.stream(s_):
+            fused()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s_):
+                fused()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize()
+        graphed = (time.perf_counter() - t0) / 20
+        out["hipgraph_step"] = {"eager_ms": eager * 1e3, "graph_replay_ms": graphed * 1e3,
+                                "note": "the fused step (resident batch, no H2D) eager vs captured in one hipGraph (main + side streams); the "
+                                        "replay serialises what the two streams overlap - the step is GPU-bound, not launch-bound; Adam's "
+                                        "bias-correction scalars are frozen in the capture (timing only)"}
+    except Exception as e:                                     # capture is a diagnostic: never fail the bench on it
+        out["hipgraph_step"] = {"eager_ms": eager * 1e3, "error": repr(e)[:200]}
+    return out
+
+
 def measured_copy_gbs():
     """Device-to-device copy rate (read + write bytes / time) of a 1 GiB buffer, best of 5."""
     n = 1 << 28
@@ -254,6 +360,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)          # discard 10 warm-up steps, time >= 50
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle", type=int, default=60, help="discarded steps before the warm-up (one-time costs of a fresh box)")
     ap.add_argument("--precision", default="f16x3,bf16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-4 / config-5 sub-benchmarks")
@@ -362,6 +469,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Settle phase, before the W warm-up steps: the first GPU process on a fresh box pays one-time costs well past its
+    # tenth step (code-object loads, workspace allocation, the first timing events of the sampled marks, the copy stream's
+    # first transfers: 25-step windows read 5.3-5.7, then 4.24 ms from the second window on, tools/settle_probe.py), and
+    # the metric is STEADY-STATE throughput.  The settle steps run the timed loop's own code path, sampled
+    # marks included, and are discarded; the contract's W untimed + K timed steps follow unchanged.
+    state["sampled"], state["k0"] = [], state["k"]
+    eng.mark_only = {"step_begin", "causal_fwd", "stack_fwd", "epilogue_bwd", "stack_bwd"}
+    for _ in range(args.settle):
+        loss = step()
+    barrier()
+    state["sampled"], eng.marks, eng.mark_only = None, None, None
     for _ in range(args.warmup):
         loss = step()
     barrier()
@@ -494,7 +612,7 @@ def main():
         "metric": "audio samples/sec trained (whole node), 30-layer WaveNet @16kHz",
         "value": world * B_LOCAL * T * args.steps / dt,
         "unit": "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (forward + recompute: f16 2-term split operands, 2^-22 per element; backward products: bf16 2-term split, 2^-17 per element, f32 range; 3 MFMA per product, f32 accumulate)" if x3 else args.precision,
@@ -508,7 +626,10 @@ def main():
         # time of the backward stack inside the timed region / its 30 blocks)
         "roofline": roof(bwd_b / n_layers, bwd_launch_ms,
                          kernel="%s: backward of one residual block, %d per step" % (BWD_KERNELS, n_layers),
-                         traffic=traffic_of(*BWD_PMC), algorithmic_bytes_per_launch=bwd_b / n_layers,
+                         traffic=traffic_of(*BWD_PMC),
+                         traffic_source="profiles/pmc_kernels.json: the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an EARLIER run of "
+                                        "this command (committed summary), corrected per MI355X_MICROARCH.md; not measured in this run",
+                         algorithmic_bytes_per_launch=bwd_b / n_layers,
                          avg_launch_ms=bwd_launch_ms, measured_copy_GBs=copy_gbs,
                          frac_of_measured_copy=(gbs(bwd_b / n_layers, bwd_launch_ms) / copy_gbs) if copy_gbs and bwd_ms == bwd_ms else None),
         # the dilated-conv stack of the north star, forward / backward / both (SURVEY 8d A_f, A_b)
@@ -534,6 +655,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         x = eng.onehot(bufs[0][0], scrambled=True)
         out["extra"] = sub_benchmarks(net, x, bufs[0][1])
+        del x
+        out["extra"]["reference_surface_step"] = surface_benchmarks(net, eng, bufs[0][0], bufs[0][1])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if use_dist:

@@ -33,7 +33,12 @@ def init_from_env(backend=None, force=False):
             # to run the N-rank code path on a 1-GPU box; production is nccl (= RCCL), one rank per GPU
             backend = os.environ.get("WN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            lr = lr % max(1, torch.cuda.device_count())
+            n_dev = max(1, torch.cuda.device_count())
+            if backend == "gloo":
+                lr = lr % n_dev              # several ranks may share one GPU under gloo (the 1-GPU-box tests)
+            elif lr >= n_dev:
+                raise RuntimeError("music_amd.dist: LOCAL_RANK %d but only %d GPU(s) visible - one rank per GPU under "
+                                   "RCCL (nproc-per-node too large?)" % (lr, n_dev))
             torch.cuda.set_device(lr)
         if backend == "nccl":
             dist.init_process_group(backend, device_id=torch.device("cuda", lr))
@@ -86,20 +91,29 @@ def allreduce_flat_(flat_grad, average=True, scale=1.0):
 
 
 def allreduce_gradients(params, average=True, scale=1.0):
-    """All-reduce the .grad of `params` as ONE flat bucket.  A parameter without a grad contributes zeros (a rank
-    whose shard of a ragged batch is empty ran no backward) and RECEIVES the reduced gradient, so every rank
-    issues the same collective and takes the same optimizer step."""
+    """All-reduce the .grad of `params` as ONE flat bucket.  A parameter without a grad on THIS rank contributes zeros (a
+    rank whose shard of a ragged batch is empty ran no backward) and receives the reduced gradient IF some rank had
+    one, so every rank issues the same collective and takes the same optimizer step.  A parameter that has no gradient
+    on ANY rank (frozen, unused: `requires_grad=False` or never reached) keeps `.grad = None`, as under the reference's
+    DataParallel - no optimizer state is created for it.  The "has a gradient" flags ride in the same bucket."""
     w = world()
     if w == 1:
         return
-    params = list(params)
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    ref = params[0]
+    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=ref.dtype, device=ref.device)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params] + [has])
     allreduce_flat_(flat, average, scale)
+    # (flags are scaled like the gradients: > 0 wherever a rank with a non-empty shard had one; read back - a device
+    # sync - only on a rank that is missing some gradient itself)
+    any_has = (flat[-len(params):] > 0).tolist() if any(p.grad is None for p in params) else [True] * len(params)
     o = 0
-    for p in params:
+    for p, h in zip(params, any_has):
         n = p.numel()
         if p.grad is not None:
             p.grad.copy_(flat[o:o + n].view_as(p))
-        else:
+        elif h:
             p.grad = flat[o:o + n].view_as(p).clone()
         o += n

@@ -47,6 +47,65 @@ def pack_index(weff, chained=False):
     return weff[row, k].astype(np.int32)
 
 
+class WorkspacePool:
+    """(B, T) -> workspaces of that shape.  A workspace whose activations a pending autograd node still needs is HELD
+    (hold() in the Function's forward, release() after its backward or when the graph dies): the next forward of the
+    same shape then gets ANOTHER workspace instead of overwriting it, so a module can have several forwards in flight
+    (gradient accumulation over micro-batches, the reference's autograd semantics, wavenet/model.py:86-145).  Shapes are
+    evicted one at a time, least recently used first, never one that is held."""
+    MAX_SHAPES = 4
+    MAX_PER_SHAPE = 4
+
+    def __init__(self, make):
+        from collections import OrderedDict
+        self._make = make
+        self._d = OrderedDict()
+
+    def get(self, B, T):
+        key = (B, T)
+        lst = self._d.get(key)
+        if lst is None:
+            if len(self._d) >= self.MAX_SHAPES:
+                for k, wl in self._d.items():
+                    if not any(w.get("held") for w in wl):
+                        del self._d[k]
+                        break
+            lst = self._d[key] = []
+        self._d.move_to_end(key)
+        for ws in lst:
+            if not ws.get("held"):
+                return ws
+        if len(lst) >= self.MAX_PER_SHAPE:
+            raise RuntimeError("music_amd: %d forwards of shape %s are waiting for their backward; run backward() (or drop "
+                               "the outputs) before another forward of this shape" % (len(lst), key))
+        ws = self._make(B, T)
+        lst.append(ws)
+        return ws
+
+    def clear(self):
+        self._d.clear()
+
+    def __len__(self):
+        return sum(len(v) for v in self._d.values())
+
+
+class WorkspaceHold:
+    """Keeps a workspace out of the pool's hands while an autograd node needs it; released explicitly after backward or
+    by garbage collection of the node (an output that was dropped without a backward)."""
+
+    def __init__(self, ws):
+        self.ws, self.gen = ws, ws["gen"]
+        ws["held"] = True
+
+    def release(self):
+        if self.ws is not None and self.ws.get("gen") == self.gen:
+            self.ws["held"] = False
+        self.ws = None
+
+    def __del__(self):
+        self.release()
+
+
 class _Spec:
     """Offsets of every reference parameter inside the flat buffer (state_dict order)."""
 
@@ -92,7 +151,7 @@ class WaveNetEngine:
         _lib.load()
         self._build_spec()
         self._build_packs()
-        self._ws = {}
+        self._ws = WorkspacePool(self._make_workspace)
         self._gen = 0
         self.adam_state = None
         self.marks = None            # list of (name, torch.cuda.Event) when profiling is on
@@ -300,12 +359,11 @@ class WaveNetEngine:
 
     # ------------------------------------------------------------------ workspace
     def workspace(self, B, T):
-        key = (B, T)
-        ws = self._ws.get(key)
-        if ws is not None:
-            return ws
-        if len(self._ws) >= 4:
-            self._ws.clear()
+        """The workspace the next forward of this shape will use (= the one the last forward used, unless that one is
+        still held by a pending backward: WorkspacePool)."""
+        return self._ws.get(B, T)
+
+    def _make_workspace(self, B, T):
         dev = self.device
         pitch = _pad(T, 256) + 512        # tiles of 512 columns may overhang T by < 512
         W = T - self.rf + 1
@@ -321,7 +379,10 @@ class WaveNetEngine:
         ws["H"] = buf(self.SP)
         ws["O"] = torch.zeros(B * self.Q * W + PAD_BACK, dtype=torch.float32, device=dev)
         ws["bwd"] = None
-        self._ws[key] = ws
+        # which backward blocks this workspace is planned for: decided ONCE here (slab layout, (P, Q) buffers, and whether
+        # the forward has to store z on each block's whole range for the fallback backward) - a switch flipped later
+        # takes effect with the next workspace, never half-way between a forward and its backward
+        ws["ms"], ws["pq"] = self._use_ms(), self._use_pq()
         return ws
 
     def _bwd_workspace(self, ws):
@@ -339,9 +400,9 @@ class WaveNetEngine:
         # weight-gradient slabs: every wgrad workgroup writes its partial C with plain stores,
         # one batched kernel then sums the slabs of all ops in a fixed order (deterministic)
         T, lo = ws["T"], self.rf - 1
-        ms = self._use_ms()
+        ms = ws["ms"]
         bw["ms"] = ms
-        bw["pq"] = self._use_pq()
+        bw["pq"] = ws["pq"]
         if bw["pq"]:
             bw["PQ"] = [(buf(self.CH), buf(self.CH)), (buf(self.CH), buf(self.CH))]
         ops = [("p2", lo, T, 1024), ("p1", lo, T, 1024), ("skip", lo, T, 2048)]
@@ -427,6 +488,8 @@ class WaveNetEngine:
             if (x._version == version and codes._version == cversion and codes.is_cuda and codes.dtype == torch.int32 and codes.is_contiguous() and
                     tuple(codes.shape) == (B, T)):
                 ws["x_codes"] = (codes, scrambled)
+        # what the backward re-checks: the causal layer's weight gradient is formed later from these same tensors
+        ws["x_ver"] = (None if x is None else x._version, None if ws["x_codes"] is None else ws["x_codes"][0]._version)
         # causal conv (wavenet/model.py:104): x0[t] = W0 in[t-1] + W1 in[t], t in [1,T)
         if ws["x_codes"] is not None:
             # the input is the one-hot of known codes: a gather of weight columns (the dense tensor is not read)
@@ -444,7 +507,7 @@ class WaveNetEngine:
         # it on the CU.  Only the fallback backward (resblock_bwd_k + wgrad_k: 32 padded channels, x1 modes) reads the
         # forward's z for dWd on the block's whole valid range [off_{i+1}, T) (19 % more z; it saves that path a second
         # copy written by its recompute kernel).
-        z_whole = self.z_from_fwd and not self._use_ms()
+        z_whole = self.z_from_fwd and not ws["ms"]
         for i, d in enumerate(self.dil):
             bn = "dilation_layer_stack.%d.bias"
             call("wn_resblock_fwd", self._x(ws, i), self._x(ws, i + 1), ptr(ws["Z"], SLACK + i * CH * pitch), xb, zb, pitch,
@@ -681,8 +744,19 @@ class WaveNetEngine:
         x = ws["x_in"]
         dx0 = ptr(bw["dX"][0], SLACK)
         desc = bw["slab_desc"]
-        if ws.get("x_codes") is not None:
-            codes, scrambled = ws["x_codes"]
+        # the input (and the codes it was built from) must still be what the forward saw: in-place writes that bump the
+        # version counter are caught here (autograd's own rule for saved tensors); writes that do not (x.data.zero_(), a
+        # raw-pointer kernel) cannot be - onehot() documents the tensor as immutable while tagged
+        xv, cv = ws.get("x_ver", (None, None))
+        if x is not None and xv is not None and x._version != xv:
+            raise RuntimeError("music_amd: the input of this forward was modified in place before backward()")
+        x_codes = ws.get("x_codes")
+        if x_codes is not None and cv is not None and x_codes[0]._version != cv:
+            if x is None:
+                raise RuntimeError("music_amd: the integer codes of this forward were modified in place before backward()")
+            x_codes = None                  # the dense tensor is intact: the dense weight-gradient product
+        if x_codes is not None:
+            codes, scrambled = x_codes
             call("wn_causal_wgrad_codes", ptr(codes), 1 if scrambled else 0, dx0, None, 0, 0, xb, pitch, CH, Q, T, B,
                  ptr(bw["slab"], plan["causal_codes"][0]), st)
             desc = bw["slab_desc_codes"]
@@ -748,7 +822,13 @@ class WaveNetEngine:
         self.mark("adam")
 
     def onehot(self, codes, scrambled=True):
-        """int32 (B,T) codes on the device -> float32 (B,Q,T) (faster_audio_data.py:62-83)."""
+        """int32 (B,T) codes on the device -> float32 (B,Q,T) (faster_audio_data.py:62-83).
+        The result carries its codes (`_wn_codes`), and a forward on it runs the causal layer from the codes instead of
+        streaming the 131 MB dense tensor.  CONTRACT: while tagged, the tensor and the codes are immutable - an in-place
+        op that bumps the version counter drops the fast path (forward) or is reported (backward); a write that does
+        not (`.data`, raw pointers, `out=` on the storage) is undetectable and would make the causal layer compute on
+        the original codes.  A copy (`.to()`, `.contiguous()` of a non-contiguous view, `.clone()`) loses the tag and
+        silently takes the dense path (+0.08 ms per step at config 2)."""
         B, T = codes.shape
         out = torch.empty(B, self.Q, T, dtype=torch.float32, device=self.device)
         call("wn_onehot", ptr(codes), ptr(out), B, self.Q, T, 1 if scrambled else 0, _lib.stream())

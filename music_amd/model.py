@@ -13,9 +13,9 @@ import torch
 import torch.nn as nn
 
 try:
-    from .engine import WaveNetEngine
+    from .engine import WaveNetEngine, WorkspaceHold
 except ImportError:                      # imported as a bare module (`from model import wavenet`)
-    from music_amd.engine import WaveNetEngine
+    from music_amd.engine import WaveNetEngine, WorkspaceHold
 
 
 class _WaveNetFunction(torch.autograd.Function):
@@ -31,6 +31,9 @@ class _WaveNetFunction(torch.autograd.Function):
                 x._wn_codes = (tag[0], tag[1], x._version, tag[3])
         probs, ws = eng.forward(x)
         ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
+        # a forward that some backward may follow keeps its workspace: the next forward of this shape gets another
+        # one (several micro-batches in flight, as the reference's autograd allows)
+        ctx.hold = WorkspaceHold(ws) if any(ctx.needs_input_grad) else None
         return probs
 
     @staticmethod
@@ -40,6 +43,8 @@ class _WaveNetFunction(torch.autograd.Function):
             raise RuntimeError("music_amd.wavenet: the activations of this forward were overwritten by a later "
                                "forward of the same module before backward() ran")
         eng.backward(ws, dprobs)
+        if ctx.hold is not None:
+            ctx.hold.release()           # (retain_graph + a second backward still works until the next forward reuses it)
         g = eng.flat_grad.clone()
         grads = []
         for name in eng.param_names:

@@ -28,11 +28,11 @@ import torch.nn.functional as F
 try:
     from . import _lib
     from ._lib import call, ptr
-    from .engine import SLACK, PAD_BACK, _Spec, _pad, pack_index
+    from .engine import SLACK, PAD_BACK, _Spec, _pad, pack_index, WorkspacePool, WorkspaceHold
 except ImportError:
     from music_amd import _lib
     from music_amd._lib import call, ptr
-    from music_amd.engine import SLACK, PAD_BACK, _Spec, _pad, pack_index
+    from music_amd.engine import SLACK, PAD_BACK, _Spec, _pad, pack_index, WorkspacePool, WorkspaceHold
 
 
 class _AutoencoderEngine:
@@ -74,8 +74,15 @@ class _AutoencoderEngine:
                 view.copy_(p.data)
                 p.data = view
         self._build_packs()
-        self._ws = {}
+        self._ws = WorkspacePool(self._make_workspace)
         self._gen = 0
+        self.marks = None            # list of (name, torch.cuda.Event) when phase timing is on (bench.py)
+
+    def mark(self, name):
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((name, ev))
 
     def _bias(self, name):
         return ptr(self.flat, self.spec.off[name + ".bias"]) if self.use_bias else None
@@ -177,10 +184,9 @@ class _AutoencoderEngine:
         self.gidx = torch.from_numpy(gidx.astype(np.int32)).to(self.device)   # -1 (biases) -> zero gradient
 
     def workspace(self, B, T):
-        ws = self._ws.get((B, T))
-        if ws is not None:
-            return ws
-        self._ws.clear()
+        return self._ws.get(B, T)
+
+    def _make_workspace(self, B, T):
         dev = self.device
         pitch = _pad(T, 256) + 512
         W = T - self.rf + 1
@@ -192,7 +198,6 @@ class _AutoencoderEngine:
         ws = dict(B=B, T=T, W=W, pitch=pitch, Xe=buf((N + 1) * self.CHe), He=buf(N * self.CHe), E=buf(self.BwP),
                   Xd=buf((N + 1) * self.CHd), Z=buf(N * self.CHd), U=buf(self.SP), R1=buf(self.SP),
                   C1=buf(self.SP), O=torch.zeros(B * self.Q * W + PAD_BACK, dtype=torch.float32, device=dev), bwd=None)
-        self._ws[(B, T)] = ws
         return ws
 
     # layer i of a stacked [(N+1) or N][B][CH][pitch] buffer
@@ -247,7 +252,9 @@ class _AutoencoderEngine:
             call("wn_gather_grads", ptr(self.flat), ptr(self.wt_idx[name]), ptr(self.wt[name]), self.wt[name].numel(), st)
             call("wn_causal_fwd_codes", ptr(codes), 1 if scrambled else 0, ptr(self.wt[name]), bias, rows, out, obs, pitch, ch, Q, T,
                  B, st)
+        self.mark("begin")
         causal("en_causal", CHe, self.Re, xe(0), eb, self._bias("en_causal_layer"))
+        self.mark("en_causal_fwd")
         for i, d in enumerate(self.dil):
             t_lo = self.off[i + 1]
             # h = dilated_conv(relu(x));   x' = dense(relu(h)) + x[tail]
@@ -260,6 +267,7 @@ class _AutoencoderEngine:
                  he(i), eb, pitch, 0, self._bias("en_dilation_layer_stack.%d" % i), NONE3, NONE3, t_lo, T, 1)
             gemm("en_dense%d" % i, he(i), None, eb, pitch, t_lo, T, 0, 0, CHe // 32, 0, CHe // 16, self.Re,
                  xe(i + 1), eb, pitch, 0, self._bias("en_dense_layer_stack.%d" % i), (xe(i), eb, pitch, t_lo), NONE3, t_lo, T, 1)
+        self.mark("enc_stack_fwd")
         gemm("bottleneck", xe(N), None, eb, pitch, lo, T, 0, 0, CHe // 32, 0, BwP // 16, self.Bw,
              E, BwP * pitch, pitch, 0, self._bias("bottleneck_layer"), NONE3, NONE3, lo, T, 0)
         enc = torch.empty(B, self.Bw, Le, dtype=torch.float32, device=self.device)
@@ -281,6 +289,7 @@ class _AutoencoderEngine:
         xd = lambda i: self._lay(ws["Xd"], i, CHd, ws)
         db, zb = CHd * pitch, N * CHd * pitch
         causal("de_causal", CHd, self.Rd, xd(0), db, self._bias("de_causal_layer"))
+        self.mark("bottleneck_cond_de_causal")
         bn = "de_dilation_layer_stack.%d"
         cmodes = []
         for i, d in enumerate(self.dil):
@@ -294,6 +303,7 @@ class _AutoencoderEngine:
                  fr("de_fg%d" % i), fr("de_d%d" % i), bf, bias_fg, self._bias(bn % (3 * i + 1)), Dd, self.Rd, CHd, d,
                  t_lo, T, t_lo, 1 if i < N - 1 else 0, ptr(tab[i]), 2 * CHd * Le, Le, mode_c, Le, q, B, m, st)   # z on the whole valid range: the backward's dWd reads it
         ws["cmodes"] = cmodes
+        self.mark("dec_stack_fwd")
         U, R1, C1 = ptr(ws["U"], SLACK), ptr(ws["R1"], SLACK), ptr(ws["C1"], SLACK)
         sb = SP * pitch
         bias_s = None
@@ -318,6 +328,7 @@ class _AutoencoderEngine:
             probs = torch.empty(B * W, Q, dtype=torch.float32, device=self.device)
             call("wn_chunk_softmax256_fwd", ptr(ws["O"]), ptr(probs), B * W, st)
         ws["probs"] = probs
+        self.mark("epilogue_fwd")
         return probs, enc, ws
 
     # ------------------------------------------------------------------ backward
@@ -473,6 +484,7 @@ class _AutoencoderEngine:
         wgrad("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CHd // 16, SP // 16, 0, N * CHd, lo, T)
         gemm("skipT", dU, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, N * CHd // 16, N * CHd, dZ, zb, pitch, 0, None, NONE3,
              NONE3, lo, T, 0)
+        self.mark("ce_epilogue_bwd")
         # ---- decoder stack
         xd = lambda i: self._lay(ws["Xd"], i, CHd, ws)
         dfg = ptr(bw["dfg"], SLACK)
@@ -533,6 +545,7 @@ class _AutoencoderEngine:
                       CHd // 16, CHd // 16, 0, CHd, t_lo, T)
             gemm("de_fgT%d" % i, dfg, dfg, 2 * CHd * pitch, pitch, t_lo, T, 0, d, 2 * CHd // 32, 2 * CHd // 32, CHd // 16, Rd,
                  ptr(bw["dXd"][i % 2], SLACK), db, pitch, 0, None, (dy, db, pitch, t_lo) if dy else NONE3, NONE3, self.off[i], T, 0)
+        self.mark("dec_stack_bwd")
         x = ws["x_in"]
         codes_path = ws.get("x_codes") is not None
 
@@ -560,6 +573,7 @@ class _AutoencoderEngine:
         dHe = ptr(bw["dHe"], SLACK)
         gemm("bottleneckT", dE, None, BwP * pitch, pitch, lo, T, 0, 0, BwP // 32, 0, CHe // 16, Re, dxe[N % 2], eb, pitch, 0, None,
              NONE3, NONE3, lo, T, 0)
+        self.mark("de_causal_cond_bottleneck_bwd")
         for i in range(N - 1, -1, -1):
             d, t_lo = self.dil[i], self.off[i + 1]
             y_lo = lo if i == N - 1 else t_lo                     # the top gradient only exists on the crop
@@ -584,6 +598,7 @@ class _AutoencoderEngine:
             # dx_i[t] = [x_i > 0] (Wdil1^T dh[t] + Wdil0^T dh[t+d]) + dy[t]
             gemm("en_dilT%d" % i, dHe, dHe, eb, pitch, t_lo, T, 0, d, CHe // 32, CHe // 32, CHe // 16, Re, dxe[i % 2], eb, pitch, 0,
                  None, (dy, eb, pitch, y_lo), (xe(i), eb, pitch), self.off[i], T, 0)
+        self.mark("enc_stack_bwd")
         causal_wgrad("en_causal", dxe[0], eb, CHe)
         bias_grad("en_causal_layer", dxe[0], eb, pitch, 0, Re, 1, T)
         call("wn_reduce_slabs", ptr(bw["desc_codes"] if codes_path else bw["desc"]), bw["nops"], bw["vec"], ptr(bw["slab"]),
@@ -591,6 +606,7 @@ class _AutoencoderEngine:
         call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
         if self.use_bias:
             self.flat_grad.index_copy_(0, b_idx, b_grad)
+        self.mark("en_causal_slab_reduce")
 
 
 class _AutoencoderFunction(torch.autograd.Function):
@@ -607,6 +623,7 @@ class _AutoencoderFunction(torch.autograd.Function):
         probs, enc, ws = eng.forward(x, cond)
         net.last_encoding = enc
         ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
+        ctx.hold = WorkspaceHold(ws) if any(ctx.needs_input_grad) else None      # see music_amd/model.py
         return probs
 
     @staticmethod
@@ -615,6 +632,8 @@ class _AutoencoderFunction(torch.autograd.Function):
         if ws.get("gen") != ctx.gen:
             raise RuntimeError("music_amd.wavenet_autoencoder: activations were overwritten by a later forward")
         eng.backward(ws, dprobs)
+        if ctx.hold is not None:
+            ctx.hold.release()
         g = eng.flat_grad.clone()
         grads = []
         for name in eng.param_names:

@@ -32,6 +32,18 @@ def main():
         loss = torch.nn.CrossEntropyLoss()(net(xs), ys.reshape(-1))
         loss.backward()
         wdist.allreduce_gradients(net.parameters(), average=True)
+        # a parameter with no gradient on ANY rank keeps .grad None, as under DataParallel (the last block's dense conv
+        # never reaches the output, wavenet/model.py:122-129); a frozen one is not touched
+        last_dense = net.dilation_layer_stack[4 * (len(cfg["dilations"]) - 1) + 2].weight
+        assert last_dense.grad is None
+        frozen = torch.nn.Parameter(torch.ones(3), requires_grad=False)
+        unused = torch.nn.Parameter(torch.ones(2))
+        only_here = torch.nn.Parameter(torch.ones(2))
+        if rank == 0:
+            only_here.grad = torch.full((2,), 4.0)
+        wdist.allreduce_gradients([frozen, unused, only_here], average=True)
+        assert frozen.grad is None and unused.grad is None
+        assert torch.equal(only_here.grad, torch.full((2,), 4.0 / world))       # a rank without it receives the mean
         if rank == 0:
             torch.save({k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in net.named_parameters()},
                        "grads_dp.pt")

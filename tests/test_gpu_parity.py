@@ -1075,3 +1075,98 @@ def test_autoencoder_causal_layers_on_codes_equal_dense_path(scrambled, monkeypa
     net.zero_grad()
     torch.nn.CrossEntropyLoss()(net(x), target).backward()
     assert eng.workspace(B, T)["x_codes"] is not None
+
+
+def test_two_forwards_in_flight_accumulate_like_the_reference():
+    """Gradient accumulation over two micro-batches of the SAME shape with both forwards run before the first backward
+    (the reference's autograd allows it, wavenet/model.py:86-145): each forward keeps its own
+    workspace until its backward has run.  .grad must equal the sum of the oracle's two gradients."""
+    meta = [m for m in g1_meta() if m["name"] == "tiny_s0_g3_w130"][0]
+    d = load_npz("g1_%s.npz" % meta["name"])
+    params = params_from(d)
+    net = build(meta["cfg"], params)
+    x1 = g1_input(d, meta)
+    t1 = torch.from_numpy(d["target"])
+    x2 = x1.flip(2).contiguous()
+    t2 = t1.flip(0).contiguous()
+    ce = torch.nn.CrossEntropyLoss()
+    p1 = net(x1.cuda())
+    p2 = net(x2.cuda())                                         # same shape, first forward still waiting for its backward
+    eng = net._engine
+    assert len(eng._ws) == 2
+    (ce(p1, t1.cuda().view(-1)) + ce(p2, t2.cuda().view(-1))).backward()
+    _, _, g1 = wo.loss_and_grads(params, meta["cfg"]["dilations"], x1, t1)
+    _, _, g2 = wo.loss_and_grads(params, meta["cfg"]["dilations"], x2, t2)
+    for name, p in net.named_parameters():
+        want = g1[name] + g2[name]
+        got = torch.zeros_like(want) if p.grad is None else p.grad.cpu()
+        err = (got - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+        assert err <= GRAD_RTOL, (name, err)
+    # both workspaces are free again: a third forward reuses the first one, no third allocation
+    with torch.no_grad():
+        net(x1.cuda())
+    assert len(eng._ws) == 2
+    # an output dropped without a backward frees its workspace when the graph dies
+    p3 = net(x1.cuda())
+    del p3
+    p4 = net(x1.cuda())
+    p5 = net(x2.cuda())
+    assert len(eng._ws) == 2
+    ce(p4, t1.cuda().view(-1)).backward()
+    ce(p5, t2.cuda().view(-1)).backward()
+
+
+def test_workspace_pool_evicts_one_shape_at_a_time():
+    """A fifth input shape evicts the least recently used shape only (round 2 dropped every cached workspace), never one
+    that a pending backward holds."""
+    meta = [m for m in g1_meta() if m["name"] == "tiny_s0_g3_w130"][0]
+    d = load_npz("g1_%s.npz" % meta["name"])
+    net = build(meta["cfg"], params_from(d))
+    rf = net.receptive_field
+    x = lambda T: torch.zeros(1, 256, T, device="cuda")
+    held = net(x(rf + 10))                                     # grad mode: held until backward
+    eng = net._engine
+    first = eng.workspace(1, rf + 10 + 1)
+    with torch.no_grad():
+        for extra in (2, 3, 4):
+            net(x(rf + 10 + extra))
+    assert len(eng._ws) == 5 and eng.workspace(1, rf + 10 + 2) is not None
+    with torch.no_grad():
+        net(x(rf + 50))                                        # a fifth shape: evicts (1, rf + 11), not the held one
+    shapes = list(eng._ws._d.keys())
+    assert (1, rf + 10) in shapes and (1, rf + 11) not in shapes and len(shapes) == 4
+    held.sum().backward()
+    assert first is not None
+
+
+def test_in_place_write_to_a_tagged_input_is_reported_at_backward():
+    """the code-aware causal layer re-checks its input at backward time - an in-place op on the one-hot (or on
+    the codes it was built from) between forward and backward is an error (dense input) or a fall-back to the dense
+    weight-gradient product (codes changed, dense tensor intact), never a silently wrong gradient."""
+    meta = [m for m in g1_meta() if m["name"] == "tiny_s0_g3_w130"][0]
+    d = load_npz("g1_%s.npz" % meta["name"])
+    params = params_from(d)
+    net = build(meta["cfg"], params)
+    idx = torch.from_numpy(d["idx"].astype(np.int32)).cuda()
+    target = torch.from_numpy(d["target"]).cuda().view(-1)
+    net(torch.zeros(1, 256, net.receptive_field, device="cuda"))
+    eng = net._engine
+    ce = torch.nn.CrossEntropyLoss()
+    x = eng.onehot(idx, scrambled=True)
+    ce(net(x), target).backward()
+    want = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    # codes modified after the forward: the dense tensor still holds what the forward saw -> dense product, same gradient
+    net.zero_grad()
+    x = eng.onehot(idx, scrambled=True)
+    out = net(x)
+    idx.add_(0)                                                # bumps the version counter, values unchanged
+    ce(out, target).backward()
+    for n, g in want.items():
+        got = dict(net.named_parameters())[n].grad
+        assert (got - g).abs().max().item() <= 1e-5 * max(g.abs().max().item(), 1e-12), n
+    # the dense tensor itself modified: reported
+    x = eng.onehot(idx, scrambled=True)
+    out = net(x)
+    x.mul_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        ce(out, target).backward()
