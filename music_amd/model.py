@@ -34,7 +34,9 @@ class _WaveNetFunction(torch.autograd.Function):
         # a forward that some backward may follow keeps its workspace: the next forward of this shape gets another
         # one (several micro-batches in flight, as the reference's autograd allows)
         ctx.hold = WorkspaceHold(ws) if any(ctx.needs_input_grad) else None
-        return probs
+        # a fresh alias goes out: the workspace keeps `probs` for the backward, and the tensor autograd hangs this node on
+        # must not be the one the workspace holds (workspace -> output -> node -> hold -> workspace would never die)
+        return probs.detach()
 
     @staticmethod
     def backward(ctx, dprobs):

@@ -77,6 +77,8 @@ class _AutoencoderEngine:
         self._ws = WorkspacePool(self._make_workspace)
         self._gen = 0
         self.marks = None            # list of (name, torch.cuda.Event) when phase timing is on (bench.py)
+        self._side = None            # second HIP stream for the epilogue's weight gradients (as music_amd/engine.py)
+        self.overlap_wgrad = os.environ.get("WN_AE_OVERLAP", "1") == "1"
 
     def mark(self, name):
         if self.marks is not None:
@@ -461,6 +463,26 @@ class _AutoencoderEngine:
             head, (ldc, t_lo, t_hi) = args[:-3], args[-3:]
             call("wn_wgrad", *head, ptr(bw["slab"], so), ldc, n, t_lo, t_hi, chunk, B, mb, st)
 
+        # the decoder epilogue's three weight gradients only feed the slab reduction at the very end: on a second
+        # (high-priority = own hardware queue) stream their half-empty last rounds of workgroups pack into the
+        # data-gradient GEMMs beside them, as in music_amd/engine.py (config 4: 1.30 -> ~1.0 ms for this phase)
+        main = torch.cuda.current_stream()
+        overlap = self.overlap_wgrad
+        if overlap and self._side is None:
+            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("WN_SIDE_PRIO", "-1")))
+        side = self._side if overlap else main
+
+        def wgrad_s(name, *args):
+            if not overlap:
+                return wgrad(name, *args)
+            so, n, chunk = plan[name]
+            head, (ldc, t_lo, t_hi) = args[:-3], args[-3:]
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                call("wn_wgrad", *head, ptr(bw["slab"], so), ldc, n, t_lo, t_hi, chunk, B, mb, _lib.stream())
+
         if dprobs is not None:
             dprobs = dprobs.contiguous()
             call("wn_chunk_softmax256_bwd", ptr(ws["probs"]), ptr(dprobs), ptr(bw["dO"]), B * W, st)
@@ -468,20 +490,20 @@ class _AutoencoderEngine:
         U, R1, Z = ptr(ws["U"], SLACK), ptr(ws["R1"], SLACK), ptr(ws["Z"], SLACK)
         sb, db, zb, eb = SP * pitch, CHd * pitch, N * CHd * pitch, CHe * pitch
         # ---- decoder epilogue: o = c2(relu(r)), r = c1(relu(u)) + cond_f, u = skip(z)
-        wgrad("c2", dO, Q * W, W, -lo, W, R1, None, sb, pitch, 0, 0, pitch, SP // 16, Q // 16, 1, SP, lo, T)
+        wgrad_s("c2", dO, Q * W, W, -lo, W, R1, None, sb, pitch, 0, 0, pitch, SP // 16, Q // 16, 1, SP, lo, T)
         gemm("c2T", dO, None, Q * W, W, 0, W, -lo, 0, Q // 32, 0, SP // 16, Sd, dR1, sb, pitch, 0, None, NONE3,
              (R1, sb, pitch), lo, T, 0)
         cmode, cq = ws["cf_mode"]
         d_enf = torch.zeros(B, Sd, Le, dtype=torch.float32, device=self.device)
         call("wn_cond_grad", dR1, sb, pitch, Sd, lo, T, cmode, Le, max(cq, 1), ptr(d_enf), Sd * Le, Le, B, st)
-        wgrad("c1", dR1, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
+        wgrad_s("c1", dR1, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
         gemm("c1T", dR1, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, SP // 16, Sd, dU, sb, pitch, 0, None, NONE3,
              (U, sb, pitch), lo, T, 0)
         bias_grad("connection_2", dO, Q * W, W, -lo, Q, lo, T)
         bias_grad("connection_1", dR1, sb, pitch, 0, Sd, lo, T)
         for i in range(N if self.use_bias else 0):
             bias_grad("de_dilation_layer_stack.%d" % (3 * i + 2), dU, sb, pitch, 0, Sd, lo, T)
-        wgrad("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CHd // 16, SP // 16, 0, N * CHd, lo, T)
+        wgrad_s("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CHd // 16, SP // 16, 0, N * CHd, lo, T)
         gemm("skipT", dU, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, N * CHd // 16, N * CHd, dZ, zb, pitch, 0, None, NONE3,
              NONE3, lo, T, 0)
         self.mark("ce_epilogue_bwd")
@@ -601,6 +623,10 @@ class _AutoencoderEngine:
         self.mark("enc_stack_bwd")
         causal_wgrad("en_causal", dxe[0], eb, CHe)
         bias_grad("en_causal_layer", dxe[0], eb, pitch, 0, Re, 1, T)
+        if overlap:
+            ev_join = torch.cuda.Event()
+            ev_join.record(side)
+            main.wait_event(ev_join)
         call("wn_reduce_slabs", ptr(bw["desc_codes"] if codes_path else bw["desc"]), bw["nops"], bw["vec"], ptr(bw["slab"]),
              ptr(self.gpack), st)
         call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
@@ -624,7 +650,7 @@ class _AutoencoderFunction(torch.autograd.Function):
         net.last_encoding = enc
         ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
         ctx.hold = WorkspaceHold(ws) if any(ctx.needs_input_grad) else None      # see music_amd/model.py
-        return probs
+        return probs.detach()            # (an alias: the workspace's own reference must not carry the autograd node)
 
     @staticmethod
     def backward(ctx, dprobs):

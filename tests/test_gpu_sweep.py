@@ -101,3 +101,18 @@ def test_too_short_input_raises():
     x = torch.zeros(1, 256, net.receptive_field - 1, device="cuda")
     with pytest.raises(Exception):
         net(x)
+
+
+def test_decode_fuzz_seeded():
+    """tools/fuzz_decode.py as a seeded test: six random decoders (depth 1..30, odd depths, mixed
+    dilations, with / without biases, both queue recurrences) - teacher-forced ids and probabilities against the oracle's
+    cached recurrence, and ragged batches of the eight-per-pair kernel against single-utterance launches."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_decode", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                              "tools", "fuzz_decode.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(2026)
+    torch.set_num_threads(8)
+    assert all([fz.one_case(rng, k) for k in range(6)])
