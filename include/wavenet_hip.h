@@ -149,6 +149,23 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
                        float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode,
                        int cond_le, int cond_q, float* dfg, int64_t dfg_bstride, int batch, int mode_fwd, int mode_bwd,
                        wn_stream_t stream);
+/* ---- the GENERAL path: shapes the specialised kernels do not cover (filter_width != 2, quantization_channels != 256, more
+ * than 64 residual / dilation channels; wavenet/model.py:8-15 takes any).  Its channel-mixing products are wn_chan_gemm /
+ * wn_wgrad launches (any row count and K, two taps per launch, more taps accumulate through `resid`); these are the
+ * elementwise pieces (music_amd/engine_generic.py sequences them).
+ * Gate (model.py:120): z[b][r][t] = tanh(fg[b][r][t]) * sigmoid(fg[b][dp + r][t]) for r < rows, t in [t_lo, t_hi);
+ * its derivative: dfg[b][r] = dz sigma(g)(1 - tanh^2 f), dfg[b][dp + r] = dz tanh(f) sigma(g)(1 - sigma(g)). */
+int wn_gate_fwd(const float* fg, int64_t fg_bstride, int dp, int rows, float* z, int64_t z_bstride, int pitch, int t_lo, int t_hi,
+                int batch, wn_stream_t stream);
+int wn_gate_bwd(const float* fg, int64_t fg_bstride, int dp, int rows, const float* dz, int64_t dz_bstride, float* dfg,
+                int64_t dfg_bstride, int pitch, int t_lo, int t_hi, int batch, wn_stream_t stream);
+/* CHUNK softmax for any row length q (model.py:142-144: the contiguous (B, Q, W) buffer viewed (-1, Q)), its
+ * backward dx = y (dy - <dy, y>), and the fused softmax + nn.CrossEntropyLoss-on-the-probabilities step of
+ * wn_chunk_softmax256_ce (train.py:146,179) for any q; loss_part has WN_CE_NUM_PARTIALS entries, probs / dx may be NULL. */
+int wn_chunk_softmax_fwd(const float* x, float* y, int64_t nrows, int q, wn_stream_t stream);
+int wn_chunk_softmax_bwd(const float* y, const float* dy, float* dx, int64_t nrows, int q, wn_stream_t stream);
+int wn_chunk_softmax_ce(const float* x, const int64_t* target, float* probs, float* dx, float* loss_part, int64_t nrows, int q,
+                        float inv_n, wn_stream_t stream);
 /* The operand format of the "x3" products: hi[i] = round16(x[i]), lo[i] = round16(x[i] - hi[i]),
  * 16-bit = IEEE half (is_bf16 = 0) or bfloat16 (1), round to nearest even.  The same device function every MFMA operand
  * of the library is split with; no counterpart in the reference (its products are fp32). */

@@ -56,6 +56,11 @@ SIGNATURES = {
     "wn_chunk_softmax256_fwd": [_p, _p, _l, _p],
     "wn_chunk_softmax256_bwd": [_p, _p, _p, _l, _p],
     "wn_chunk_softmax256_ce": [_p, _p, _p, _p, _p, _l, _f, _p],
+    "wn_gate_fwd": [_p, _l, _i, _i, _p, _l, _i, _i, _i, _i, _p],
+    "wn_gate_bwd": [_p, _l, _i, _i, _p, _l, _p, _l, _i, _i, _i, _i, _p],
+    "wn_chunk_softmax_fwd": [_p, _p, _l, _i, _p],
+    "wn_chunk_softmax_bwd": [_p, _p, _p, _l, _i, _p],
+    "wn_chunk_softmax_ce": [_p, _p, _p, _p, _p, _l, _i, _f, _p],
     "wn_adam_flat": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p],
     "wn_gather_grads": [_p, _p, _p, _i, _p],
     "wn_onehot": [_p, _p, _i, _i, _i, _i, _p],

@@ -224,6 +224,30 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
     a.cond_le = cond_le; a.cond_q = cond_q; a.dfg = dfg; a.dfg_bstride = dfg_bstride;
     return wn_launch_resblock_bwd_pq(a, batch, (hipStream_t)stream);
 }
+int wn_gate_fwd(const float* fg, int64_t fg_bstride, int dp, int rows, float* z, int64_t z_bstride, int pitch, int t_lo, int t_hi,
+                int batch, wn_stream_t stream) {
+    if (!fg || !z || rows > dp) return wn_set_error_msg(-4, "wn_gate_fwd: bad argument");
+    return wn_launch_gate_fwd(fg, (long)fg_bstride, dp, rows, z, (long)z_bstride, pitch, t_lo, t_hi, batch, (hipStream_t)stream);
+}
+int wn_gate_bwd(const float* fg, int64_t fg_bstride, int dp, int rows, const float* dz, int64_t dz_bstride, float* dfg,
+                int64_t dfg_bstride, int pitch, int t_lo, int t_hi, int batch, wn_stream_t stream) {
+    if (!fg || !dz || !dfg || rows > dp) return wn_set_error_msg(-4, "wn_gate_bwd: bad argument");
+    return wn_launch_gate_bwd(fg, (long)fg_bstride, dp, rows, dz, (long)dz_bstride, dfg, (long)dfg_bstride, pitch, t_lo, t_hi, batch,
+                              (hipStream_t)stream);
+}
+int wn_chunk_softmax_fwd(const float* x, float* y, int64_t nrows, int q, wn_stream_t stream) {
+    if (q < 1 || (nrows > 0 && (!x || !y))) return wn_set_error_msg(-4, "wn_chunk_softmax_fwd: bad argument");
+    return wn_launch_softmaxq_fwd(x, y, (long)nrows, q, (hipStream_t)stream);
+}
+int wn_chunk_softmax_bwd(const float* y, const float* dy, float* dx, int64_t nrows, int q, wn_stream_t stream) {
+    if (q < 1 || (nrows > 0 && (!y || !dy || !dx))) return wn_set_error_msg(-4, "wn_chunk_softmax_bwd: bad argument");
+    return wn_launch_softmaxq_bwd(y, dy, dx, (long)nrows, q, (hipStream_t)stream);
+}
+int wn_chunk_softmax_ce(const float* x, const int64_t* target, float* probs, float* dx, float* loss_part, int64_t nrows, int q,
+                        float inv_n, wn_stream_t stream) {
+    if (q < 1 || (nrows > 0 && (!x || !target))) return wn_set_error_msg(-4, "wn_chunk_softmax_ce: bad argument");
+    return wn_launch_softmaxq_ce(x, target, probs, dx, loss_part, (long)nrows, q, inv_n, (hipStream_t)stream);
+}
 int wn_split16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, int is_bf16, wn_stream_t stream) {
     if (n > 0 && (!x || !hi || !lo)) return wn_set_error_msg(-4, "wn_split16: null argument");
     return wn_launch_split16(x, hi, lo, (long)n, is_bf16, (hipStream_t)stream);

@@ -159,6 +159,16 @@ int wn_launch_avgpool_bwd(const float* denc, long denc_bstride, int denc_pitch, 
 int wn_launch_avgpool(const float* in, long in_bstride, int in_pitch, int t0, int pool, int n_out, int rows,
                       float* out, long out_bstride, int out_pitch, int batch, hipStream_t st);
 
+// general path (wn_generic.hip): gate and chunk softmax for any shape
+int wn_launch_gate_fwd(const float* fg, long fg_bstride, int dp, int rows, float* z, long z_bstride, int pitch, int t_lo, int t_hi,
+                       int batch, hipStream_t st);
+int wn_launch_gate_bwd(const float* fg, long fg_bstride, int dp, int rows, const float* dz, long dz_bstride, float* dfg,
+                       long dfg_bstride, int pitch, int t_lo, int t_hi, int batch, hipStream_t st);
+int wn_launch_softmaxq_fwd(const float* x, float* y, long nrows, int q, hipStream_t st);
+int wn_launch_softmaxq_bwd(const float* y, const float* dy, float* dx, long nrows, int q, hipStream_t st);
+int wn_launch_softmaxq_ce(const float* x, const int64_t* target, float* probs, float* dx, float* loss_part, long nrows, int q,
+                          float inv_n, hipStream_t st);
+
 #define WN_DEC_MAX_LAYERS 64
 struct WnDecodeArgs {
     int n_layers, R, D, S, Q;

@@ -45,6 +45,11 @@ class _DecodePack:
 
     def __init__(self, eng):
         sp, R, D, S, Q, N = eng.spec, eng.R, eng.D, eng.S, eng.Q, eng.N
+        if getattr(eng, "k", 2) != 2:
+            # the reference's own cached-queue decoder keeps d_i columns per block and convolves [queue | note] once
+            # (wavenet/fast_generate.py:73-90): it only exists for filter_width 2
+            raise NotImplementedError("fast_generate implements the reference's cached-queue recurrence, which is defined for "
+                                      "filter_width == 2 only (wavenet/fast_generate.py:73-90)")
         parts = []
         wc = sp.conv("causal_layer.weight")                                 # [R,Q,2]
         self.o_causal = 0

@@ -14,8 +14,10 @@ import torch.nn as nn
 
 try:
     from .engine import WaveNetEngine, WorkspaceHold
+    from .engine_generic import GenericWaveNetEngine
 except ImportError:                      # imported as a bare module (`from model import wavenet`)
     from music_amd.engine import WaveNetEngine, WorkspaceHold
+    from music_amd.engine_generic import GenericWaveNetEngine
 
 
 class _WaveNetFunction(torch.autograd.Function):
@@ -108,9 +110,14 @@ class wavenet(nn.Module):
                 return eng
         if any(p.device != device for _, p in named):
             raise RuntimeError("music_amd.wavenet: parameters and input are on different devices")
-        eng = WaveNetEngine(self.dilations, self.residual_channels, self.dilation_channels, self.skip_channels,
-                            self.quantization_channels, self.filter_width, self.use_bias,
-                            mode_fwd=self.precision[0], mode_bwd=self.precision[1], device=device)
+        # the specialised kernels cover filter_width 2, 256 quantisation channels and up to 64 residual / dilation channels
+        # (everything the reference ships and BASELINE.json names); any other constructor argument takes the general plan
+        fast = (self.filter_width == 2 and self.quantization_channels == 256 and
+                max(self.residual_channels, self.dilation_channels) <= 64)
+        eng = (WaveNetEngine if fast else GenericWaveNetEngine)(
+            self.dilations, self.residual_channels, self.dilation_channels, self.skip_channels,
+            self.quantization_channels, self.filter_width, self.use_bias,
+            mode_fwd=self.precision[0], mode_bwd=self.precision[1], device=device)
         eng.mode_names = tuple(self.precision)
         assert [n for n, _ in named] == eng.param_names, "parameter order differs from the reference layout"
         with torch.no_grad():

@@ -166,3 +166,42 @@ def test_optimizer_state_survives_a_restart(tmp_path, monkeypatch):
     same = all(torch.equal(a, b) for a, b in zip(finals["straight"].values(), finals["resumed"].values()))
     cold_same = all(torch.equal(a, b) for a, b in zip(finals["straight"].values(), finals["resumed_cold"].values()))
     assert same and not cold_same
+
+
+def test_generic_engine_index_maps_cover_every_parameter_once():
+    """music_amd/engine_generic.py (any filter_width / channel counts): every weight appears exactly once in the forward
+    packs and (except the causal layer, which has no data gradient) once in the backward packs, at the (row, k) its
+    product expects; the gradient gather map is a bijection into the gradient matrices."""
+    import numpy as np
+    import torch
+    from music_amd.engine import pack_positions
+    from music_amd.engine_generic import GenericWaveNetEngine
+    eng = GenericWaveNetEngine([1, 2, 4], 20, 24, 40, quantization_channels=48, filter_width=3, use_bias=True, device="cpu")
+    assert eng.rf == 2 * (7 + 1) + 1 and eng.off == [2, 4, 8, 16] and eng.pairs == [(0, 1), (2, None)]
+    n_w = sum(int(np.prod(eng.spec.shape[n])) for n in eng.param_names if n.endswith(".weight"))
+    fidx = eng.pk_f_idx.numpy()
+    seen = fidx[fidx >= 0]
+    assert len(seen) == n_w and len(np.unique(seen)) == n_w
+    bidx = eng.pk_b_idx.numpy()
+    seen_b = bidx[bidx >= 0]
+    n_causal = int(np.prod(eng.spec.shape["causal_layer.weight"]))
+    assert len(seen_b) == n_w - n_causal and len(np.unique(seen_b)) == n_w - n_causal
+    g = eng.gidx.numpy()
+    assert len(np.unique(g)) == eng.spec.total and g.min() >= 0 and g.max() < eng.gpack.numel()
+    # one pack checked element by element: fg of layer 1, tap pair 0 = taps (0, 1): rows [f | g] x K = [tap 0 ch | tap 1 ch]
+    o = eng.pk_f_off["fg1_0"] // 2                     # fragments are 1024 halfs (x3): offset in index entries
+    mt, ks = 2 * eng.DP // 16, 2 * eng.RP // 32
+    row, k = pack_positions(mt, ks, False)
+    idx = fidx[o:o + mt * ks * 512]
+    wf = eng.spec.conv("dilation_layer_stack.4.weight")
+    wg = eng.spec.conv("dilation_layer_stack.5.weight")
+    for r, kk, v in zip(row[::97], k[::97], idx[::97]):
+        h, c = divmod(int(r), eng.DP)
+        tap, ch = divmod(int(kk), eng.RP)
+        want = (wf, wg)[h][c, ch, tap] if (c < eng.D and ch < eng.R) else -1
+        assert v == want, (r, kk, v, want)
+    # and the gradient of that weight lands where wn_wgrad writes it: C[h*DP + c][tap*RP + ch] of matrix fg1_0
+    go, rows, cols = eng.gp_off["fg1_0"]
+    assert g[wg[3, 5, 1]] == go + (eng.DP + 3) * cols + eng.RP + 5
+    go2, _, cols2 = eng.gp_off["fg1_1"]
+    assert g[wf[2, 7, 2]] == go2 + 2 * cols2 + 7
