@@ -47,8 +47,17 @@ __device__ __forceinline__ f32x2 pq_ld2u(const float* p) {
     f32x2 r = {u.v[0], u.v[1]};
     return r;
 }
-// (a, b) -> packed bf16 pairs hi = (bf16(a), bf16(b)) and lo = (bf16(a - hi_a), bf16(b - hi_b))
-__device__ __forceinline__ void pq_split2(float a, float b, uint32_t& hi, uint32_t& lo) { split2<BF16>(a, b, hi, lo); }
+// The 16-bit type of the GRADIENT operands: bf16 (float32's exponent range).  -DPQ_GRAD_F16 is a TIMING build
+// (an unscaled f16 split underflows on real gradients): what the cheaper f16 split (1.5 instead of ~3.5 vector instructions
+// per element) would buy this kernel.
+#ifdef PQ_GRAD_F16
+typedef F16 PQG;
+#else
+typedef BF16 PQG;
+#endif
+typedef PQG::vec8 pqg8;
+// (a, b) -> packed 16-bit pairs hi = (cvt(a), cvt(b)) and lo = (cvt(a - hi_a), cvt(b - hi_b))
+__device__ __forceinline__ void pq_split2(float a, float b, uint32_t& hi, uint32_t& lo) { split2<PQG>(a, b, hi, lo); }
 
 // LDS map, in halfs (uint16): per stage 8 x fragments | 4 dy fragments | 12 result tiles; then the packed (P, Q) weights
 #define PQ_XF 0
@@ -224,10 +233,10 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #ifndef PQ_T_NOPQ
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            Frag<BF16> w;
-            load_a<BF16, 3>(w, pw, (sel * 4 + g) * 4 + s, lane);
+            Frag<PQG> w;
+            load_a<PQG, 3>(w, pw, (sel * 4 + g) * 4 + s, lane);
             const uint16_t* tb = tt + ((s >> 1) * 4 + 2 * (s & 1) + (q >> 1)) * 1024;
-            Frag<BF16> ad[2];
+            Frag<PQG> ad[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -237,16 +246,16 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[1] + 4 * m));
                 s16x8 hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                 s16x8 ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-                ad[m].hi = __builtin_bit_cast(bf16x8, hh);
-                ad[m].lo = __builtin_bit_cast(bf16x8, ll);
+                ad[m].hi = __builtin_bit_cast(pqg8, hh);
+                ad[m].lo = __builtin_bit_cast(pqg8, ll);
             }
             f32x4* ac = (s & 1) ? acb : acc;
-            ac[0] = BF16::mfma(ad[0].lo, w.hi, ac[0]);
-            ac[1] = BF16::mfma(ad[1].lo, w.hi, ac[1]);
-            ac[0] = BF16::mfma(ad[0].hi, w.lo, ac[0]);
-            ac[1] = BF16::mfma(ad[1].hi, w.lo, ac[1]);
-            ac[0] = BF16::mfma(ad[0].hi, w.hi, ac[0]);
-            ac[1] = BF16::mfma(ad[1].hi, w.hi, ac[1]);
+            ac[0] = PQG::mfma(ad[0].lo, w.hi, ac[0]);
+            ac[1] = PQG::mfma(ad[1].lo, w.hi, ac[1]);
+            ac[0] = PQG::mfma(ad[0].hi, w.lo, ac[0]);
+            ac[1] = PQG::mfma(ad[1].hi, w.lo, ac[1]);
+            ac[0] = PQG::mfma(ad[0].hi, w.hi, ac[0]);
+            ac[1] = PQG::mfma(ad[1].hi, w.hi, ac[1]);
         }
         acc[0] += acb[0];
         acc[1] += acb[1];
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             }
         };
         Frag<F16> wf[4], wg[4];
-        Frag<BF16> wd[2];
+        Frag<PQG> wd[2];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             load_a<F16, 3>(wf[s], a.wfg, g * 4 + s, lane);
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         }
         if (HAS_DY) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) load_a<BF16, 3>(wd[s], a.wdT, g * 2 + s, lane);
+            for (int s = 0; s < 2; ++s) load_a<PQG, 3>(wd[s], a.wdT, g * 2 + s, lane);
         }
         // this lane's dwords in the result tiles: row 4q + i, samples 2c, 2c+1 -> position 8*((2c & 15) >> 2) + 4*(c >> 3) +
         // (2c & 3): chunk (c & 7) >> 1, dword 2*(c >> 3) + (c & 1)
@@ -376,16 +385,16 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                     acc = t == 0 ? TT::mfma(wa.lo, xb.hi, acc) : t == 1 ? TT::mfma(wa.hi, xb.lo, acc) : TT::mfma(wa.hi, xb.hi, acc);
                 };
                 Frag<F16> bx[2][2];
-                Frag<BF16> by[2];
+                Frag<PQG> by[2];
                 load_a<F16, 3>(bx[0][0], xf, 0, lane);
                 load_a<F16, 3>(bx[0][1], xf, 1, lane);
-                if (HAS_DY) load_a<BF16, 3>(by[0], dyf, 0, lane);
+                if (HAS_DY) load_a<PQG, 3>(by[0], dyf, 0, lane);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     if (ks + 1 < 4) {
                         load_a<F16, 3>(bx[(ks + 1) & 1][0], xf, 2 * ks + 2, lane);
                         load_a<F16, 3>(bx[(ks + 1) & 1][1], xf, 2 * ks + 3, lane);
-                        if (HAS_DY) load_a<BF16, 3>(by[(ks + 1) & 1], dyf, ks + 1, lane);      // dy fragment (k-step (ks+1)>>1, N-tile (ks+1)&1)
+                        if (HAS_DY) load_a<PQG, 3>(by[(ks + 1) & 1], dyf, ks + 1, lane);      // dy fragment (k-step (ks+1)>>1, N-tile (ks+1)&1)
                     }
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                         term(F16(), ag[0], wg[ks], bx[ks & 1][0], t);
                         term(F16(), af[1], wf[ks], bx[ks & 1][1], t);
                         term(F16(), ag[1], wg[ks], bx[ks & 1][1], t);
-                        if (HAS_DY) term(BF16(), dz[ks & 1], wd[ks >> 1], by[ks & 1], t);
+                        if (HAS_DY) term(PQG(), dz[ks & 1], wd[ks >> 1], by[ks & 1], t);
                     }
                 }
             }
@@ -509,8 +518,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     };
     // this wave's B operands of the weight-gradient products (k = the 8 positions of the lane's chunk) and its dy rows
     // in fp32 (the residual term of P)
-    struct Ops { Frag<BF16> x0, x1, dy; float dy32[8]; };
-    auto to_frag = [&](Frag<BF16>& f, const float* w) {
+    struct Ops { Frag<PQG> x0, x1, dy; float dy32[8]; };
+    auto to_frag = [&](Frag<PQG>& f, const float* w) {
         u32x4 fh, fl;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -519,8 +528,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             fh[jj] = hi;
             fl[jj] = lo;
         }
-        f.hi = __builtin_bit_cast(bf16x8, fh);
-        f.lo = __builtin_bit_cast(bf16x8, fl);
+        f.hi = __builtin_bit_cast(pqg8, fh);
+        f.lo = __builtin_bit_cast(pqg8, fl);
     };
     auto convert = [&](Ops& o, const RawRows& r, Pos ps) {
         float w[8];
@@ -547,10 +556,10 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             for (int jj = 0; jj < 8; ++jj) o.dy32[jj] = 0.f;
         }
     };
-    auto load_tile = [&](Frag<BF16>& f, const uint16_t* base, int tile) {
+    auto load_tile = [&](Frag<PQG>& f, const uint16_t* base, int tile) {
         const u32x4* p = reinterpret_cast<const u32x4*>(base + tile * 1024 + tile_rd);
-        f.hi = __builtin_bit_cast(bf16x8, p[0]);
-        f.lo = __builtin_bit_cast(bf16x8, p[64]);
+        f.hi = __builtin_bit_cast(pqg8, p[0]);
+        f.lo = __builtin_bit_cast(pqg8, p[64]);
     };
     auto products = [&](int stage, const Ops& o, Pos ps) {
         PQ_TICK(p0);
@@ -560,10 +569,10 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         {
             // the three products of an x3 term are walked across FOUR accumulators (two tiles x two column blocks), so
             // no MFMA waits for the one in front of it; the next pair of tiles is read meanwhile
-            auto term = [](f32x4& acc, const Frag<BF16>& wa, const Frag<BF16>& xb, int t) {
-                acc = t == 0 ? BF16::mfma(wa.lo, xb.hi, acc) : t == 1 ? BF16::mfma(wa.hi, xb.lo, acc) : BF16::mfma(wa.hi, xb.hi, acc);
+            auto term = [](f32x4& acc, const Frag<PQG>& wa, const Frag<PQG>& xb, int t) {
+                acc = t == 0 ? PQG::mfma(wa.lo, xb.hi, acc) : t == 1 ? PQG::mfma(wa.hi, xb.lo, acc) : PQG::mfma(wa.hi, xb.hi, acc);
             };
-            Frag<BF16> am[2][2];
+            Frag<PQG> am[2][2];
             load_tile(am[0][0], tt, 0);
             load_tile(am[0][1], tt, 1);
 #pragma unroll

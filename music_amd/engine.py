@@ -60,8 +60,16 @@ class WorkspacePool:
         from collections import OrderedDict
         self._make = make
         self._d = OrderedDict()
+        self._last = {}
+
+    def peek(self, B, T):
+        """The workspace the LAST forward of this shape used (held or not) - what a caller inspects after a step; a
+        fresh one if there has been none."""
+        ws = self._last.get((B, T))
+        return ws if ws is not None else self.get(B, T)
 
     def get(self, B, T):
+        """A workspace for the NEXT forward of this shape: the first one no pending backward holds, else a new one."""
         key = (B, T)
         lst = self._d.get(key)
         if lst is None:
@@ -69,21 +77,25 @@ class WorkspacePool:
                 for k, wl in self._d.items():
                     if not any(w.get("held") for w in wl):
                         del self._d[k]
+                        self._last.pop(k, None)
                         break
             lst = self._d[key] = []
         self._d.move_to_end(key)
         for ws in lst:
             if not ws.get("held"):
+                self._last[key] = ws
                 return ws
         if len(lst) >= self.MAX_PER_SHAPE:
             raise RuntimeError("music_amd: %d forwards of shape %s are waiting for their backward; run backward() (or drop "
                                "the outputs) before another forward of this shape" % (len(lst), key))
         ws = self._make(B, T)
         lst.append(ws)
+        self._last[key] = ws
         return ws
 
     def clear(self):
         self._d.clear()
+        self._last.clear()
 
     def __len__(self):
         return sum(len(v) for v in self._d.values())
@@ -359,9 +371,9 @@ class WaveNetEngine:
 
     # ------------------------------------------------------------------ workspace
     def workspace(self, B, T):
-        """The workspace the next forward of this shape will use (= the one the last forward used, unless that one is
-        still held by a pending backward: WorkspacePool)."""
-        return self._ws.get(B, T)
+        """The workspace the last forward of this shape used (what callers inspect after a step; WorkspacePool.peek).  A
+        forward takes its own through WorkspacePool.get: the first one no pending backward holds."""
+        return self._ws.peek(B, T)
 
     def _make_workspace(self, B, T):
         dev = self.device
@@ -470,7 +482,7 @@ class WaveNetEngine:
         W = T - self.rf + 1
         if W <= 0:
             raise ValueError("wave sample not long enough")          # wavenet/model.py:100-101
-        ws = ws or self.workspace(B, T)
+        ws = ws or self._ws.get(B, T)
         st = _lib.stream()
         CH, N, SP, pitch, mf = self.CH, self.N, self.SP, ws["pitch"], self.mode_fwd
         fr = lambda name: ptr(self.pk_f, self.pk_f_off[name])

@@ -14,8 +14,8 @@ general kernels, one product per launch:
     weight gradients        wn_wgrad slabs + wn_reduce_slabs (bit-reproducible), data gradients wn_chan_gemm on W^T
 
 Same x3 arithmetic (f16 split forward, bf16 split backward), same HBM layout (absolute time, one pitch, channels padded to
-32 with zero weights), same flat parameter / gradient buffers, same workspace pool as the fast engine; ~3x slower per step
-at config-2 shapes (it is round 1's first correct structure), which is why it is only selected where the fast engine does
+32 with zero weights), same flat parameter / gradient buffers, same workspace pool as the fast engine; 2x slower per step
+at config-2 shapes (8.6 vs 4.3 ms: it is round 1's first correct structure), which is why it is only selected where the fast engine does
 not apply.  PyTorch is used for device memory and streams only.  Nothing here imports oracle/.
 """
 import os
@@ -220,7 +220,7 @@ class GenericWaveNetEngine:
 
     # ------------------------------------------------------------------ workspace
     def workspace(self, B, T):
-        return self._ws.get(B, T)
+        return self._ws.peek(B, T)
 
     def _make_workspace(self, B, T):
         dev = self.device
@@ -265,7 +265,7 @@ class GenericWaveNetEngine:
         W = T - self.rf + 1
         if W <= 0:
             raise ValueError("wave sample not long enough")          # wavenet/model.py:100-101
-        ws = ws or self.workspace(B, T)
+        ws = ws or self._ws.get(B, T)
         st = _lib.stream()
         N, RP, DP, SP, QP, pitch, mf = self.N, self.RP, self.DP, self.SP, self.QP, ws["pitch"], self.mode_fwd
         fr = lambda name: ptr(self.pk_f, self.pk_f_off[name])

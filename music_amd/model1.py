@@ -186,7 +186,7 @@ class _AutoencoderEngine:
         self.gidx = torch.from_numpy(gidx.astype(np.int32)).to(self.device)   # -1 (biases) -> zero gradient
 
     def workspace(self, B, T):
-        return self._ws.get(B, T)
+        return self._ws.peek(B, T)
 
     def _make_workspace(self, B, T):
         dev = self.device
@@ -220,7 +220,7 @@ class _AutoencoderEngine:
         Le = W // self.pool
         if Le < 1:
             raise RuntimeError("Output size is too small: %d samples of encoding cannot be pooled by %d" % (W, self.pool))
-        ws = self.workspace(B, T)
+        ws = self._ws.get(B, T)
         self._gen += 1
         ws["gen"], ws["x_in"], ws["Le"] = self._gen, x, Le
         # a one-hot built from integer codes (engine.onehot / the loader) carries them: both causal layers then run on the

@@ -32,7 +32,7 @@ def _net(case, gain=2.5):
     name, fw, dil, D, R, S, Q, bias, B, win = case
     cfg = dict(filter_width=fw, dilations=dil, dilation_channels=D, residual_channels=R, skip_channels=S,
                quantization_channels=Q, use_bias=bias)
-    torch.manual_seed(hash(name) % 1000)
+    torch.manual_seed(100 + [c[0] for c in CASES + [case]].index(name))
     net = wavenet(**cfg)
     with torch.no_grad():
         for p in net.parameters():
@@ -57,11 +57,20 @@ def test_general_plan_forward_and_gradients_vs_oracle(case):
     assert isinstance(net._engine, GenericWaveNetEngine)
     loss = torch.nn.functional.cross_entropy(probs, target.cuda())
     loss.backward()
-    inter = {}
-    l_ref, p_ref, g_ref = wo.loss_and_grads(params, dil, x, target, filter_width=fw, quantization_channels=Q, intermediates=inter)
-    e_p = (probs.detach().cpu() - p_ref).abs().max().item()
     eng = net._engine
     W = win
+    # the reference gradient takes the device's sign at ReLU pre-activations within 2e-4 of zero (tests/test_gpu_fullsize.py
+    # explains why: one flipped element moves a whole gradient tensor by ~1e-3) and insists on equal signs elsewhere
+    from music_amd.engine import SLACK
+    from tests.test_gpu_fullsize import _device_relu
+    wsd = eng.workspace(B, T)
+    pitch, lo = wsd["pitch"], rf - 1
+    v = lambda buf: buf[SLACK:SLACK + B * eng.SP * pitch].view(B, eng.SP, pitch)[:, :S, lo:T].cpu()
+    relu, stats = _device_relu({"skip_sum": v(wsd["U"]), "post_process_1": v(wsd["H"])})
+    inter = {}
+    l_ref, p_ref, g_ref = wo.loss_and_grads(params, dil, x, target, filter_width=fw, quantization_channels=Q, intermediates=inter,
+                                            relu=relu)
+    e_p = (probs.detach().cpu() - p_ref).abs().max().item()
     o_dev = eng.workspace(B, T)["O"][:B * Q * W].view(B, Q, W).cpu()
     e_o = (o_dev - inter["pre_softmax"].detach()).abs().max().item()
     assert probs.shape == (B * W, Q) and e_p <= LOGIT_TOL and e_o <= LOGIT_TOL, (e_p, e_o)

@@ -1124,19 +1124,20 @@ def test_workspace_pool_evicts_one_shape_at_a_time():
     net = build(meta["cfg"], params_from(d))
     rf = net.receptive_field
     x = lambda T: torch.zeros(1, 256, T, device="cuda")
-    held = net(x(rf + 10))                                     # grad mode: held until backward
+    held = net(x(rf + 10))                                     # grad mode: shape A, held until its backward
     eng = net._engine
-    first = eng.workspace(1, rf + 10 + 1)
     with torch.no_grad():
-        for extra in (2, 3, 4):
-            net(x(rf + 10 + extra))
-    assert len(eng._ws) == 5 and eng.workspace(1, rf + 10 + 2) is not None
+        for extra in (1, 2, 3):
+            net(x(rf + 10 + extra))                             # shapes B, C, D: four shapes cached
+    assert sorted(eng._ws._d.keys()) == [(1, rf + 10 + e) for e in (0, 1, 2, 3)]
+    a_ws = eng.workspace(1, rf + 10)
     with torch.no_grad():
-        net(x(rf + 50))                                        # a fifth shape: evicts (1, rf + 11), not the held one
-    shapes = list(eng._ws._d.keys())
-    assert (1, rf + 10) in shapes and (1, rf + 11) not in shapes and len(shapes) == 4
+        net(x(rf + 50))                                        # a fifth shape evicts the least recently used one that is free: B
+    shapes = sorted(eng._ws._d.keys())
+    assert shapes == [(1, rf + 10), (1, rf + 12), (1, rf + 13), (1, rf + 50)], shapes
+    assert eng.workspace(1, rf + 10) is a_ws and a_ws.get("held")
     held.sum().backward()
-    assert first is not None
+    assert not a_ws.get("held")
 
 
 def test_in_place_write_to_a_tagged_input_is_reported_at_backward():
