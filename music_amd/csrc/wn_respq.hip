@@ -47,6 +47,20 @@ __device__ __forceinline__ f32x2 pq_ld2u(const float* p) {
     f32x2 r = {u.v[0], u.v[1]};
     return r;
 }
+#ifdef PQ_T_SC1
+// TIMING build (results unchanged): every load and store of the (P, Q) pair on the write-through / L2-bypassing `sc1` path, i.e.
+// what a whole-stack persistent kernel would have to use to hand the pair from workgroup to workgroup (cdna_hip_programming.md
+// Guideline 16, R1).  Prices the payload side of that design without building it.
+typedef unsigned int pq_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int pq_u32x2 __attribute__((ext_vector_type(2)));
+#define PQ_RSRC(p) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, 0x7fffffff, 0x00020000)
+#define PQ_LD2(rs, base, off) __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)((off) * 4), 0, 16))
+#define PQ_LD4(rs, base, off) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((off) * 4), 0, 16))
+#else
+#define PQ_RSRC(p) 0
+#define PQ_LD2(rs, base, off) pq_ld2u((base) + (off))
+#define PQ_LD4(rs, base, off) ld4u((base) + (off))
+#endif
 // The 16-bit type of the GRADIENT operands: bf16 (float32's exponent range).  -DPQ_GRAD_F16 is a TIMING build
 // (an unscaled f16 split underflows on real gradients): what the cheaper f16 split (1.5 instead of ~3.5 vector instructions
 // per element) would buy this kernel.
@@ -172,6 +186,10 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 
     const float* p_or_x = HAS_DY ? a.p_in : a.x_in;         // loads stay unconditional
     const float* q_or_x = HAS_DY ? a.q_in : a.x_in;
+    const auto rs_p = PQ_RSRC(p_or_x);
+    const auto rs_q = PQ_RSRC(q_or_x);
+    const auto rs_po = PQ_RSRC(a.p_out);
+    const auto rs_qo = PQ_RSRC(a.q_out);
     // dy rows for the R waves' dz product, as recompute-style fragments: wave g converts rows 4(g&1).. of k-step g>>1
     struct RawD { f32x2 p[4], qq[4]; };
     auto load_dy = [&](RawD& r, Pos ps) {
@@ -181,8 +199,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             const int dn = ps.live ? a.dn : 0;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                r.p[jj] = pq_ld2u(p_or_x + ro + jj * rp);
-                r.qq[jj] = pq_ld2u(q_or_x + ro + dn + jj * rp);
+                r.p[jj] = PQ_LD2(rs_p, p_or_x, ro + jj * rp);
+                r.qq[jj] = PQ_LD2(rs_q, q_or_x, ro + dn + jj * rp);
             }
         }
     };
@@ -271,7 +289,12 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] += dy32[4 * m + i];
                 }
+#ifdef PQ_T_SC1
+                if (whole) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pq_u32x4, v), sel ? rs_qo : rs_po,
+                                                                  (int)((out + 16 * m - (sel ? a.q_out : a.p_out)) * 4), 0, 16);
+#else
                 if (whole) *reinterpret_cast<f32x4*>(out + 16 * m) = v;      // plain: the next launch finds P and Q in L2 (streaming stores: 2.21 vs 2.00 ms for the stack)
+#endif
                 else st4m(out + 16 * m, v, ps.t0 + 16 * m + 4 * q, a.t_lo, a.t_hi);
             }
         }
@@ -510,10 +533,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         r.x0[0] = ld4u(xr - dd); r.x0[1] = ld4u(xr - dd + h);
         r.x1[0] = ld4u(xr); r.x1[1] = ld4u(xr + h);
         if (HAS_DY) {
-            const float* pr = p_or_x + ro;
-            const float* qr = q_or_x + ro + dn;
-            r.p[0] = ld4u(pr); r.p[1] = ld4u(pr + h);
-            r.qq[0] = ld4u(qr); r.qq[1] = ld4u(qr + h);
+            r.p[0] = PQ_LD4(rs_p, p_or_x, ro); r.p[1] = PQ_LD4(rs_p, p_or_x, ro + h);
+            r.qq[0] = PQ_LD4(rs_q, q_or_x, ro + dn); r.qq[1] = PQ_LD4(rs_q, q_or_x, ro + dn + h);
         }
     };
     // this wave's B operands of the weight-gradient products (k = the 8 positions of the lane's chunk) and its dy rows
