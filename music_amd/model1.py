@@ -314,17 +314,42 @@ class _AutoencoderEngine:
             bsum = sum(self.flat[o[bn % (3 * i + 2) + ".bias"]:o[bn % (3 * i + 2) + ".bias"] + Sd] for i in range(N)).contiguous()
             ws["bias_skip"] = bsum
             bias_s = ptr(bsum)
-        gemm("skip", ptr(ws["Z"], SLACK), None, zb, pitch, lo, T, 0, 0, N * CHd // 32, 0, SP // 16, Sd,
-             U, sb, pitch, 0, bias_s, NONE3, NONE3, lo, T, 0)
         # final conditioning expanded over time (stretch / tile rule on the length-W sequence)
         tr = torch.arange(W, device=self.device)
         ws["cf_mode"] = (1, W // Le) if W % Le == 0 else (2, 0)
         idx = tr // (W // Le) if W % Le == 0 else tr % Le
         ws["C1"][SLACK:SLACK + B * SP * pitch].view(B, SP, pitch)[:, :Sd, lo:T] = enf[:, :, idx]
-        gemm("c1", U, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, SP // 16, Sd,
-             R1, sb, pitch, 0, self._bias("connection_1"), (C1, sb, pitch, lo), NONE3, lo, T, 1)
-        gemm("c2", R1, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, Q // 16, Q,
-             ptr(ws["O"]), Q * W, W, -lo, self._bias("connection_2"), NONE3, NONE3, lo, T, 1)
+
+        def chain(b0, nb, s_):
+            """skip product -> connection_1 (+ conditioning) -> connection_2 for clips b0 .. b0 + nb - 1 on stream s_"""
+            g_ = lambda pack, *a: self._gemm(s_, nb, m, fr(pack), *a)
+            o = b0 * sb
+            g_("skip", ptr(ws["Z"], SLACK + b0 * zb), None, zb, pitch, lo, T, 0, 0, N * CHd // 32, 0, SP // 16, Sd,
+               ptr(ws["U"], SLACK + o), sb, pitch, 0, bias_s, NONE3, NONE3, lo, T, 0)
+            g_("c1", ptr(ws["U"], SLACK + o), None, sb, pitch, lo, T, 0, 0, SP // 32, 0, SP // 16, Sd,
+               ptr(ws["R1"], SLACK + o), sb, pitch, 0, self._bias("connection_1"), (ptr(ws["C1"], SLACK + o), sb, pitch, lo), NONE3, lo, T, 1)
+            g_("c2", ptr(ws["R1"], SLACK + o), None, sb, pitch, lo, T, 0, 0, SP // 32, 0, Q // 16, Q,
+               ptr(ws["O"], b0 * Q * W), Q * W, W, -lo, self._bias("connection_2"), NONE3, NONE3, lo, T, 1)
+        # two per-clip-group chains, the second on the side stream: a product's half-empty last round of workgroups packs into
+        # the other chain's launches (music_amd/engine.py, WN_EPI_SPLIT; bit-identical results)
+        nsplit = min(int(os.environ.get("WN_EPI_SPLIT", "2")), B)
+        if nsplit >= 2 and self.overlap_wgrad:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("WN_SIDE_PRIO", "-1")))
+            side = self._side
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            half = B // 2
+            chain(0, half, st)
+            with torch.cuda.stream(side):
+                chain(half, B - half, _lib.stream())
+            ev2 = torch.cuda.Event()
+            ev2.record(side)
+            main.wait_event(ev2)
+        else:
+            chain(0, B, st)
         probs = None
         if want_probs:
             probs = torch.empty(B * W, Q, dtype=torch.float32, device=self.device)
