@@ -27,6 +27,8 @@
 // 16-byte row read gives the samples of the lane's two 4-sample groups; the R waves' pair writes, the row reads and the
 // transposed reads are all conflict free / 2-way with the chunk swizzle K[] below (MI355X_MICROARCH.md LDS table).
 //
+// (-DPQ_T_NOQ: neither stores nor loads the Q half - the upper bound of what handing dx on WHOLE could save; -DPQ_T_SC1,
+// -DPQ_GRAD_F16: see below.)
 // PQ_T_* macros are timing-build switches (remove one ingredient; results are then wrong) used to see what a launch is
 // made of: -DPQ_T_NOREC / NOGATE / NOWG / NOPQ / NOSTORE / NOFILLDY / NOCONV via `make EXTRA=...` (tools/pq_phases.sh).
 #include <stdlib.h>
@@ -200,7 +202,11 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 r.p[jj] = PQ_LD2(rs_p, p_or_x, ro + jj * rp);
+#ifdef PQ_T_NOQ
+                r.qq[jj] = f32x2{0.f, 0.f};
+#else
                 r.qq[jj] = PQ_LD2(rs_q, q_or_x, ro + dn + jj * rp);
+#endif
             }
         }
     };
@@ -279,7 +285,11 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         acc[1] += acb[1];
 #endif
 #ifndef PQ_T_NOSTORE
+#ifdef PQ_T_NOQ
+        if (ps.live && !sel) {
+#else
         if (ps.live) {
+#endif
             float* out = (sel ? a.q_out : a.p_out) + (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q;
             const bool whole = ps.t0 >= a.t_lo && ps.t0 + PQ_COLS <= a.t_hi;
 #pragma unroll
@@ -534,7 +544,11 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         r.x1[0] = ld4u(xr); r.x1[1] = ld4u(xr + h);
         if (HAS_DY) {
             r.p[0] = PQ_LD4(rs_p, p_or_x, ro); r.p[1] = PQ_LD4(rs_p, p_or_x, ro + h);
+#ifdef PQ_T_NOQ
+            r.qq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; r.qq[1] = r.qq[0];
+#else
             r.qq[0] = PQ_LD4(rs_q, q_or_x, ro + dn); r.qq[1] = PQ_LD4(rs_q, q_or_x, ro + dn + h);
+#endif
         }
     };
     // this wave's B operands of the weight-gradient products (k = the 8 positions of the lane's chunk) and its dy rows
