@@ -593,3 +593,69 @@ def test_split16_is_round_to_nearest_hi_and_lo(bf16):
     ok = fin & (xr.abs() > 0.5)                    # (an f16 lo below 6e-5 is subnormal: absolute, not relative, precision)
     rel = ((h_got.float() + l_got.float() - xr).abs() / xr.abs())[ok].max().item()
     assert rel < (2.0 ** -16 if bf16 else 2.0 ** -21), rel
+
+
+@pytest.mark.parametrize("q", [1, 7, 64, 100, 256, 300, 1000])
+def test_chunk_softmax_any_width_fwd_bwd_ce(q):
+    """wn_chunk_softmax_fwd / _bwd / _ce (the general plan's softmax, any row length) against torch in float64; for q = 256
+    they must agree with the specialised 256-wide kernels to the last few ulps."""
+    n = 1237
+    g = torch.Generator().manual_seed(q)
+    x = (torch.randn(n, q, generator=g) * 3).to(DEV)
+    dy = torch.randn(n, q, generator=g).to(DEV) * 1e-3
+    tgt = torch.randint(0, q, (n,), generator=g).to(DEV)
+    y = torch.empty_like(x)
+    dx = torch.empty_like(x)
+    st = _lib.stream()
+    call("wn_chunk_softmax_fwd", ptr(x), ptr(y), n, q, st)
+    y64 = torch.softmax(x.double(), 1)
+    assert (y.double() - y64).abs().max().item() < 5e-7
+    call("wn_chunk_softmax_bwd", ptr(y), ptr(dy), ptr(dx), n, q, st)
+    want = y64 * (dy.double() - (dy.double() * y64).sum(1, keepdim=True))
+    assert (dx.double() - want).abs().max().item() < 1e-9
+    # fused softmax + CrossEntropyLoss on the probabilities (wavenet/train.py:146,179) + both backward steps
+    probs = torch.empty_like(x)
+    part = torch.zeros(_lib.CE_NUM_PARTIALS, dtype=torch.float32, device=DEV)
+    call("wn_chunk_softmax_ce", ptr(x), ptr(tgt), ptr(probs), ptr(dx), ptr(part), n, q, 1.0 / n, st)
+    xr = x.double().clone().requires_grad_(True)
+    loss = F.cross_entropy(torch.softmax(xr, 1), tgt)
+    loss.backward()
+    assert abs(part.sum().item() - loss.item()) < 1e-5
+    assert (probs.double() - y64).abs().max().item() < 5e-7
+    assert (dx.double() - xr.grad).abs().max().item() <= 1e-4 * xr.grad.abs().max().item() + 1e-12
+    if q == 256:
+        y2 = torch.empty_like(x)
+        call("wn_chunk_softmax256_fwd", ptr(x), ptr(y2), n, st)
+        assert (y - y2).abs().max().item() < 1e-6
+    # a target outside [0, q) poisons the loss and that row's gradient (nn.CrossEntropyLoss raises for it)
+    bad = tgt.clone()
+    bad[5] = q
+    call("wn_chunk_softmax_ce", ptr(x), ptr(bad), None, ptr(dx), ptr(part), n, q, 1.0 / n, st)
+    assert torch.isnan(part.sum()) and torch.isnan(dx[5]).all() and torch.isfinite(dx[6]).all()
+
+
+def test_gate_kernels_vs_torch():
+    """wn_gate_fwd / wn_gate_bwd (general plan): z = tanh f * sigmoid g on [t_lo, t_hi) of the first `rows` rows, untouched
+    elsewhere; the derivative of SURVEY Appendix B."""
+    b, dp, rows, pitch, t_lo, t_hi = 2, 64, 50, 1024, 37, 901
+    fg = _buf(b, 2 * dp, pitch, fill=2.0, seed=1)
+    dz = _buf(b, dp, pitch, fill=1.0, seed=2)
+    z = _buf(b, dp, pitch)
+    dfg = _buf(b, 2 * dp, pitch)
+    z.fill_(7.0)
+    dfg.fill_(7.0)
+    st = _lib.stream()
+    call("wn_gate_fwd", ptr(fg, SLACK), 2 * dp * pitch, dp, rows, ptr(z, SLACK), dp * pitch, pitch, t_lo, t_hi, b, st)
+    call("wn_gate_bwd", ptr(fg, SLACK), 2 * dp * pitch, dp, rows, ptr(dz, SLACK), dp * pitch, ptr(dfg, SLACK), 2 * dp * pitch, pitch,
+         t_lo, t_hi, b, st)
+    f64 = _view(fg, b, 2 * dp, pitch).double()
+    f, g = f64[:, :dp], f64[:, dp:]
+    th, sg = torch.tanh(f), torch.sigmoid(g)
+    zv, dv, gz = _view(z, b, dp, pitch), _view(dfg, b, 2 * dp, pitch), _view(dz, b, dp, pitch).double()
+    sl = (slice(None), slice(0, rows), slice(t_lo, t_hi))
+    assert (zv[sl].double() - (th * sg)[sl]).abs().max().item() < 5e-7
+    assert (dv[:, :dp][sl].double() - (gz * sg * (1 - th * th))[sl]).abs().max().item() < 2e-6
+    assert (dv[:, dp:][sl].double() - (gz * th * sg * (1 - sg))[sl]).abs().max().item() < 2e-6
+    # nothing outside the range / rows is written
+    assert (zv[:, rows:] == 7.0).all() and (zv[:, :, :t_lo] == 7.0).all() and (zv[:, :, t_hi:] == 7.0).all()
+    assert (dv[:, rows:dp] == 7.0).all() and (dv[:, dp + rows:] == 7.0).all() and (dv[:, :, t_hi:] == 7.0).all()

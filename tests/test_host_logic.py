@@ -205,3 +205,58 @@ def test_generic_engine_index_maps_cover_every_parameter_once():
     assert g[wg[3, 5, 1]] == go + (eng.DP + 3) * cols + eng.RP + 5
     go2, _, cols2 = eng.gp_off["fg1_1"]
     assert g[wf[2, 7, 2]] == go2 + 2 * cols2 + 7
+
+
+def test_workspace_pool_semantics_without_a_gpu():
+    """WorkspacePool / WorkspaceHold (music_amd/engine.py): get() hands out the first workspace no pending backward holds,
+    a held one is never reused or evicted, peek() is what the last forward used, shapes are evicted one at a time (LRU),
+    a dropped hold releases on garbage collection, a fifth in-flight forward of one shape is an error."""
+    import pytest
+    from music_amd.engine import WorkspaceHold, WorkspacePool
+    made = []
+
+    def make(B, T):
+        ws = {"id": len(made), "gen": 0}
+        made.append(ws)
+        return ws
+    pool = WorkspacePool(make)
+    a = pool.get(1, 100)
+    assert pool.get(1, 100) is a and pool.peek(1, 100) is a and len(pool) == 1
+    a["gen"] = 1
+    h = WorkspaceHold(a)
+    b = pool.get(1, 100)                       # the first one is held: a second workspace of that shape
+    assert b is not a and pool.peek(1, 100) is b and len(pool) == 2
+    h.release()
+    assert pool.get(1, 100) is a               # free again: reused, no third allocation
+    # a hold whose workspace has been reused by a later forward (generation moved on) must not release it
+    a["gen"] = 2
+    stale = WorkspaceHold(a)
+    a["gen"] = 3
+    a["held"] = True
+    stale.release()
+    assert a["held"] is True
+    a["held"] = False
+    # garbage collection of the hold releases
+    a["gen"] = 4
+    h2 = WorkspaceHold(a)
+    assert a["held"]
+    del h2
+    assert not a["held"]
+    # LRU eviction of whole shapes, never a held one
+    a["gen"] = 5
+    keep = WorkspaceHold(a)
+    for t in (101, 102, 103):
+        pool.get(1, t)
+    pool.get(1, 104)                           # fifth shape: (1, 100) is the oldest but held -> (1, 101) goes
+    assert sorted(pool._d.keys()) == [(1, 100), (1, 102), (1, 103), (1, 104)]
+    keep.release()
+    # at most MAX_PER_SHAPE forwards in flight
+    holds = []
+    for g in range(WorkspacePool.MAX_PER_SHAPE):
+        w = pool.get(2, 50)
+        w["gen"] = g
+        holds.append(WorkspaceHold(w))
+    with pytest.raises(RuntimeError, match="waiting for their backward"):
+        pool.get(2, 50)
+    pool.clear()
+    assert len(pool) == 0
