@@ -313,7 +313,14 @@ __device__ __forceinline__ bool dec_poll2(const unsigned long long* p, unsigned 
     v0 = v1 = 0.f;
     return false;
 }
-template <bool BIAS>
+// T0 ("tap 0 ahead"): the tap-0 half of every block's f / g product, W_tap0 x(t - d), depends only on the queues, and all of
+// them are final once the previous sample's chain pass has stored its columns.  The chain workgroup therefore forms these
+// partial sums for ALL blocks of the next sample in the window in which it otherwise only waits for the other workgroup's
+// code (skip sum + post-processing of the current sample, ~5 us), and a block's critical path keeps the tap-1 half only:
+// 8 instead of 16 f / g MFMAs, half the LDS operand reads, half the weight re-arm loads.  The partial sums (4 floats per
+// thread and block) take the place of the split queue columns in LDS (n_layers x 4 KB; chosen when that fits: <= 32 blocks).
+#define DEC_T0_CHUNK 4
+template <bool BIAS, bool T0>
 __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
     constexpr int NU = 8, R = 64, D = 64, S = 256, Q = 256;
     // LDS strides between utterances (halfs): the eight utterances of a 16-lane group read 16-byte pieces at the same offset of
@@ -343,12 +350,14 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
         float* xc0 = note + NU * Q;                         // [NU][R] fp32 residual stream (two buffers)
         float* xc1 = xc0 + NU * R;
         float* bias = xc1 + NU * R;                         // [n_layers][bf D | bg D | bd R] (BIAS)
-        uint16_t* xh0 = reinterpret_cast<uint16_t*>(bias + (BIAS && a.b_layers ? a.n_layers * BL : 0));   // [NU][hi R | lo R]
+        // (T0: no bias table in LDS - the f / g biases ride in the tap-0 partial sums, a block's dense bias is fetched at its top)
+        uint16_t* xh0 = reinterpret_cast<uint16_t*>(bias + (BIAS && a.b_layers && !T0 ? a.n_layers * BL : 0));   // [NU][hi R | lo R]
         uint16_t* xh1 = xh0 + NU * VS;
         uint16_t* zh = xh1 + NU * VS;                    // [NU][hi D | lo D], chained k order
-        uint16_t* oldh = zh + NU * VS;                   // [n_layers][NU][hi R | lo R] queue columns of this sample
+        uint16_t* oldh = zh + NU * VS;                   // [n_layers][NU][hi R | lo R] queue columns of this sample (T0: of DEC_T0_CHUNK blocks)
+        f32x4* part = reinterpret_cast<f32x4*>(oldh + (size_t)DEC_T0_CHUNK * NU * VS);      // T0: [n_layers][256] tap-0 partial sums (f0, f1, g0, g1)
         for (int i = tid; i < NU * Q; i += 256) { const int uu = i / Q, e = i - uu * Q; note[i] = a.note0[ux(uu) * Q + e]; prev[i] = a.prev0[ux(uu) * Q + e]; }
-        if (BIAS && a.b_layers) for (int i = tid; i < a.n_layers * BL; i += 256) { const int l = i / BL, e = i - l * BL; bias[i] = a.b_layers[(size_t)l * (BL + S) + e]; }
+        if (BIAS && a.b_layers && !T0) for (int i = tid; i < a.n_layers * BL; i += 256) { const int l = i / BL, e = i - l * BL; bias[i] = a.b_layers[(size_t)l * (BL + S) + e]; }
         if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
         if (tid < NU) { s_pc[tid] = -1; s_nc[tid] = -1; }
         dec_sync();
@@ -380,14 +389,90 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                 }
             }
         };
-        load_queues();
+        // T0: queue columns of DEC_T0_CHUNK blocks at a time -> halfs in LDS -> this wave's 16 rows of W_tap0 x for f and g of each
+        // block -> part[l][tid].  (Same two-column products and pair sums as the block itself runs for its tap-1 half.)
+        auto tap0_ahead = [&]() {
+            const uint16_t* fgw = a.pk + a.pk_fg0;
+            Frag<F16> tf[2][2], tg[2][2];                   // [set][k-step 0, 1] of block l (set l & 1), re-armed one block ahead
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                load_a<F16, 3>(tf[0][ks], fgw, w * 4 + ks, lane);
+                load_a<F16, 3>(tg[0][ks], fgw, (4 + w) * 4 + ks, lane);
+            }
+            // the f / g biases of this thread's two rows, fetched one block ahead like the weights (a load issued where it is used
+            // would put an L2 round trip per block into this window)
+            auto bias4 = [&](int l) {
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (BIAS && a.b_layers) {
+                    const float* bl = a.b_layers + (size_t)l * (BL + S);
+                    b = f32x4{bl[ra], bl[ra + 1], bl[D + ra], bl[D + ra + 1]};
+                }
+                return b;
+            };
+            f32x4 bcur = bias4(0);
+            for (int l0 = 0; l0 < a.n_layers; l0 += DEC_T0_CHUNK) {
+                // DEC_T0_CHUNK blocks x 8 utterances x 16 float4 = 512 loads of 16 bytes: two per thread
+                f32x4 qv[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int e = j * 256 + tid;
+                    int l = l0 + (e >> 7);
+                    l = l < a.n_layers ? l : a.n_layers - 1;
+                    const int uu = (e >> 4) & (NU - 1), r4 = e & 15;
+                    qv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(
+                        a.queues + ux(uu) * (size_t)a.queues_ustride + a.q_off[l] + (size_t)slots[l] * R + 4 * r4));
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int e = j * 256 + tid;
+                    dec_put4(oldh + (size_t)(e >> 4) * VS, R, 4 * (e & 15), qv[j]);       // (e >> 4) = (l - l0) * NU + uu
+                }
+                dec_sync();
+#pragma unroll
+                for (int lc = 0; lc < DEC_T0_CHUNK; ++lc) {
+                    const int l = l0 + lc;
+                    if (l < a.n_layers) {
+                        const int ln = l + 1 < a.n_layers ? l + 1 : l;
+                        const uint16_t* fgn = fgw + (size_t)ln * a.pk_lstride;
+                        Frag<F16> (&cf)[2] = tf[lc & 1];
+                        Frag<F16> (&cg)[2] = tg[lc & 1];
+                        Frag<F16> (&nf)[2] = tf[(lc + 1) & 1];
+                        Frag<F16> (&ng)[2] = tg[(lc + 1) & 1];
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            load_a<F16, 3>(nf[ks], fgn, w * 4 + ks, lane);
+                            load_a<F16, 3>(ng[ks], fgn, (4 + w) * 4 + ks, lane);
+                        }
+                        const f32x4 bnext = bias4(ln);
+                        const uint16_t* ob = oldh + ((size_t)lc * NU + u) * VS + h * R;
+                        f16x8 bx[2];
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) bx[ks] = *reinterpret_cast<const f16x8*>(ob + 32 * ks + 8 * q);
+                        f32x4 pf[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, pg[2] = {pf[0], pf[0]};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) { pf[ks] = F16::mfma(cf[ks].hi, bx[ks], pf[ks]); pg[ks] = F16::mfma(cg[ks].hi, bx[ks], pg[ks]); }
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) { pf[ks] = F16::mfma(cf[ks].lo, bx[ks], pf[ks]); pg[ks] = F16::mfma(cg[ks].lo, bx[ks], pg[ks]); }
+                        const f32x4 af = dec_pairsum(pf[0] + pf[1]), ag = dec_pairsum(pg[0] + pg[1]);
+                        f32x4 pv = {h ? af[2] : af[0], h ? af[3] : af[1], h ? ag[2] : ag[0], h ? ag[3] : ag[1]};
+                        pv += bcur;                          // the block's f / g biases ride along
+                        bcur = bnext;
+                        part[(size_t)l * 256 + tid] = pv;
+                    }
+                }
+                dec_sync();                                  // the chunk's halfs are consumed: the next chunk may overwrite them
+            }
+        };
+        if (T0) tap0_ahead();
+        else load_queues();
+        float bdn0 = 0.f, bdn1 = 0.f;                        // T0: the next block's dense bias (two rows of this thread)
         for (int step = 0; step < a.n_steps; ++step) {
             const unsigned tag = (unsigned)step + 1u;
             // weight fragments: two register sets, each re-armed two blocks ahead (as in decode_duo_mfma_k)
             Frag<F16> wfA[4], wgA[4], wdA[2], wfB[4], wgB[4], wdB[2];
             const size_t lb1 = a.n_layers > 1 ? (size_t)a.pk_lstride : 0;
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
+            for (int s2 = T0 ? 2 : 0; s2 < 4; ++s2) {             // T0: the tap-0 k-steps (0, 1) were multiplied a sample ahead
                 load_a<F16, 3>(wfA[s2], fgb, w * 4 + s2, lane);
                 load_a<F16, 3>(wgA[s2], fgb, (4 + w) * 4 + s2, lane);
                 load_a<F16, 3>(wfB[s2], fgb + lb1, w * 4 + s2, lane);
@@ -421,6 +506,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
             float* nxt = xc1;
             uint16_t* curh = xh0;
             uint16_t* nxth = xh1;
+            if (BIAS && a.b_layers && T0 && step == 0) { bdn0 = a.b_layers[2 * D + ra]; bdn1 = a.b_layers[2 * D + ra + 1]; }
             auto blk = [&](const int l, Frag<F16> (&wf)[4], Frag<F16> (&wg)[4], Frag<F16> (&wd2)[2]) {
                 const int l2 = l + 2 < a.n_layers ? l + 2 : a.n_layers - 1;      // the set's next use (clamped: harmless reload)
                 const uint16_t* fgn = fgb + (size_t)l2 * a.pk_lstride;
@@ -429,24 +515,38 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                 const uint16_t* xb = curh + u * VS + h * R;
                 f16x8 bx[4];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) bx[ks] = *reinterpret_cast<const f16x8*>(ks < 2 ? ob + 32 * ks + 8 * q : xb + 32 * (ks - 2) + 8 * q);
+                for (int ks = T0 ? 2 : 0; ks < 4; ++ks) bx[ks] = *reinterpret_cast<const f16x8*>(ks < 2 ? ob + 32 * ks + 8 * q : xb + 32 * (ks - 2) + 8 * q);
                 f32x4 pf[4], pg[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) { pf[ks] = f32x4{0.f, 0.f, 0.f, 0.f}; pg[ks] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) { pf[ks] = F16::mfma(wf[ks].hi, bx[ks], pf[ks]); pg[ks] = F16::mfma(wg[ks].hi, bx[ks], pg[ks]); }
+                for (int ks = T0 ? 2 : 0; ks < 4; ++ks) { pf[ks] = F16::mfma(wf[ks].hi, bx[ks], pf[ks]); pg[ks] = F16::mfma(wg[ks].hi, bx[ks], pg[ks]); }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) { pf[ks] = F16::mfma(wf[ks].lo, bx[ks], pf[ks]); pg[ks] = F16::mfma(wg[ks].lo, bx[ks], pg[ks]); }
+                for (int ks = T0 ? 2 : 0; ks < 4; ++ks) { pf[ks] = F16::mfma(wf[ks].lo, bx[ks], pf[ks]); pg[ks] = F16::mfma(wg[ks].lo, bx[ks], pg[ks]); }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+                for (int ks = T0 ? 2 : 0; ks < 4; ++ks) {
                     load_a<F16, 3>(wf[ks], fgn, w * 4 + ks, lane);
                     load_a<F16, 3>(wg[ks], fgn, (4 + w) * 4 + ks, lane);
                 }
-                const f32x4 af = dec_pairsum((pf[0] + pf[1]) + (pf[2] + pf[3])), ag = dec_pairsum((pg[0] + pg[1]) + (pg[2] + pg[3]));
-                float f0 = h ? af[2] : af[0], f1 = h ? af[3] : af[1], g0 = h ? ag[2] : ag[0], g1 = h ? ag[3] : ag[1];
-                if (BIAS && a.b_layers) {
+                float f0, f1, g0, g1;
+                if (T0) {
+                    const f32x4 t0 = part[(size_t)l * 256 + tid];                  // W_tap0 x(t - d), formed a sample ahead
+                    const f32x4 af = dec_pairsum(pf[2] + pf[3]), ag = dec_pairsum(pg[2] + pg[3]);
+                    f0 = (h ? af[2] : af[0]) + t0[0]; f1 = (h ? af[3] : af[1]) + t0[1];
+                    g0 = (h ? ag[2] : ag[0]) + t0[2]; g1 = (h ? ag[3] : ag[1]) + t0[3];
+                } else {
+                    const f32x4 af = dec_pairsum((pf[0] + pf[1]) + (pf[2] + pf[3])), ag = dec_pairsum((pg[0] + pg[1]) + (pg[2] + pg[3]));
+                    f0 = h ? af[2] : af[0]; f1 = h ? af[3] : af[1]; g0 = h ? ag[2] : ag[0]; g1 = h ? ag[3] : ag[1];
+                }
+                if (BIAS && a.b_layers && !T0) {
                     f0 += bias[l * BL + ra]; f1 += bias[l * BL + ra + 1];
                     g0 += bias[l * BL + D + ra]; g1 += bias[l * BL + D + ra + 1];
+                }
+                const float bd0 = bdn0, bd1 = bdn1;          // T0: this block's dense bias was fetched during the block before
+                if (BIAS && a.b_layers && T0) {
+                    const int ln1 = l + 1 < a.n_layers ? l + 1 : 0;              // (block 0's for the next sample)
+                    const float* bl = a.b_layers + (size_t)ln1 * (BL + S) + 2 * D;
+                    bdn0 = bl[ra]; bdn1 = bl[ra + 1];
                 }
                 const float z0 = wn_tanh(f0) * wn_sigmoid(g0), z1 = wn_tanh(f1) * wn_sigmoid(g1);
                 dec_put2(zh + u * VS, D, 32 * (w >> 1) + 8 * q + 4 * (w & 1) + 2 * h, z0, z1);     // chained k order of the dense weights
@@ -466,7 +566,10 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                 for (int s2 = 0; s2 < 2; ++s2) load_a<F16, 3>(wd2[s2], dn, w * 2 + s2, lane);
                 const float xa = cur[u * R + ra], xb1 = cur[u * R + ra + 1];
                 float v0 = (h ? ad[2] : ad[0]) + xa, v1 = (h ? ad[3] : ad[1]) + xb1;
-                if (BIAS && a.b_layers) { v0 += bias[l * BL + 2 * D + ra]; v1 += bias[l * BL + 2 * D + ra + 1]; }
+                if (BIAS && a.b_layers) {
+                    if (T0) { v0 += bd0; v1 += bd1; }
+                    else { v0 += bias[l * BL + 2 * D + ra]; v1 += bias[l * BL + 2 * D + ra + 1]; }
+                }
                 nxt[u * R + ra] = v0; nxt[u * R + ra + 1] = v1;
                 dec_put2(nxth + u * VS, R, ra, v0, v1);
                 float* qd = uq + a.q_off[l] + (size_t)slots[l] * R + ra;          // the slot read at the top of this sample
@@ -483,7 +586,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
             __syncthreads();                       // all queue stores of this sample are complete (dilation 1 reads them back next)
             if (tid < a.n_layers) { int sl = slots[tid] + 1; slots[tid] = sl == a.dil[tid] ? 0 : sl; }
             dec_sync();
-            if (step + 1 < a.n_steps) load_queues();
+            if (step + 1 < a.n_steps) { if (T0) tap0_ahead(); else load_queues(); }
             if (tid < NU) {
                 float cv = 0.f;
                 dec_poll(cg_of(tid), tag, cv, cg_of(tid) + 1);
@@ -635,12 +738,33 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
         const size_t nsync = (size_t)a.sync_ustride * sizeof(unsigned long long) * (size_t)nu;
         hipError_t e = hipMemsetAsync(a.sync, 0, nsync, st);              // tags start at 1
         if (e != hipSuccess) return wn_set_error(e, __FILE__, __LINE__);
-        const size_t s80 = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R + (a.b_layers ? a.n_layers * (2 * a.D + a.R) : 0)) +
-                           sizeof(uint16_t) * (size_t)(8 * 136 * (3 + (size_t)a.n_layers));
+        const size_t s80_f = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R + (a.b_layers ? a.n_layers * (2 * a.D + a.R) : 0));
+        const size_t s80 = s80_f + sizeof(uint16_t) * (size_t)(8 * 136 * (3 + (size_t)a.n_layers));
+        // tap 0 ahead (decode_duo_mfma8_k<.., true>): split queue columns of DEC_T0_CHUNK blocks + 4 KB of partial sums per block
+        const size_t s80_t0 = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R) + sizeof(uint16_t) * (size_t)(8 * 136 * (3 + DEC_T0_CHUNK)) +
+                              (size_t)a.n_layers * 256 * sizeof(f32x4);
         const size_t s81 = sizeof(uint16_t) * (size_t)(2 * 8 * 136 + 2 * 8 * 648) + sizeof(float) * (size_t)(8 * a.Q + 2 * a.S + a.Q);
-        if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pairs x 8 utterances: %d utterances, %d steps, biases %d\n", nu, a.n_steps, any_bias ? 1 : 0);
-        if (any_bias) hipLaunchKernelGGL(decode_duo_mfma8_k<true>, dim3(2 * ((nu + 7) / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
-        else hipLaunchKernelGGL(decode_duo_mfma8_k<false>, dim3(2 * ((nu + 7) / 8)), dim3(DEC_MT), s80 > s81 ? s80 : s81, st, a);
+        static int t0_env = -1;
+        if (t0_env < 0) { const char* e = getenv("WN_DEC_T0"); t0_env = e ? atoi(e) : 1; }
+        const bool t0 = t0_env && s80_t0 + 1024 <= 160 * 1024;
+        const size_t sh = t0 ? (s80_t0 > s81 ? s80_t0 : s81) : (s80 > s81 ? s80 : s81);
+        if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pairs x 8 utterances: %d utterances, %d steps, biases %d, tap-0 ahead %d\n", nu, a.n_steps, any_bias ? 1 : 0, t0 ? 1 : 0);
+        static unsigned long long attr_done = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!((attr_done >> dev) & 1ull)) {
+            const int mx = 160 * 1024 - 1024;           // (the kernel also has ~350 bytes of static LDS)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_duo_mfma8_k<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_duo_mfma8_k<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_duo_mfma8_k<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_duo_mfma8_k<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+            attr_done |= 1ull << dev;
+        }
+        const dim3 gr(2 * ((nu + 7) / 8)), bl(DEC_MT);
+        if (any_bias && t0) hipLaunchKernelGGL((decode_duo_mfma8_k<true, true>), gr, bl, sh, st, a);
+        else if (any_bias) hipLaunchKernelGGL((decode_duo_mfma8_k<true, false>), gr, bl, sh, st, a);
+        else if (t0) hipLaunchKernelGGL((decode_duo_mfma8_k<false, true>), gr, bl, sh, st, a);
+        else hipLaunchKernelGGL((decode_duo_mfma8_k<false, false>), gr, bl, sh, st, a);
     } else {
         if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] generic fp32 kernel: %d utterances, %d steps\n", nu, a.n_steps);
         size_t sh = sizeof(float) * (size_t)(3 * a.Q + 3 * a.R + 3 * a.D + 2 * a.S + 64);

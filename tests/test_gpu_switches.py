@@ -55,6 +55,55 @@ def test_decode_generic_kernel_stays_correct():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
+def test_decode_without_tap0_ahead_stays_correct():
+    """The matrix-core decoder forms the tap-0 half of every block's f / g product a sample ahead (WN_DEC_T0, default 1, when
+    its partial sums fit LDS: <= 32 blocks); WN_DEC_T0=0 is the kernel deeper models run: the config-5 oracle tests, the
+    batched / sampling tests and the autoencoder's cached generation on it."""
+    e = dict(os.environ, WN_DEC_T0="0")
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", "decode or generat"]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+
+
+def test_decode_deeper_than_the_tap0_table_matches_the_oracle():
+    """36 blocks: the tap-0 partial sums (4 KB per block) no longer fit beside the rest of the chain's LDS, the launcher
+    falls back to the kernel that multiplies both taps in the block; ids and probabilities against the oracle."""
+    import numpy as np
+    import torch
+    from music_amd import fast_generate as fg
+    from music_amd.model import wavenet
+    from oracle import intops
+    from oracle import wavenet_oracle as wo
+    dil = [1, 2, 4, 8] * 9
+    cfg = dict(filter_width=2, dilations=dil, dilation_channels=64, residual_channels=64, skip_channels=256,
+               quantization_channels=256, use_bias=False)
+    torch.manual_seed(41)
+    net = wavenet(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    rng = np.random.default_rng(42)
+    oh = lambda ix: torch.from_numpy(intops.one_hot_proper(np.atleast_1d(ix)))[None]
+    start = rng.integers(0, 256, size=(net.receptive_field,))
+    forced = rng.integers(0, 256, size=(12,))
+    torch.set_num_threads(8)
+    pred_o, q_o = wo.fast_predict_next(params, dil, oh(start), None)
+    want = [int(pred_o[0])]
+    want_p = []
+    for s_ in forced:
+        pred_o, q_o, pr = wo.fast_predict_next(params, dil, oh(s_), q_o, return_probs=True)
+        want.append(int(pred_o[0]))
+        want_p.append(pr.numpy())
+    pred, st = fg.predict_next(net, oh(start).cuda(), None)
+    nxt = torch.from_numpy(np.concatenate([forced[1:], [0]]).astype(np.int32))
+    codes, probs, _ = fg._decode(net, st, oh(forced[0]).reshape(-1).cuda(), len(forced), forced=nxt, want_probs=True)
+    assert [int(pred[0])] + codes.cpu().tolist() == want
+    assert np.abs(probs.cpu().numpy() - np.stack(want_p)).max() < 1e-4
+
+
 @pytest.mark.parametrize("bias", [False, True])
 def test_forward_epilogue_chains_give_the_same_bits(bias, monkeypatch):
     """The skip product and the two post-processing products run as per-clip-group chains on two streams (WN_EPI_SPLIT,
