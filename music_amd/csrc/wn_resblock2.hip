@@ -229,28 +229,13 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
             int ix = a.cond_mode == 1 ? tr / a.cond_q : tr % a.cond_le;
             idx[n] = ix < a.cond_le ? ix : a.cond_le - 1;
         }
-        // a lane's NT consecutive samples read NT consecutive table entries (tile rule, no wrap inside the group) or ONE entry
-        // (stretch rule inside a bucket): one 16-byte or one 4-byte load per row instead of NT scattered ones (128 -> 32 loads per
-        // lane and block; config 4's decoder forward 33 -> ~29 us per block)
-        const bool run = NT == 4 && idx[3] == idx[0] + 3 && idx[1] == idx[0] + 1 && idx[2] == idx[0] + 2;
-        const bool same = NT == 4 && idx[3] == idx[0] && idx[1] == idx[0] && idx[2] == idx[0];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float* cr = cb + (size_t)(16 * m + 4 * q + i) * a.cond_pitch;
-                if (run) {
-                    const f32x4 v = ld4u(cr + idx[0]);
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[m][n][i] += v[n];
-                } else if (same) {
-                    const float v = cr[idx[0]];
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[m][n][i] += v;
-                } else {
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[m][n][i] += cr[idx[n]];
-                }
+                for (int n = 0; n < NT; ++n) acc[m][n][i] += cr[idx[n]];
             }
     }
 
