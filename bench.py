@@ -396,7 +396,11 @@ def main():
             print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": t.item()}), flush=True)
         return
     backend = os.environ.get("WN_DIST_BACKEND", "nccl")       # gloo: several ranks on one GPU (tests on a 1-GPU box)
-    local = local % max(1, torch.cuda.device_count())
+    n_dev = max(1, torch.cuda.device_count())
+    if backend == "gloo":
+        local = local % n_dev
+    elif local >= n_dev:
+        raise SystemExit("bench.py: LOCAL_RANK %d but %d GPU(s) visible: one rank per GPU under RCCL" % (local, n_dev))
     torch.cuda.set_device(local)
     dist = None
     # under torchrun (RANK/MASTER_ADDR set) the process group is always created, also for 1 rank,

@@ -32,8 +32,9 @@ def _run(nproc, tmp_path, with_launcher=True, shards=1, backend=None):
         env["WN_DIST_BACKEND"] = backend
     worker = os.path.join(ROOT, "tests", "dist_worker_gpu.py")
     if with_launcher:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, str(tmp_path), str(shards)]
+        # --standalone: torchrun picks and HOLDS the rendezvous port (no bind / close / hand-over race)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", str(nproc), worker, str(tmp_path), str(shards)]
     else:
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
@@ -109,6 +110,7 @@ def test_bench_under_launcher_prints_one_json_line_with_rccl():
     still carry exactly ONE line, the JSON."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                             "WN_DIST_BACKEND")}
+    # the DRIVER's launch form, verbatim (explicit master address and port)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
            "--no-cpu-baseline", "--no-extras"]
