@@ -138,7 +138,8 @@ def _packed_chain(eng):
     dilation channels, f16x3 forward mode; biases are fine) or WN_DEC_MFMA=0; plus the fragment bases of the skip and
     post-processing products (256 skip / quantisation channels), or -1."""
     import os
-    if (os.environ.get("WN_DEC_MFMA", "1") != "1" or eng.R != 64 or eng.D != 64 or eng.mode_fwd != _lib.F16X3):
+    if (os.environ.get("WN_DEC_MFMA", "1") != "1" or eng.R != 64 or eng.D != 64 or eng.mode_fwd != _lib.F16X3 or
+            "fg0" not in eng.pk_f_off):        # (the general plan's packs have another fragment order: fp32 decode kernel)
         return None, 0, 0, 0, -1, -1, -1
     off = eng.pk_f_off
     fg0, d0 = off["fg0"], off["d0"]

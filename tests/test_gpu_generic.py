@@ -133,3 +133,23 @@ def test_general_plan_trains_and_generates():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+def test_cached_queue_decode_on_the_general_plan_with_64_channels():
+    """64 / 64 channels but 128 quantisation channels: the model runs the general plan, whose weight packs the matrix-core
+    decoder cannot use - fast_generate must fall back to the generic decode kernel, and agree with the oracle."""
+    from music_amd import fast_generate as fg
+    case = ("gen64_q128", 2, [1, 2, 4], 64, 64, 96, 128, False, 1, 8)
+    net, cfg, params = _net(case, gain=2.0)
+    rf = net.receptive_field
+    rng = np.random.default_rng(5)
+    codes = rng.integers(0, 128, size=(rf + 12,))
+    onehot = torch.zeros(1, 128, len(codes))
+    onehot[0, torch.from_numpy(codes), torch.arange(len(codes))] = 1.0
+    pred, st = fg.predict_next(net, onehot[:, :, :rf].cuda(), None)
+    pred_o, q_o = wo.fast_predict_next(params, cfg["dilations"], onehot[:, :, :rf], None, quantization_channels=128)
+    assert int(pred[0]) == int(pred_o[0])
+    for t in range(rf, rf + 12):
+        pred, st = fg.predict_next(net, onehot[:, :, t:t + 1].cuda(), st)
+        pred_o, q_o = wo.fast_predict_next(params, cfg["dilations"], onehot[:, :, t:t + 1], q_o, quantization_channels=128)
+        assert int(pred[0]) == int(pred_o[0]), t
