@@ -151,3 +151,22 @@ def ptr(t, offset=0):
 def stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+_side_streams = {}
+
+
+def side_stream(device):
+    """THE second HIP stream of `device` for every engine of this process (epilogue weight gradients, the second forward
+    epilogue chain).  HIGH priority = a hardware queue of its own: a default-priority stream is dealt one of a few hardware
+    queues round-robin and can land on the main stream's (the overlap then silently disappears).  One per device, created
+    once: streams created later map onto the queues round-robin again - the 4th and 5th engine of a process, each with a
+    side stream of its own, ran their config-2 step in 7.6 instead of 4.2 ms (tools/shape_sweep.py)."""
+    import os
+    import torch
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("WN_SIDE_PRIO", "-1")))
+    return st

@@ -553,7 +553,7 @@ class WaveNetEngine:
             # chain's launches (0.435-0.445 vs 0.466-0.469 ms with two chains)
             main = torch.cuda.current_stream()
             if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("WN_SIDE_PRIO", "-1")))
+                self._side = _lib.side_stream(self.device)
             side = self._side
             ev = torch.cuda.Event()
             ev.record(main)
@@ -610,7 +610,7 @@ class WaveNetEngine:
             # HIGH priority = its own hardware queue.  A default-priority stream is dealt one of a few hardware
             # queues round-robin; once RCCL has created its streams (torchrun) the side stream landed on the
             # MAIN stream's queue and the overlap silently disappeared (epilogue_bwd 0.99 -> 1.26 ms).
-            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("WN_SIDE_PRIO", "-1")))
+            self._side = _lib.side_stream(self.device)
         side = self._side if overlap else main
 
         def on_side(fn):

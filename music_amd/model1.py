@@ -363,7 +363,7 @@ class _AutoencoderEngine:
         if nsplit >= 2 and self.overlap_wgrad:
             main = torch.cuda.current_stream()
             if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("WN_SIDE_PRIO", "-1")))
+                self._side = _lib.side_stream(self.device)
             side = self._side
             ev = torch.cuda.Event()
             ev.record(main)
@@ -521,7 +521,7 @@ class _AutoencoderEngine:
         main = torch.cuda.current_stream()
         overlap = self.overlap_wgrad
         if overlap and self._side is None:
-            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("WN_SIDE_PRIO", "-1")))
+            self._side = _lib.side_stream(self.device)
         side = self._side if overlap else main
 
         def wgrad_s(name, *args):
