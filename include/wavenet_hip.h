@@ -147,8 +147,19 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
                        float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
                        const uint16_t* wdT, const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, int z_lo,
                        float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode,
-                       int cond_le, int cond_q, float* dfg, int64_t dfg_bstride, int batch, int mode_fwd, int mode_bwd,
-                       wn_stream_t stream);
+                       int cond_le, int cond_q, float* dfg, int64_t dfg_bstride, const uint8_t* cond_idx, float* cslab,
+                       int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
+/* The conditioning gradient INSIDE that launch (wavenet_autoencoder/model1.py:183,227-247: d en[b][row][j] = sum of
+ * [df;dg][b][row][t] over the samples t of bucket j).  cond_idx (optional with cond): the bucket of every sample as bytes,
+ * cond_idx[WN_COND_IDX_PAD + (t - t_lo)] for t in [t_lo, t_hi), WN_COND_IDX_PAD zero bytes in front and 64 behind - the
+ * launch reads it instead of dividing.  cslab (needs cond_idx, cond_le <= 32; wn_resblock_bwd_pq_cond_floats() floats):
+ * every workgroup leaves its bucket sums per clip there (a 0/1 selection product on the matrix cores, exact) and
+ * wn_resblock_bwd_pq_cond_reduce adds them in a fixed order into out[b][2ch rows][cond_le] (no float atomics) - [df;dg]
+ * never reaches HBM then (dfg may stay NULL; wn_cond_grad on a written dfg gives the same sums up to summation order). */
+#define WN_COND_IDX_PAD 64
+int wn_resblock_bwd_pq_cond_floats(int t_lo, int t_hi, int batch);
+int wn_resblock_bwd_pq_cond_reduce(const float* cslab, int t_lo, int t_hi, int batch, int cond_le, float* out, int64_t out_bstride,
+                                   int out_pitch, wn_stream_t stream);
 /* ---- the GENERAL path: shapes the specialised kernels do not cover (filter_width != 2, quantization_channels != 256, more
  * than 64 residual / dilation channels; wavenet/model.py:8-15 takes any).  Its channel-mixing products are wn_chan_gemm /
  * wn_wgrad launches (any row count and K, two taps per launch, more taps accumulate through `resid`); these are the

@@ -45,7 +45,9 @@ SIGNATURES = {
                            _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_bwd_ms_slabs": [_i, _i, _i],
     "wn_resblock_bwd_pq": [_p, _p, _p, _i, _i, _p, _p, _p, _l, _l, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p,
-                           _p, _l, _i, _i, _i, _i, _p, _l, _i, _i, _i, _p],
+                           _p, _l, _i, _i, _i, _i, _p, _l, _p, _p, _i, _i, _i, _p],
+    "wn_resblock_bwd_pq_cond_floats": [_i, _i, _i],
+    "wn_resblock_bwd_pq_cond_reduce": [_p, _i, _i, _i, _i, _p, _l, _i, _p],
     "wn_split16": [_p, _p, _p, _l, _i, _p],
     "wn_shift_add": [_p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_causal_wgrad_codes": [_p, _i, _p, _p, _i, _i, _l, _i, _i, _i, _i, _i, _p, _p],
@@ -116,6 +118,9 @@ def wgrad_slabs(t_lo, t_hi, chunk, batch):
 def causal_codes_slabs(t, batch):
     """Number of slabs one wn_causal_wgrad_codes call writes (plain int return, not a status)."""
     return load().wn_causal_wgrad_codes_slabs(t, batch)
+
+
+COND_IDX_PAD = 64       # include/wavenet_hip.h WN_COND_IDX_PAD
 
 
 def ms_slabs(t_lo, t_hi, batch):

@@ -6,6 +6,7 @@
 #include "wn_common.h"
 #include "wn_kernels.h"
 
+static_assert(WN_COND_IDX_PAD == WN_PQ_IDX_PAD, "public and kernel-side pad of the bucket bytes differ");
 static thread_local char g_err[512] = "";
 
 int wn_set_error(hipError_t e, const char* file, int line) {
@@ -206,9 +207,11 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
                        float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
                        const uint16_t* wdT, const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, int z_lo,
                        float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode,
-                       int cond_le, int cond_q, float* dfg, int64_t dfg_bstride, int batch, int mode_fwd, int mode_bwd,
-                       wn_stream_t stream) {
+                       int cond_le, int cond_q, float* dfg, int64_t dfg_bstride, const uint8_t* cond_idx, float* cslab,
+                       int batch, int mode_fwd, int mode_bwd, wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: pitch must be a multiple of 4");
+    if (cslab && (!cond || !cond_idx || cond_le > 32))
+        return wn_set_error_msg(-4, "wn_resblock_bwd_pq: cslab needs cond, cond_idx and at most 32 buckets");
     if (cond && (cond_le <= 0 || (cond_mode == 1 && cond_q <= 0) || (cond_mode != 1 && cond_mode != 2)))
         return wn_set_error_msg(-4, "wn_resblock_bwd_pq: bad conditioning arguments");
     if (ch != 64) return wn_set_error_msg(-3, "wn_resblock_bwd_pq: 64 padded channels only");
@@ -222,7 +225,14 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
     a.slab_fg = slab_fg; a.slab_d = p_in ? slab_d : nullptr; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = z_lo;
     a.cond = cond; a.cond_bstride = cond_bstride; a.cond_pitch = cond_pitch; a.cond_mode = cond_mode;
     a.cond_le = cond_le; a.cond_q = cond_q; a.dfg = dfg; a.dfg_bstride = dfg_bstride;
+    a.cond_idx = cond ? cond_idx : nullptr; a.cslab = cslab;
     return wn_launch_resblock_bwd_pq(a, batch, (hipStream_t)stream);
+}
+int wn_resblock_bwd_pq_cond_floats(int t_lo, int t_hi, int batch) { return wn_pq_cond_slab_floats(t_lo, t_hi, batch); }
+int wn_resblock_bwd_pq_cond_reduce(const float* cslab, int t_lo, int t_hi, int batch, int cond_le, float* out, int64_t out_bstride,
+                                   int out_pitch, wn_stream_t stream) {
+    if (!cslab || !out || cond_le < 1 || cond_le > 32) return wn_set_error_msg(-4, "wn_resblock_bwd_pq_cond_reduce: bad argument");
+    return wn_launch_pq_cond_reduce(cslab, t_lo, t_hi, batch, cond_le, out, (long)out_bstride, out_pitch, (hipStream_t)stream);
 }
 int wn_gate_fwd(const float* fg, int64_t fg_bstride, int dp, int rows, float* z, int64_t z_bstride, int pitch, int t_lo, int t_hi,
                 int batch, wn_stream_t stream) {

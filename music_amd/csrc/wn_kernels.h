@@ -103,11 +103,21 @@ struct WnResPqArgs {
     const float* cond; long cond_bstride; int cond_pitch;  // conditioning table as in WnResArgs (null: none)
     int cond_mode, cond_le, cond_q;
     float* dfg; long dfg_bstride;                          // optional: [df;dg] written out as well ([B][2CH][pitch]); null: not
+    // optional: bucket of every sample as bytes, cond_idx[WN_PQ_IDX_PAD + (t - t_lo)] (zeros in front and 64 behind): the
+    // conditioning gather reads it instead of dividing, and with cslab the conditioning GRADIENT's bucket sums are formed in the
+    // launch (cond_le <= 32): workgroup w writes cslab[w][slot][2CH][32] = sum over its items of clip (first clip of w) + slot
+    // of [df;dg][row][t] by bucket; wn_launch_pq_cond_reduce adds the workgroups
+    const uint8_t* cond_idx; float* cslab; int cslab_slots;
 #ifdef PQ_SPAN
     int span_slot;                                      // developer build: slot of this launch in the span log
 #endif
 };
+#define WN_PQ_IDX_PAD 64
 int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st);
+int wn_pq_cond_slots(int t_lo, int t_hi, int batch);       // slots per workgroup of WnResPqArgs::cslab
+int wn_pq_cond_slab_floats(int t_lo, int t_hi, int batch); // floats of the whole cslab of one launch
+int wn_launch_pq_cond_reduce(const float* cslab, int t_lo, int t_hi, int batch, int le, float* out, long out_bstride,
+                             int out_pitch, hipStream_t st);
 int wn_launch_split16(const float* x, uint16_t* hi, uint16_t* lo, long n, int is_bf16, hipStream_t st);
 int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride, int pitch, int rows, int dn,
                         int p_lo, int t_lo, int t_hi, int batch, hipStream_t st);

@@ -68,8 +68,10 @@ typedef unsigned int pq_u32x2 __attribute__((ext_vector_type(2)));
 // per element) would buy this kernel.
 #ifdef PQ_GRAD_F16
 typedef F16 PQG;
+#define PQ_ONE16 0x3C00u                                   // 1.0 in the gradient operand type
 #else
 typedef BF16 PQG;
+#define PQ_ONE16 0x3F80u
 #endif
 typedef PQG::vec8 pqg8;
 // (a, b) -> packed 16-bit pairs hi = (cvt(a), cvt(b)) and lo = (cvt(a - hi_a), cvt(b - hi_b))
@@ -402,6 +404,11 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             const uint16_t* xf = st + PQ_XF;
             const uint16_t* dyf = st + PQ_DYF;
 
+            int cidx[2] = {0, 0};
+            if (COND && a.cond && a.cond_idx) {
+                const uint8_t* ip = a.cond_idx + (WN_PQ_IDX_PAD + tl - a.t_lo);
+                cidx[0] = ip[0]; cidx[1] = ip[1];
+            }
             f32x4 af[2], ag[2], dz[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -443,12 +450,16 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             if (COND && a.cond) {       // same conditioning bias as the forward (wavenet_autoencoder/model1.py:183)
                 const float* cb = a.cond + (size_t)p_cur.b * a.cond_bstride;
                 int idx[2];
+                if (a.cond_idx) {       // bucket bytes (samples in front of t_lo: bucket 0, their results are masked)
+                    idx[0] = cidx[0]; idx[1] = cidx[1];
+                } else {
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    int tr = tl + n - a.t_lo;
-                    tr = tr < 0 ? 0 : tr;
-                    const int ix = a.cond_mode == 1 ? tr / a.cond_q : tr % a.cond_le;
-                    idx[n] = ix < a.cond_le ? ix : a.cond_le - 1;
+                    for (int n = 0; n < 2; ++n) {
+                        int tr = tl + n - a.t_lo;
+                        tr = tr < 0 ? 0 : tr;
+                        const int ix = a.cond_mode == 1 ? tr / a.cond_q : tr % a.cond_le;
+                        idx[n] = ix < a.cond_le ? ix : a.cond_le - 1;
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -535,7 +546,9 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     for (int m = 0; m < 4; ++m) cd[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // raw rows of this wave's row tile: lane (row c, q) holds samples t0 + 4q .. + 3 and t0 + 16 + 4q .. + 3
-    struct RawRows { f32x4 x0[2], x1[2], p[2], qq[2]; };
+    struct PqU32U { uint32_t v; } __attribute__((packed, aligned(1)));
+    struct RawRows { f32x4 x0[2], x1[2], p[2], qq[2]; uint32_t bk[2]; };
+    const bool do_c = COND && a.cslab != nullptr;
     auto load_rows = [&](RawRows& r, Pos ps) {
         const size_t ro = ps.live ? (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q : 0;
         const int dd = ps.live ? a.d : 0, dn = ps.live ? a.dn : 0, h = ps.live ? 16 : 0;
@@ -550,10 +563,15 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             r.qq[0] = PQ_LD4(rs_q, q_or_x, ro + dn); r.qq[1] = PQ_LD4(rs_q, q_or_x, ro + dn + h);
 #endif
         }
+        if (COND && do_c) {                                 // buckets of the lane's 4 + 4 samples
+            const uint8_t* ip = a.cond_idx + (WN_PQ_IDX_PAD + ps.t0 + 4 * q - a.t_lo);
+            r.bk[0] = reinterpret_cast<const PqU32U*>(ip)->v;
+            r.bk[1] = reinterpret_cast<const PqU32U*>(ip + 16)->v;
+        }
     };
     // this wave's B operands of the weight-gradient products (k = the 8 positions of the lane's chunk) and its dy rows
     // in fp32 (the residual term of P)
-    struct Ops { Frag<PQG> x0, x1, dy; float dy32[8]; };
+    struct Ops { Frag<PQG> x0, x1, dy; float dy32[8]; uint32_t bk[2]; };
     auto to_frag = [&](Frag<PQG>& f, const float* w) {
         u32x4 fh, fl;
 #pragma unroll
@@ -568,6 +586,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     };
     auto convert = [&](Ops& o, const RawRows& r, Pos ps) {
         float w[8];
+        if (COND) { o.bk[0] = r.bk[0]; o.bk[1] = r.bk[1]; }
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) w[jj] = ps.live ? r.x0[jj >> 2][jj & 3] : 0.f;
         to_frag(o.x0, w);
@@ -596,9 +615,43 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         f.hi = __builtin_bit_cast(pqg8, p[0]);
         f.lo = __builtin_bit_cast(pqg8, p[64]);
     };
-    auto products = [&](int stage, const Ops& o, Pos ps) {
+    // ---- conditioning gradient in the launch (COND, a.cslab): d cond[b][row][bucket] = sum_t [df;dg][row][t] over
+    // bucket(t) == bucket is a product with a 0/1 selection matrix S[time][bucket] (exact in 16 bits: two MFMAs per tile,
+    // hi S + lo S).  W wave g takes row tiles 2g, 2g+1 of [df;dg]; S is built per item from the buckets of the lane's own 8
+    // samples (the k order of the tiles); the sums run over all items of one clip, then go to the workgroup's slot of that
+    // clip (plain stores; wn_launch_pq_cond_reduce adds the workgroups in a fixed order: no float atomics, bit-reproducible)
+    f32x4 cacc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { cacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; cacc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    int c_b = -1, c_next = 0;
+    const int c_first = pos_k(0).b;
+    float* const cs_base = do_c ? a.cslab + (size_t)wgid * a.cslab_slots * (2 * CH * 32) : nullptr;
+    auto c_store = [&](int slot, bool zero) __attribute__((always_inline)) {
+        float* sp = cs_base + (size_t)slot * (2 * CH * 32);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    sp[(size_t)(16 * (2 * g + m) + 4 * q + i) * 32 + 16 * n + c] = zero ? 0.f : cacc[m][n][i];
+    };
+    auto c_flush = [&](int newb) __attribute__((always_inline)) {      // the sums of clip c_b are complete: write its slot (zeros into skipped ones)
+        if (c_b >= 0) {
+            const int slot = c_b - c_first;
+            for (int s_ = c_next; s_ < slot && s_ < a.cslab_slots; ++s_) c_store(s_, true);
+            if (slot < a.cslab_slots) c_store(slot, false);
+            c_next = slot + 1;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { cacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; cacc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        c_b = newb;
+    };
+    auto products = [&](int stage, const Ops& o, Pos ps) __attribute__((always_inline)) {
         PQ_TICK(p0);
         const uint16_t* tt = lds + (size_t)stage * PQ_STAGE + PQ_T;
+        const bool c_item = COND && do_c && ps.live;
+        if (COND && c_item && ps.b != c_b) c_flush(ps.b);
         // ---- weight gradients: rows = all [df;dg] / z tiles, columns = this wave's x / dy rows
 #ifndef PQ_T_NOWG
         {
@@ -625,6 +678,25 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                         term(cfg[mm + 1][0], am[cur][1], o.x0, t);
                         term(cfg[mm + 1][1], am[cur][1], o.x1, t);
                     }
+                    if (COND && c_item && mm == 2 * g) {          // this wave's two row tiles of the bucket sums
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            const uint32_t key = (uint32_t)(16 * n + c) * 0x01010101u;
+                            const uint32_t x0 = o.bk[0] ^ key, x1 = o.bk[1] ^ key;
+                            u32x4 sv;
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const uint32_t xx = jj < 2 ? x0 : x1;
+                                const uint32_t e0 = (xx >> (16 * (jj & 1))) & 0xFFu, e1 = (xx >> (16 * (jj & 1) + 8)) & 0xFFu;
+                                sv[jj] = (e0 == 0 ? (uint32_t)PQ_ONE16 : 0u) | (e1 == 0 ? (uint32_t)PQ_ONE16 << 16 : 0u);
+                            }
+                            const pqg8 sel = __builtin_bit_cast(pqg8, sv);
+                            cacc[0][n] = PQG::mfma(am[cur][0].lo, sel, cacc[0][n]);
+                            cacc[1][n] = PQG::mfma(am[cur][1].lo, sel, cacc[1][n]);
+                            cacc[0][n] = PQG::mfma(am[cur][0].hi, sel, cacc[0][n]);
+                            cacc[1][n] = PQG::mfma(am[cur][1].hi, sel, cacc[1][n]);
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
@@ -644,9 +716,10 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 
     {
         RawRows rr, rr2;                                    // raw rows of items it / it+1: requested two items ahead
-        Ops ops;                                            // (one item ahead: 1.968 vs 1.941 ms for the stack)
+        Ops ops;                                            // (one item ahead: 1.968 vs 1.941 ms for the stack; the conditioned
+        constexpr int WD = COND ? 1 : 2;                    // form does that and spends the 32 registers on its bucket sums)
         load_rows(rr, pos_k(0));
-        load_rows(rr2, pos_k(1));
+        if (!COND) load_rows(rr2, pos_k(1));
         convert(ops, rr, pos_k(-1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
         __syncthreads();
         if (wv == 4) PQ_STAMP(3);
@@ -659,7 +732,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             PQ_TICK(k2);
 #ifndef PQ_T_NOCONV
             convert(ops, rr, pos_k(it));
-            load_rows(rr, pos_k(it + 2));
+            load_rows(rr, pos_k(it + WD));
 #endif
             PQ_TICK(k3);
             __syncthreads();
@@ -667,12 +740,13 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             PQ_ACC(4, k1 - k0); PQ_ACC(8, k3 - k2); PQ_ACC(9, k4 - k3);
         };
         const int n_even = (n_items + 1) & ~1;
-        for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, rr2); }
+        for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, COND ? rr : rr2); }
         if (pos_k(n_even - 1).live) products((n_even - 1) & 1, ops, pos_k(n_even - 1));    // the last item, unless it is the void one
         __syncthreads();
         if (wv == 4) PQ_STAMP(4);
         PQ_FLUSH(4, 6);
     }
+    if (COND && do_c) c_flush(-1);                      // the last clip's sums
 
     // ---- slab of this workgroup (every workgroup writes one, also an idle one: zeros)
     float* sfg = a.slab_fg + (size_t)wgid * (4 * CH * CH);
@@ -699,6 +773,75 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     }
 }
 
+// slots per workgroup of the conditioning-gradient slabs: a workgroup's items are at most (items_per_wg - 1) x (workgroups of its
+// XCD) items apart, i.e. span that many / steps_per_clip + 2 clips at most (never more than the batch)
+int wn_pq_cond_slots(int t_lo, int t_hi, int batch) {
+    if (t_hi <= t_lo || batch <= 0) return 0;
+    int t_base, steps, ipw, nwg;
+    wn_resrw_plan(t_lo, t_hi, batch, t_base, steps, ipw, nwg);
+    const int cnt_max = wn_xcd_swizzle_enabled() ? (nwg >> 3) + 1 : nwg;
+    const int s = ((ipw - 1) * cnt_max) / steps + 2;
+    return s < batch ? s : batch;
+}
+int wn_pq_cond_slab_floats(int t_lo, int t_hi, int batch) {
+    if (t_hi <= t_lo || batch <= 0) return 0;
+    int t_base, steps, ipw, nwg;
+    wn_resrw_plan(t_lo, t_hi, batch, t_base, steps, ipw, nwg);
+    return nwg * wn_pq_cond_slots(t_lo, t_hi, batch) * (2 * PQ_CH * 32);
+}
+
+// out[b][row][bucket] = sum over the workgroups w of cslab[w][b - first_clip(w)][row][bucket], over the workgroups whose items
+// reach clip b; first / last clip of w from the same plan as the block kernel's item walk (wave-uniform integer work).
+// A workgroup takes 64 consecutive (row, bucket) elements of one clip; its four waves take every fourth workgroup of an XCD's
+// range (two loads in flight each) and their partial sums are added in a fixed order: bit-reproducible.
+__global__ __launch_bounds__(256) void pq_cond_reduce_k(const float* __restrict__ cslab, int slots, int nwg, int swz, int ipw, int steps,
+                                                        int batch, int le, float* __restrict__ out, long out_bstride, int out_pitch) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int b = blockIdx.y;
+    const int total = steps * batch;
+    const int qn = nwg >> 3, rn = nwg & 7;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int x = 0; x < (swz ? 8 : 1); ++x) {
+        const int first = swz ? (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) : 0;
+        const int cnt = swz ? (x < rn ? qn + 1 : qn) : nwg;
+        int i_hi = (first + cnt) * ipw;
+        i_hi = i_hi > total ? total : i_hi;
+        // clips of this XCD's item range: skip the whole range when clip b is outside
+        if (cnt == 0 || first * ipw >= i_hi || b < (first * ipw) / steps || b > (i_hi - 1) / steps) continue;
+        auto term = [&](int j) {
+            const int i_lo = first * ipw + j;
+            if (j >= cnt || i_lo >= i_hi) return 0.f;
+            const int n_items = (i_hi - i_lo + cnt - 1) / cnt;
+            const int b_first = i_lo / steps, b_last = (i_lo + (n_items - 1) * cnt) / steps;
+            const int slot = b - b_first;
+            if (slot < 0 || b > b_last || slot >= slots) return 0.f;
+            return cslab[((size_t)(first + j) * slots + slot) * (2 * PQ_CH * 32) + e];
+        };
+        for (int j = wave; j < cnt; j += 8) {
+            const float v0 = term(j), v1 = term(j + 4);
+            acc0 += v0;
+            acc1 += v1;
+        }
+    }
+    part[wave][lane] = acc0 + acc1;
+    __syncthreads();
+    if (wave == 0 && (e & 31) < le)
+        out[(size_t)b * out_bstride + (size_t)(e >> 5) * out_pitch + (e & 31)] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+int wn_launch_pq_cond_reduce(const float* cslab, int t_lo, int t_hi, int batch, int le, float* out, long out_bstride,
+                             int out_pitch, hipStream_t st) {
+    if (t_hi <= t_lo || batch <= 0) return 0;
+    int t_base, steps, ipw, nwg;
+    wn_resrw_plan(t_lo, t_hi, batch, t_base, steps, ipw, nwg);
+    hipLaunchKernelGGL(pq_cond_reduce_k, dim3(2 * PQ_CH * 32 / 64, batch), dim3(256), 0, st, cslab,
+                       wn_pq_cond_slots(t_lo, t_hi, batch), nwg, wn_xcd_swizzle_enabled(), ipw, steps, batch, le, out, out_bstride,
+                       out_pitch);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
 int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
     if (a.t_hi <= a.t_lo || batch <= 0) return 0;
     WnResPqArgs k = a;
@@ -706,6 +849,11 @@ int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
     wn_resrw_plan(a.t_lo, a.t_hi, batch, k.t_base, k.steps_per_clip, k.items_per_wg, nwg);      // same items and slabs as wn_resrw.hip
     k.batch = batch;
     k.swz = wn_xcd_swizzle_enabled();
+    if (k.cslab) {
+        if (!k.cond_idx || k.cond_le > 32) return wn_set_error_msg(-4, "resblock_bwd_pq: cslab needs cond_idx and at most 32 buckets");
+        k.cslab_slots = wn_pq_cond_slots(a.t_lo, a.t_hi, batch);
+    }
+    if (k.cond_idx && a.t_lo - k.t_base > WN_PQ_IDX_PAD) return wn_set_error_msg(-4, "resblock_bwd_pq: item alignment beyond the cond_idx pad");
 #ifdef PQ_SPAN
     k.span_slot = pq_span_slot;
     pq_span_slot = (pq_span_slot + 1) & 63;
@@ -725,7 +873,7 @@ int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         done |= 1ull << dev;
     }
-    const bool has_dy = k.p_in && k.q_in, cnd = k.cond != nullptr || k.dfg != nullptr;
+    const bool has_dy = k.p_in && k.q_in, cnd = k.cond != nullptr || k.dfg != nullptr || k.cslab != nullptr;
     if (has_dy && cnd) hipLaunchKernelGGL((resblock_bwd_pq_k<true, true>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
     else if (has_dy) hipLaunchKernelGGL((resblock_bwd_pq_k<true, false>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
     else if (cnd) hipLaunchKernelGGL((resblock_bwd_pq_k<false, true>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);

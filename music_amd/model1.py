@@ -332,6 +332,17 @@ class _AutoencoderEngine:
                  fr("de_fg%d" % i), fr("de_d%d" % i), bf, bias_fg, self._bias(bn % (3 * i + 1)), Dd, self.Rd, CHd, d,
                  t_lo, T, t_lo, 1 if i < N - 1 else 0, ptr(tab[i]), 2 * CHd * Le, Le, mode_c, Le, q, B, m, st)   # z on the whole valid range: the backward's dWd reads it
         ws["cmodes"] = cmodes
+        if "cidx" not in ws and Le <= 32:
+            # bucket of every sample of every block as bytes (the backward block launch reads them instead of dividing, and
+            # sums [df;dg] by bucket inside the launch): row i = PAD zeros, bucket(t - t_lo) for t in [t_lo, T), zeros
+            PADI = _lib.COND_IDX_PAD
+            cidx = torch.zeros(N, PADI + T + 64, dtype=torch.uint8, device=self.device)
+            for i in range(N):
+                L = T - self.off[i + 1]
+                trr = torch.arange(L, device=self.device)
+                mode_c, q = cmodes[i]
+                cidx[i, PADI:PADI + L] = (torch.clamp(trr // q, max=Le - 1) if mode_c == 1 else trr % Le).to(torch.uint8)
+            ws["cidx"] = cidx
         self.mark("dec_stack_fwd")
         U, R1, C1 = ptr(ws["U"], SLACK), ptr(ws["R1"], SLACK), ptr(ws["C1"], SLACK)
         sb = SP * pitch
@@ -563,6 +574,11 @@ class _AutoencoderEngine:
         xd = lambda i: self._lay(ws["Xd"], i, CHd, ws)
         dfg = ptr(bw["dfg"], SLACK)
         d_tab = torch.zeros(N, B, 2 * CHd, Le, dtype=torch.float32, device=self.device)
+        # conditioning gradient inside the block launch (bucket sums on the matrix cores, [df;dg] never written) where it applies
+        fused_c = bw["pq"] and "cidx" in ws and os.environ.get("WN_AE_COND_FUSED", "1") == "1"
+        if fused_c and "cslab" not in bw:
+            bw["cslab"] = torch.empty(max(_lib.load().wn_resblock_bwd_pq_cond_floats(self.off[i + 1], T, B) for i in range(N)),
+                                      dtype=torch.float32, device=self.device)
         for i in range(N - 1, -1, -1):
             d, t_lo = self.dil[i], self.off[i + 1]
             dy = ptr(bw["dXd"][(i + 1) % 2], SLACK) if i < N - 1 else None
@@ -589,9 +605,13 @@ class _AutoencoderEngine:
                 call("wn_resblock_bwd_pq", xd(i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CHd * pitch), p_out, q_out,
                      db, zb, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), br("de_pq%d" % i), CHd, d, t_lo, T, lo,
                      ptr(bw["slab"], plan["de_fg%d" % i][0]), ptr(bw["slab"], plan["de_d%d" % i][0]) if i < N - 1 else None,
-                     ptr(ws["tab"][i]), 2 * CHd * Le, Le, mode_c, Le, max(q, 1), dfg, 2 * CHd * pitch, B, mf, mb, st)
-                call("wn_cond_grad", dfg, 2 * CHd * pitch, pitch, 2 * CHd, t_lo, T, mode_c, Le, max(q, 1),
-                     ptr(d_tab[i]), 2 * CHd * Le, Le, B, st)
+                     ptr(ws["tab"][i]), 2 * CHd * Le, Le, mode_c, Le, max(q, 1), None if fused_c else dfg, 2 * CHd * pitch,
+                     ptr(ws["cidx"][i]) if "cidx" in ws else None, ptr(bw["cslab"]) if fused_c else None, B, mf, mb, st)
+                if fused_c:
+                    call("wn_resblock_bwd_pq_cond_reduce", ptr(bw["cslab"]), t_lo, T, B, Le, ptr(d_tab[i]), 2 * CHd * Le, Le, st)
+                else:
+                    call("wn_cond_grad", dfg, 2 * CHd * pitch, pitch, 2 * CHd, t_lo, T, mode_c, Le, max(q, 1),
+                         ptr(d_tab[i]), 2 * CHd * Le, Le, B, st)
                 if i == 0:
                     call("wn_shift_add", p_out, q_out, ptr(bw["dXd"][0], SLACK), db, pitch, CHd, d, t_lo, self.off[0], T, B, st)
                 continue
