@@ -133,30 +133,29 @@ int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch);
 
 /* The whole backward of one residual block in ONE launch, data gradient of the dilated convs included (64 padded
  * channels, modes (f16x3, bf16x3), no biases): what wn_resblock_bwd_ms + the wn_chan_gemm launch on its dfg compute,
- * without [df;dg] ever reaching HBM (unless asked for: dfg != NULL writes it as wn_resblock_bwd_ms does - the
- * autoencoder's conditioned decoder blocks need it for wn_cond_grad; cond* = the conditioning table of wn_resblock_fwd,
- * NULL = none).  The data gradient travels between blocks as an UNSHIFTED pair:
+ * without [df;dg] ever reaching HBM.  The data gradient travels between blocks as an UNSHIFTED pair:
  *   in : dx_{i+1}[t] = p_in[t] (t >= p_lo) + q_in[t + dn]   (the pair the block above wrote; dn = ITS dilation, p_lo =
  *        ITS t_lo; both NULL for the last block: no dz product, no dWd);
  *   out: p_out[t] = W1^T [df;dg][t] + dx_{i+1}[t],  q_out[t] = W0^T [df;dg][t]  on [t_lo, t_hi), so that
  *        dx_i[t] = p_out[t] + q_out[t + d] (wn_shift_add makes it whole where a plain tensor is needed).
  * x / P / Q share x_bstride and pitch; q buffers must read as zero beyond t_hi (never written there).  wpq: packed
  * [W1^T; W0^T] ([2ch rows][K = df | dg], bf16x3).  Slabs as wn_resblock_bwd_ms (same count: wn_resblock_bwd_ms_slabs).
- * Autograd of wavenet/model.py:111-129 for one layer. */
+ * Autograd of wavenet/model.py:111-129 for one layer.
+ * The autoencoder's conditioned decoder blocks (wavenet_autoencoder/model1.py:183,227-247): cond != NULL is the table
+ * cond[b][2ch rows][cond_le <= 32] whose column bucket(t) is added to [f;g][.][t]; the buckets come as bytes,
+ * cond_idx[WN_COND_IDX_PAD + (t - t_lo)] for t in [t_lo, t_hi) with WN_COND_IDX_PAD zero bytes in front and 64 behind
+ * (stretch or tile rule: whatever the caller wrote there), and the bias is formed on the matrix cores as one more k-step
+ * of the recompute (table x 0/1 matrix).  cslab != NULL (wn_resblock_bwd_pq_cond_floats() floats): the conditioning
+ * GRADIENT d cond[b][row][j] = sum of [df;dg][b][row][t] over bucket j is formed inside the launch as well (a 0/1
+ * selection product, exact): every workgroup leaves its sums per clip in cslab and wn_resblock_bwd_pq_cond_reduce adds
+ * them in a fixed order into out[b][2ch rows][cond_le] (no float atomics; the same sums as wn_cond_grad on the [df;dg]
+ * wn_resblock_bwd_ms writes, up to summation order).  More than 32 buckets: wn_resblock_bwd_ms + wn_cond_grad. */
+#define WN_COND_IDX_PAD 64
 int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, int dn, int p_lo, const float* dz,
                        float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
                        const uint16_t* wdT, const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, int z_lo,
-                       float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode,
-                       int cond_le, int cond_q, float* dfg, int64_t dfg_bstride, const uint8_t* cond_idx, float* cslab,
-                       int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
-/* The conditioning gradient INSIDE that launch (wavenet_autoencoder/model1.py:183,227-247: d en[b][row][j] = sum of
- * [df;dg][b][row][t] over the samples t of bucket j).  cond_idx (optional with cond): the bucket of every sample as bytes,
- * cond_idx[WN_COND_IDX_PAD + (t - t_lo)] for t in [t_lo, t_hi), WN_COND_IDX_PAD zero bytes in front and 64 behind - the
- * launch reads it instead of dividing.  cslab (needs cond_idx, cond_le <= 32; wn_resblock_bwd_pq_cond_floats() floats):
- * every workgroup leaves its bucket sums per clip there (a 0/1 selection product on the matrix cores, exact) and
- * wn_resblock_bwd_pq_cond_reduce adds them in a fixed order into out[b][2ch rows][cond_le] (no float atomics) - [df;dg]
- * never reaches HBM then (dfg may stay NULL; wn_cond_grad on a written dfg gives the same sums up to summation order). */
-#define WN_COND_IDX_PAD 64
+                       float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_le,
+                       const uint8_t* cond_idx, float* cslab, int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
 int wn_resblock_bwd_pq_cond_floats(int t_lo, int t_hi, int batch);
 int wn_resblock_bwd_pq_cond_reduce(const float* cslab, int t_lo, int t_hi, int batch, int cond_le, float* out, int64_t out_bstride,
                                    int out_pitch, wn_stream_t stream);

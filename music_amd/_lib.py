@@ -45,7 +45,7 @@ SIGNATURES = {
                            _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_bwd_ms_slabs": [_i, _i, _i],
     "wn_resblock_bwd_pq": [_p, _p, _p, _i, _i, _p, _p, _p, _l, _l, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p,
-                           _p, _l, _i, _i, _i, _i, _p, _l, _p, _p, _i, _i, _i, _p],
+                           _p, _l, _i, _i, _p, _p, _i, _i, _i, _p],
     "wn_resblock_bwd_pq_cond_floats": [_i, _i, _i],
     "wn_resblock_bwd_pq_cond_reduce": [_p, _i, _i, _i, _i, _p, _l, _i, _p],
     "wn_split16": [_p, _p, _p, _l, _i, _p],

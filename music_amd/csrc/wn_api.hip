@@ -206,14 +206,12 @@ int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch) { return wn_resms_sl
 int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, int dn, int p_lo, const float* dz,
                        float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
                        const uint16_t* wdT, const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, int z_lo,
-                       float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode,
-                       int cond_le, int cond_q, float* dfg, int64_t dfg_bstride, const uint8_t* cond_idx, float* cslab,
-                       int batch, int mode_fwd, int mode_bwd, wn_stream_t stream) {
+                       float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_le,
+                       const uint8_t* cond_idx, float* cslab, int batch, int mode_fwd, int mode_bwd, wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: pitch must be a multiple of 4");
-    if (cslab && (!cond || !cond_idx || cond_le > 32))
-        return wn_set_error_msg(-4, "wn_resblock_bwd_pq: cslab needs cond, cond_idx and at most 32 buckets");
-    if (cond && (cond_le <= 0 || (cond_mode == 1 && cond_q <= 0) || (cond_mode != 1 && cond_mode != 2)))
-        return wn_set_error_msg(-4, "wn_resblock_bwd_pq: bad conditioning arguments");
+    if (cond && (!cond_idx || cond_le < 1 || cond_le > 32))
+        return wn_set_error_msg(-4, "wn_resblock_bwd_pq: a conditioned block needs cond_idx and 1..32 buckets");
+    if (cslab && !cond) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: cslab without cond");
     if (ch != 64) return wn_set_error_msg(-3, "wn_resblock_bwd_pq: 64 padded channels only");
     if (mode_fwd != WN_MODE_F16X3 || mode_bwd != WN_MODE_BF16X3) return wn_set_error_msg(-2, "wn_resblock_bwd_pq: (f16x3, bf16x3) only");
     if (!x_in || !dz || !p_out || !q_out || !wfg || !wpq || !slab_fg) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: null argument");
@@ -223,8 +221,7 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
     a.x_in = x_in; a.p_in = p_in; a.q_in = q_in; a.dn = dn; a.p_lo = p_lo; a.dz = dz; a.p_out = p_out; a.q_out = q_out;
     a.x_bstride = x_bstride; a.dz_bstride = dz_bstride; a.pitch = pitch; a.wfg = wfg; a.wdT = wdT; a.wpq = wpq;
     a.slab_fg = slab_fg; a.slab_d = p_in ? slab_d : nullptr; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = z_lo;
-    a.cond = cond; a.cond_bstride = cond_bstride; a.cond_pitch = cond_pitch; a.cond_mode = cond_mode;
-    a.cond_le = cond_le; a.cond_q = cond_q; a.dfg = dfg; a.dfg_bstride = dfg_bstride;
+    a.cond = cond; a.cond_bstride = cond_bstride; a.cond_pitch = cond_pitch; a.cond_le = cond_le;
     a.cond_idx = cond ? cond_idx : nullptr; a.cslab = cslab;
     return wn_launch_resblock_bwd_pq(a, batch, (hipStream_t)stream);
 }

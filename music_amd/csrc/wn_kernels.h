@@ -100,13 +100,11 @@ struct WnResPqArgs {
     int d, t_lo, t_hi, z_lo, t_base;
     int steps_per_clip, items_per_wg, batch;               // set by the launcher
     int swz;
-    const float* cond; long cond_bstride; int cond_pitch;  // conditioning table as in WnResArgs (null: none)
-    int cond_mode, cond_le, cond_q;
-    float* dfg; long dfg_bstride;                          // optional: [df;dg] written out as well ([B][2CH][pitch]); null: not
-    // optional: bucket of every sample as bytes, cond_idx[WN_PQ_IDX_PAD + (t - t_lo)] (zeros in front and 64 behind): the
-    // conditioning gather reads it instead of dividing, and with cslab the conditioning GRADIENT's bucket sums are formed in the
-    // launch (cond_le <= 32): workgroup w writes cslab[w][slot][2CH][32] = sum over its items of clip (first clip of w) + slot
-    // of [df;dg][row][t] by bucket; wn_launch_pq_cond_reduce adds the workgroups
+    // conditioned form (null: plain): cond[b][2CH rows][cond_le <= 32 buckets] is added to [f;g][row][t] at bucket(t), read as
+    // bytes from cond_idx[WN_PQ_IDX_PAD + (t - t_lo)] (zeros in front and 64 behind).  With cslab the conditioning
+    // GRADIENT's bucket sums are formed in the launch: workgroup w writes cslab[w][slot][2CH][32] = sum over its items of
+    // clip (first clip of w) + slot of [df;dg][row][t] by bucket; wn_launch_pq_cond_reduce adds the workgroups
+    const float* cond; long cond_bstride; int cond_pitch; int cond_le;
     const uint8_t* cond_idx; float* cslab; int cslab_slots;
 #ifdef PQ_SPAN
     int span_slot;                                      // developer build: slot of this launch in the span log

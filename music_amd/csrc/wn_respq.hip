@@ -1,8 +1,8 @@
 // Backward of one gated residual block in ONE launch, data gradient included (CH = 64, recompute in F16x3,
 // gradient products in BF16x3; no biases: biased blocks keep resblock_bwd_rw_k + chan_gemm_rw_k).  The autoencoder's
-// conditioned decoder blocks run it too: the conditioning table is added in the recompute as in the forward, and since
-// its gradient is a bucket sum over [df;dg] (wn_cond_grad) the R waves then ALSO write [df;dg] out (dfg != NULL) -
-// 2 more tensors of stores, still one launch less and no [df;dg] re-read by a data-gradient product.
+// conditioned decoder blocks run it too (COND, at most 32 buckets): the conditioning bias T_b[row][bucket(t)] is one more
+// k-step of the recompute (T_b times a 0/1 matrix), and its gradient - a bucket sum over [df;dg] - a 0/1 selection
+// product in the W waves (cslab), so that [df;dg] stays on the CU there as well.
 //
 // What resblock_bwd_rw_k (wn_resrw.hip) leaves to a second launch is the data gradient of the dilated convs,
 //     dx_i[t] = W1^T [df;dg][t] + W0^T [df;dg][t + d] + dx_{i+1}[t],
@@ -127,8 +127,8 @@ __device__ __forceinline__ void pq_store_frag(uint16_t* base, int idx, int lane,
     p[64] = __builtin_bit_cast(u32x4, f.lo);
 }
 
-// COND: the conditioned form (conditioning table in the recompute, [df;dg] also written out); compiled apart so that the
-// plain form keeps its register budget (240, no spills; the conditioned one spills 14)
+// COND: the conditioned form (conditioning table in the recompute, bucket sums of [df;dg]); compiled apart so that the
+// plain form keeps its register budget (242, no spills)
 template <bool HAS_DY, bool COND>
 __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     constexpr int CH = PQ_CH;
@@ -378,6 +378,26 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         load_dy(rd, pos_k(1));
         __syncthreads();                                    // stage 0 operands of the first item, the weights, the zeros
         if (wv == 0) PQ_STAMP(1);
+        // conditioned form with the bucket bytes and <= 32 buckets: the conditioning bias T_b[row][bucket(t)] is one more
+        // k-step of the recompute, T_b (this wave's f and g rows, k = bucket, f16 hi + lo) times the 0/1 matrix
+        // E[bucket][t] = (bucket(t) == bucket) - four MFMAs per N-tile instead of 16 gathered loads per lane
+        Frag<F16> tcf, tcg;
+        int tc_b = -1;
+        auto load_tab = [&](int b) __attribute__((always_inline)) {
+            const float* rf = a.cond + (size_t)b * a.cond_bstride + (size_t)(16 * g + c) * a.cond_pitch;
+            const float* rg = rf + (size_t)CH * a.cond_pitch;
+            float vf[8], vg[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int bk = 8 * q + jj;
+                const int bc = bk < a.cond_le ? bk : 0;
+                vf[jj] = bk < a.cond_le ? rf[bc] : 0.f;
+                vg[jj] = bk < a.cond_le ? rg[bc] : 0.f;
+            }
+            split8<F16, 3>(tcf, vf);
+            split8<F16, 3>(tcg, vg);
+            tc_b = b;
+        };
         auto r_body = [&](const int it, f32x2* cr, RawX& rx) {
 #ifndef PQ_NO_VOIDSKIP
             if (it >= n_items) {
@@ -389,6 +409,11 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             }
 #endif
             PQ_TICK(k0);
+            int cidx[2] = {0, 0};                            // buckets of this lane's two samples (used after the Q rows below)
+            if (COND) {
+                const uint8_t* ip = a.cond_idx + (WN_PQ_IDX_PAD + pos_k(it).t0 + 2 * c - a.t_lo);
+                cidx[0] = ip[0]; cidx[1] = ip[1];
+            }
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
             load_x(rx, pos_k(it + 3));                       // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
 #ifndef PQ_T_NOFILLDY
@@ -404,11 +429,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             const uint16_t* xf = st + PQ_XF;
             const uint16_t* dyf = st + PQ_DYF;
 
-            int cidx[2] = {0, 0};
-            if (COND && a.cond && a.cond_idx) {
-                const uint8_t* ip = a.cond_idx + (WN_PQ_IDX_PAD + tl - a.t_lo);
-                cidx[0] = ip[0]; cidx[1] = ip[1];
-            }
             f32x4 af[2], ag[2], dz[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -447,26 +467,21 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 }
             }
 #endif
-            if (COND && a.cond) {       // same conditioning bias as the forward (wavenet_autoencoder/model1.py:183)
-                const float* cb = a.cond + (size_t)p_cur.b * a.cond_bstride;
-                int idx[2];
-                if (a.cond_idx) {       // bucket bytes (samples in front of t_lo: bucket 0, their results are masked)
-                    idx[0] = cidx[0]; idx[1] = cidx[1];
-                } else {
+            if (COND) {
+                if (p_cur.b != tc_b) load_tab(p_cur.b);
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        int tr = tl + n - a.t_lo;
-                        tr = tr < 0 ? 0 : tr;
-                        const int ix = a.cond_mode == 1 ? tr / a.cond_q : tr % a.cond_le;
-                        idx[n] = ix < a.cond_le ? ix : a.cond_le - 1;
-                    }
-                }
+                for (int n = 0; n < 2; ++n) {
+                    const int id = cidx[n];
+                    const bool mine = (id >> 3) == q;
+                    const uint32_t one = 0x3C00u << (16 * (id & 1));
+                    u32x4 ev;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float* rf = cb + (size_t)(16 * g + 4 * q + i) * a.cond_pitch;
-                    const float* rg = cb + (size_t)(CH + 16 * g + 4 * q + i) * a.cond_pitch;
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) { af[n][i] += rf[idx[n]]; ag[n][i] += rg[idx[n]]; }
+                    for (int w = 0; w < 4; ++w) ev[w] = (mine && ((id & 7) >> 1) == w) ? one : 0u;
+                    const F16::vec8 e = __builtin_bit_cast(F16::vec8, ev);
+                    af[n] = F16::mfma(tcf.lo, e, af[n]);
+                    ag[n] = F16::mfma(tcg.lo, e, ag[n]);
+                    af[n] = F16::mfma(tcf.hi, e, af[n]);
+                    ag[n] = F16::mfma(tcg.hi, e, ag[n]);
                 }
             }
             PQ_TICK(k2);
@@ -494,17 +509,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                     vz[n] = ok ? th * sg : 0.f;
                     vf[n] = ok ? gz * sg * (1.0f - th * th) : 0.f;
                     vg[n] = ok ? gz * th * sg * (1.0f - sg) : 0.f;
-                }
-                if (COND && a.dfg != nullptr) {      // conditioned blocks: [df;dg] is also wanted in HBM (wn_cond_grad sums it by bucket)
-                    float* pf = a.dfg + (size_t)p_cur.b * a.dfg_bstride + (size_t)(16 * g + 4 * q + i) * a.pitch + tl;
-                    float* pg = pf + (size_t)CH * a.pitch;
-                    if (ok0 && ok1) {
-                        *reinterpret_cast<PqF2U*>(pf) = PqF2U{{vf[0], vf[1]}};
-                        *reinterpret_cast<PqF2U*>(pg) = PqF2U{{vg[0], vg[1]}};
-                    } else {
-                        if (ok0) { pf[0] = vf[0]; pg[0] = vg[0]; }
-                        if (ok1) { pf[1] = vf[1]; pg[1] = vg[1]; }
-                    }
                 }
                 // 16-bit hi/lo pairs of (sample 2c, sample 2c+1) -> one dword each in the [channel][time] tiles
                 auto put = [&](int kind, const float* v) {
@@ -849,11 +853,12 @@ int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
     wn_resrw_plan(a.t_lo, a.t_hi, batch, k.t_base, k.steps_per_clip, k.items_per_wg, nwg);      // same items and slabs as wn_resrw.hip
     k.batch = batch;
     k.swz = wn_xcd_swizzle_enabled();
-    if (k.cslab) {
-        if (!k.cond_idx || k.cond_le > 32) return wn_set_error_msg(-4, "resblock_bwd_pq: cslab needs cond_idx and at most 32 buckets");
-        k.cslab_slots = wn_pq_cond_slots(a.t_lo, a.t_hi, batch);
-    }
-    if (k.cond_idx && a.t_lo - k.t_base > WN_PQ_IDX_PAD) return wn_set_error_msg(-4, "resblock_bwd_pq: item alignment beyond the cond_idx pad");
+    if (k.cond) {
+        if (!k.cond_idx || k.cond_le > 32 || k.cond_le < 1)
+            return wn_set_error_msg(-4, "resblock_bwd_pq: a conditioned block needs cond_idx and 1..32 buckets");
+        if (a.t_lo - k.t_base > WN_PQ_IDX_PAD) return wn_set_error_msg(-4, "resblock_bwd_pq: item alignment beyond the cond_idx pad");
+        k.cslab_slots = k.cslab ? wn_pq_cond_slots(a.t_lo, a.t_hi, batch) : 0;
+    } else if (k.cslab) return wn_set_error_msg(-4, "resblock_bwd_pq: cslab without cond");
 #ifdef PQ_SPAN
     k.span_slot = pq_span_slot;
     pq_span_slot = (pq_span_slot + 1) & 63;
@@ -873,7 +878,7 @@ int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         done |= 1ull << dev;
     }
-    const bool has_dy = k.p_in && k.q_in, cnd = k.cond != nullptr || k.dfg != nullptr || k.cslab != nullptr;
+    const bool has_dy = k.p_in && k.q_in, cnd = k.cond != nullptr;
     if (has_dy && cnd) hipLaunchKernelGGL((resblock_bwd_pq_k<true, true>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
     else if (has_dy) hipLaunchKernelGGL((resblock_bwd_pq_k<true, false>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
     else if (cnd) hipLaunchKernelGGL((resblock_bwd_pq_k<false, true>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);

@@ -678,7 +678,7 @@ class WaveNetEngine:
                 call("wn_resblock_bwd_pq", self._x(ws, i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CH * pitch),
                      p_out, q_out, xb, zb, pitch, fr("fg%d" % i), br("dT%d" % i), br("pq%d" % i), CH, d, t_lo, T, lo,
                      ptr(bw["slab"], plan["fg%d" % i][0]), ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None,
-                     None, 0, 0, 0, 0, 0, None, 0, None, None, B, mf, mb, st)
+                     None, 0, 0, 0, None, None, B, mf, mb, st)
                 self.fmark("b_block")
                 if i == 0:
                     # dx_0 for the causal layer: the pair made whole once (19 us; the scatter from codes can also take the

@@ -407,7 +407,7 @@ class _AutoencoderEngine:
 
         bw = dict(dO=torch.zeros(B * self.Q * W + PAD_BACK, dtype=torch.float32, device=dev),
                   dR1=buf(self.SP), dU=buf(self.SP), dZ=buf(N * self.CHd), dXd=[buf(self.CHd), buf(self.CHd)],
-                  dfg=buf(2 * self.CHd), dE=buf(self.BwP), dXe=[buf(self.CHe), buf(self.CHe)],
+                  dE=buf(self.BwP), dXe=[buf(self.CHe), buf(self.CHe)],
                   dHe=buf(self.CHe))
         lo = self.rf - 1
         ops = [("c2", lo, T, 1024), ("c1", lo, T, 1024), ("skip", lo, T, 2048), ("bottleneck", lo, T, 512),
@@ -418,9 +418,14 @@ class _AutoencoderEngine:
               and os.environ.get("WN_MS_BWD", "1") == "1")
         bw["ms"] = ms
         # ... and the data gradient inside the same launch, as the (P, Q) pair (wn_resblock_bwd_pq), without biases
-        bw["pq"] = ms and not self.use_bias and os.environ.get("WN_PQ_BWD", "1") == "1"
+        # (the conditioning gradient too, as bucket sums on the matrix cores: at most 32 pooled frames; WN_AE_COND_FUSED=0
+        # keeps the blocks on wn_resblock_bwd_ms + wn_cond_grad, what longer encodings run)
+        bw["pq"] = (ms and not self.use_bias and os.environ.get("WN_PQ_BWD", "1") == "1" and "cidx" in ws
+                    and os.environ.get("WN_AE_COND_FUSED", "1") == "1")
         if bw["pq"]:
             bw["PQ"] = [(buf(self.CHd), buf(self.CHd)), (buf(self.CHd), buf(self.CHd))]
+        else:
+            bw["dfg"] = buf(2 * self.CHd)               # [df;dg] in HBM: only the other block kernels write it
         # encoder blocks: wn_enc_resblock_bwd (dh + both weight gradients in one launch) where it applies
         enc_fused = (self.CHe == 64 and self.mode_b == _lib.BF16X3 and os.environ.get("WN_AE_FUSED_ENC_BWD", "1") == "1")
         bw["enc_fused"] = enc_fused
@@ -572,11 +577,9 @@ class _AutoencoderEngine:
         self.mark("ce_epilogue_bwd")
         # ---- decoder stack
         xd = lambda i: self._lay(ws["Xd"], i, CHd, ws)
-        dfg = ptr(bw["dfg"], SLACK)
+        dfg = ptr(bw["dfg"], SLACK) if "dfg" in bw else None
         d_tab = torch.zeros(N, B, 2 * CHd, Le, dtype=torch.float32, device=self.device)
-        # conditioning gradient inside the block launch (bucket sums on the matrix cores, [df;dg] never written) where it applies
-        fused_c = bw["pq"] and "cidx" in ws and os.environ.get("WN_AE_COND_FUSED", "1") == "1"
-        if fused_c and "cslab" not in bw:
+        if bw["pq"] and "cslab" not in bw:
             bw["cslab"] = torch.empty(max(_lib.load().wn_resblock_bwd_pq_cond_floats(self.off[i + 1], T, B) for i in range(N)),
                                       dtype=torch.float32, device=self.device)
         for i in range(N - 1, -1, -1):
@@ -605,13 +608,8 @@ class _AutoencoderEngine:
                 call("wn_resblock_bwd_pq", xd(i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CHd * pitch), p_out, q_out,
                      db, zb, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), br("de_pq%d" % i), CHd, d, t_lo, T, lo,
                      ptr(bw["slab"], plan["de_fg%d" % i][0]), ptr(bw["slab"], plan["de_d%d" % i][0]) if i < N - 1 else None,
-                     ptr(ws["tab"][i]), 2 * CHd * Le, Le, mode_c, Le, max(q, 1), None if fused_c else dfg, 2 * CHd * pitch,
-                     ptr(ws["cidx"][i]) if "cidx" in ws else None, ptr(bw["cslab"]) if fused_c else None, B, mf, mb, st)
-                if fused_c:
-                    call("wn_resblock_bwd_pq_cond_reduce", ptr(bw["cslab"]), t_lo, T, B, Le, ptr(d_tab[i]), 2 * CHd * Le, Le, st)
-                else:
-                    call("wn_cond_grad", dfg, 2 * CHd * pitch, pitch, 2 * CHd, t_lo, T, mode_c, Le, max(q, 1),
-                         ptr(d_tab[i]), 2 * CHd * Le, Le, B, st)
+                     ptr(ws["tab"][i]), 2 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"]), B, mf, mb, st)
+                call("wn_resblock_bwd_pq_cond_reduce", ptr(bw["cslab"]), t_lo, T, B, Le, ptr(d_tab[i]), 2 * CHd * Le, Le, st)
                 if i == 0:
                     call("wn_shift_add", p_out, q_out, ptr(bw["dXd"][0], SLACK), db, pitch, CHd, d, t_lo, self.off[0], T, B, st)
                 continue

@@ -1,12 +1,17 @@
 """Developer aid: per-phase clock sums of the one-launch backward block (needs a -DPQ_DBG build of the library, passed as
-WAVENET_HIP_LIB).  Prints the share of each phase in the R and W waves' loop time."""
+WAVENET_HIP_LIB).  Prints the share of each phase in the R and W waves' loop time.  `ae`: the conditioned form, on the
+config-4 autoencoder step (tools/ae_phases.py) instead of the config-2 backward."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from music_amd import _lib
 lib = _lib.load()
 out = (ctypes.c_ulonglong * 16)()
-import tools.kbench as kb
+AE = sys.argv[1:2] == ["ae"]
+if AE:
+    import tools.ae_phases as kb
+else:
+    import tools.kbench as kb
 sys.argv = ["kbench", "bwd", "--reps", "2"]
 kb.main()
 torch.cuda.synchronize()
