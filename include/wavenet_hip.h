@@ -73,13 +73,17 @@ int wn_chan_gemm(const float* in0, const float* in1, int64_t in_bstride, int in_
  * Optional conditioning of the autoencoder's decoder (wavenet_autoencoder/model1.py:175-192,
  * 227-247): [f;g][row][t] += cond[b][row][idx(t)], cond = [B][2*ch][cond_pitch] (rows f then g),
  * idx = (t - t_lo) / cond_q when cond_mode == 1 ("stretch"), (t - t_lo) % cond_le when 2 ("tile");
- * cond == NULL disables it. */
+ * cond == NULL disables it.  Optional, for ch = 64, mode f16x3 and cond_le <= 32: the same table once more as packed
+ * A fragments, cond_pack[b] = wn_pack_weights order of the [2*ch rows][K = 32 buckets, zero beyond cond_le] matrix
+ * (8 fragments = cond_pack_bstride 8192 halfs per clip), and the buckets as bytes, cond_idx (layout under
+ * wn_resblock_bwd_pq) - the bias is then one more k-step of the fg product (table x 0/1 matrix on the matrix cores,
+ * hi + lo: the table to ~2^-22) instead of 128 gathered loads per lane; NULL: the gather. */
 int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bstride, int64_t z_bstride,
                     int pitch, const uint16_t* wfg, const uint16_t* wd, const float* bias_f,
                     const float* bias_g, const float* bias_d, int n_f, int n_d, int ch, int d,
                     int t_lo, int t_hi, int z_lo, int write_x, const float* cond, int64_t cond_bstride,
-                    int cond_pitch, int cond_mode, int cond_le, int cond_q, int batch, int mode,
-                    wn_stream_t stream);
+                    int cond_pitch, int cond_mode, int cond_le, int cond_q, const uint16_t* cond_pack,
+                    int64_t cond_pack_bstride, const uint8_t* cond_idx, int batch, int mode, wn_stream_t stream);
 
 /* Fused gated residual block, backward recompute half (autograd of model.py:118-124, SURVEY
  * Appendix B): recomputes f,g,z from x_in; dz = Wd^T dy (+ dz_crop on t >= z_lo);
@@ -148,8 +152,10 @@ int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch);
  * of the recompute (table x 0/1 matrix).  cslab != NULL (wn_resblock_bwd_pq_cond_floats() floats): the conditioning
  * GRADIENT d cond[b][row][j] = sum of [df;dg][b][row][t] over bucket j is formed inside the launch as well (a 0/1
  * selection product, exact): every workgroup leaves its sums per clip in cslab and wn_resblock_bwd_pq_cond_reduce adds
- * them in a fixed order into out[b][2ch rows][cond_le] (no float atomics; the same sums as wn_cond_grad on the [df;dg]
- * wn_resblock_bwd_ms writes, up to summation order).  More than 32 buckets: wn_resblock_bwd_ms + wn_cond_grad. */
+ * them in a fixed order (no float atomics; the same sums as wn_cond_grad on the [df;dg] wn_resblock_bwd_ms writes, up to
+ * summation order) - for n_launches block launches in ONE reduce: launch l ran with t_lo[l] (HOST array, as slab_off) and
+ * the same t_hi / batch and wrote its slabs at cslab + slab_off[l] floats; out[l][b][2ch rows][cond_le] with the strides
+ * given.  More than 32 buckets: wn_resblock_bwd_ms + wn_cond_grad. */
 #define WN_COND_IDX_PAD 64
 int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, int dn, int p_lo, const float* dz,
                        float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
@@ -157,8 +163,9 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
                        float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_le,
                        const uint8_t* cond_idx, float* cslab, int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
 int wn_resblock_bwd_pq_cond_floats(int t_lo, int t_hi, int batch);
-int wn_resblock_bwd_pq_cond_reduce(const float* cslab, int t_lo, int t_hi, int batch, int cond_le, float* out, int64_t out_bstride,
-                                   int out_pitch, wn_stream_t stream);
+int wn_resblock_bwd_pq_cond_reduce(const float* cslab, const int64_t* slab_off, const int* t_lo, int n_launches, int t_hi, int batch,
+                                   int cond_le, float* out, int64_t out_lstride, int64_t out_bstride, int out_pitch,
+                                   wn_stream_t stream);
 /* ---- the GENERAL path: shapes the specialised kernels do not cover (filter_width != 2, quantization_channels != 256, more
  * than 64 residual / dilation channels; wavenet/model.py:8-15 takes any).  Its channel-mixing products are wn_chan_gemm /
  * wn_wgrad launches (any row count and K, two taps per launch, more taps accumulate through `resid`); these are the

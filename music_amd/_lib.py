@@ -29,7 +29,7 @@ SIGNATURES = {
                      _p, _l, _i,
                      _i, _i, _i, _i, _i, _p],
     "wn_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i,
-                        _i, _i, _i, _i, _p, _l, _i, _i, _i, _i, _i, _i, _p],
+                        _i, _i, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _i, _i, _p],
     "wn_enc_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_enc_resblock_bwd": [_p, _p, _p, _p, _l, _l, _l, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p],
     "wn_enc_resblock_bwd_slabs": [_i, _i, _i],
@@ -47,7 +47,7 @@ SIGNATURES = {
     "wn_resblock_bwd_pq": [_p, _p, _p, _i, _i, _p, _p, _p, _l, _l, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p,
                            _p, _l, _i, _i, _p, _p, _i, _i, _i, _p],
     "wn_resblock_bwd_pq_cond_floats": [_i, _i, _i],
-    "wn_resblock_bwd_pq_cond_reduce": [_p, _i, _i, _i, _i, _p, _l, _i, _p],
+    "wn_resblock_bwd_pq_cond_reduce": [_p, _p, _p, _i, _i, _i, _i, _p, _l, _l, _i, _p],
     "wn_split16": [_p, _p, _p, _l, _i, _p],
     "wn_shift_add": [_p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_causal_wgrad_codes": [_p, _i, _p, _p, _i, _i, _l, _i, _i, _i, _i, _i, _p, _p],

@@ -83,8 +83,8 @@ int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bst
                     int pitch, const uint16_t* wfg, const uint16_t* wd, const float* bias_f,
                     const float* bias_g, const float* bias_d, int n_f, int n_d, int ch, int d,
                     int t_lo, int t_hi, int z_lo, int write_x, const float* cond, int64_t cond_bstride,
-                    int cond_pitch, int cond_mode, int cond_le, int cond_q, int batch, int mode,
-                    wn_stream_t stream) {
+                    int cond_pitch, int cond_mode, int cond_le, int cond_q, const uint16_t* cond_pack,
+                    int64_t cond_pack_bstride, const uint8_t* cond_idx, int batch, int mode, wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_fwd: pitch must be a multiple of 4");
     if (cond && (cond_le <= 0 || (cond_mode == 1 && cond_q <= 0) || (cond_mode != 1 && cond_mode != 2)))
         return wn_set_error_msg(-4, "wn_resblock_fwd: bad conditioning arguments");
@@ -96,6 +96,7 @@ int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bst
     a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = z_lo; a.write_x = write_x;
     a.cond = cond; a.cond_bstride = cond_bstride; a.cond_pitch = cond_pitch; a.cond_mode = cond_mode;
     a.cond_le = cond_le; a.cond_q = cond_q;
+    if (cond && cond_pack && cond_idx) { a.cond_pack = cond_pack; a.cond_pack_bstride = cond_pack_bstride; a.cond_idx = cond_idx; }
     return wn_launch_resblock_fwd(a, ch, batch, mode, (hipStream_t)stream);
 }
 
@@ -226,10 +227,14 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
     return wn_launch_resblock_bwd_pq(a, batch, (hipStream_t)stream);
 }
 int wn_resblock_bwd_pq_cond_floats(int t_lo, int t_hi, int batch) { return wn_pq_cond_slab_floats(t_lo, t_hi, batch); }
-int wn_resblock_bwd_pq_cond_reduce(const float* cslab, int t_lo, int t_hi, int batch, int cond_le, float* out, int64_t out_bstride,
-                                   int out_pitch, wn_stream_t stream) {
-    if (!cslab || !out || cond_le < 1 || cond_le > 32) return wn_set_error_msg(-4, "wn_resblock_bwd_pq_cond_reduce: bad argument");
-    return wn_launch_pq_cond_reduce(cslab, t_lo, t_hi, batch, cond_le, out, (long)out_bstride, out_pitch, (hipStream_t)stream);
+int wn_resblock_bwd_pq_cond_reduce(const float* cslab, const int64_t* slab_off, const int* t_lo, int n_launches, int t_hi, int batch,
+                                   int cond_le, float* out, int64_t out_lstride, int64_t out_bstride, int out_pitch,
+                                   wn_stream_t stream) {
+    if (!cslab || !out || !slab_off || !t_lo || n_launches < 1 || cond_le < 1 || cond_le > 32)
+        return wn_set_error_msg(-4, "wn_resblock_bwd_pq_cond_reduce: bad argument");
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+    return wn_launch_pq_cond_reduce(cslab, reinterpret_cast<const long*>(slab_off), t_lo, n_launches, t_hi, batch, cond_le, out,
+                                    (long)out_lstride, (long)out_bstride, out_pitch, (hipStream_t)stream);
 }
 int wn_gate_fwd(const float* fg, int64_t fg_bstride, int dp, int rows, float* z, int64_t z_bstride, int pitch, int t_lo, int t_hi,
                 int batch, wn_stream_t stream) {

@@ -39,6 +39,7 @@ struct __attribute__((packed, aligned(4))) F4U { float v[4]; };   // 16-B load, 
 struct F16 {
     typedef f16x8 vec8;
     typedef _Float16 elem;
+    static constexpr uint32_t one16 = 0x3C00u;             // 1.0
     static __device__ __forceinline__ elem cvt(float x) { return (_Float16)x; }
     static __device__ __forceinline__ float back(elem h) { return (float)h; }
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
@@ -51,6 +52,7 @@ struct F16 {
 struct BF16 {
     typedef bf16x8 vec8;
     typedef __bf16 elem;
+    static constexpr uint32_t one16 = 0x3F80u;
     static __device__ __forceinline__ elem cvt(float x) { return (__bf16)x; }
     static __device__ __forceinline__ float back(elem h) { return (float)h; }
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {

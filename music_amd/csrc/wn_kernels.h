@@ -46,6 +46,10 @@ struct WnResArgs {
     // optional conditioning (wavenet_autoencoder/model1.py:183,227-247): [f;g] += cond[b][row][idx(t)]
     const float* cond; long cond_bstride; int cond_pitch;   // [B][2CH][cond_pitch]
     int cond_mode, cond_le, cond_q;                     // 1: idx = (t-t_lo)/cond_q (stretch); 2: idx = (t-t_lo) % cond_le (tile)
+    // the same bias on the matrix cores (64 channels, f16x3, cond_le <= 32): cond_pack[b] = the table as 8 packed A fragments
+    // ([2CH rows][K = 32 buckets], wn_pack_weights order), cond_idx = bucket bytes as in WnResPqArgs; one more k-step of
+    // the fg product against a 0/1 matrix instead of 128 gathered loads per lane
+    const uint16_t* cond_pack; long cond_pack_bstride; const uint8_t* cond_idx;
     int swz;
 };
 int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);
@@ -114,8 +118,8 @@ struct WnResPqArgs {
 int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st);
 int wn_pq_cond_slots(int t_lo, int t_hi, int batch);       // slots per workgroup of WnResPqArgs::cslab
 int wn_pq_cond_slab_floats(int t_lo, int t_hi, int batch); // floats of the whole cslab of one launch
-int wn_launch_pq_cond_reduce(const float* cslab, int t_lo, int t_hi, int batch, int le, float* out, long out_bstride,
-                             int out_pitch, hipStream_t st);
+int wn_launch_pq_cond_reduce(const float* cslab, const long* off, const int* t_lo, int n, int t_hi, int batch, int le, float* out,
+                             long out_lstride, long out_bstride, int out_pitch, hipStream_t st);
 int wn_launch_split16(const float* x, uint16_t* hi, uint16_t* lo, long n, int is_bf16, hipStream_t st);
 int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride, int pitch, int rows, int dn,
                         int p_lo, int t_lo, int t_hi, int batch, hipStream_t st);

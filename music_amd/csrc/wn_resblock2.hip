@@ -3,6 +3,7 @@
 // workgroup, one copy of the packed weights in LDS.  (NT = 2, 16 waves x 32 columns, measured 33 vs 26.6 us per
 // config-2 block and is not instantiated.)
 #include <stdlib.h>
+#include <type_traits>
 #include "wn_common.h"
 #include "wn_kernels.h"
 
@@ -57,8 +58,9 @@ extern "C" int wn_fw_dbg_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fw_dbg), sizeof(unsigned long long) * 64 * 256 * 8);
 }
 #endif
-template <class T, int NS, int CH, int NT, bool ENC = false, int WV = NtCfg<NT>::WAVES>
+template <class T, int NS, int CH, int NT, bool ENC = false, int WV = NtCfg<NT>::WAVES, bool CND = false>
 __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
+    static_assert(!CND || (NT == 4 && NS == 3 && !ENC), "conditioning k-step: 4 samples per lane, x3 packs");
 #ifdef FW_DBG
     const int dbg_wg = blockIdx.y * gridDim.x + blockIdx.x;
     if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8] = __builtin_amdgcn_s_memrealtime();
@@ -106,6 +108,14 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
         }
     };
     issue(0);      // first activation loads are in flight while the weights are staged
+    // CND: buckets of the lane's 4 samples (columns beyond t_hi: any valid bytes, their results are masked)
+    uint32_t cbytes = 0;
+    if (CND) {
+        struct U32U { uint32_t v; } __attribute__((packed, aligned(1)));
+        int off = tl - a.t_lo;
+        off = off < a.t_hi - a.t_lo ? off : a.t_hi - a.t_lo;
+        cbytes = reinterpret_cast<const U32U*>(a.cond_idx + (WN_PQ_IDX_PAD + off))->v;
+    }
 
     // The packed weights go to LDS one k-step at a time: only the MT fragments of k-step 0 are waited for before the first
     // MFMA; the fragments of k-step s + 1 (after the last one: the dense product's) are fetched from L2 while k-step s is
@@ -116,8 +126,17 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
     constexpr int DPT = (ND * FRV + THREADS - 1) / THREADS;   // ... for the dense product's fragments
     constexpr int SPT = WPT > DPT ? WPT : DPT;
     u32x4 wst[SPT];
+    // CND: s == KS are the MT fragments of this clip's conditioning table (they take the place of k-step 0's in LDS), the
+    // dense fragments follow as s == KS + 1
     auto stage_ld = [&](int s) {          // s < KS: fg fragments (m, s), m = 0..MT-1 ; s == KS: the dense fragments
-        if (s < KS) {
+        if (CND && s == KS) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(a.cond_pack + (size_t)b * a.cond_pack_bstride);
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int v = threadIdx.x + i * THREADS;
+                if (MT * FRV % THREADS == 0 || v < MT * FRV) wst[i] = src[v];
+            }
+        } else if (s < KS) {
             const u32x4* src = reinterpret_cast<const u32x4*>(a.wfg);
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
@@ -134,7 +153,14 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
         }
     };
     auto stage_st = [&](int s) {
-        if (s < KS) {
+        if (CND && s == KS) {
+            u32x4* dst = reinterpret_cast<u32x4*>(l_fg);
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int v = threadIdx.x + i * THREADS;
+                if (MT * FRV % THREADS == 0 || v < MT * FRV) dst[(size_t)((v / FRV) * KS) * FRV + v % FRV] = wst[i];
+            }
+        } else if (s < KS) {
             u32x4* dst = reinterpret_cast<u32x4*>(l_fg);
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
@@ -219,7 +245,35 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
     if (threadIdx.x == 0 && dbg_wg < 256) fw_clk[((size_t)a.n_d_dbg * 256 + dbg_wg) * 2 + 1] = __builtin_readcyclecounter();
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    if (!ENC && a.cond) {       // per-(channel, time-bucket) conditioning bias, gathered from a tiny table
+    if (CND) {
+        // conditioning bias as one more k-step: table fragments (hi + lo) times E[bucket][t] = (bucket(t) == bucket)
+        typename T::vec8 e[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int id = (cbytes >> (8 * n)) & 0xFF;
+            const bool mine = (id >> 3) == q;
+            const uint32_t one = T::one16 << (16 * (id & 1));
+            u32x4 ev;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) ev[w] = (mine && ((id & 7) >> 1) == w) ? one : 0u;
+            e[n] = __builtin_bit_cast(typename T::vec8, ev);
+        }
+        stage_ld(KS + 1);
+        Frag<T> af[2];
+        load_a<T, NS>(af[0], l_fg, 0, lane);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m + 1 < MT) load_a<T, NS>(af[(m + 1) & 1], l_fg, (m + 1) * KS, lane);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                acc[m][n] = T::mfma(af[m & 1].lo, e[n], acc[m][n]);
+                acc[m][n] = T::mfma(af[m & 1].hi, e[n], acc[m][n]);
+            }
+        }
+        stage_st(KS + 1);
+        __syncthreads();
+    }
+    if (!ENC && !CND && a.cond) {       // per-(channel, time-bucket) conditioning bias, gathered from a tiny table
         const float* cb = a.cond + (size_t)b * a.cond_bstride;
         int idx[NT];
 #pragma unroll
@@ -397,6 +451,20 @@ static int launch_fwd_nt(const WnResArgs& a, int ch, int batch, hipStream_t st) 
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_fwd_nt_k<T, NS, 64, NT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
             done |= 1ull << dev;
+        }
+        if constexpr (NS == 3 && NT == 4 && std::is_same<T, F16>::value) {
+            if (k.cond && k.cond_pack && k.cond_idx && k.cond_le <= 32) {       // conditioning bias on the matrix cores
+                if (a.t_lo - k.t_base > WN_PQ_IDX_PAD) return wn_set_error_msg(-4, "resblock_fwd: tile origin beyond the cond_idx pad");
+                static unsigned long long done_c = 0;
+                if (!((done_c >> dev) & 1ull)) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_fwd_nt_k<T, NS, 64, NT, false, NtCfg<NT>::WAVES, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+                    done_c |= 1ull << dev;
+                }
+                hipLaunchKernelGGL((resblock_fwd_nt_k<T, NS, 64, NT, false, NtCfg<NT>::WAVES, true>), g, b, sh, st, k);
+                WN_CHECK_LAUNCH();
+                return 0;
+            }
         }
         hipLaunchKernelGGL((resblock_fwd_nt_k<T, NS, 64, NT>), g, b, sh, st, k);
     } else {

@@ -32,6 +32,7 @@
 // PQ_T_* macros are timing-build switches (remove one ingredient; results are then wrong) used to see what a launch is
 // made of: -DPQ_T_NOREC / NOGATE / NOWG / NOPQ / NOSTORE / NOFILLDY / NOCONV via `make EXTRA=...` (tools/pq_phases.sh).
 #include <stdlib.h>
+#include <string.h>
 #include "wn_common.h"
 #include "wn_kernels.h"
 
@@ -794,16 +795,21 @@ int wn_pq_cond_slab_floats(int t_lo, int t_hi, int batch) {
     return nwg * wn_pq_cond_slots(t_lo, t_hi, batch) * (2 * PQ_CH * 32);
 }
 
-// out[b][row][bucket] = sum over the workgroups w of cslab[w][b - first_clip(w)][row][bucket], over the workgroups whose items
-// reach clip b; first / last clip of w from the same plan as the block kernel's item walk (wave-uniform integer work).
-// A workgroup takes 64 consecutive (row, bucket) elements of one clip; its four waves take every fourth workgroup of an XCD's
-// range (two loads in flight each) and their partial sums are added in a fixed order: bit-reproducible.
-__global__ __launch_bounds__(256) void pq_cond_reduce_k(const float* __restrict__ cslab, int slots, int nwg, int swz, int ipw, int steps,
-                                                        int batch, int le, float* __restrict__ out, long out_bstride, int out_pitch) {
+// out[l][b][row][bucket] = sum over the workgroups w of block launch l of cslab_l[w][b - first_clip(w)][row][bucket], over the
+// workgroups whose items reach clip b; first / last clip of w from the same plan as the block kernel's item walk
+// (wave-uniform integer work).  A workgroup takes 64 consecutive (row, bucket) elements of one clip of one launch; its four
+// waves take every fourth workgroup of an XCD's range (two loads in flight each) and their partial sums are added in a
+// fixed order: bit-reproducible.  Up to PQ_RED_LAYERS launches' slabs per reduce (blockIdx.z), one plan each.
+#define PQ_RED_LAYERS 64
+struct PqRedPlan { long off[PQ_RED_LAYERS]; int nwg[PQ_RED_LAYERS], ipw[PQ_RED_LAYERS], steps[PQ_RED_LAYERS], slots[PQ_RED_LAYERS]; };
+__global__ __launch_bounds__(256) void pq_cond_reduce_k(const float* __restrict__ cslab_all, PqRedPlan pl, int swz, int batch, int le,
+                                                        float* __restrict__ out, long out_lstride, long out_bstride, int out_pitch) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, l = blockIdx.z;
+    const float* cslab = cslab_all + pl.off[l];
+    const int nwg = pl.nwg[l], ipw = pl.ipw[l], steps = pl.steps[l], slots = pl.slots[l];
     const int total = steps * batch;
     const int qn = nwg >> 3, rn = nwg & 7;
     float acc0 = 0.f, acc1 = 0.f;
@@ -832,17 +838,28 @@ __global__ __launch_bounds__(256) void pq_cond_reduce_k(const float* __restrict_
     part[wave][lane] = acc0 + acc1;
     __syncthreads();
     if (wave == 0 && (e & 31) < le)
-        out[(size_t)b * out_bstride + (size_t)(e >> 5) * out_pitch + (e & 31)] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        out[(size_t)l * out_lstride + (size_t)b * out_bstride + (size_t)(e >> 5) * out_pitch + (e & 31)] =
+            (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
-int wn_launch_pq_cond_reduce(const float* cslab, int t_lo, int t_hi, int batch, int le, float* out, long out_bstride,
-                             int out_pitch, hipStream_t st) {
-    if (t_hi <= t_lo || batch <= 0) return 0;
-    int t_base, steps, ipw, nwg;
-    wn_resrw_plan(t_lo, t_hi, batch, t_base, steps, ipw, nwg);
-    hipLaunchKernelGGL(pq_cond_reduce_k, dim3(2 * PQ_CH * 32 / 64, batch), dim3(256), 0, st, cslab,
-                       wn_pq_cond_slots(t_lo, t_hi, batch), nwg, wn_xcd_swizzle_enabled(), ipw, steps, batch, le, out, out_bstride,
-                       out_pitch);
-    WN_CHECK_LAUNCH();
+// n launches' slabs at once: launch l ran with t_lo[l] (host array) and wrote its slabs at cslab + off[l] floats
+int wn_launch_pq_cond_reduce(const float* cslab, const long* off, const int* t_lo, int n, int t_hi, int batch, int le, float* out,
+                             long out_lstride, long out_bstride, int out_pitch, hipStream_t st) {
+    if (batch <= 0) return 0;
+    for (int l0 = 0; l0 < n; l0 += PQ_RED_LAYERS) {
+        const int nl = n - l0 < PQ_RED_LAYERS ? n - l0 : PQ_RED_LAYERS;
+        PqRedPlan pl;
+        memset(&pl, 0, sizeof(pl));
+        for (int l = 0; l < nl; ++l) {
+            if (t_hi <= t_lo[l0 + l]) return wn_set_error_msg(-4, "pq_cond_reduce: empty launch");
+            int t_base;
+            wn_resrw_plan(t_lo[l0 + l], t_hi, batch, t_base, pl.steps[l], pl.ipw[l], pl.nwg[l]);
+            pl.slots[l] = wn_pq_cond_slots(t_lo[l0 + l], t_hi, batch);
+            pl.off[l] = off[l0 + l];
+        }
+        hipLaunchKernelGGL(pq_cond_reduce_k, dim3(2 * PQ_CH * 32 / 64, batch, nl), dim3(256), 0, st, cslab, pl,
+                           wn_xcd_swizzle_enabled(), batch, le, out + (size_t)l0 * out_lstride, out_lstride, out_bstride, out_pitch);
+        WN_CHECK_LAUNCH();
+    }
     return 0;
 }
 

@@ -526,7 +526,7 @@ class WaveNetEngine:
                  fr("fg%d" % i), fr("d%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),
                  self._bias_ptr(bn % (4 * i + 2)), self.D, self.R, CH, d, self.off[i + 1], T,
                  self.off[i + 1] if z_whole else self.rf - 1,
-                 1 if i < N - 1 else 0, None, 0, 0, 0, 0, 0, B, mf, st)
+                 1 if i < N - 1 else 0, None, 0, 0, 0, 0, 0, None, 0, None, B, mf, st)
         self.mark("stack_fwd")
         lo = self.rf - 1
         bias_s = None

@@ -28,11 +28,11 @@ import torch.nn.functional as F
 try:
     from . import _lib
     from ._lib import call, ptr
-    from .engine import SLACK, PAD_BACK, _Spec, _pad, pack_index, WorkspacePool, WorkspaceHold
+    from .engine import SLACK, PAD_BACK, _Spec, _pad, pack_index, pack_positions, WorkspacePool, WorkspaceHold
 except ImportError:
     from music_amd import _lib
     from music_amd._lib import call, ptr
-    from music_amd.engine import SLACK, PAD_BACK, _Spec, _pad, pack_index, WorkspacePool, WorkspaceHold
+    from music_amd.engine import SLACK, PAD_BACK, _Spec, _pad, pack_index, pack_positions, WorkspacePool, WorkspaceHold
 
 
 class _AutoencoderEngine:
@@ -321,28 +321,43 @@ class _AutoencoderEngine:
         self.mark("bottleneck_cond_de_causal")
         bn = "de_dilation_layer_stack.%d"
         cmodes = []
+        for i in range(N):
+            L = T - self.off[i + 1]
+            cmodes.append((1, L // Le) if L % Le == 0 else (2, 0))
+        ws["cmodes"] = cmodes
+        cpk = cix = None
+        if Le <= 32 and CHd == 64 and m == _lib.F16X3 and os.environ.get("WN_AE_COND_MFMA", "1") == "1":
+            # the conditioning bias on the matrix cores: bucket of every sample of every block as bytes (built once per
+            # workspace: row i = PAD zeros, bucket(t - t_lo) for t in [t_lo, T), zeros) and, per forward, the tables as
+            # packed A fragments ([2CH rows][32 buckets] per block and clip)
+            if "cidx" not in ws:
+                PADI = _lib.COND_IDX_PAD
+                cidx = torch.zeros(N, PADI + T + 64, dtype=torch.uint8, device=self.device)
+                for i in range(N):
+                    L = T - self.off[i + 1]
+                    trr = torch.arange(L, device=self.device)
+                    mode_c, q = cmodes[i]
+                    cidx[i, PADI:PADI + L] = (torch.clamp(trr // q, max=Le - 1) if mode_c == 1 else trr % Le).to(torch.uint8)
+                ws["cidx"] = cidx
+                row, k = pack_positions(2 * CHd // 16, 1, False)
+                one = np.where(k < Le, row * Le + k, -1).astype(np.int64)                  # one [2CH][Le] table
+                base = np.arange(N * B, dtype=np.int64)[:, None] * (2 * CHd * Le)
+                ws["ctab_idx"] = torch.from_numpy(np.where(one[None, :] >= 0, base + one[None, :], -1).astype(np.int32)
+                                                  .reshape(-1)).to(self.device)
+                ws["ctab_pk"] = torch.empty(N * B * 2 * CHd * 32 * 2, dtype=torch.int16, device=self.device)
+            call("wn_pack_weights", ptr(tab), ptr(ws["ctab_idx"]), ptr(ws["ctab_pk"]), ws["ctab_idx"].numel(), m, st)
+            cpk, cix = ws["ctab_pk"], ws["cidx"]
+        cpb = 2 * CHd * 32 * 2                          # halfs of one clip's packed table (hi + lo planes)
         for i, d in enumerate(self.dil):
             t_lo = self.off[i + 1]
-            L = T - t_lo
-            mode_c, q = (1, L // Le) if L % Le == 0 else (2, 0)
-            cmodes.append((mode_c, q))
+            mode_c, q = cmodes[i]
             bias_fg = self._bias(bn % (3 * i))
             bf = bias_fg + 4 * Dd if bias_fg is not None else None      # filter_gate bias: gate rows first
             call("wn_resblock_fwd", xd(i), xd(i + 1), ptr(ws["Z"], SLACK + i * CHd * pitch), db, zb, pitch,
                  fr("de_fg%d" % i), fr("de_d%d" % i), bf, bias_fg, self._bias(bn % (3 * i + 1)), Dd, self.Rd, CHd, d,
-                 t_lo, T, t_lo, 1 if i < N - 1 else 0, ptr(tab[i]), 2 * CHd * Le, Le, mode_c, Le, q, B, m, st)   # z on the whole valid range: the backward's dWd reads it
-        ws["cmodes"] = cmodes
-        if "cidx" not in ws and Le <= 32:
-            # bucket of every sample of every block as bytes (the backward block launch reads them instead of dividing, and
-            # sums [df;dg] by bucket inside the launch): row i = PAD zeros, bucket(t - t_lo) for t in [t_lo, T), zeros
-            PADI = _lib.COND_IDX_PAD
-            cidx = torch.zeros(N, PADI + T + 64, dtype=torch.uint8, device=self.device)
-            for i in range(N):
-                L = T - self.off[i + 1]
-                trr = torch.arange(L, device=self.device)
-                mode_c, q = cmodes[i]
-                cidx[i, PADI:PADI + L] = (torch.clamp(trr // q, max=Le - 1) if mode_c == 1 else trr % Le).to(torch.uint8)
-            ws["cidx"] = cidx
+                 t_lo, T, t_lo, 1 if i < N - 1 else 0, ptr(tab[i]), 2 * CHd * Le, Le, mode_c, Le, q,
+                 ptr(cpk, i * B * cpb) if cpk is not None else None, cpb, ptr(cix[i]) if cix is not None else None,
+                 B, m, st)   # z on the whole valid range: the backward's dWd reads it
         self.mark("dec_stack_fwd")
         U, R1, C1 = ptr(ws["U"], SLACK), ptr(ws["R1"], SLACK), ptr(ws["C1"], SLACK)
         sb = SP * pitch
@@ -580,8 +595,12 @@ class _AutoencoderEngine:
         dfg = ptr(bw["dfg"], SLACK) if "dfg" in bw else None
         d_tab = torch.zeros(N, B, 2 * CHd, Le, dtype=torch.float32, device=self.device)
         if bw["pq"] and "cslab" not in bw:
-            bw["cslab"] = torch.empty(max(_lib.load().wn_resblock_bwd_pq_cond_floats(self.off[i + 1], T, B) for i in range(N)),
-                                      dtype=torch.float32, device=self.device)
+            # per-workgroup bucket sums of every block launch (one region each), added by ONE reduce behind the stack
+            import ctypes
+            fl = [_lib.load().wn_resblock_bwd_pq_cond_floats(self.off[i + 1], T, B) for i in range(N)]
+            bw["cs_off"] = (ctypes.c_int64 * N)(*np.concatenate([[0], np.cumsum(fl)[:-1]]).tolist())
+            bw["cs_tlo"] = (ctypes.c_int * N)(*[self.off[i + 1] for i in range(N)])
+            bw["cslab"] = torch.empty(sum(fl), dtype=torch.float32, device=self.device)
         for i in range(N - 1, -1, -1):
             d, t_lo = self.dil[i], self.off[i + 1]
             dy = ptr(bw["dXd"][(i + 1) % 2], SLACK) if i < N - 1 else None
@@ -608,8 +627,7 @@ class _AutoencoderEngine:
                 call("wn_resblock_bwd_pq", xd(i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CHd * pitch), p_out, q_out,
                      db, zb, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), br("de_pq%d" % i), CHd, d, t_lo, T, lo,
                      ptr(bw["slab"], plan["de_fg%d" % i][0]), ptr(bw["slab"], plan["de_d%d" % i][0]) if i < N - 1 else None,
-                     ptr(ws["tab"][i]), 2 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"]), B, mf, mb, st)
-                call("wn_resblock_bwd_pq_cond_reduce", ptr(bw["cslab"]), t_lo, T, B, Le, ptr(d_tab[i]), 2 * CHd * Le, Le, st)
+                     ptr(ws["tab"][i]), 2 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"], bw["cs_off"][i]), B, mf, mb, st)
                 if i == 0:
                     call("wn_shift_add", p_out, q_out, ptr(bw["dXd"][0], SLACK), db, pitch, CHd, d, t_lo, self.off[0], T, B, st)
                 continue
@@ -637,6 +655,9 @@ class _AutoencoderEngine:
                       CHd // 16, CHd // 16, 0, CHd, t_lo, T)
             gemm("de_fgT%d" % i, dfg, dfg, 2 * CHd * pitch, pitch, t_lo, T, 0, d, 2 * CHd // 32, 2 * CHd // 32, CHd // 16, Rd,
                  ptr(bw["dXd"][i % 2], SLACK), db, pitch, 0, None, (dy, db, pitch, t_lo) if dy else NONE3, NONE3, self.off[i], T, 0)
+        if bw["pq"]:
+            call("wn_resblock_bwd_pq_cond_reduce", ptr(bw["cslab"]), bw["cs_off"], bw["cs_tlo"], N, T, B, Le, ptr(d_tab),
+                 B * 2 * CHd * Le, 2 * CHd * Le, Le, st)
         self.mark("dec_stack_bwd")
         x = ws["x_in"]
         codes_path = ws.get("x_codes") is not None

@@ -238,7 +238,7 @@ def test_resblock_fwd(CH, R, D, d, mode):
     off_in = 5
     t_lo, z_lo = off_in + d, off_in + d + 300
     call("wn_resblock_fwd", ptr(xin, SLACK), ptr(xout, SLACK), ptr(zout, SLACK), CH * pitch, CH * pitch, pitch,
-         ptr(pfg), ptr(pd), None, None, None, D, R, CH, d, t_lo, T, z_lo, 1, None, 0, 0, 0, 0, 0, B, mode, _lib.stream())
+         ptr(pfg), ptr(pd), None, None, None, D, R, CH, d, t_lo, T, z_lo, 1, None, 0, 0, 0, 0, 0, None, 0, None, B, mode, _lib.stream())
     torch.cuda.synchronize()
     x = _view(xin, B, CH, pitch).cpu()[:, :R, off_in:T].double()
     f, g, z, y = _res_ref(x, torch.from_numpy(wf).double(), torch.from_numpy(wg).double(), torch.from_numpy(wd).double(), d)
