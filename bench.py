@@ -234,7 +234,7 @@ def sub_benchmarks(net, x, target):
                                  "frac_encoder_bwd": frac(eb_, ph.get("enc_stack_bwd", float("nan"))),
                                  "frac": frac(df + db_ + ef + eb_, st_ms), "stacks_ms": st_ms,
                                  "note": "decoder stack: SURVEY 8(d) A_f / A_b; encoder stack: the same accounting (enc_stack_bytes); the "
-                                         "decoder backward also stores [df;dg] for the conditioning gradient, not counted"}}
+                                         "conditioning (packed tables, bucket bytes, per-workgroup bucket sums) is not counted"}}
     del ae, aeng
     from music_amd import fast_generate as fg
     start = torch.zeros(1, 256, net.receptive_field, device=dev)
