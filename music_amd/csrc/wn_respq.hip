@@ -797,22 +797,22 @@ int wn_pq_cond_slab_floats(int t_lo, int t_hi, int batch) {
 
 // out[l][b][row][bucket] = sum over the workgroups w of block launch l of cslab_l[w][b - first_clip(w)][row][bucket], over the
 // workgroups whose items reach clip b; first / last clip of w from the same plan as the block kernel's item walk
-// (wave-uniform integer work).  A workgroup takes 64 consecutive (row, bucket) elements of one clip of one launch; its four
-// waves take every fourth workgroup of an XCD's range (two loads in flight each) and their partial sums are added in a
-// fixed order: bit-reproducible.  Up to PQ_RED_LAYERS launches' slabs per reduce (blockIdx.z), one plan each.
+// (wave-uniform integer work).  A workgroup takes 256 consecutive (row, bucket) elements of one clip of one launch (16 bytes
+// per lane); its four waves take every fourth workgroup of an XCD's range (eight loads in flight each) and their partial
+// sums are added in a fixed order: bit-reproducible.  Up to PQ_RED_LAYERS launches' slabs per reduce (blockIdx.z), one plan each.
 #define PQ_RED_LAYERS 64
 struct PqRedPlan { long off[PQ_RED_LAYERS]; int nwg[PQ_RED_LAYERS], ipw[PQ_RED_LAYERS], steps[PQ_RED_LAYERS], slots[PQ_RED_LAYERS]; };
 __global__ __launch_bounds__(256) void pq_cond_reduce_k(const float* __restrict__ cslab_all, PqRedPlan pl, int swz, int batch, int le,
                                                         float* __restrict__ out, long out_lstride, long out_bstride, int out_pitch) {
-    __shared__ float part[4][64];
+    __shared__ f32x4 part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
+    const int e = blockIdx.x * 256 + lane * 4;                 // four consecutive buckets of one row
     const int b = blockIdx.y, l = blockIdx.z;
     const float* cslab = cslab_all + pl.off[l];
     const int nwg = pl.nwg[l], ipw = pl.ipw[l], steps = pl.steps[l], slots = pl.slots[l];
     const int total = steps * batch;
     const int qn = nwg >> 3, rn = nwg & 7;
-    float acc0 = 0.f, acc1 = 0.f;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     for (int x = 0; x < (swz ? 8 : 1); ++x) {
         const int first = swz ? (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) : 0;
         const int cnt = swz ? (x < rn ? qn + 1 : qn) : nwg;
@@ -820,26 +820,35 @@ __global__ __launch_bounds__(256) void pq_cond_reduce_k(const float* __restrict_
         i_hi = i_hi > total ? total : i_hi;
         // clips of this XCD's item range: skip the whole range when clip b is outside
         if (cnt == 0 || first * ipw >= i_hi || b < (first * ipw) / steps || b > (i_hi - 1) / steps) continue;
+        // unconditional loads (an invalid term reads the region's first slab and is dropped): eight 16-byte loads in flight
         auto term = [&](int j) {
             const int i_lo = first * ipw + j;
-            if (j >= cnt || i_lo >= i_hi) return 0.f;
-            const int n_items = (i_hi - i_lo + cnt - 1) / cnt;
-            const int b_first = i_lo / steps, b_last = (i_lo + (n_items - 1) * cnt) / steps;
+            const bool in = j < cnt && i_lo < i_hi;
+            const int i_lc = in ? i_lo : first * ipw;
+            const int n_items = (i_hi - i_lc + cnt - 1) / cnt;
+            const int b_first = i_lc / steps, b_last = (i_lc + (n_items - 1) * cnt) / steps;
             const int slot = b - b_first;
-            if (slot < 0 || b > b_last || slot >= slots) return 0.f;
-            return cslab[((size_t)(first + j) * slots + slot) * (2 * PQ_CH * 32) + e];
+            const bool ok = in && slot >= 0 && b <= b_last && slot < slots;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(cslab + (ok ? ((size_t)(first + j) * slots + slot) * (2 * PQ_CH * 32) : 0) + e);
+            return ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         };
-        for (int j = wave; j < cnt; j += 8) {
-            const float v0 = term(j), v1 = term(j + 4);
-            acc0 += v0;
-            acc1 += v1;
+        for (int j0 = wave; j0 < cnt; j0 += 32) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = term(j0 + 4 * u);
+            acc0 += (v[0] + v[2]) + (v[4] + v[6]);
+            acc1 += (v[1] + v[3]) + (v[5] + v[7]);
         }
     }
     part[wave][lane] = acc0 + acc1;
     __syncthreads();
-    if (wave == 0 && (e & 31) < le)
-        out[(size_t)l * out_lstride + (size_t)b * out_bstride + (size_t)(e >> 5) * out_pitch + (e & 31)] =
-            (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (wave == 0) {
+        const f32x4 r = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        float* o = out + (size_t)l * out_lstride + (size_t)b * out_bstride + (size_t)(e >> 5) * out_pitch + (e & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((e & 31) + i < le) o[i] = r[i];
+    }
 }
 // n launches' slabs at once: launch l ran with t_lo[l] (host array) and wrote its slabs at cslab + off[l] floats
 int wn_launch_pq_cond_reduce(const float* cslab, const long* off, const int* t_lo, int n, int t_hi, int batch, int le, float* out,
@@ -856,7 +865,7 @@ int wn_launch_pq_cond_reduce(const float* cslab, const long* off, const int* t_l
             pl.slots[l] = wn_pq_cond_slots(t_lo[l0 + l], t_hi, batch);
             pl.off[l] = off[l0 + l];
         }
-        hipLaunchKernelGGL(pq_cond_reduce_k, dim3(2 * PQ_CH * 32 / 64, batch, nl), dim3(256), 0, st, cslab, pl,
+        hipLaunchKernelGGL(pq_cond_reduce_k, dim3(2 * PQ_CH * 32 / 256, batch, nl), dim3(256), 0, st, cslab, pl,
                            wn_xcd_swizzle_enabled(), batch, le, out + (size_t)l0 * out_lstride, out_lstride, out_bstride, out_pitch);
         WN_CHECK_LAUNCH();
     }
