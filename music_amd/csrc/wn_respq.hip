@@ -468,6 +468,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 }
             }
 #endif
+#ifndef PQ_T_NOCBIAS
             if (COND) {
                 if (p_cur.b != tc_b) load_tab(p_cur.b);
 #pragma unroll
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                     ag[n] = F16::mfma(tcg.hi, e, ag[n]);
                 }
             }
+#endif
             PQ_TICK(k2);
             uint16_t* tt = st + PQ_T;
             const bool ok0 = live && tl >= a.t_lo && tl < a.t_hi, ok1 = live && tl + 1 >= a.t_lo && tl + 1 < a.t_hi;
@@ -683,6 +685,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                         term(cfg[mm + 1][0], am[cur][1], o.x0, t);
                         term(cfg[mm + 1][1], am[cur][1], o.x1, t);
                     }
+#ifndef PQ_T_NOCSUM
                     if (COND && c_item && mm == 2 * g) {          // this wave's two row tiles of the bucket sums
 #pragma unroll
                         for (int n = 0; n < 2; ++n) {
@@ -702,6 +705,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                             cacc[1][n] = PQG::mfma(am[cur][1].hi, sel, cacc[1][n]);
                         }
                     }
+#endif
                 } else {
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
@@ -722,9 +726,13 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     {
         RawRows rr, rr2;                                    // raw rows of items it / it+1: requested two items ahead
         Ops ops;                                            // (one item ahead: 1.968 vs 1.941 ms for the stack; the conditioned
+#ifdef PQ_T_WD2
+        constexpr int WD = 2;
+#else
         constexpr int WD = COND ? 1 : 2;                    // form does that and spends the 32 registers on its bucket sums)
+#endif
         load_rows(rr, pos_k(0));
-        if (!COND) load_rows(rr2, pos_k(1));
+        if (WD == 2) load_rows(rr2, pos_k(1));
         convert(ops, rr, pos_k(-1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
         __syncthreads();
         if (wv == 4) PQ_STAMP(3);
@@ -745,7 +753,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             PQ_ACC(4, k1 - k0); PQ_ACC(8, k3 - k2); PQ_ACC(9, k4 - k3);
         };
         const int n_even = (n_items + 1) & ~1;
-        for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, COND ? rr : rr2); }
+        for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, WD == 1 ? rr : rr2); }
         if (pos_k(n_even - 1).live) products((n_even - 1) & 1, ops, pos_k(n_even - 1));    // the last item, unless it is the void one
         __syncthreads();
         if (wv == 4) PQ_STAMP(4);
