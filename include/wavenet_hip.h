@@ -116,6 +116,17 @@ int wn_enc_resblock_bwd(const float* x_in, const float* dy, const float* h, floa
                         int64_t h_bstride, int64_t dh_bstride, int pitch, const uint16_t* wdT, int ch, int d, int t_lo,
                         int t_hi, int y_lo, float* slab_dil, float* slab_d, int batch, int mode_bwd, wn_stream_t stream);
 int wn_enc_resblock_bwd_slabs(int t_lo, int t_hi, int batch);
+/* The same backward with the data gradient INSIDE the launch (no biases), handed on as the unshifted pair of
+ * wn_resblock_bwd_pq:  in : dy[t] = p_in[t] (t >= p_lo) + q_in[t + dn]  (the pair the block above wrote, dn = ITS dilation,
+ * p_lo = ITS t_lo; q_in = NULL: p_in is a plain tensor valid from p_lo - the top block);
+ * out: p_out[t] = dy[t] + [x(t) > 0] W1^T dh[t],  q_out[t] = [x(t-d) > 0] W0^T dh[t]  on [t_lo, t_hi), so that
+ * dx[s] = p_out[s] + q_out[s + d] (wn_shift_add makes it whole); dh never reaches HBM.  x / P / Q share x_bstride and pitch,
+ * q buffers must read as zero beyond t_hi.  wpq: packed [W1^T; W0^T] ([2ch rows][K = ch dh channels], bf16x3); slabs as
+ * wn_enc_resblock_bwd.  Autograd of wavenet_autoencoder/model1.py:143-152 for one layer. */
+int wn_enc_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, int dn, int p_lo, const float* h,
+                           float* p_out, float* q_out, int64_t x_bstride, int64_t h_bstride, int pitch, const uint16_t* wdT,
+                           const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, float* slab_dil, float* slab_d, int batch,
+                           int mode_bwd, wn_stream_t stream);
 
 /* Backward of one residual block with BOTH weight gradients in the launch (channel-split form,
  * 64 padded channels, modes (f16x3, bf16x3)): what wn_resblock_bwd + the two per-layer wn_wgrad calls

@@ -33,6 +33,7 @@ SIGNATURES = {
     "wn_enc_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_enc_resblock_bwd": [_p, _p, _p, _p, _l, _l, _l, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p],
     "wn_enc_resblock_bwd_slabs": [_i, _i, _i],
+    "wn_enc_resblock_bwd_pq": [_p, _p, _p, _i, _i, _p, _p, _p, _l, _l, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _i, _p],
     "wn_avgpool": [_p, _l, _i, _i, _i, _i, _i, _p, _l, _i, _i, _p],
     "wn_resblock_bwd": [_p, _p, _p, _p, _p, _l, _l, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
                         _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -126,6 +126,19 @@ int wn_launch_shift_add(const float* p, const float* q, float* out, long bstride
 // backward of an autoencoder ENCODER block with both weight gradients (wn_encrw.hip); WnResMsArgs fields as documented there
 int wn_launch_enc_bwd_rw(const WnResMsArgs& a, int ch, int batch, int mode_bwd, hipStream_t st);
 int wn_enc_bwd_slabs(int t_lo, int t_hi, int batch);
+// ... and with the data gradient inside, as the unshifted (P, Q) pair (wn_encpq.hip)
+struct WnEncPqArgs {
+    const float* x_in;                                     // x_i (the block's input)
+    const float* p_in; const float* q_in; int dn, p_lo;    // dy[t] = p_in[t] (t >= p_lo) + q_in[t + dn]; q_in null: a plain tensor
+    const float* h; long h_bstride;                        // stored pre-activation of the block
+    float* p_out; float* q_out;                            // dx_i[t] = p_out[t] + q_out[t + d], both written on [t_lo, t_hi)
+    long x_bstride; int pitch;                             // x / P / Q share x_bstride; every tensor shares pitch
+    const uint16_t* wdT; const uint16_t* wpq;              // Wd^T [CH/16][CH/32] and [W1^T; W0^T] [2CH/16][CH/32] packs (bf16x3)
+    float* slab_dil; float* slab_d;                        // one slab per workgroup: [CH][2CH] and [CH][CH] (enc_bwd_rw_k's)
+    int d, t_lo, t_hi, t_base;
+    int steps_per_clip, items_per_wg, batch, swz;          // set by the launcher
+};
+int wn_launch_enc_bwd_pq(const WnEncPqArgs& a, int ch, int batch, int mode_bwd, hipStream_t st);
 
 struct WnWgradArgs {
     const float* a; long a_bstride; int a_pitch; int a_shift; int a_cols;   // A: [M rows][time]

@@ -156,6 +156,9 @@ class _AutoencoderEngine:
             wt = full(CHe, 2 * CHe)                                            # dx: rows Re, K = [tap1^T | tap0^T] over De
             wt[:Re, :De], wt[:Re, CHe:CHe + De] = wd[:, :, 1].T, wd[:, :, 0].T
             bwd.append(("en_dilT%d" % i, pack_index(wt)))
+            wq = full(2 * CHe, CHe)                     # [W1^T; W0^T] over dh: the one-launch backward block of the encoder
+            wq[:CHe], wq[CHe:] = wt[:, :CHe], wt[:, CHe:]
+            bwd.append(("en_pq%d" % i, pack_index(wq)))
             w = full(CHe, CHe)
             w[:Re, :De] = sp.conv("en_dense_layer_stack.%d.weight" % i)[:, :, 0]
             add("en_dense%d" % i, w)
@@ -444,6 +447,11 @@ class _AutoencoderEngine:
         # encoder blocks: wn_enc_resblock_bwd (dh + both weight gradients in one launch) where it applies
         enc_fused = (self.CHe == 64 and self.mode_b == _lib.BF16X3 and os.environ.get("WN_AE_FUSED_ENC_BWD", "1") == "1")
         bw["enc_fused"] = enc_fused
+        # ... and the data gradient inside the same launch, as the (P, Q) pair (wn_enc_resblock_bwd_pq), without biases
+        bw["enc_pq"] = enc_fused and not self.use_bias and os.environ.get("WN_AE_ENC_PQ", "1") == "1"
+        if bw["enc_pq"]:
+            bw["PQe"] = (bw["PQ"] if bw["pq"] and self.CHe == self.CHd else     # the decoder's pairs are free again by then
+                         [(buf(self.CHe), buf(self.CHe)), (buf(self.CHe), buf(self.CHe))])
         for i in range(N):
             ench = -2 if enc_fused else 512
             ops += [("de_fg%d" % i, self.off[i + 1], T, -1 if ms else 512), ("en_dil%d" % i, self.off[i + 1], T, ench),
@@ -691,6 +699,20 @@ class _AutoencoderEngine:
             d, t_lo = self.dil[i], self.off[i + 1]
             y_lo = lo if i == N - 1 else t_lo                     # the top gradient only exists on the crop
             dy = dxe[(i + 1) % 2]
+            if bw["enc_pq"]:
+                # the whole backward of the block in one launch; dx travels as the unshifted pair (P, Q)
+                p_out, q_out = (ptr(t, SLACK) for t in bw["PQe"][i % 2])
+                if i < N - 1:
+                    p_in, q_in = (ptr(t, SLACK) for t in bw["PQe"][(i + 1) % 2])
+                    dn, p_lo = self.dil[i + 1], self.off[i + 2]
+                else:
+                    p_in, q_in, dn, p_lo = dy, None, 0, y_lo
+                call("wn_enc_resblock_bwd_pq", xe(i), p_in, q_in, dn, p_lo, he(i), p_out, q_out, eb, eb, pitch,
+                     br("en_denseT%d" % i), br("en_pq%d" % i), CHe, d, t_lo, T, ptr(bw["slab"], plan["en_dil%d" % i][0]),
+                     ptr(bw["slab"], plan["en_dense%d" % i][0]), B, mb, st)
+                if i == 0:
+                    call("wn_shift_add", p_out, q_out, dxe[0], eb, pitch, CHe, d, t_lo, self.off[0], T, B, st)
+                continue
             if bw["enc_fused"]:
                 # dh, dW1 = sum dy relu(h)^T and dWdil = sum dh [relu x(t-d) | relu x(t)]^T in one launch
                 call("wn_enc_resblock_bwd", xe(i), dy, he(i), dHe, eb, eb, eb, pitch, br("en_denseT%d" % i), CHe, d, t_lo, T, y_lo,

@@ -31,13 +31,14 @@ def test_alternative_paths_stay_correct(env):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
-@pytest.mark.parametrize("env", [{"WN_AE_FUSED_ENC": "0"}, {"WN_AE_FUSED_ENC_BWD": "0"}, {"WN_PQ_BWD": "0"}, {"WN_AE_COND_FUSED": "0"}, {"WN_AE_COND_MFMA": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+@pytest.mark.parametrize("env", [{"WN_AE_FUSED_ENC": "0"}, {"WN_AE_FUSED_ENC_BWD": "0"}, {"WN_PQ_BWD": "0"}, {"WN_AE_COND_FUSED": "0"}, {"WN_AE_COND_MFMA": "0"}, {"WN_AE_ENC_PQ": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_autoencoder_alternative_paths_stay_correct(env):
     """The autoencoder with its encoder blocks as two channel GEMMs (instead of wn_enc_resblock_fwd) / its encoder
     blocks' backward as GEMM + weight-gradient launches (the paths 32-channel encoders run) / its decoder blocks on
     wn_resblock_bwd_ms + the data-gradient GEMM (what biased decoders run) / the conditioning gradient as bucket sums of a
     written [df;dg] (wn_cond_grad: what more than 32 pooled frames run) / the conditioning bias gathered in the forward block
-    instead of multiplied (same): the G8 forward fixture and the 64-channel backward parity test."""
+    instead of multiplied (same) / the encoder blocks' data gradient as a launch of its own on a written dh (what biased
+    encoders run): the G8 forward fixture and the 64-channel backward parity test."""
     e = dict(os.environ, **env)
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", "g8_autoencoder_forward or autoencoder_backward_64"]
