@@ -258,6 +258,11 @@ int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float 
 /* flat_grad[i] = packed[idx[i]] (idx<0 -> 0): dense wgrad results -> state_dict (out,in,k) layout. */
 int wn_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, wn_stream_t stream);
 
+/* The conditioning term expanded over time (model1.py:227-247 `_conditon`, both branches): out[b][row][t] =
+ * tab[b][row][idx(t)] for t in [t_lo, t_hi), idx as in wn_resblock_fwd (mode 1: (t - t_lo) / q clamped to le - 1, "stretch";
+ * mode 2: (t - t_lo) % le, "tile").  What the reference's repeat / index expressions build as a tensor. */
+int wn_cond_expand(const float* tab, int64_t tab_bstride, int tab_pitch, int rows, int t_lo, int t_hi, int mode, int le, int q,
+                   float* out, int64_t out_bstride, int out_pitch, int batch, wn_stream_t stream);
 /* Gradient of the conditioning table: out[b][row][j] = sum over t in [t_lo,t_hi) with idx(t) == j of
  * in[b][row][t]; idx as in wn_resblock_fwd (mode 1 stretch by q, mode 2 tile modulo le)
  * (autograd of wavenet_autoencoder/model1.py:227-247). */

@@ -37,6 +37,7 @@ SIGNATURES = {
     "wn_avgpool": [_p, _l, _i, _i, _i, _i, _i, _p, _l, _i, _i, _p],
     "wn_resblock_bwd": [_p, _p, _p, _p, _p, _l, _l, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
                         _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
+    "wn_cond_expand": [_p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _l, _i, _i, _p],
     "wn_cond_grad": [_p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _l, _i, _i, _p],
     "wn_avgpool_bwd": [_p, _l, _i, _i, _i, _i, _i, _p, _l, _i, _i, _i, _p],
     "wn_wgrad": [_p, _l, _i, _i, _i, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _i,

@@ -302,6 +302,13 @@ int wn_cond_grad(const float* in, int64_t in_bstride, int in_pitch, int rows, in
     return wn_launch_cond_grad(in, in_bstride, in_pitch, rows, t_lo, t_hi, mode, le, q, out, out_bstride, out_pitch, batch,
                                (hipStream_t)stream);
 }
+int wn_cond_expand(const float* tab, int64_t tab_bstride, int tab_pitch, int rows, int t_lo, int t_hi, int mode, int le, int q,
+                   float* out, int64_t out_bstride, int out_pitch, int batch, wn_stream_t stream) {
+    if (!tab || !out || le <= 0 || (mode == 1 && q <= 0) || (mode != 1 && mode != 2))
+        return wn_set_error_msg(-4, "wn_cond_expand: bad argument");
+    return wn_launch_cond_expand(tab, (long)tab_bstride, tab_pitch, rows, t_lo, t_hi, mode, le, q, out, (long)out_bstride, out_pitch,
+                                 batch, (hipStream_t)stream);
+}
 int wn_avgpool_bwd(const float* denc, int64_t denc_bstride, int denc_pitch, int t0, int pool, int n_out, int rows,
                    float* out, int64_t out_bstride, int out_pitch, int t_hi, int batch, wn_stream_t stream) {
     return wn_launch_avgpool_bwd(denc, denc_bstride, denc_pitch, t0, pool, n_out, rows, out, out_bstride, out_pitch, t_hi,

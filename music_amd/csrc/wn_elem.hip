@@ -392,6 +392,34 @@ int wn_launch_cond_grad(const float* in, long in_bstride, int in_pitch, int rows
     return 0;
 }
 
+// The conditioning term itself expanded over time (wavenet_autoencoder/model1.py:227-247, `_conditon`): out[b][row][t] =
+// tab[b][row][bucket(t)] for t in [t_lo, t_hi), bucket as above.  One thread per four samples of one row.
+__global__ __launch_bounds__(256) void cond_expand_k(const float* __restrict__ tab, long tab_bstride, int tab_pitch, int t_lo, int t_hi,
+                                                     int mode, int le, int q, float* __restrict__ out, long out_bstride, int out_pitch) {
+    const int t0 = t_lo + 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (t0 >= t_hi) return;
+    const int row = blockIdx.y, b = blockIdx.z;
+    const float* tr = tab + (size_t)b * tab_bstride + (size_t)row * tab_pitch;
+    float* o = out + (size_t)b * out_bstride + (size_t)row * out_pitch;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int t = t0 + e;
+        if (t >= t_hi) break;
+        const int r = t - t_lo;
+        int ix = mode == 1 ? r / q : r % le;
+        ix = ix < le ? ix : le - 1;
+        o[t] = tr[ix];
+    }
+}
+int wn_launch_cond_expand(const float* tab, long tab_bstride, int tab_pitch, int rows, int t_lo, int t_hi, int mode, int le, int q,
+                          float* out, long out_bstride, int out_pitch, int batch, hipStream_t st) {
+    if (rows <= 0 || batch <= 0 || le <= 0 || t_hi <= t_lo) return 0;
+    hipLaunchKernelGGL(cond_expand_k, dim3((t_hi - t_lo + 1023) / 1024, rows, batch), dim3(256), 0, st, tab, tab_bstride, tab_pitch,
+                       t_lo, t_hi, mode, le, q, out, out_bstride, out_pitch);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
 __global__ void avgpool_bwd_k(const float* __restrict__ denc, long denc_bstride, int denc_pitch, int t0, int pool,
                               int n_out, float* __restrict__ out, long out_bstride, int out_pitch, int t_hi) {
     const int t = t0 + blockIdx.x * blockDim.x + threadIdx.x;

@@ -177,6 +177,8 @@ int wn_launch_mulaw_decode(const uint8_t* codes, const float* table, float* audi
 int wn_launch_bias_grad(const float* a, long a_bstride, int a_pitch, int a_shift, int rows, int t_lo,
                         int t_hi, int batch, float* out, hipStream_t st);
 
+int wn_launch_cond_expand(const float* tab, long tab_bstride, int tab_pitch, int rows, int t_lo, int t_hi, int mode, int le, int q,
+                          float* out, long out_bstride, int out_pitch, int batch, hipStream_t st);
 int wn_launch_cond_grad(const float* in, long in_bstride, int in_pitch, int rows, int t_lo, int t_hi, int mode, int le,
                         int q, float* out, long out_bstride, int out_pitch, int batch, hipStream_t st);
 int wn_launch_avgpool_bwd(const float* denc, long denc_bstride, int denc_pitch, int t0, int pool, int n_out, int rows,

@@ -371,10 +371,9 @@ class _AutoencoderEngine:
             ws["bias_skip"] = bsum
             bias_s = ptr(bsum)
         # final conditioning expanded over time (stretch / tile rule on the length-W sequence)
-        tr = torch.arange(W, device=self.device)
         ws["cf_mode"] = (1, W // Le) if W % Le == 0 else (2, 0)
-        idx = tr // (W // Le) if W % Le == 0 else tr % Le
-        ws["C1"][SLACK:SLACK + B * SP * pitch].view(B, SP, pitch)[:, :Sd, lo:T] = enf[:, :, idx]
+        enf = enf.contiguous()
+        call("wn_cond_expand", ptr(enf), Sd * Le, Le, Sd, lo, T, ws["cf_mode"][0], Le, max(ws["cf_mode"][1], 1), C1, sb, pitch, B, st)
 
         def chain(b0, nb, s_):
             """skip product -> connection_1 (+ conditioning) -> connection_2 for clips b0 .. b0 + nb - 1 on stream s_"""

@@ -489,6 +489,23 @@ def test_cond_grad_bucket_sums(mode, le, q):
     assert err < 2e-4
 
 
+@pytest.mark.parametrize("mode,le,q", [(1, 7, 41), (1, 31, 16), (2, 31, 0), (2, 5, 0), (2, 100, 0)])
+def test_cond_expand_matches_the_index_expression(mode, le, q):
+    """wn_cond_expand (the conditioning term over time, model1.py:227-247 `_conditon`): out[b][row][t] = tab[b][row][idx(t)],
+    stretch (idx = (t - t_lo) // q, clamped) and tile (idx = (t - t_lo) % le) rules, a length that is no multiple of four,
+    nothing written outside [t_lo, t_hi)."""
+    B, rows, pitch, t_lo = 2, 10, 1300, 37
+    t_hi = t_lo + (le * q + 13 if mode == 1 else 1103)
+    tab = torch.randn(B, rows, le, device=DEV)
+    out = torch.full((B, rows, pitch), 7.0, dtype=torch.float32, device=DEV)
+    call("wn_cond_expand", ptr(tab), rows * le, le, rows, t_lo, t_hi, mode, le, max(q, 1), ptr(out), rows * pitch, pitch, B,
+         _lib.stream())
+    tr = torch.arange(t_hi - t_lo, device=DEV)
+    ix = torch.clamp(tr // q, max=le - 1) if mode == 1 else tr % le
+    assert torch.equal(out[:, :, t_lo:t_hi], tab[:, :, ix])
+    assert (out[:, :, :t_lo] == 7.0).all() and (out[:, :, t_hi:] == 7.0).all()
+
+
 @pytest.mark.parametrize("scrambled", [True, False], ids=["scrambled", "proper"])
 @pytest.mark.parametrize("ch,T,B", [(64, 1000, 3), (32, 517, 2), (64, 16000, 2)])
 def test_causal_wgrad_from_codes_equals_dense_product(scrambled, ch, T, B):
