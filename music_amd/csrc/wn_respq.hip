@@ -30,7 +30,9 @@
 // (-DPQ_T_NOQ: neither stores nor loads the Q half - the upper bound of what handing dx on WHOLE could save; -DPQ_T_SC1,
 // -DPQ_GRAD_F16: see below.)
 // PQ_T_* macros are timing-build switches (remove one ingredient; results are then wrong) used to see what a launch is
-// made of: -DPQ_T_NOREC / NOGATE / NOWG / NOPQ / NOSTORE / NOFILLDY / NOCONV via `make EXTRA=...` (tools/pq_phases.sh).
+// made of: -DPQ_T_NOREC / NOGATE / NOWG / NOPQ / NOSTORE / NOFILLDY / NOCONV via `make EXTRA=...` (tools/pq_phases.sh); for the
+// conditioned form -DPQ_T_NOCBIAS (no bias k-step), -DPQ_T_NOCSUM (no bucket sums), -DPQ_T_WD2 (rows two items ahead: spills)
+// with tools/ae_variant.sh.
 #include <stdlib.h>
 #include <string.h>
 #include "wn_common.h"
