@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Randomised parity fuzz of the autoencoder (GPU): random widths (decoder 64 channels half of the time, so that the
-two-role backward block runs WITH the conditioning table), dilations, pooling (stretch and tile conditioning), batch,
-clip length and bias; loss and every gradient against autograd on oracle/wavenet_oracle.py with the same per-forward
+"""Randomised parity fuzz of the autoencoder (GPU): random widths (decoder / encoder at 64 padded channels half of the time
+each, so that the one-launch backward blocks run - the decoder's WITH the conditioning on the matrix cores), dilations,
+pooling (stretch and tile conditioning, more than 32 pooled frames included), batch (a quarter of the cases: 20-60 short
+clips), clip length and bias; loss and every gradient against autograd on oracle/wavenet_oracle.py with the same per-forward
 projections.  Test infrastructure (imports oracle/); not part of the product path.
 
     python tools/fuzz_ae.py [--cases N] [--seed S]"""
@@ -23,12 +24,14 @@ def one_case(rng, k):
     n = int(rng.integers(2, 7))
     dil = [int(rng.choice([1, 2, 3, 4, 8, 16, 5])) for _ in range(n)]
     wide = rng.random() < 0.5
+    ewide = rng.random() < 0.5                  # 64 padded encoder channels: the one-launch encoder backward block
     cfg = dict(filter_width=2, quantization_channel=256, dilations=dil,
-               en_residual_channel=int(rng.integers(8, 65)), en_dilation_channel=int(rng.integers(8, 65)),
+               en_residual_channel=int(rng.integers(33, 65) if ewide else rng.integers(8, 33)),
+               en_dilation_channel=int(rng.integers(33, 65) if ewide else rng.integers(8, 33)),
                en_bottleneck_width=int(rng.integers(2, 17)), en_pool_kernel_size=int(rng.choice([7, 16, 25, 50, 64])),
                de_residual_channel=int(rng.integers(33, 65)) if wide else int(rng.integers(8, 33)),
                de_dilation_channel=int(rng.integers(33, 65)) if wide else int(rng.integers(8, 33)),
-               de_skip_channel=int(rng.choice([16, 40, 64, 100])), use_bias=bool(rng.random() < 0.5))
+               de_skip_channel=int(rng.choice([16, 40, 64, 100])), use_bias=bool(rng.random() < 0.35))
     torch.manual_seed(500 + k)
     net = wavenet_autoencoder(**cfg)
     with torch.no_grad():
@@ -37,8 +40,9 @@ def one_case(rng, k):
     params = {kk: v.clone() for kk, v in net.state_dict().items()}
     net = net.cuda()
     rf = net.receptive_field
-    B = int(rng.integers(1, 4))
-    W = int(cfg["en_pool_kernel_size"] * rng.integers(1, 9) + rng.choice([0, 0, 1, 3, 17]))
+    many = rng.random() < 0.25                  # many short clips: a workgroup's items then span several clips
+    B = int(rng.integers(20, 60)) if many else int(rng.integers(1, 4))
+    W = int(cfg["en_pool_kernel_size"] * (rng.integers(1, 3) if many else rng.integers(1, 9)) + rng.choice([0, 0, 1, 3, 17]))
     idx = rng.integers(0, 256, size=(B, rf + W - 1))
     x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx]))
     target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64))
