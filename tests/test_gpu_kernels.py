@@ -489,6 +489,27 @@ def test_cond_grad_bucket_sums(mode, le, q):
     assert err < 2e-4
 
 
+def test_conditioned_block_entry_points_refuse_bad_arguments():
+    """The conditioned form of wn_resblock_bwd_pq needs the bucket bytes and at most 32 buckets, its bucket-sum slabs need a
+    table, the reduce and wn_cond_expand check their shapes: status -4 and a message, nothing launched."""
+    buf = torch.zeros(1 << 16, device=DEV)
+    i8 = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    pk = torch.zeros(1 << 16, dtype=torch.int16, device=DEV)
+    pq = lambda cond, le, idx, cslab: call(
+        "wn_resblock_bwd_pq", ptr(buf), None, None, 0, 0, ptr(buf), ptr(buf), ptr(buf), 64 * 256, 64 * 256, 256, ptr(pk), ptr(pk), ptr(pk),
+        64, 1, 8, 200, 8, ptr(buf), ptr(buf), cond, 128 * 8, 8, le, idx, cslab, 1, _lib.F16X3, _lib.BF16X3, _lib.stream())
+    for args, what in (((ptr(buf), 8, None, None), "cond_idx"), ((ptr(buf), 33, ptr(i8), None), "buckets"),
+                       ((None, 8, ptr(i8), ptr(buf)), "cslab without cond")):
+        with pytest.raises(_lib.WavenetHipError, match=what):
+            pq(*args)
+    import ctypes
+    off, tlo = (ctypes.c_int64 * 1)(0), (ctypes.c_int * 1)(8)
+    with pytest.raises(_lib.WavenetHipError, match="bad argument"):
+        call("wn_resblock_bwd_pq_cond_reduce", ptr(buf), off, tlo, 1, 200, 1, 40, ptr(buf), 0, 128 * 40, 40, _lib.stream())
+    with pytest.raises(_lib.WavenetHipError, match="bad argument"):
+        call("wn_cond_expand", ptr(buf), 8 * 8, 8, 8, 8, 200, 3, 8, 1, ptr(buf), 8 * 256, 256, 1, _lib.stream())
+
+
 @pytest.mark.parametrize("mode,le,q", [(1, 7, 41), (1, 31, 16), (2, 31, 0), (2, 5, 0), (2, 100, 0)])
 def test_cond_expand_matches_the_index_expression(mode, le, q):
     """wn_cond_expand (the conditioning term over time, model1.py:227-247 `_conditon`): out[b][row][t] = tab[b][row][idx(t)],
