@@ -77,13 +77,18 @@ int wn_chan_gemm(const float* in0, const float* in1, int64_t in_bstride, int in_
  * A fragments, cond_pack[b] = wn_pack_weights order of the [2*ch rows][K = 32 buckets, zero beyond cond_le] matrix
  * (8 fragments = cond_pack_bstride 8192 halfs per clip), and the buckets as bytes, cond_idx (layout under
  * wn_resblock_bwd_pq) - the bias is then one more k-step of the fg product (table x 0/1 matrix on the matrix cores,
- * hi + lo: the table to ~2^-22) instead of 128 gathered loads per lane; NULL: the gather. */
+ * hi + lo: the table to ~2^-22) instead of 128 gathered loads per lane; NULL: the gather.
+ * z_half_stride != 0 (ch = 64): TWO clips of a model with <= 32 channels side by side on the 64-channel block - x / x_out
+ * are the two clips' 32-row tensors back to back (x_bstride = 64 rows), the packs block-diagonal ([W 0; 0 W] per product:
+ * the zero blocks cost matrix time, no traffic), and the z rows of the second clip go z_half_stride floats behind the
+ * first clip's (its own z slice) instead of 32 rows below them.  Same results as two launches of the 32-channel form. */
 int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bstride, int64_t z_bstride,
                     int pitch, const uint16_t* wfg, const uint16_t* wd, const float* bias_f,
                     const float* bias_g, const float* bias_d, int n_f, int n_d, int ch, int d,
                     int t_lo, int t_hi, int z_lo, int write_x, const float* cond, int64_t cond_bstride,
                     int cond_pitch, int cond_mode, int cond_le, int cond_q, const uint16_t* cond_pack,
-                    int64_t cond_pack_bstride, const uint8_t* cond_idx, int batch, int mode, wn_stream_t stream);
+                    int64_t cond_pack_bstride, const uint8_t* cond_idx, int64_t z_half_stride, int batch, int mode,
+                    wn_stream_t stream);
 
 /* Fused gated residual block, backward recompute half (autograd of model.py:118-124, SURVEY
  * Appendix B): recomputes f,g,z from x_in; dz = Wd^T dy (+ dz_crop on t >= z_lo);
@@ -164,7 +169,9 @@ int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch);
  * GRADIENT d cond[b][row][j] = sum of [df;dg][b][row][t] over bucket j is formed inside the launch as well (a 0/1
  * selection product, exact): every workgroup leaves its sums per clip in cslab and wn_resblock_bwd_pq_cond_reduce adds
  * them in a fixed order (no float atomics; the same sums as wn_cond_grad on the [df;dg] wn_resblock_bwd_ms writes, up to
- * summation order) - for n_launches block launches in ONE reduce: launch l ran with t_lo[l] (HOST array, as slab_off) and
+ * summation order; dz_half_stride != 0: two 32-channel clips side by side as under wn_resblock_fwd - the dz-crop rows of the
+ * second clip sit that many floats behind the first clip's, the slabs hold the block-diagonal gradients, wn_gather_grads2
+ * adds the two copies) - for n_launches block launches in ONE reduce: launch l ran with t_lo[l] (HOST array, as slab_off) and
  * the same t_hi / batch and wrote its slabs at cslab + slab_off[l] floats; out[l][b][2ch rows][cond_le] with the strides
  * given.  More than 32 buckets: wn_resblock_bwd_ms + wn_cond_grad. */
 #define WN_COND_IDX_PAD 64
@@ -172,7 +179,8 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
                        float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
                        const uint16_t* wdT, const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, int z_lo,
                        float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_le,
-                       const uint8_t* cond_idx, float* cslab, int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
+                       const uint8_t* cond_idx, float* cslab, int64_t dz_half_stride, int batch, int mode_fwd, int mode_bwd,
+                       wn_stream_t stream);
 int wn_resblock_bwd_pq_cond_floats(int t_lo, int t_hi, int batch);
 int wn_resblock_bwd_pq_cond_reduce(const float* cslab, const int64_t* slab_off, const int* t_lo, int n_launches, int t_hi, int batch,
                                    int cond_le, float* out, int64_t out_lstride, int64_t out_bstride, int out_pitch,
@@ -257,6 +265,9 @@ int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float 
                  wn_stream_t stream);
 /* flat_grad[i] = packed[idx[i]] (idx<0 -> 0): dense wgrad results -> state_dict (out,in,k) layout. */
 int wn_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, wn_stream_t stream);
+/* ... with two sources per element, flat_grad[i] = packed[idx[i]] + packed[idx2[i]] (< 0: nothing): the gradient of a weight
+ * that occupies two places of a block-diagonal effective matrix (see z_half_stride of wn_resblock_fwd). */
+int wn_gather_grads2(const float* packed, const int32_t* idx, const int32_t* idx2, float* flat_grad, int n, wn_stream_t stream);
 
 /* The conditioning term expanded over time (model1.py:227-247 `_conditon`, both branches): out[b][row][t] =
  * tab[b][row][idx(t)] for t in [t_lo, t_hi), idx as in wn_resblock_fwd (mode 1: (t - t_lo) / q clamped to le - 1, "stretch";

@@ -29,7 +29,7 @@ SIGNATURES = {
                      _p, _l, _i,
                      _i, _i, _i, _i, _i, _p],
     "wn_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i,
-                        _i, _i, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _i, _i, _p],
+                        _i, _i, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l, _i, _i, _p],
     "wn_enc_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_enc_resblock_bwd": [_p, _p, _p, _p, _l, _l, _l, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p],
     "wn_enc_resblock_bwd_slabs": [_i, _i, _i],
@@ -47,7 +47,7 @@ SIGNATURES = {
                            _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_bwd_ms_slabs": [_i, _i, _i],
     "wn_resblock_bwd_pq": [_p, _p, _p, _i, _i, _p, _p, _p, _l, _l, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p,
-                           _p, _l, _i, _i, _p, _p, _i, _i, _i, _p],
+                           _p, _l, _i, _i, _p, _p, _l, _i, _i, _i, _p],
     "wn_resblock_bwd_pq_cond_floats": [_i, _i, _i],
     "wn_resblock_bwd_pq_cond_reduce": [_p, _p, _p, _i, _i, _i, _i, _p, _l, _l, _i, _p],
     "wn_split16": [_p, _p, _p, _l, _i, _p],
@@ -67,6 +67,7 @@ SIGNATURES = {
     "wn_chunk_softmax_ce": [_p, _p, _p, _p, _p, _l, _i, _f, _p],
     "wn_adam_flat": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p],
     "wn_gather_grads": [_p, _p, _p, _i, _p],
+    "wn_gather_grads2": [_p, _p, _p, _p, _i, _p],
     "wn_onehot": [_p, _p, _i, _i, _i, _i, _p],
     "wn_mulaw_encode_tbl": [_p, _p, _p, _l, _p],
     "wn_mulaw_decode_lut": [_p, _p, _p, _l, _p],

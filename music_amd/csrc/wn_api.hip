@@ -84,7 +84,8 @@ int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bst
                     const float* bias_g, const float* bias_d, int n_f, int n_d, int ch, int d,
                     int t_lo, int t_hi, int z_lo, int write_x, const float* cond, int64_t cond_bstride,
                     int cond_pitch, int cond_mode, int cond_le, int cond_q, const uint16_t* cond_pack,
-                    int64_t cond_pack_bstride, const uint8_t* cond_idx, int batch, int mode, wn_stream_t stream) {
+                    int64_t cond_pack_bstride, const uint8_t* cond_idx, int64_t z_half_stride, int batch, int mode,
+                    wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_fwd: pitch must be a multiple of 4");
     if (cond && (cond_le <= 0 || (cond_mode == 1 && cond_q <= 0) || (cond_mode != 1 && cond_mode != 2)))
         return wn_set_error_msg(-4, "wn_resblock_fwd: bad conditioning arguments");
@@ -97,6 +98,8 @@ int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bst
     a.cond = cond; a.cond_bstride = cond_bstride; a.cond_pitch = cond_pitch; a.cond_mode = cond_mode;
     a.cond_le = cond_le; a.cond_q = cond_q;
     if (cond && cond_pack && cond_idx) { a.cond_pack = cond_pack; a.cond_pack_bstride = cond_pack_bstride; a.cond_idx = cond_idx; }
+    if (z_half_stride && ch != 64) return wn_set_error_msg(-4, "wn_resblock_fwd: z_half_stride is for two 32-channel clips on the 64-channel block");
+    a.z_half = z_half_stride;
     return wn_launch_resblock_fwd(a, ch, batch, mode, (hipStream_t)stream);
 }
 
@@ -160,6 +163,10 @@ int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float 
 int wn_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, wn_stream_t stream) {
     return wn_launch_gather_grads(packed, idx, flat_grad, n, (hipStream_t)stream);
 }
+int wn_gather_grads2(const float* packed, const int32_t* idx, const int32_t* idx2, float* flat_grad, int n, wn_stream_t stream) {
+    if (!packed || !idx || !idx2 || !flat_grad) return wn_set_error_msg(-4, "wn_gather_grads2: null argument");
+    return wn_launch_gather_grads2(packed, idx, idx2, flat_grad, n, (hipStream_t)stream);
+}
 int wn_onehot(const int32_t* codes, float* out, int batch, int q, int t, int scrambled, wn_stream_t stream) {
     return wn_launch_onehot(codes, out, batch, q, t, scrambled, (hipStream_t)stream);
 }
@@ -222,7 +229,8 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
                        float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
                        const uint16_t* wdT, const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, int z_lo,
                        float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_le,
-                       const uint8_t* cond_idx, float* cslab, int batch, int mode_fwd, int mode_bwd, wn_stream_t stream) {
+                       const uint8_t* cond_idx, float* cslab, int64_t dz_half_stride, int batch, int mode_fwd, int mode_bwd,
+                       wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: pitch must be a multiple of 4");
     if (cond && (!cond_idx || cond_le < 1 || cond_le > 32))
         return wn_set_error_msg(-4, "wn_resblock_bwd_pq: a conditioned block needs cond_idx and 1..32 buckets");
@@ -237,7 +245,7 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
     a.x_bstride = x_bstride; a.dz_bstride = dz_bstride; a.pitch = pitch; a.wfg = wfg; a.wdT = wdT; a.wpq = wpq;
     a.slab_fg = slab_fg; a.slab_d = p_in ? slab_d : nullptr; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = z_lo;
     a.cond = cond; a.cond_bstride = cond_bstride; a.cond_pitch = cond_pitch; a.cond_le = cond_le;
-    a.cond_idx = cond ? cond_idx : nullptr; a.cslab = cslab;
+    a.cond_idx = cond ? cond_idx : nullptr; a.cslab = cslab; a.dz_half = dz_half_stride;
     return wn_launch_resblock_bwd_pq(a, batch, (hipStream_t)stream);
 }
 int wn_resblock_bwd_pq_cond_floats(int t_lo, int t_hi, int batch) { return wn_pq_cond_slab_floats(t_lo, t_hi, batch); }

@@ -187,6 +187,20 @@ __global__ void gather_grads_k(const float* __restrict__ packed, const int32_t* 
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flat[i] = idx[i] >= 0 ? packed[idx[i]] : 0.f;
 }
+// ... with a second source per element: flat[i] = packed[idx[i]] + packed[idx2[i]] (either < 0: nothing).  A weight that sits
+// in two places of a block-diagonal effective matrix (two clips of a 32-channel model side by side on the 64-channel block
+// kernels, music_amd/engine.py) has its gradient in both.
+__global__ void gather_grads2_k(const float* __restrict__ packed, const int32_t* __restrict__ idx, const int32_t* __restrict__ idx2,
+                                float* __restrict__ flat, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flat[i] = (idx[i] >= 0 ? packed[idx[i]] : 0.f) + (idx2[i] >= 0 ? packed[idx2[i]] : 0.f);
+}
+int wn_launch_gather_grads2(const float* packed, const int32_t* idx, const int32_t* idx2, float* flat_grad, int n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gather_grads2_k, dim3((n + 255) / 256), dim3(256), 0, st, packed, idx, idx2, flat_grad, n);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
 int wn_launch_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, hipStream_t st) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(gather_grads_k, dim3((n + 255) / 256), dim3(256), 0, st, packed, idx, flat_grad, n);

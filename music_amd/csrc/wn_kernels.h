@@ -50,6 +50,9 @@ struct WnResArgs {
     // ([2CH rows][K = 32 buckets], wn_pack_weights order), cond_idx = bucket bytes as in WnResPqArgs; one more k-step of
     // the fg product against a 0/1 matrix instead of 128 gathered loads per lane
     const uint16_t* cond_pack; long cond_pack_bstride; const uint8_t* cond_idx;
+    // 64 channels as TWO 32-channel clips side by side (block-diagonal packs): the z rows of the second clip (32..63) are
+    // stored z_half floats behind the first clip's instead of 32 rows below them (0: one 64-row tensor)
+    long z_half;
     int swz;
 };
 int wn_launch_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);
@@ -110,6 +113,7 @@ struct WnResPqArgs {
     // clip (first clip of w) + slot of [df;dg][row][t] by bucket; wn_launch_pq_cond_reduce adds the workgroups
     const float* cond; long cond_bstride; int cond_pitch; int cond_le;
     const uint8_t* cond_idx; float* cslab; int cslab_slots;
+    long dz_half;                                          // two 32-channel clips side by side: dz rows 32..63 sit dz_half floats behind rows 0..31 (0: 64 rows)
 #ifdef PQ_SPAN
     int span_slot;                                      // developer build: slot of this launch in the span log
 #endif
@@ -171,6 +175,7 @@ int wn_launch_softmax_ce(const float* x, const int64_t* target, float* probs, fl
 int wn_launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                    float eps, float bc1, float bc2, float gscale, hipStream_t st);
 int wn_launch_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, hipStream_t st);
+int wn_launch_gather_grads2(const float* packed, const int32_t* idx, const int32_t* idx2, float* flat_grad, int n, hipStream_t st);
 int wn_launch_onehot(const int32_t* idx, float* out, int batch, int q, int t, int scrambled, hipStream_t st);
 int wn_launch_mulaw_encode(const float* audio, const float* thr, uint8_t* codes, long n, hipStream_t st);
 int wn_launch_mulaw_decode(const uint8_t* codes, const float* table, float* audio, long n, hipStream_t st);

@@ -320,11 +320,13 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
 #endif
     // z-crop store (rows 16m+4q+i; the lane's 4 N-tiles are 4 consecutive samples)
     {
-        float* zo = a.z_out + (size_t)b * a.z_bstride;
+        float* zo0 = a.z_out + (size_t)b * a.z_bstride;
+        const long zx = a.z_half ? a.z_half - (long)(CH / 2) * a.pitch : 0;        // second clip of a pair (rows CH/2..)
 #pragma unroll
         for (int m = 0; m < MT2; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                float* zo = zo0 + (CH == 64 && m >= MT2 / 2 ? zx : 0);
                 fvec v;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) v[n] = z[m][n][i];

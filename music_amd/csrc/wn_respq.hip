@@ -360,8 +360,9 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) t_wr[i] = (16 * chk + ((4 * q + i) ^ pq_k(chk))) * 8 + dw * 2;
         }
+        const long dzx = a.dz_half ? a.dz_half - (long)(CH / 2) * a.pitch : 0;     // second clip of a pair
         auto load_cr = [&](f32x2* cr, Pos ps) {
-            const float* dzc = ps.live ? a.dz + (size_t)ps.b * a.dz_bstride + (size_t)(16 * g + 4 * q) * a.pitch + ps.t0 + 2 * c : a.dz;
+            const float* dzc = ps.live ? a.dz + (size_t)ps.b * a.dz_bstride + (size_t)(16 * g + 4 * q) * a.pitch + ps.t0 + 2 * c + (g >= 2 ? dzx : 0) : a.dz;
             const size_t rp = ps.live ? (size_t)a.pitch : 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) cr[i] = pq_ld2u(dzc + i * rp);

@@ -159,6 +159,11 @@ class WaveNetEngine:
         assert self.off[-1] == self.rf - 1
         self.mode_fwd = _lib.MODE_NAMES[mode_fwd] if isinstance(mode_fwd, str) else mode_fwd
         self.mode_bwd = _lib.MODE_NAMES[mode_bwd] if isinstance(mode_bwd, str) else mode_bwd
+        # <= 32 channels: TWO clips side by side are one 64-row tensor, and with block-diagonal packs the stack runs on the
+        # 64-channel block kernels (one-launch backward included) on exactly the bytes of the 32-channel tensors - the
+        # zero blocks cost matrix time only.  Even batches, no biases, (f16x3, bf16x3); WN_PAIR32=0: the 32-channel kernels.
+        self.pair_ok = (self.CH == 32 and not self.use_bias and self.mode_fwd == _lib.F16X3 and self.mode_bwd == _lib.BF16X3
+                        and os.environ.get("WN_PAIR32", "1") == "1" and os.environ.get("WN_PQ_BWD", "1") == "1")
         self.device = torch.device(device if device is not None else "cuda")
         _lib.load()
         self._build_spec()
@@ -277,6 +282,30 @@ class WaveNetEngine:
                 w[:R, h * CH:h * CH + D] = src[:, :, 1].T
                 w[CH:CH + R, h * CH:h * CH + D] = src[:, :, 0].T
             bwd.append(("pq%d" % i, pack_index(w)))
+            if self.pair_ok:
+                # 12. the same four matrices block-diagonal for two clips side by side (rows / columns of a 32-block: clip A
+                #     then clip B) - what the 64-channel block kernels multiply in pair mode
+                def diag(m32, rb, cb):
+                    """m32: [rb*32][cb*32] blocks of 32 x 32 -> [rb*64][cb*64] with every block doubled on the diagonal"""
+                    out = full(rb * 64, cb * 64)
+                    for a_ in range(rb):
+                        for b_ in range(cb):
+                            blk = m32[a_ * 32:(a_ + 1) * 32, b_ * 32:(b_ + 1) * 32]
+                            for c_ in range(2):
+                                out[a_ * 64 + c_ * 32:a_ * 64 + (c_ + 1) * 32, b_ * 64 + c_ * 32:b_ * 64 + (c_ + 1) * 32] = blk
+                    return out
+                wfg32 = full(2 * CH, 2 * CH)
+                for h, src in enumerate((wf, wg)):
+                    wfg32[h * CH:h * CH + D, 0:R] = src[:, :, 0]
+                    wfg32[h * CH:h * CH + D, CH:CH + R] = src[:, :, 1]
+                wd32 = full(CH, CH)
+                wd32[:R, :D] = wd[:, :, 0]
+                fwd.append(("fg2_%d" % i, pack_index(diag(wfg32, 2, 2))))
+                fwd.append(("d2_%d" % i, pack_index(diag(wd32, 1, 1), chained=True)))
+                bwd.append(("dT2_%d" % i, pack_index(diag(np.ascontiguousarray(wd32.T), 1, 1))))
+                bwd.append(("pq2_%d" % i, pack_index(diag(w, 2, 2))))
+                gp.append(("fg2_%d" % i, 4 * CH, 4 * CH))
+                gp.append(("d2_%d" % i, 2 * CH, 2 * CH))
         # 4. skip over the concatenated z-crops: rows S, K = N*CH
         w = full(SP, N * CH)
         for i in range(N):
@@ -357,6 +386,26 @@ class WaveNetEngine:
             put(name, bo + np.arange(self.spec.shape[name][0]))
         assert (gidx >= 0).all()
         self.gidx = torch.from_numpy(gidx.astype(np.int32)).to(dev)
+        if self.pair_ok:
+            # pair mode: the stack's weight gradients come out of the 64-channel block kernels as block-diagonal matrices -
+            # a weight's gradient is the sum of its two copies (wn_gather_grads2); everything else as above
+            ga, gb = gidx.copy(), np.full(self.spec.total, -1, dtype=np.int64)
+
+            def put2(pname, off_a, off_b):
+                po = self.spec.off[pname]
+                ga[po:po + off_a.size] = off_a.reshape(-1)
+                gb[po:po + off_b.size] = off_b.reshape(-1)
+            for i in range(N):
+                o0, r, c = self.gp_off["fg2_%d" % i]
+                for h in range(2):
+                    rows = h * 64 + np.arange(D)[:, None, None]
+                    cols = np.arange(2)[None, None, :] * 64 + np.arange(R)[None, :, None]
+                    put2("dilation_layer_stack.%d.weight" % (4 * i + h), o0 + rows * c + cols, o0 + (rows + 32) * c + cols + 32)
+                o0, r, c = self.gp_off["d2_%d" % i]
+                rows, cols = np.arange(R)[:, None, None], np.arange(D)[None, :, None]
+                put2("dilation_layer_stack.%d.weight" % (4 * i + 2), o0 + rows * c + cols, o0 + (rows + 32) * c + cols + 32)
+            self.gidx_pa = torch.from_numpy(ga.astype(np.int32)).to(dev)
+            self.gidx_pb = torch.from_numpy(gb.astype(np.int32)).to(dev)
         # causal weight re-laid as [tap][q][ch] for the forward from codes (wn_causal_fwd_codes): a gather map over the
         # flat parameter buffer (-1 = padded channel, reads as 0)
         wt = np.full((2, Q, CH), -1, dtype=np.int64)
@@ -395,6 +444,7 @@ class WaveNetEngine:
         # the forward has to store z on each block's whole range for the fallback backward) - a switch flipped later
         # takes effect with the next workspace, never half-way between a forward and its backward
         ws["ms"], ws["pq"] = self._use_ms(), self._use_pq()
+        ws["pair"] = self.pair_ok and B % 2 == 0
         return ws
 
     def _bwd_workspace(self, ws):
@@ -415,10 +465,16 @@ class WaveNetEngine:
         ms = ws["ms"]
         bw["ms"] = ms
         bw["pq"] = ws["pq"]
-        if bw["pq"]:
+        pair = bw["pair"] = ws["pair"]
+        if bw["pq"] or pair:
             bw["PQ"] = [(buf(self.CH), buf(self.CH)), (buf(self.CH), buf(self.CH))]
         ops = [("p2", lo, T, 1024), ("p1", lo, T, 1024), ("skip", lo, T, 2048)]
         for i in range(self.N):
+            if pair:                                          # the 64-channel one-launch block on B / 2 clip pairs
+                ops.append(("fg2_%d" % i, self.off[i + 1], T, -2))
+                if i < self.N - 1:
+                    ops.append(("d2_%d" % i, self.off[i + 1], T, -2))
+                continue
             ops.append(("fg%d" % i, self.off[i + 1], T, -1 if ms else 512))
             if i < self.N - 1:
                 ops.append(("d%d" % i, self.off[i + 1], T, -1 if ms else 512))
@@ -434,6 +490,8 @@ class WaveNetEngine:
                 ns = _lib.causal_codes_slabs(T, B)
             elif chunk > 0:
                 ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B)
+            elif chunk == -2:                                 # ... on clip pairs
+                ns = _lib.ms_slabs(t_lo, t_hi, B // 2)
             else:                                             # channel-split block: one slab per workgroup
                 ns = _lib.ms_slabs(t_lo, t_hi, B)
             plan[name] = (so, n, chunk)
@@ -519,14 +577,20 @@ class WaveNetEngine:
         # it on the CU.  Only the fallback backward (resblock_bwd_k + wgrad_k: 32 padded channels, x1 modes) reads the
         # forward's z for dWd on the block's whole valid range [off_{i+1}, T) (19 % more z; it saves that path a second
         # copy written by its recompute kernel).
-        z_whole = self.z_from_fwd and not ws["ms"]
+        z_whole = self.z_from_fwd and not ws["ms"] and not ws["pair"]
         for i, d in enumerate(self.dil):
             bn = "dilation_layer_stack.%d.bias"
+            if ws["pair"]:
+                # two clips per 64-row tensor, block-diagonal packs; the second clip's z rows go to its own slice (z_half = zb)
+                call("wn_resblock_fwd", self._x(ws, i), self._x(ws, i + 1), ptr(ws["Z"], SLACK + i * CH * pitch), 2 * xb, 2 * zb,
+                     pitch, fr("fg2_%d" % i), fr("d2_%d" % i), None, None, None, 64, 64, 64, d, self.off[i + 1], T, self.rf - 1,
+                     1 if i < N - 1 else 0, None, 0, 0, 0, 0, 0, None, 0, None, zb, B // 2, mf, st)
+                continue
             call("wn_resblock_fwd", self._x(ws, i), self._x(ws, i + 1), ptr(ws["Z"], SLACK + i * CH * pitch), xb, zb, pitch,
                  fr("fg%d" % i), fr("d%d" % i), self._bias_ptr(bn % (4 * i)), self._bias_ptr(bn % (4 * i + 1)),
                  self._bias_ptr(bn % (4 * i + 2)), self.D, self.R, CH, d, self.off[i + 1], T,
                  self.off[i + 1] if z_whole else self.rf - 1,
-                 1 if i < N - 1 else 0, None, 0, 0, 0, 0, 0, None, 0, None, B, mf, st)
+                 1 if i < N - 1 else 0, None, 0, 0, 0, 0, 0, None, 0, None, 0, B, mf, st)
         self.mark("stack_fwd")
         lo = self.rf - 1
         bias_s = None
@@ -667,7 +731,7 @@ class WaveNetEngine:
             bn = "dilation_layer_stack.%d.bias"
             if overlap and ev_w[k] is not None:
                 main.wait_event(ev_w[k])
-            if bw["pq"]:
+            if bw["pq"] or bw["pair"]:
                 p_out, q_out = (ptr(t, SLACK) for t in bw["PQ"][i % 2])
                 if i < N - 1:
                     p_in, q_in = (ptr(t, SLACK) for t in bw["PQ"][(i + 1) % 2])
@@ -675,10 +739,17 @@ class WaveNetEngine:
                 else:
                     p_in = q_in = None
                     dn = p_lo = 0
-                call("wn_resblock_bwd_pq", self._x(ws, i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CH * pitch),
-                     p_out, q_out, xb, zb, pitch, fr("fg%d" % i), br("dT%d" % i), br("pq%d" % i), CH, d, t_lo, T, lo,
-                     ptr(bw["slab"], plan["fg%d" % i][0]), ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None,
-                     None, 0, 0, 0, None, None, B, mf, mb, st)
+                if bw["pair"]:
+                    # clip pairs on the 64-channel block: block-diagonal packs, the second clip's dz rows in its own slice
+                    call("wn_resblock_bwd_pq", self._x(ws, i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CH * pitch),
+                         p_out, q_out, 2 * xb, 2 * zb, pitch, fr("fg2_%d" % i), br("dT2_%d" % i), br("pq2_%d" % i), 64, d, t_lo, T, lo,
+                         ptr(bw["slab"], plan["fg2_%d" % i][0]), ptr(bw["slab"], plan["d2_%d" % i][0]) if i < N - 1 else None,
+                         None, 0, 0, 0, None, None, zb, B // 2, mf, mb, st)
+                else:
+                    call("wn_resblock_bwd_pq", self._x(ws, i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CH * pitch),
+                         p_out, q_out, xb, zb, pitch, fr("fg%d" % i), br("dT%d" % i), br("pq%d" % i), CH, d, t_lo, T, lo,
+                         ptr(bw["slab"], plan["fg%d" % i][0]), ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None,
+                         None, 0, 0, 0, None, None, 0, B, mf, mb, st)
                 self.fmark("b_block")
                 if i == 0:
                     # dx_0 for the causal layer: the pair made whole once (19 us; the scatter from codes can also take the
@@ -778,7 +849,10 @@ class WaveNetEngine:
             call("wn_bias_grad", dx0, xb, pitch, 0, self.R, 1, T, B, ptr(self.gpack, self.gp_bias_off["causal_layer.bias"]), st)
         self.mark("causal_bwd")
         call("wn_reduce_slabs", ptr(desc), bw["slab_nops"], bw["slab_vec"], ptr(bw["slab"]), ptr(self.gpack), st)
-        call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
+        if bw["pair"]:
+            call("wn_gather_grads2", ptr(self.gpack), ptr(self.gidx_pa), ptr(self.gidx_pb), ptr(self.flat_grad), self.spec.total, st)
+        else:
+            call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
         self.mark("slab_reduce")
 
     def backward(self, ws, dprobs):

@@ -360,7 +360,7 @@ class _AutoencoderEngine:
                  fr("de_fg%d" % i), fr("de_d%d" % i), bf, bias_fg, self._bias(bn % (3 * i + 1)), Dd, self.Rd, CHd, d,
                  t_lo, T, t_lo, 1 if i < N - 1 else 0, ptr(tab[i]), 2 * CHd * Le, Le, mode_c, Le, q,
                  ptr(cpk, i * B * cpb) if cpk is not None else None, cpb, ptr(cix[i]) if cix is not None else None,
-                 B, m, st)   # z on the whole valid range: the backward's dWd reads it
+                 0, B, m, st)   # z on the whole valid range: the backward's dWd reads it
         self.mark("dec_stack_fwd")
         U, R1, C1 = ptr(ws["U"], SLACK), ptr(ws["R1"], SLACK), ptr(ws["C1"], SLACK)
         sb = SP * pitch
@@ -634,7 +634,7 @@ class _AutoencoderEngine:
                 call("wn_resblock_bwd_pq", xd(i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CHd * pitch), p_out, q_out,
                      db, zb, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), br("de_pq%d" % i), CHd, d, t_lo, T, lo,
                      ptr(bw["slab"], plan["de_fg%d" % i][0]), ptr(bw["slab"], plan["de_d%d" % i][0]) if i < N - 1 else None,
-                     ptr(ws["tab"][i]), 2 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"], bw["cs_off"][i]), B, mf, mb, st)
+                     ptr(ws["tab"][i]), 2 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"], bw["cs_off"][i]), 0, B, mf, mb, st)
                 if i == 0:
                     call("wn_shift_add", p_out, q_out, ptr(bw["dXd"][0], SLACK), db, pitch, CHd, d, t_lo, self.off[0], T, B, st)
                 continue

@@ -238,7 +238,7 @@ def test_resblock_fwd(CH, R, D, d, mode):
     off_in = 5
     t_lo, z_lo = off_in + d, off_in + d + 300
     call("wn_resblock_fwd", ptr(xin, SLACK), ptr(xout, SLACK), ptr(zout, SLACK), CH * pitch, CH * pitch, pitch,
-         ptr(pfg), ptr(pd), None, None, None, D, R, CH, d, t_lo, T, z_lo, 1, None, 0, 0, 0, 0, 0, None, 0, None, B, mode, _lib.stream())
+         ptr(pfg), ptr(pd), None, None, None, D, R, CH, d, t_lo, T, z_lo, 1, None, 0, 0, 0, 0, 0, None, 0, None, 0, B, mode, _lib.stream())
     torch.cuda.synchronize()
     x = _view(xin, B, CH, pitch).cpu()[:, :R, off_in:T].double()
     f, g, z, y = _res_ref(x, torch.from_numpy(wf).double(), torch.from_numpy(wg).double(), torch.from_numpy(wd).double(), d)
@@ -497,7 +497,7 @@ def test_conditioned_block_entry_points_refuse_bad_arguments():
     pk = torch.zeros(1 << 16, dtype=torch.int16, device=DEV)
     pq = lambda cond, le, idx, cslab: call(
         "wn_resblock_bwd_pq", ptr(buf), None, None, 0, 0, ptr(buf), ptr(buf), ptr(buf), 64 * 256, 64 * 256, 256, ptr(pk), ptr(pk), ptr(pk),
-        64, 1, 8, 200, 8, ptr(buf), ptr(buf), cond, 128 * 8, 8, le, idx, cslab, 1, _lib.F16X3, _lib.BF16X3, _lib.stream())
+        64, 1, 8, 200, 8, ptr(buf), ptr(buf), cond, 128 * 8, 8, le, idx, cslab, 0, 1, _lib.F16X3, _lib.BF16X3, _lib.stream())
     for args, what in (((ptr(buf), 8, None, None), "cond_idx"), ((ptr(buf), 33, ptr(i8), None), "buckets"),
                        ((None, 8, ptr(i8), ptr(buf)), "cslab without cond")):
         with pytest.raises(_lib.WavenetHipError, match=what):

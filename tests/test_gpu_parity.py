@@ -832,6 +832,39 @@ def test_autoencoder_fused_step_equals_autograd_path():
             assert (pa - pb).detach()[big].abs().max().item() <= 3e-6, n
 
 
+def test_clip_pairs_on_the_64_channel_blocks_equal_the_32_channel_kernels(monkeypatch):
+    """A model with <= 32 channels and an even batch runs its stack on the 64-channel block kernels, two clips per 64-row
+    tensor with block-diagonal packs (ws["pair"]); WN_PAIR32=0 and odd batches keep the 32-channel kernels.  Same function:
+    probabilities, loss and every gradient of the two paths agree to rounding, and an odd batch takes the old path."""
+    from music_amd.engine import WaveNetEngine
+    cfg = dict(dilations=[1, 2, 4, 8, 3, 16], residual_channels=24, dilation_channels=32, skip_channels=72)
+    rng = np.random.default_rng(5)
+    engs = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("WN_PAIR32", env)
+        torch.manual_seed(9)
+        e = WaveNetEngine(**cfg, device="cuda")
+        torch.nn.init.uniform_(e.flat, -0.3, 0.3)
+        engs.append(e)
+    engs[1].flat.copy_(engs[0].flat)
+    assert engs[0].pair_ok and not engs[1].pair_ok
+    rf = engs[0].rf
+    for B, W in ((4, 333), (3, 120)):
+        T = rf + W - 1
+        codes = torch.from_numpy(rng.integers(0, 256, size=(B, T)).astype(np.int32)).cuda()
+        target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).cuda()
+        outs = []
+        for e in engs:
+            loss = e.loss_and_grad_codes(codes, target, scrambled=True, want_probs=True)
+            ws = e.workspace(B, T)
+            outs.append((loss.item(), ws["probs"].clone(), e.flat_grad.clone(), ws["pair"]))
+        assert outs[0][3] == (B % 2 == 0) and not outs[1][3]
+        assert abs(outs[0][0] - outs[1][0]) < 1e-6
+        assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-6
+        gmax = outs[1][2].abs().max().item()
+        assert (outs[0][2] - outs[1][2]).abs().max().item() <= 2e-5 * gmax
+
+
 def test_training_reduces_the_loss_64_channels():
     """End-to-end sanity of the production kernels (channel-split backward block, fused CE, flat
     Adam): 60 fused steps on one fixed small batch drive the loss from ln(256) towards its floor.

@@ -29,6 +29,9 @@ CASES = [
     ([1, 2, 4, 8, 16, 32, 64, 128, 256, 512], 64, 64, 128, False, 2, 515, 2.0),
     ([2, 6], 64, 40, 24, True, 3, 511, 3.0),
     ([1, 1, 1, 1], 8, 8, 8, True, 2, 3, 4.0),
+    # <= 32 channels, no bias, even batch: clip PAIRS on the 64-channel block kernels (block-diagonal packs, music_amd/engine.py)
+    ([1, 2, 4, 8, 16], 32, 32, 64, False, 2, 300, 2.5),
+    ([3, 1, 9, 2], 20, 28, 48, False, 4, 77, 3.0),
 ]
 
 

@@ -46,6 +46,17 @@ def test_autoencoder_alternative_paths_stay_correct(env):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
+def test_32_channel_kernels_stay_correct_without_clip_pairs():
+    """Models with <= 32 channels run even batches as clip pairs on the 64-channel block kernels; WN_PAIR32=0 keeps every
+    batch on the 32-channel kernels (what odd batches, biased models and x1 modes run): the ragged-shape cases of both
+    kinds against the oracle."""
+    e = dict(os.environ, WN_PAIR32="0")
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_gpu_sweep.py"), "-k", "d5_R32 or d4_R20 or d3_R16 or d7_R32"]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+
+
 def test_decode_generic_kernel_stays_correct():
     """The cached-queue decoder on the generic fp32 kernel (decode_k: what every shape other than 64/64/256/256 runs),
     forced at the config-5 shapes with WN_DEC_MFMA=0: the config-5 oracle test (both queue recurrences), the one-launch

@@ -56,7 +56,7 @@ def main():
             for _ in range(args.reps):
                 call("wn_resblock_fwd", eng._x(ws, i), eng._x(ws, i + 1), ptr(ws["Z"], SLACK + i * CH * pitch), xb, zb, pitch,
                      fr("fg%d" % i), fr("d%d" % i), None, None, None, eng.D, eng.R, CH, d, eng.off[i + 1], T, eng.rf - 1,
-                     1, None, 0, 0, 0, 0, 0, None, 0, None, B_LOCAL, eng.mode_fwd, st)
+                     1, None, 0, 0, 0, 0, 0, None, 0, None, 0, B_LOCAL, eng.mode_fwd, st)
             ev[1].record()
             torch.cuda.synchronize()
             per_layer.append(ev[0].elapsed_time(ev[1]) / args.reps * 1e3)
