@@ -158,7 +158,11 @@ def cpu_baseline():
     # ATen's CPU conv kernels stop scaling (and then collapse) long before a 256-core host is full: one probe step
     # on ONE clip each at all physical cores and at 32 threads (the second of two, the first warms the allocator up),
     # the timed steps run at the faster setting
-    cand = sorted({min(physical, 256), min(32, physical)}, reverse=True)
+    # ... and at the container's CPU quota when there is one (cgroup cpu.max: more threads than that only spin and get the
+    # process throttled)
+    from music_amd import _lib as _wn_lib
+    quota = _wn_lib.cpu_quota()
+    cand = sorted({min(physical, 256), min(32, physical)} | ({min(quota, physical)} if quota else set()), reverse=True)
     probe = {}
     for n in cand:
         torch.set_num_threads(n)
@@ -173,7 +177,7 @@ def cpu_baseline():
     torch.set_num_threads(1)
     t1 = step(x[:1], target[:W])
     return {"value": B_LOCAL * T / best, "unit": "samples/s", "cores": cores, "kind": "port",
-            "host_logical_cpus": logical, "host_physical_cores": physical,
+            "host_logical_cpus": logical, "host_physical_cores": physical, "host_cpu_quota": quota,
             "probe_s_per_step": {str(k): round(v, 3) for k, v in probe.items()},
             "mean_value": B_LOCAL * T * len(times) / sum(times),
             "one_thread": {"value": T / t1, "unit": "samples/s", "sample": "1 step on 1 clip x 16000, 1 thread"},

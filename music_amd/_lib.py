@@ -87,6 +87,35 @@ class WavenetHipError(RuntimeError):
     pass
 
 
+def cpu_quota():
+    """CPUs this process may use per its cgroup's bandwidth limit (cpu.max / cfs_quota_us), or None without one."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(q) // int(per))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, q // per)
+    except (OSError, ValueError):
+        return None
+
+
+def respect_cpu_quota():
+    """torch sizes its intra-op thread pool by the machine's cores (128 on an MI355X host) and does not look at the
+    container's CPU quota; an OpenMP region then wakes all of them, they spin, and the scheduler throttles the WHOLE process
+    for the rest of the period - host code that feeds a GPU loses 80 ms out of every 100 (measured: the autoencoder with the
+    reference's shipped parameters, 68 instead of 10 ms per step).  Called once when the library is loaded: the pool is
+    cut to the quota.  WN_KEEP_TORCH_THREADS=1 leaves it alone."""
+    import torch
+    if os.environ.get("WN_KEEP_TORCH_THREADS", "0") == "1":
+        return
+    q = cpu_quota()
+    if q is not None and torch.get_num_threads() > q:
+        torch.set_num_threads(q)
+
+
 def load():
     """Load the shared library (once).  Raises WavenetHipError if it has not been built."""
     global _lib
@@ -110,6 +139,7 @@ def load():
     if lib.wn_version() != ABI_VERSION:
         raise WavenetHipError("libwavenet_hip.so ABI version %d != expected %d" % (lib.wn_version(), ABI_VERSION))
     _lib = lib
+    respect_cpu_quota()
     return lib
 
 

@@ -18,6 +18,7 @@ The arithmetic runs through libwavenet_hip.so only (no CPU path).  ``forward`` i
 (``loss.backward()`` fills every parameter's gradient, the encoder's through the random projections
 exactly as in the reference).
 """
+import math
 import os
 
 import numpy as np
@@ -100,10 +101,14 @@ class _AutoencoderEngine:
         pin, ev = self._cpin[k]
         if ev is not None:
             ev.synchronize()
-        torch.stack([c[0][:, :, 0] for c in cond[:N]], out=pin[:n_cw].view(N, 2 * Dd, Bw))
-        torch.stack([c[1] for c in cond[:N]], out=pin[n_cw:n_cw + n_cb].view(N, 2 * Dd))
-        pin[n_cw + n_cb:n_cw + n_cb + n_fw].view(Sd, Bw, 1).copy_(cond[N][0])
-        pin[n_cw + n_cb + n_fw:].copy_(cond[N][1])
+        # plain memcpys (numpy): a torch CPU op on more than 32768 elements opens an OpenMP region that wakes EVERY intra-op
+        # thread (128 on an MI355X host), and in a container with a CPU quota those spinning threads get the whole process
+        # throttled - 80 ms out of every 100 with the reference's shipped parameters (Bw = 512)
+        pn = pin.numpy()
+        pn[:n_cw].reshape(N, 2 * Dd * Bw)[...] = np.stack([c[0].numpy().reshape(-1) for c in cond[:N]])
+        pn[n_cw:n_cw + n_cb].reshape(N, 2 * Dd)[...] = np.stack([c[1].numpy() for c in cond[:N]])
+        pn[n_cw + n_cb:n_cw + n_cb + n_fw] = cond[N][0].numpy().reshape(-1)
+        pn[n_cw + n_cb + n_fw:] = cond[N][1].numpy()
         dev = torch.empty(total, dtype=torch.float32, device=self.device)
         dev.copy_(pin, non_blocking=True)
         ev = torch.cuda.Event()
@@ -489,6 +494,12 @@ class _AutoencoderEngine:
         """Fused training step body (the autoencoder counterpart of engine.loss_and_grad): forward to the logits, ONE
         kernel for chunk softmax + CrossEntropyLoss on the probabilities (wavenet_autoencoder/train.py:146-160) + both
         backward steps, then the backward.  Returns the loss (0-d device tensor); gradients land in self.flat_grad."""
+        # at most two fused steps in flight: a host that enqueues a little faster than the device executes otherwise runs into the
+        # runtime's own back-pressure, which parks the thread until the queues are EMPTY (80 ms every third step with the
+        # reference's shipped parameters - 470 launches and 160 events per step -, the device idle for most of it)
+        q = self.__dict__.setdefault("_inflight", [])
+        if len(q) >= int(os.environ.get("WN_RUN_AHEAD", "2")):
+            q.pop(0).synchronize()
         _, enc, ws = self.forward(x, cond, want_probs=False)
         bw = self._bwd_workspace(ws)
         n = ws["B"] * ws["W"]
@@ -499,6 +510,9 @@ class _AutoencoderEngine:
         call("wn_chunk_softmax256_ce", ptr(ws["O"]), ptr(target), None, ptr(bw["dO"]), ptr(ws["loss_part"]), n, 1.0 / n,
              _lib.stream())
         self.backward(ws, None)
+        ev = torch.cuda.Event()
+        ev.record()
+        q.append(ev)
         return ws["loss_part"].sum()
 
     def adam_init(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
@@ -827,12 +841,21 @@ class wavenet_autoencoder(nn.Module):
     def _draw_conditioning(self):
         """The 31 per-forward conditioning convs, drawn on the CPU from the global RNG in the
         reference's order (model1.py:178 per layer, :216 final)."""
+        # nn.Conv1d(Bw, C, 1).reset_parameters() without the module around it: the same two uniform_ draws per conv, in the same
+        # order, with the bounds computed as torch.nn.init does (kaiming_uniform_(a = sqrt(5)) on the weight, then
+        # U(-1/sqrt(fan_in), 1/sqrt(fan_in)) on the bias) - bit-identical tensors (tests/test_host_logic.py) at a fraction of the
+        # Python objects (41 modules per forward otherwise)
         n = len(self.dilations)
+        fan_in = self.en_bottleneck_width                      # kernel size 1
+        gain = math.sqrt(2.0 / (1 + math.sqrt(5) ** 2))
+        bound_w = math.sqrt(3.0) * (gain / math.sqrt(fan_in))
+        bound_b = 1 / math.sqrt(fan_in)
         cond = []
         for i in range(n + 1):
-            c = nn.Conv1d(self.en_bottleneck_width,
-                          2 * self.de_dilation_channel if i < n else self.de_skip_channel, 1)
-            cond.append((c.weight.detach(), c.bias.detach()))
+            c_out = 2 * self.de_dilation_channel if i < n else self.de_skip_channel
+            w = torch.empty(c_out, fan_in, 1).uniform_(-bound_w, bound_w)
+            b = torch.empty(c_out).uniform_(-bound_b, bound_b)
+            cond.append((w, b))
         return cond
 
     def _engine_for(self, device):

@@ -260,3 +260,47 @@ def test_workspace_pool_semantics_without_a_gpu():
         pool.get(2, 50)
     pool.clear()
     assert len(pool) == 0
+
+
+def test_conditioning_draw_equals_the_reference_modules_bit_for_bit():
+    """wavenet_autoencoder._draw_conditioning draws the 31 per-forward conditioning convs WITHOUT building nn.Conv1d modules
+    (wavenet_autoencoder/model1.py:178,216 builds them: SURVEY Q8): the same values from the same global RNG state, and the
+    generator is left where the reference would leave it."""
+    import torch.nn as nn
+    from music_amd.model1 import wavenet_autoencoder
+    for bw, dd, sk in ((512, 32, 512), (64, 64, 256), (10, 60, 72), (3, 7, 5)):
+        cfg = dict(filter_width=2, quantization_channel=256, dilations=[1, 2, 4], en_residual_channel=8, en_dilation_channel=8,
+                   en_bottleneck_width=bw, en_pool_kernel_size=4, de_residual_channel=8, de_dilation_channel=dd,
+                   de_skip_channel=sk, use_bias=False)
+        ae = wavenet_autoencoder(**cfg)
+        torch.manual_seed(11)
+        got = ae._draw_conditioning()
+        after = torch.rand(1).item()
+        torch.manual_seed(11)
+        for i, (w, b) in enumerate(got):
+            c = nn.Conv1d(bw, 2 * dd if i < 3 else sk, 1)
+            assert torch.equal(w, c.weight.detach()) and torch.equal(b, c.bias.detach())
+        assert torch.rand(1).item() == after
+
+
+def test_cpu_quota_is_read_and_respected(monkeypatch):
+    """_lib.cpu_quota(): None or the CPUs of the cgroup's bandwidth limit; respect_cpu_quota() never raises the thread count and
+    cuts it to the quota (torch ignores container quotas; spinning OpenMP threads get the process throttled)."""
+    from music_amd import _lib
+    q = _lib.cpu_quota()
+    assert q is None or q >= 1
+    n0 = torch.get_num_threads()
+    try:
+        monkeypatch.setattr(_lib, "cpu_quota", lambda: 1)
+        _lib.respect_cpu_quota()
+        assert torch.get_num_threads() == 1
+        monkeypatch.setattr(_lib, "cpu_quota", lambda: 4096)
+        _lib.respect_cpu_quota()
+        assert torch.get_num_threads() == 1
+        torch.set_num_threads(n0)
+        monkeypatch.setenv("WN_KEEP_TORCH_THREADS", "1")
+        monkeypatch.setattr(_lib, "cpu_quota", lambda: 1)
+        _lib.respect_cpu_quota()
+        assert torch.get_num_threads() == n0
+    finally:
+        torch.set_num_threads(n0)
