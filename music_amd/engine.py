@@ -445,6 +445,10 @@ class WaveNetEngine:
         # takes effect with the next workspace, never half-way between a forward and its backward
         ws["ms"], ws["pq"] = self._use_ms(), self._use_pq()
         ws["pair"] = self.pair_ok and B % 2 == 0
+        # the FORWARD block of the 64-channel form takes 512 columns per workgroup: below ~200 workgroups (B / 2 pairs x T / 512)
+        # the 32-channel forward fills the chip better (same X / Z layout either way; the backward pairs regardless)
+        fw = os.environ.get("WN_PAIR32_FWD", "auto")
+        ws["pair_fwd"] = ws["pair"] and (fw == "1" or (fw == "auto" and (B // 2) * ((T + 511) // 512) >= 200))
         return ws
 
     def _bwd_workspace(self, ws):
@@ -577,10 +581,10 @@ class WaveNetEngine:
         # it on the CU.  Only the fallback backward (resblock_bwd_k + wgrad_k: 32 padded channels, x1 modes) reads the
         # forward's z for dWd on the block's whole valid range [off_{i+1}, T) (19 % more z; it saves that path a second
         # copy written by its recompute kernel).
-        z_whole = self.z_from_fwd and not ws["ms"] and not ws["pair"]
+        z_whole = self.z_from_fwd and not ws["ms"] and not ws["pair"]      # (pair: the one-launch backward recomputes z)
         for i, d in enumerate(self.dil):
             bn = "dilation_layer_stack.%d.bias"
-            if ws["pair"]:
+            if ws["pair_fwd"]:
                 # two clips per 64-row tensor, block-diagonal packs; the second clip's z rows go to its own slice (z_half = zb)
                 call("wn_resblock_fwd", self._x(ws, i), self._x(ws, i + 1), ptr(ws["Z"], SLACK + i * CH * pitch), 2 * xb, 2 * zb,
                      pitch, fr("fg2_%d" % i), fr("d2_%d" % i), None, None, None, 64, 64, 64, d, self.off[i + 1], T, self.rf - 1,

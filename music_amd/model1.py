@@ -63,6 +63,10 @@ class _AutoencoderEngine:
         self.use_bias = bool(net.use_bias)
         # one launch per encoder block (wn_enc_resblock_fwd) instead of two channel GEMMs; WN_AE_FUSED_ENC=0 = the GEMMs
         self.fused_encoder = os.environ.get("WN_AE_FUSED_ENC", "1") == "1"
+        # 32 / 32 channels on both sides (the reference's shipped model_params.json): even batches run BOTH stacks on the
+        # 64-channel one-launch blocks, two clips per 64-row tensor with block-diagonal packs (music_amd/engine.py "pair")
+        self.pair_ok = (self.CHe == 32 and self.CHd == 32 and not self.use_bias and self.mode == _lib.F16X3 and
+                        self.mode_b == _lib.BF16X3 and os.environ.get("WN_PAIR32", "1") == "1")
         named = list(net.named_parameters())
         self.param_names = [n for n, _ in named]
         self.spec = _Spec([(n, tuple(p.shape)) for n, p in named])
@@ -142,6 +146,30 @@ class _AutoencoderEngine:
                 gidx[w[r, c]] = o + r * w.shape[1] + c
                 gsize[0] += w.size
 
+        pa, pb = {}, {}                                      # pair mode: parameter offset -> its two places in a block-diagonal gradient
+
+        def diag(m32, rb, cb):
+            """[rb*32][cb*32] blocks of 32 x 32 -> [rb*64][cb*64], every block doubled on the diagonal (clip A, clip B)"""
+            out = full(rb * 64, cb * 64)
+            for a_ in range(rb):
+                for b_ in range(cb):
+                    blk = m32[a_ * 32:(a_ + 1) * 32, b_ * 32:(b_ + 1) * 32]
+                    for c_ in range(2):
+                        out[a_ * 64 + c_ * 32:a_ * 64 + (c_ + 1) * 32, b_ * 64 + c_ * 32:b_ * 64 + (c_ + 1) * 32] = blk
+            return out
+
+        def add2(name, w32, rb, cb, chained=False):
+            """pair-mode forward pack + gradient matrix of the block-diagonal form of w32, and where each parameter's two
+            gradient copies sit in it"""
+            fwd.append((name, pack_index(diag(w32, rb, cb), chained)))
+            o, cols = gsize[0], cb * 64
+            gp.append((name, o, rb * 64, cols))
+            r, c = np.nonzero(w32 >= 0)
+            base = o + ((r // 32) * 64 + r % 32) * cols + (c // 32) * 64 + c % 32
+            for par, pos in zip(w32[r, c], base):
+                pa[int(par)], pb[int(par)] = int(pos), int(pos) + 32 * cols + 32
+            gsize[0] += rb * 64 * cols
+
         self.wt_idx, self.wt = {}, {}
         for name, ch, r in (("en_causal", CHe, Re), ("de_causal", CHd, Rd)):
             wc = sp.conv(name + "_layer.weight")
@@ -164,11 +192,19 @@ class _AutoencoderEngine:
             wq = full(2 * CHe, CHe)                     # [W1^T; W0^T] over dh: the one-launch backward block of the encoder
             wq[:CHe], wq[CHe:] = wt[:, :CHe], wt[:, CHe:]
             bwd.append(("en_pq%d" % i, pack_index(wq)))
+            if self.pair_ok:
+                wdil32 = full(CHe, 2 * CHe)
+                wdil32[:De, :Re], wdil32[:De, CHe:CHe + Re] = wd[:, :, 0], wd[:, :, 1]
+                add2("en_dil2_%d" % i, wdil32, 1, 2)
+                bwd.append(("en_pq2_%d" % i, pack_index(diag(wq, 2, 1))))
             w = full(CHe, CHe)
             w[:Re, :De] = sp.conv("en_dense_layer_stack.%d.weight" % i)[:, :, 0]
             add("en_dense%d" % i, w)
             fwd.append(("en_dense_c%d" % i, pack_index(w, True)))               # chained k order: the fused encoder block
             bwd.append(("en_denseT%d" % i, pack_index(np.ascontiguousarray(w.T))))
+            if self.pair_ok:
+                add2("en_dense2_%d" % i, w, 1, 1, chained=True)                 # (its pack doubles as "en_dense_c2")
+                bwd.append(("en_denseT2_%d" % i, pack_index(diag(np.ascontiguousarray(w.T), 1, 1))))
             wfg = sp.conv("de_dilation_layer_stack.%d.weight" % (3 * i))       # [2Dd,Rd,2], gate rows first
             w = full(2 * CHd, 2 * CHd)
             wx = full(CHd, 4 * CHd)
@@ -182,10 +218,20 @@ class _AutoencoderEngine:
             wq = full(2 * CHd, 2 * CHd)                 # [W1^T; W0^T] over (df | dg): the one-launch backward block
             wq[:CHd], wq[CHd:] = wx[:, :2 * CHd], wx[:, 2 * CHd:]
             bwd.append(("de_pq%d" % i, pack_index(wq)))
+            if self.pair_ok:
+                wfg32 = full(2 * CHd, 2 * CHd)
+                for h, rows in enumerate((slice(Dd, 2 * Dd), slice(0, Dd))):
+                    wfg32[h * CHd:h * CHd + Dd, :Rd] = wfg[rows, :, 0]
+                    wfg32[h * CHd:h * CHd + Dd, CHd:CHd + Rd] = wfg[rows, :, 1]
+                add2("de_fg2_%d" % i, wfg32, 2, 2)
+                bwd.append(("de_pq2_%d" % i, pack_index(diag(wq, 2, 2))))
             w = full(CHd, CHd)
             w[:Rd, :Dd] = sp.conv("de_dilation_layer_stack.%d.weight" % (3 * i + 1))[:, :, 0]
             add("de_d%d" % i, w, chained=True)
             bwd.append(("de_dT%d" % i, pack_index(np.ascontiguousarray(w.T))))
+            if self.pair_ok:
+                add2("de_d2_%d" % i, w, 1, 1, chained=True)
+                bwd.append(("de_dT2_%d" % i, pack_index(diag(np.ascontiguousarray(w.T), 1, 1))))
         w = full(BwP, CHe)
         w[:Bw, :Re] = sp.conv("bottleneck_layer.weight")[:, :, 0]
         add("bottleneck", w)
@@ -218,6 +264,12 @@ class _AutoencoderEngine:
         self.gp_off = {name: (o, r, c) for name, o, r, c in gp}
         self.gpack = torch.zeros(gsize[0], dtype=torch.float32, device=self.device)
         self.gidx = torch.from_numpy(gidx.astype(np.int32)).to(self.device)   # -1 (biases) -> zero gradient
+        if self.pair_ok:                                  # pair mode: a stack weight's gradient = the sum of its two copies
+            ga, gb = gidx.copy(), np.full(self.spec.total, -1, dtype=np.int64)
+            for par, pos in pa.items():
+                ga[par], gb[par] = pos, pb[par]
+            self.gidx_pa = torch.from_numpy(ga.astype(np.int32)).to(self.device)
+            self.gidx_pb = torch.from_numpy(gb.astype(np.int32)).to(self.device)
 
     def workspace(self, B, T):
         return self._ws.peek(B, T)
@@ -257,6 +309,10 @@ class _AutoencoderEngine:
         ws = self._ws.get(B, T)
         self._gen += 1
         ws["gen"], ws["x_in"], ws["Le"] = self._gen, x, Le
+        pair = ws["pair"] = self.pair_ok and B % 2 == 0 and Le <= 32      # decided per workspace shape (B, T fix Le)
+        # the forward blocks pair only when that fills the chip (music_amd/engine.py); the backward blocks always
+        fw = os.environ.get("WN_PAIR32_FWD", "auto")
+        pair_f = pair and (fw == "1" or (fw == "auto" and (B // 2) * ((T + 511) // 512) >= 200))
         # a one-hot built from integer codes (engine.onehot / the loader) carries them: both causal layers then run on the
         # codes (gather forward, scatter backward), as in music_amd/engine.py
         ws["x_codes"] = None
@@ -298,6 +354,10 @@ class _AutoencoderEngine:
         for i, d in enumerate(self.dil):
             t_lo = self.off[i + 1]
             # h = dilated_conv(relu(x));   x' = dense(relu(h)) + x[tail]
+            if pair_f:                       # two clips per 64-row tensor, block-diagonal packs
+                call("wn_enc_resblock_fwd", xe(i), xe(i + 1), he(i), 2 * eb, 2 * eb, pitch, fr("en_dil2_%d" % i), fr("en_dense2_%d" % i),
+                     None, None, 64, 64, 64, d, t_lo, T, B // 2, m, st)
+                continue
             if self.fused_encoder:
                 call("wn_enc_resblock_fwd", xe(i), xe(i + 1), he(i), eb, eb, pitch, fr("en_dil%d" % i), fr("en_dense_c%d" % i),
                      self._bias("en_dilation_layer_stack.%d" % i), self._bias("en_dense_layer_stack.%d" % i), self.De, self.Re,
@@ -334,7 +394,12 @@ class _AutoencoderEngine:
             cmodes.append((1, L // Le) if L % Le == 0 else (2, 0))
         ws["cmodes"] = cmodes
         cpk = cix = None
-        if Le <= 32 and CHd == 64 and m == _lib.F16X3 and os.environ.get("WN_AE_COND_MFMA", "1") == "1":
+        CHp, Bp = (64, B // 2) if pair else (CHd, B)         # pair mode: 64-row tensors of two clips, rows [f: A B | g: A B]
+        tab_c = tab                                         # per clip, rows [f | g]: what the 32-channel forward block gathers from
+        if pair:
+            tab = tab.view(N, Bp, 2, 2, CHd, Le).permute(0, 1, 3, 2, 4, 5).reshape(N, Bp, 4 * CHd, Le).contiguous()
+            ws["tab"] = tab
+        if Le <= 32 and CHp == 64 and m == _lib.F16X3 and (pair or os.environ.get("WN_AE_COND_MFMA", "1") == "1"):
             # the conditioning bias on the matrix cores: bucket of every sample of every block as bytes (built once per
             # workspace: row i = PAD zeros, bucket(t - t_lo) for t in [t_lo, T), zeros) and, per forward, the tables as
             # packed A fragments ([2CH rows][32 buckets] per block and clip)
@@ -347,23 +412,30 @@ class _AutoencoderEngine:
                     mode_c, q = cmodes[i]
                     cidx[i, PADI:PADI + L] = (torch.clamp(trr // q, max=Le - 1) if mode_c == 1 else trr % Le).to(torch.uint8)
                 ws["cidx"] = cidx
-                row, k = pack_positions(2 * CHd // 16, 1, False)
+                row, k = pack_positions(2 * CHp // 16, 1, False)
                 one = np.where(k < Le, row * Le + k, -1).astype(np.int64)                  # one [2CH][Le] table
-                base = np.arange(N * B, dtype=np.int64)[:, None] * (2 * CHd * Le)
+                base = np.arange(N * Bp, dtype=np.int64)[:, None] * (2 * CHp * Le)
                 ws["ctab_idx"] = torch.from_numpy(np.where(one[None, :] >= 0, base + one[None, :], -1).astype(np.int32)
                                                   .reshape(-1)).to(self.device)
-                ws["ctab_pk"] = torch.empty(N * B * 2 * CHd * 32 * 2, dtype=torch.int16, device=self.device)
-            call("wn_pack_weights", ptr(tab), ptr(ws["ctab_idx"]), ptr(ws["ctab_pk"]), ws["ctab_idx"].numel(), m, st)
-            cpk, cix = ws["ctab_pk"], ws["cidx"]
-        cpb = 2 * CHd * 32 * 2                          # halfs of one clip's packed table (hi + lo planes)
+                ws["ctab_pk"] = torch.empty(N * Bp * 2 * CHp * 32 * 2, dtype=torch.int16, device=self.device)
+            if pair_f or not pair:                        # (the backward blocks read the fp32 table; only a 64-channel forward the pack)
+                call("wn_pack_weights", ptr(tab), ptr(ws["ctab_idx"]), ptr(ws["ctab_pk"]), ws["ctab_idx"].numel(), m, st)
+                cpk, cix = ws["ctab_pk"], ws["cidx"]
+        cpb = 2 * CHp * 32 * 2                          # halfs of one clip's packed table (hi + lo planes)
         for i, d in enumerate(self.dil):
             t_lo = self.off[i + 1]
             mode_c, q = cmodes[i]
+            if pair_f:
+                call("wn_resblock_fwd", xd(i), xd(i + 1), ptr(ws["Z"], SLACK + i * CHd * pitch), 2 * db, 2 * zb, pitch,
+                     fr("de_fg2_%d" % i), fr("de_d2_%d" % i), None, None, None, 64, 64, 64, d,
+                     t_lo, T, t_lo, 1 if i < N - 1 else 0, ptr(tab[i]), 4 * CHd * Le, Le, mode_c, Le, q,
+                     ptr(cpk, i * Bp * cpb), cpb, ptr(cix[i]), zb, Bp, m, st)
+                continue
             bias_fg = self._bias(bn % (3 * i))
             bf = bias_fg + 4 * Dd if bias_fg is not None else None      # filter_gate bias: gate rows first
             call("wn_resblock_fwd", xd(i), xd(i + 1), ptr(ws["Z"], SLACK + i * CHd * pitch), db, zb, pitch,
                  fr("de_fg%d" % i), fr("de_d%d" % i), bf, bias_fg, self._bias(bn % (3 * i + 1)), Dd, self.Rd, CHd, d,
-                 t_lo, T, t_lo, 1 if i < N - 1 else 0, ptr(tab[i]), 2 * CHd * Le, Le, mode_c, Le, q,
+                 t_lo, T, t_lo, 1 if i < N - 1 else 0, ptr(tab_c[i]), 2 * CHd * Le, Le, mode_c, Le, q,
                  ptr(cpk, i * B * cpb) if cpk is not None else None, cpb, ptr(cix[i]) if cix is not None else None,
                  0, B, m, st)   # z on the whole valid range: the backward's dWd reads it
         self.mark("dec_stack_fwd")
@@ -436,39 +508,42 @@ class _AutoencoderEngine:
                ("de_causal", 1, T, 512), ("en_causal", 1, T, 512)]
         # decoder blocks: the channel-split block kernel (both weight gradients inside the block launch)
         # where it applies, else resblock_bwd + two wgrad launches
-        ms = (self.CHd == 64 and self.mode == _lib.F16X3 and self.mode_b == _lib.BF16X3
-              and os.environ.get("WN_MS_BWD", "1") == "1")
+        pair = bw["pair"] = ws.get("pair", False)            # both stacks as clip pairs on the 64-channel one-launch blocks
+        ms = pair or (self.CHd == 64 and self.mode == _lib.F16X3 and self.mode_b == _lib.BF16X3
+                      and os.environ.get("WN_MS_BWD", "1") == "1")
         bw["ms"] = ms
         # ... and the data gradient inside the same launch, as the (P, Q) pair (wn_resblock_bwd_pq), without biases
         # (the conditioning gradient too, as bucket sums on the matrix cores: at most 32 pooled frames; WN_AE_COND_FUSED=0
         # keeps the blocks on wn_resblock_bwd_ms + wn_cond_grad, what longer encodings run)
-        bw["pq"] = (ms and not self.use_bias and os.environ.get("WN_PQ_BWD", "1") == "1" and "cidx" in ws
-                    and os.environ.get("WN_AE_COND_FUSED", "1") == "1")
+        bw["pq"] = pair or (ms and not self.use_bias and os.environ.get("WN_PQ_BWD", "1") == "1" and "cidx" in ws
+                            and os.environ.get("WN_AE_COND_FUSED", "1") == "1")
         if bw["pq"]:
             bw["PQ"] = [(buf(self.CHd), buf(self.CHd)), (buf(self.CHd), buf(self.CHd))]
         else:
             bw["dfg"] = buf(2 * self.CHd)               # [df;dg] in HBM: only the other block kernels write it
         # encoder blocks: wn_enc_resblock_bwd (dh + both weight gradients in one launch) where it applies
-        enc_fused = (self.CHe == 64 and self.mode_b == _lib.BF16X3 and os.environ.get("WN_AE_FUSED_ENC_BWD", "1") == "1")
+        enc_fused = pair or (self.CHe == 64 and self.mode_b == _lib.BF16X3 and os.environ.get("WN_AE_FUSED_ENC_BWD", "1") == "1")
         bw["enc_fused"] = enc_fused
         # ... and the data gradient inside the same launch, as the (P, Q) pair (wn_enc_resblock_bwd_pq), without biases
-        bw["enc_pq"] = enc_fused and not self.use_bias and os.environ.get("WN_AE_ENC_PQ", "1") == "1"
+        bw["enc_pq"] = pair or (enc_fused and not self.use_bias and os.environ.get("WN_AE_ENC_PQ", "1") == "1")
         if bw["enc_pq"]:
             bw["PQe"] = (bw["PQ"] if bw["pq"] and self.CHe == self.CHd else     # the decoder's pairs are free again by then
                          [(buf(self.CHe), buf(self.CHe)), (buf(self.CHe), buf(self.CHe))])
+        sfx = "2_" if pair else ""                            # pair mode: the block-diagonal gradient matrices, B / 2 "clips"
         for i in range(N):
             ench = -2 if enc_fused else 512
-            ops += [("de_fg%d" % i, self.off[i + 1], T, -1 if ms else 512), ("en_dil%d" % i, self.off[i + 1], T, ench),
-                    ("en_dense%d" % i, self.off[i + 1], T, ench)]
+            ops += [("de_fg%s%d" % (sfx, i), self.off[i + 1], T, -1 if ms else 512), ("en_dil%s%d" % (sfx, i), self.off[i + 1], T, ench),
+                    ("en_dense%s%d" % (sfx, i), self.off[i + 1], T, ench)]
             if i < N - 1:
-                ops.append(("de_d%d" % i, self.off[i + 1], T, -1 if ms else 512))
+                ops.append(("de_d%s%d" % (sfx, i), self.off[i + 1], T, -1 if ms else 512))
         plan, desc, so, vs = {}, [], 0, 0
         row_of = {}
         for name, t_lo, t_hi, chunk in ops:
             go, r, c = self.gp_off[name]
             n = r * c
+            Bs = B // 2 if pair and chunk < 0 else B
             ns = (_lib.wgrad_slabs(t_lo, t_hi, chunk, B) if chunk > 0 else
-                  _lib.ms_slabs(t_lo, t_hi, B) if chunk == -1 else _lib.enc_slabs(t_lo, t_hi, B))
+                  _lib.ms_slabs(t_lo, t_hi, Bs) if chunk == -1 else _lib.enc_slabs(t_lo, t_hi, Bs))
             plan[name] = (so, n, chunk)
             row_of[name] = len(desc)
             desc.append([vs, so, ns, n, go, n])
@@ -615,10 +690,14 @@ class _AutoencoderEngine:
         xd = lambda i: self._lay(ws["Xd"], i, CHd, ws)
         dfg = ptr(bw["dfg"], SLACK) if "dfg" in bw else None
         d_tab = torch.zeros(N, B, 2 * CHd, Le, dtype=torch.float32, device=self.device)
+        pair = bw["pair"]
+        Bp, sfx = (B // 2, "2_") if pair else (B, "")
+        if pair:
+            d_tab = torch.zeros(N, Bp, 4 * CHd, Le, dtype=torch.float32, device=self.device)     # rows [f: A B | g: A B]
         if bw["pq"] and "cslab" not in bw:
             # per-workgroup bucket sums of every block launch (one region each), added by ONE reduce behind the stack
             import ctypes
-            fl = [_lib.load().wn_resblock_bwd_pq_cond_floats(self.off[i + 1], T, B) for i in range(N)]
+            fl = [_lib.load().wn_resblock_bwd_pq_cond_floats(self.off[i + 1], T, Bp) for i in range(N)]
             bw["cs_off"] = (ctypes.c_int64 * N)(*np.concatenate([[0], np.cumsum(fl)[:-1]]).tolist())
             bw["cs_tlo"] = (ctypes.c_int * N)(*[self.off[i + 1] for i in range(N)])
             bw["cslab"] = torch.empty(sum(fl), dtype=torch.float32, device=self.device)
@@ -645,10 +724,16 @@ class _AutoencoderEngine:
                 else:
                     p_in = q_in = None
                     dn = p_lo = 0
-                call("wn_resblock_bwd_pq", xd(i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CHd * pitch), p_out, q_out,
-                     db, zb, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), br("de_pq%d" % i), CHd, d, t_lo, T, lo,
-                     ptr(bw["slab"], plan["de_fg%d" % i][0]), ptr(bw["slab"], plan["de_d%d" % i][0]) if i < N - 1 else None,
-                     ptr(ws["tab"][i]), 2 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"], bw["cs_off"][i]), 0, B, mf, mb, st)
+                if pair:
+                    call("wn_resblock_bwd_pq", xd(i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CHd * pitch), p_out, q_out,
+                         2 * db, 2 * zb, pitch, fr("de_fg2_%d" % i), br("de_dT2_%d" % i), br("de_pq2_%d" % i), 64, d, t_lo, T, lo,
+                         ptr(bw["slab"], plan["de_fg2_%d" % i][0]), ptr(bw["slab"], plan["de_d2_%d" % i][0]) if i < N - 1 else None,
+                         ptr(ws["tab"][i]), 4 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"], bw["cs_off"][i]), zb, Bp, mf, mb, st)
+                else:
+                    call("wn_resblock_bwd_pq", xd(i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CHd * pitch), p_out, q_out,
+                         db, zb, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), br("de_pq%d" % i), CHd, d, t_lo, T, lo,
+                         ptr(bw["slab"], plan["de_fg%d" % i][0]), ptr(bw["slab"], plan["de_d%d" % i][0]) if i < N - 1 else None,
+                         ptr(ws["tab"][i]), 2 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"], bw["cs_off"][i]), 0, B, mf, mb, st)
                 if i == 0:
                     call("wn_shift_add", p_out, q_out, ptr(bw["dXd"][0], SLACK), db, pitch, CHd, d, t_lo, self.off[0], T, B, st)
                 continue
@@ -677,8 +762,11 @@ class _AutoencoderEngine:
             gemm("de_fgT%d" % i, dfg, dfg, 2 * CHd * pitch, pitch, t_lo, T, 0, d, 2 * CHd // 32, 2 * CHd // 32, CHd // 16, Rd,
                  ptr(bw["dXd"][i % 2], SLACK), db, pitch, 0, None, (dy, db, pitch, t_lo) if dy else NONE3, NONE3, self.off[i], T, 0)
         if bw["pq"]:
-            call("wn_resblock_bwd_pq_cond_reduce", ptr(bw["cslab"]), bw["cs_off"], bw["cs_tlo"], N, T, B, Le, ptr(d_tab),
-                 B * 2 * CHd * Le, 2 * CHd * Le, Le, st)
+            rows = 4 * CHd if pair else 2 * CHd
+            call("wn_resblock_bwd_pq_cond_reduce", ptr(bw["cslab"]), bw["cs_off"], bw["cs_tlo"], N, T, Bp, Le, ptr(d_tab),
+                 Bp * rows * Le, rows * Le, Le, st)
+            if pair:                                    # back to per-clip tables, rows [f | g]
+                d_tab = d_tab.view(N, Bp, 2, 2, CHd, Le).permute(0, 1, 3, 2, 4, 5).reshape(N, B, 2 * CHd, Le)
         self.mark("dec_stack_bwd")
         x = ws["x_in"]
         codes_path = ws.get("x_codes") is not None
@@ -720,9 +808,14 @@ class _AutoencoderEngine:
                     dn, p_lo = self.dil[i + 1], self.off[i + 2]
                 else:
                     p_in, q_in, dn, p_lo = dy, None, 0, y_lo
-                call("wn_enc_resblock_bwd_pq", xe(i), p_in, q_in, dn, p_lo, he(i), p_out, q_out, eb, eb, pitch,
-                     br("en_denseT%d" % i), br("en_pq%d" % i), CHe, d, t_lo, T, ptr(bw["slab"], plan["en_dil%d" % i][0]),
-                     ptr(bw["slab"], plan["en_dense%d" % i][0]), B, mb, st)
+                if pair:
+                    call("wn_enc_resblock_bwd_pq", xe(i), p_in, q_in, dn, p_lo, he(i), p_out, q_out, 2 * eb, 2 * eb, pitch,
+                         br("en_denseT2_%d" % i), br("en_pq2_%d" % i), 64, d, t_lo, T, ptr(bw["slab"], plan["en_dil2_%d" % i][0]),
+                         ptr(bw["slab"], plan["en_dense2_%d" % i][0]), Bp, mb, st)
+                else:
+                    call("wn_enc_resblock_bwd_pq", xe(i), p_in, q_in, dn, p_lo, he(i), p_out, q_out, eb, eb, pitch,
+                         br("en_denseT%d" % i), br("en_pq%d" % i), CHe, d, t_lo, T, ptr(bw["slab"], plan["en_dil%d" % i][0]),
+                         ptr(bw["slab"], plan["en_dense%d" % i][0]), B, mb, st)
                 if i == 0:
                     call("wn_shift_add", p_out, q_out, dxe[0], eb, pitch, CHe, d, t_lo, self.off[0], T, B, st)
                 continue
@@ -755,7 +848,10 @@ class _AutoencoderEngine:
             main.wait_event(ev_join)
         call("wn_reduce_slabs", ptr(bw["desc_codes"] if codes_path else bw["desc"]), bw["nops"], bw["vec"], ptr(bw["slab"]),
              ptr(self.gpack), st)
-        call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
+        if pair:
+            call("wn_gather_grads2", ptr(self.gpack), ptr(self.gidx_pa), ptr(self.gidx_pb), ptr(self.flat_grad), self.spec.total, st)
+        else:
+            call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
         if self.use_bias:
             self.flat_grad.index_copy_(0, b_idx, b_grad)
         self.mark("en_causal_slab_reduce")
