@@ -57,6 +57,17 @@ def test_32_channel_kernels_stay_correct_without_clip_pairs():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
+def test_autoencoder_32_channel_kernels_stay_correct_without_clip_pairs():
+    """The autoencoder with 32 / 32 padded channels runs even batches as clip pairs on the 64-channel one-launch blocks
+    (the G8 configuration does); WN_PAIR32=0 keeps the 32-channel block kernels (what odd batches and biased models run):
+    the G8 forward fixture and the backward against the oracle on them."""
+    e = dict(os.environ, WN_PAIR32="0")
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", "g8_autoencoder_forward or autoencoder_backward_vs_oracle"]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+
+
 def test_decode_generic_kernel_stays_correct():
     """The cached-queue decoder on the generic fp32 kernel (decode_k: what every shape other than 64/64/256/256 runs),
     forced at the config-5 shapes with WN_DEC_MFMA=0: the config-5 oracle test (both queue recurrences), the one-launch
