@@ -268,6 +268,75 @@ def sub_benchmarks(net, x, target):
     return out
 
 
+def shipped_benchmarks(dev):
+    """The reference's SHIPPED parameter files (wavenet/params/wavenet_params.json, wavenet_autoencoder/params/model_params.json:
+    40 blocks, 32 / 32 channels, 512 skip channels; bottleneck 512, pool 512), fused training step: the WaveNet at its shipped
+    batch 4 x 44093 (wavenet/params/train_params.json + dataset_params.json), the autoencoder at 4 clips of 16384 predicted
+    samples.  Not a BASELINE config; these are the shapes a user of the reference starts from (32-channel models run as
+    clip pairs on the 64-channel block kernels)."""
+    import numpy as np
+    from music_amd.model import wavenet
+    from music_amd.model1 import wavenet_autoencoder
+    out = {}
+    dil = [2 ** i for i in range(10)] * 4
+    rng = np.random.default_rng(0)
+
+    def timed(step, n):
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        while time.perf_counter() - t_s < 0.3:            # clocks back up after the lighter work before
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    torch.manual_seed(0)
+    net = wavenet(filter_width=2, dilations=dil, dilation_channels=32, residual_channels=32, skip_channels=512,
+                  quantization_channels=256, use_bias=False).cuda()
+    eng = net._engine_for(dev)
+    eng.adam_init(lr=1e-4)
+    B, T = 4, 44093
+    W = T - net.receptive_field + 1
+    codes = torch.from_numpy(rng.integers(0, 256, size=(B, T)).astype(np.int32)).to(dev)
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).to(dev)
+
+    def wn_step():
+        eng.loss_and_grad_codes(codes, target, scrambled=True)
+        eng.adam_step()
+    dt = timed(wn_step, 10)
+    out["wavenet"] = {"workload": "wavenet_params.json (40 blocks, 32 / 32 / 512) at 4 x 44093, fused step from codes",
+                      "ms_per_step": dt * 1e3, "samples_per_s": B * T / dt, "clip_pairs": bool(eng.workspace(B, T)["pair"])}
+    del net, eng
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    ae = wavenet_autoencoder(filter_width=2, quantization_channel=256, dilations=dil, en_residual_channel=32, en_dilation_channel=32,
+                             en_bottleneck_width=512, en_pool_kernel_size=512, de_residual_channel=32, de_dilation_channel=32,
+                             de_skip_channel=512, use_bias=False).cuda()
+    aeng = ae._engine_for(dev)
+    aeng.adam_init(lr=1e-4)
+    B, W = 4, 16384
+    T = ae.receptive_field + W - 1
+    codes = torch.from_numpy(rng.integers(0, 256, size=(B, T)).astype(np.int32)).to(dev)
+    x = torch.zeros(B, 256, T, device=dev)
+    x.scatter_(1, codes.long().unsqueeze(1), 1.0)
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).to(dev)
+
+    def ae_step():
+        aeng.loss_and_grad(x, target, ae._draw_conditioning())
+        aeng.adam_step()
+    dt = timed(ae_step, 10)
+    out["autoencoder"] = {"workload": "model_params.json (40 + 40 blocks, 32 / 32, bottleneck 512, pool 512, skip 512) at 4 x %d "
+                                      "(16384 predicted samples per clip), fused step, dense one-hot input" % T,
+                          "ms_per_step": dt * 1e3, "samples_per_s": B * T / dt, "clip_pairs": bool(aeng.workspace(B, T)["pair"])}
+    del ae, aeng
+    torch.cuda.empty_cache()
+    return out
+
+
 def surface_benchmarks(net, eng, piece, target):
     """What a caller of the REFERENCE SURFACE gets: the loop of wavenet/train.py:171-182 as written -
     optimizer.zero_grad(), net(x), nn.CrossEntropyLoss on the probabilities, backward(), torch.optim.Adam.step() - at
@@ -673,6 +742,10 @@ def main():
             out["extra"]["reference_surface_step"] = surface_benchmarks(net, eng, bufs[0][0], bufs[0][1])
         except Exception as e:
             out["extra"]["reference_surface_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            out["extra"]["shipped_params"] = shipped_benchmarks(torch.device("cuda", 0))
+        except Exception as e:
+            out["extra"]["shipped_params"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline()
