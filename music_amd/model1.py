@@ -569,12 +569,6 @@ class _AutoencoderEngine:
         """Fused training step body (the autoencoder counterpart of engine.loss_and_grad): forward to the logits, ONE
         kernel for chunk softmax + CrossEntropyLoss on the probabilities (wavenet_autoencoder/train.py:146-160) + both
         backward steps, then the backward.  Returns the loss (0-d device tensor); gradients land in self.flat_grad."""
-        # at most two fused steps in flight: a host that enqueues a little faster than the device executes otherwise runs into the
-        # runtime's own back-pressure, which parks the thread until the queues are EMPTY (80 ms every third step with the
-        # reference's shipped parameters - 470 launches and 160 events per step -, the device idle for most of it)
-        q = self.__dict__.setdefault("_inflight", [])
-        if len(q) >= int(os.environ.get("WN_RUN_AHEAD", "2")):
-            q.pop(0).synchronize()
         _, enc, ws = self.forward(x, cond, want_probs=False)
         bw = self._bwd_workspace(ws)
         n = ws["B"] * ws["W"]
@@ -585,9 +579,6 @@ class _AutoencoderEngine:
         call("wn_chunk_softmax256_ce", ptr(ws["O"]), ptr(target), None, ptr(bw["dO"]), ptr(ws["loss_part"]), n, 1.0 / n,
              _lib.stream())
         self.backward(ws, None)
-        ev = torch.cuda.Event()
-        ev.record()
-        q.append(ev)
         return ws["loss_part"].sum()
 
     def adam_init(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
