@@ -310,6 +310,19 @@ def shipped_benchmarks(dev):
     dt = timed(wn_step, 10)
     out["wavenet"] = {"workload": "wavenet_params.json (40 blocks, 32 / 32 / 512) at 4 x 44093, fused step from codes",
                       "ms_per_step": dt * 1e3, "samples_per_s": B * T / dt, "clip_pairs": bool(eng.workspace(B, T)["pair"])}
+    # ... and its cached-queue generation (fast_generate.py): 8000 greedy samples from the class-128 start piece
+    from music_amd import fast_generate as fg
+    start = torch.zeros(1, 256, net.receptive_field, device=dev)
+    start[:, 128, :] = 1.0
+    fg.generate_codes(net, start, 200)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gen = fg.generate_codes(net, start, 8000)
+    torch.cuda.synchronize()
+    dtg = time.perf_counter() - t0
+    out["wavenet"]["decode_single_stream_samples_per_s"] = 8000 / dtg
+    out["wavenet"]["decode_matrix_core_kernels"] = bool(fg._mfma_decode(net._engine))
+    out["wavenet"]["decode_distinct_codes"] = int(torch.unique(gen).numel())
     del net, eng
     torch.cuda.empty_cache()
     torch.manual_seed(0)

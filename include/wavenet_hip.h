@@ -336,8 +336,11 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
 /* wn_decode_batch with the chain's products on the matrix cores: pk = the packed f16 hi/lo weight fragments of the
  * forward blocks (wn_pack_weights, mode WN_F16X3: per block l "fg" at pk + pk_fg0 + l*pk_lstride halfs in natural k
  * order, "d" at pk + pk_d0 + l*pk_lstride in chained k order, as wn_resblock_fwd takes them; pk_skip / pk_p1 / pk_p2 >= 0:
- * the skip product and the two post-processing products as well (S = Q = 256), else -1).  Used when R = D = 64 and
- * S = Q = 256 with all of pk given (biases allowed); NULL or other shapes = wn_decode_batch.
+ * the skip product and the two post-processing products as well (S = 256 or 512, Q = 256), else -1).  Used when R = D = 64,
+ * S = 256 or 512 and Q = 256 with all of pk given (biases allowed); NULL or other shapes = wn_decode_batch.  A model with
+ * FEWER residual / dilation channels (the reference's shipped 32 / 32 / 512) runs here as the 64 / 64 model it is with zero
+ * rows and columns: the decoder is bound by latency, not by traffic, so the padding is free (music_amd/fast_generate.py
+ * hands over padded weights, packs and 64-wide queue columns).
  * sync here holds wn_decode_sync_granules(n_layers, D, S) uint64 PER UTTERANCE (error flag = the last word of an
  * utterance's region).  Eight utterances share a workgroup pair, one pair of MFMA result columns each (n_utt <= 1024
  * on this path; when fewer than eight are left for a pair the spare columns mirror the last utterance; same arithmetic

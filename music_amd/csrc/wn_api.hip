@@ -427,7 +427,7 @@ static int decode_impl(int n_layers, int R, int D, int S, int Q, const int32_t* 
     a.pk_skip = -1;
     // the matrix-core kernel needs all of pk (chain, skip, post-processing: 64 / 64 / 256 / 256 channels); biases are fine
     const bool any_bias = b_layers || b_causal || b_p1 || b_p2;
-    const bool post_pk = S == 256 && Q == 256 && pk_skip >= 0 && pk_p1 >= 0 && pk_p2 >= 0;
+    const bool post_pk = (S == 256 || S == 512) && Q == 256 && pk_skip >= 0 && pk_p1 >= 0 && pk_p2 >= 0;
     if (pk && R == 64 && D == 64 && (post_pk || !any_bias)) {
         a.pk = pk; a.pk_fg0 = pk_fg0; a.pk_d0 = pk_d0; a.pk_lstride = pk_lstride;
         if (post_pk) { a.pk_skip = pk_skip; a.pk_p1 = pk_p1; a.pk_p2 = pk_p2; }

@@ -11,6 +11,7 @@
 //
 // As written in the reference, block i pushes its OUTPUT into its own queue
 // (fast_generate.py:128-129); push_input != 0 selects the corrected recurrence.
+#include <type_traits>
 #include "wn_common.h"
 #include "wn_kernels.h"
 
@@ -320,13 +321,14 @@ __device__ __forceinline__ bool dec_poll2(const unsigned long long* p, unsigned 
 // 8 instead of 16 f / g MFMAs, half the LDS operand reads, half the weight re-arm loads.  The partial sums (4 floats per
 // thread and block) take the place of the split queue columns in LDS (n_layers x 4 KB; chosen when that fits: <= 32 blocks).
 #define DEC_T0_CHUNK 4
-template <bool BIAS, bool T0>
+// S = 256 or 512 skip channels (the reference's shipped parameters have 512): MS = S / 64 row tiles of an S-vector per wave.
+template <bool BIAS, bool T0, int S = 256>
 __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
-    constexpr int NU = 8, R = 64, D = 64, S = 256, Q = 256;
+    constexpr int NU = 8, R = 64, D = 64, Q = 256, MS = S / 64;
     // LDS strides between utterances (halfs): the eight utterances of a 16-lane group read 16-byte pieces at the same offset of
     // their own vectors - with the natural strides (256 B, 1 KB) all of them in the same banks.  +16 B per utterance spreads the
     // group over all 64 banks (hi | lo halves are 128 B apart for the 64-vectors; 640 B for the 256-vectors)
-    constexpr int VS = 2 * R + 8, WS = 648, WLO = 320;
+    constexpr int VS = 2 * R + 8, WLO = S + 64, WS = 2 * WLO + 8;       // (S = 256: 320 and 648)
     const int pair = blockIdx.x >> 1, role = blockIdx.x & 1;
     const size_t ubase = (size_t)pair * NU;
     // a pair with fewer than eight utterances left (n_utt not a multiple of 8; a single utterance): the spare columns MIRROR the
@@ -608,61 +610,69 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
         float* logit = reinterpret_cast<float*>(h1 + NU * WS);   // [NU][Q]
         float* bsk = logit + NU * Q;                            // [S] summed skip biases, [S] post_process_1 bias, [Q] post_process_2 bias
         if (BIAS && a.b_layers) {
-            float t = 0.f;
-            for (int l = 0; l < a.n_layers; ++l) t += a.b_layers[(size_t)l * (2 * D + R + S) + 2 * D + R + tid];
-            bsk[tid] = t;
+            for (int r = tid; r < S; r += 256) {
+                float t = 0.f;
+                for (int l = 0; l < a.n_layers; ++l) t += a.b_layers[(size_t)l * (2 * D + R + S) + 2 * D + R + r];
+                bsk[r] = t;
+            }
         }
-        if (BIAS && a.b_p1) bsk[S + tid] = a.b_p1[tid];
+        if (BIAS && a.b_p1) for (int r = tid; r < S; r += 256) bsk[S + r] = a.b_p1[r];
         if (BIAS && a.b_p2) bsk[2 * S + tid] = a.b_p2[tid];
         dec_sync();
         const int KSS = a.n_layers * D / 32;
         const uint16_t* skb = a.pk + a.pk_skip;
         const uint16_t* p1b = a.pk + a.pk_p1;
         const uint16_t* p2b = a.pk + a.pk_p2;
-        // rows 64w + 16m + 4q + 2h, + 1 of this lane's utterance
-        auto post = [&](const uint16_t* wb, const uint16_t* in, uint16_t* outh, float* outf, const float* bvec) {
-            f32x4 acc[4];
+        // NG groups of 256 output rows, four row tiles per wave and group (rows 256 g + 64 w + 16 m + 4q + 2h, + 1 of this lane's
+        // utterance), K = S.  (All 8 tiles of a 512-row product at once: the unrolled k loop's fragment loads are hoisted and
+        // 480 registers spill.)
+        auto post = [&](const int ng, const uint16_t* wb, const uint16_t* in, uint16_t* outh, float* outf, const float* bvec) {
+            constexpr int KP = S / 32;
+            for (int gr = 0; gr < ng; ++gr) {
+                f32x4 acc[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            Frag<F16> wa[2][4];
+                for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int rt0 = 16 * gr + 4 * w;
+                Frag<F16> wa[2][4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) load_a<F16, 3>(wa[0][m], wb, (4 * w + m) * 8, lane);
+                for (int m = 0; m < 4; ++m) load_a<F16, 3>(wa[0][m], wb, (rt0 + m) * KP, lane);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                if (ks + 1 < 8) {
+                for (int ks = 0; ks < KP; ++ks) {
+                    if (ks + 1 < KP) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) load_a<F16, 3>(wa[(ks + 1) & 1][m], wb, (4 * w + m) * 8 + ks + 1, lane);
+                        for (int m = 0; m < 4; ++m) load_a<F16, 3>(wa[(ks + 1) & 1][m], wb, (rt0 + m) * KP + ks + 1, lane);
+                    }
+                    const f16x8 bx = *reinterpret_cast<const f16x8*>(in + u * WS + h * WLO + 32 * ks + 8 * q);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = F16::mfma(wa[ks & 1][m].hi, bx, acc[m]);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = F16::mfma(wa[ks & 1][m].lo, bx, acc[m]);
                 }
-                const f16x8 bx = *reinterpret_cast<const f16x8*>(in + u * WS + h * WLO + 32 * ks + 8 * q);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = F16::mfma(wa[ks & 1][m].hi, bx, acc[m]);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = F16::mfma(wa[ks & 1][m].lo, bx, acc[m]);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f32x4 t = dec_pairsum(acc[m]);
-                const int row = 64 * w + 16 * m + 4 * q + 2 * h;
-                float v0 = h ? t[2] : t[0], v1 = h ? t[3] : t[1];
-                if (bvec) { v0 += bvec[row]; v1 += bvec[row + 1]; }
-                if (outh) dec_put2(outh + u * WS, WLO, row, fmaxf(v0, 0.f), fmaxf(v1, 0.f));
-                else { outf[u * Q + row] = v0; outf[u * Q + row + 1] = v1; }
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 t = dec_pairsum(acc[m]);
+                    const int row = 16 * (rt0 + m) + 4 * q + 2 * h;
+                    float v0 = h ? t[2] : t[0], v1 = h ? t[3] : t[1];
+                    if (bvec) { v0 += bvec[row]; v1 += bvec[row + 1]; }
+                    if (outh) dec_put2(outh + u * WS, WLO, row, fmaxf(v0, 0.f), fmaxf(v1, 0.f));
+                    else { outf[u * Q + row] = v0; outf[u * Q + row + 1] = v1; }
+                }
             }
         };
         const unsigned long long* const zmine = zg_of(tid >> 5) + (tid & 31) * 2;       // this thread's two granules of block 0
         unsigned long long pa = 0, pb = 0;                                               // prefetched pair (tag 0 = nothing yet)
         for (int step = 0; step < a.n_steps; ++step) {
             const unsigned tag = (unsigned)step + 1u;
-            f32x4 acc2[2][4];
+            f32x4 acc2[2][MS];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc2[s2][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            Frag<F16> ws[2][4];
+                for (int m = 0; m < MS; ++m) acc2[s2][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            Frag<F16> ws[2][MS];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) load_a<F16, 3>(ws[s2][m], skb, (4 * w + m) * KSS + s2, lane);
+                for (int m = 0; m < MS; ++m) load_a<F16, 3>(ws[s2][m], skb, (16 * (m >> 2) + 4 * w + (m & 3)) * KSS + s2, lane);
             for (int l = 0; l < a.n_layers; ++l) {
                 uint16_t* zz = zz0 + (l & 1) * NU * VS;
                 {   // two adjacent granules per thread.  They were asked for one block EARLIER (a hand-off-scope load is a
@@ -682,28 +692,28 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) acc2[s2][m] = F16::mfma(ws[s2][m].hi, bz[s2], acc2[s2][m]);
+                    for (int m = 0; m < MS; ++m) acc2[s2][m] = F16::mfma(ws[s2][m].hi, bz[s2], acc2[s2][m]);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) acc2[s2][m] = F16::mfma(ws[s2][m].lo, bz[s2], acc2[s2][m]);
+                    for (int m = 0; m < MS; ++m) acc2[s2][m] = F16::mfma(ws[s2][m].lo, bz[s2], acc2[s2][m]);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) load_a<F16, 3>(ws[s2][m], skb, (4 * w + m) * KSS + 2 * ln + s2, lane);      // next block (unconditional)
+                    for (int m = 0; m < MS; ++m) load_a<F16, 3>(ws[s2][m], skb, (16 * (m >> 2) + 4 * w + (m & 3)) * KSS + 2 * ln + s2, lane);      // next block (unconditional)
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MS; ++m) {
                 const f32x4 t = dec_pairsum(acc2[0][m] + acc2[1][m]);
-                const int row = 64 * w + 16 * m + 4 * q + 2 * h;
+                const int row = 16 * (16 * (m >> 2) + 4 * w + (m & 3)) + 4 * q + 2 * h;
                 float v0 = h ? t[2] : t[0], v1 = h ? t[3] : t[1];
                 if (BIAS && a.b_layers) { v0 += bsk[row]; v1 += bsk[row + 1]; }
                 dec_put2(skip + u * WS, WLO, row, fmaxf(v0, 0.f), fmaxf(v1, 0.f));
             }
             dec_sync();
-            post(p1b, skip, h1, nullptr, BIAS && a.b_p1 ? bsk + S : nullptr);
+            post(S / 256, p1b, skip, h1, nullptr, BIAS && a.b_p1 ? bsk + S : nullptr);
             dec_sync();
-            post(p2b, h1, nullptr, logit, BIAS && a.b_p2 ? bsk + 2 * S : nullptr);
+            post(Q / 256, p2b, h1, nullptr, logit, BIAS && a.b_p2 ? bsk + 2 * S : nullptr);
             dec_sync();
 #pragma unroll
             for (int e = 0; e < 2; ++e) {          // wave w chooses for utterances 2w and 2w + 1
@@ -732,7 +742,7 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
     // 1024 utterances per launch.  Everything else (other channel counts, fewer than 4 steps) runs on decode_k: one
     // workgroup per utterance, fp32 FMA.
     const bool any_bias = a.b_layers || a.b_causal || a.b_p1 || a.b_p2;
-    const bool mf = a.pk && a.pk_skip >= 0 && a.sync && a.n_steps >= 4 && !(a.dbg & 31);
+    const bool mf = a.pk && a.pk_skip >= 0 && a.sync && a.n_steps >= 4 && !(a.dbg & 31) && (a.S == 256 || a.S == 512);
     if (nu > (mf ? 1024 : 128)) return wn_set_error_msg(-4, "decode: at most 128 utterances per launch (1024 on the matrix-core path)");
     if (mf) {
         const size_t nsync = (size_t)a.sync_ustride * sizeof(unsigned long long) * (size_t)nu;
@@ -743,28 +753,36 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
         // tap 0 ahead (decode_duo_mfma8_k<.., true>): split queue columns of DEC_T0_CHUNK blocks + 4 KB of partial sums per block
         const size_t s80_t0 = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R) + sizeof(uint16_t) * (size_t)(8 * 136 * (3 + DEC_T0_CHUNK)) +
                               (size_t)a.n_layers * 256 * sizeof(f32x4);
-        const size_t s81 = sizeof(uint16_t) * (size_t)(2 * 8 * 136 + 2 * 8 * 648) + sizeof(float) * (size_t)(8 * a.Q + 2 * a.S + a.Q);
+        const size_t ws_h = 2 * ((size_t)a.S + 64) + 8;               // halfs of one utterance's split S-vector (the kernel's WS)
+        const size_t s81 = sizeof(uint16_t) * (size_t)(2 * 8 * 136 + 2 * 8 * ws_h) + sizeof(float) * (size_t)(8 * a.Q + 2 * a.S + a.Q);
         static int t0_env = -1;
         if (t0_env < 0) { const char* e = getenv("WN_DEC_T0"); t0_env = e ? atoi(e) : 1; }
         const bool t0 = t0_env && s80_t0 + 1024 <= 160 * 1024;
         const size_t sh = t0 ? (s80_t0 > s81 ? s80_t0 : s81) : (s80 > s81 ? s80 : s81);
-        if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pairs x 8 utterances: %d utterances, %d steps, biases %d, tap-0 ahead %d\n", nu, a.n_steps, any_bias ? 1 : 0, t0 ? 1 : 0);
+        if (sh + 1024 > 160 * 1024) return wn_set_error_msg(-4, "decode: this many blocks do not fit the matrix-core kernel's LDS");
+        if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pairs x 8 utterances: %d utterances, %d steps, %d skip channels, biases %d, tap-0 ahead %d\n", nu, a.n_steps, a.S, any_bias ? 1 : 0, t0 ? 1 : 0);
         static unsigned long long attr_done = 0;
         int dev = 0;
         (void)hipGetDevice(&dev);
+        const int mx = 160 * 1024 - 1024;           // (the kernel also has ~350 bytes of static LDS)
+#define DEC_ATTR(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, mx)
         if (!((attr_done >> dev) & 1ull)) {
-            const int mx = 160 * 1024 - 1024;           // (the kernel also has ~350 bytes of static LDS)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_duo_mfma8_k<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_duo_mfma8_k<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_duo_mfma8_k<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_duo_mfma8_k<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+            DEC_ATTR((decode_duo_mfma8_k<true, true, 256>)); DEC_ATTR((decode_duo_mfma8_k<false, true, 256>));
+            DEC_ATTR((decode_duo_mfma8_k<true, false, 256>)); DEC_ATTR((decode_duo_mfma8_k<false, false, 256>));
+            DEC_ATTR((decode_duo_mfma8_k<true, true, 512>)); DEC_ATTR((decode_duo_mfma8_k<false, true, 512>));
+            DEC_ATTR((decode_duo_mfma8_k<true, false, 512>)); DEC_ATTR((decode_duo_mfma8_k<false, false, 512>));
             attr_done |= 1ull << dev;
         }
+#undef DEC_ATTR
         const dim3 gr(2 * ((nu + 7) / 8)), bl(DEC_MT);
-        if (any_bias && t0) hipLaunchKernelGGL((decode_duo_mfma8_k<true, true>), gr, bl, sh, st, a);
-        else if (any_bias) hipLaunchKernelGGL((decode_duo_mfma8_k<true, false>), gr, bl, sh, st, a);
-        else if (t0) hipLaunchKernelGGL((decode_duo_mfma8_k<false, true>), gr, bl, sh, st, a);
-        else hipLaunchKernelGGL((decode_duo_mfma8_k<false, false>), gr, bl, sh, st, a);
+#define DEC_GO(SS) do { \
+        if (any_bias && t0) hipLaunchKernelGGL((decode_duo_mfma8_k<true, true, SS>), gr, bl, sh, st, a); \
+        else if (any_bias) hipLaunchKernelGGL((decode_duo_mfma8_k<true, false, SS>), gr, bl, sh, st, a); \
+        else if (t0) hipLaunchKernelGGL((decode_duo_mfma8_k<false, true, SS>), gr, bl, sh, st, a); \
+        else hipLaunchKernelGGL((decode_duo_mfma8_k<false, false, SS>), gr, bl, sh, st, a); } while (0)
+        if (a.S == 512) DEC_GO(512);
+        else DEC_GO(256);
+#undef DEC_GO
     } else {
         if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] generic fp32 kernel: %d utterances, %d steps\n", nu, a.n_steps);
         size_t sh = sizeof(float) * (size_t)(3 * a.Q + 3 * a.R + 3 * a.D + 2 * a.S + 64);

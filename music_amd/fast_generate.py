@@ -28,20 +28,35 @@ try:
     from . import _lib
     from ._lib import call, ptr
     from .audio_func import mu_law_decode
-    from .engine import SLACK
+    from .engine import SLACK, pack_index
     from .model import wavenet
     from .train import load_model
 except ImportError:
     from music_amd import _lib
     from music_amd._lib import call, ptr
     from music_amd.audio_func import mu_law_decode
-    from music_amd.engine import SLACK
+    from music_amd.engine import SLACK, pack_index
     from music_amd.model import wavenet
     from music_amd.train import load_model
 
 
+def _mfma_decode(eng):
+    """True when the matrix-core decode kernels serve this model (wn_decode_batch_pk): up to 64 residual / dilation channels -
+    fewer are PADDED to 64 with zero rows and columns (the decoder is bound by latency, not traffic: the padding is free) -,
+    256 or 512 skip channels, 256 quantisation channels, f16x3 forward mode; biases are fine.  WN_DEC_MFMA=0: never."""
+    return (os.environ.get("WN_DEC_MFMA", "1") == "1" and getattr(eng, "k", 2) == 2 and eng.R <= 64 and eng.D <= 64 and
+            eng.S in (256, 512) and eng.Q == 256 and eng.mode_fwd == _lib.F16X3 and "fg0" in getattr(eng, "pk_f_off", {}))
+
+
+def _ring_width(eng):
+    """Floats per queue column: the (padded) residual channel count the decode kernels run with."""
+    return 64 if _mfma_decode(eng) else eng.R
+
+
 class _DecodePack:
-    """fp32 weights in the layout wn_decode reads (rebuilt from the engine's flat buffer)."""
+    """fp32 weights in the layout wn_decode reads (rebuilt from the engine's flat buffer), and for the matrix-core kernels
+    the same weights as packed f16 hi/lo fragments.  With fewer than 64 residual / dilation channels on that path every
+    matrix is laid out for Rp = Dp = 64 channels with structural zeros (index -1)."""
 
     def __init__(self, eng):
         sp, R, D, S, Q, N = eng.spec, eng.R, eng.D, eng.S, eng.Q, eng.N
@@ -50,20 +65,39 @@ class _DecodePack:
             # (wavenet/fast_generate.py:73-90): it only exists for filter_width 2
             raise NotImplementedError("fast_generate implements the reference's cached-queue recurrence, which is defined for "
                                       "filter_width == 2 only (wavenet/fast_generate.py:73-90)")
-        parts = []
+        self.mfma = _mfma_decode(eng)
+        Rp = Dp = self.Rp = self.Dp = 64 if self.mfma else None
+        if not self.mfma:
+            Rp, Dp = self.Rp, self.Dp = R, D
+
+        def pad(m, rows, cols):
+            out = np.full((rows, cols), -1, dtype=np.int64)
+            out[:m.shape[0], :m.shape[1]] = m
+            return out
+
+        def padv(v, n):
+            out = np.full(n, -1, dtype=np.int64)
+            out[:len(v)] = v
+            return out
+        parts, mats = [], {}
         wc = sp.conv("causal_layer.weight")                                 # [R,Q,2]
         self.o_causal = 0
-        parts.append(np.concatenate([wc[:, :, 0], wc[:, :, 1]], 1).reshape(-1))
-        self.layer_stride = 2 * D * 2 * R + R * D + S * D
+        parts.append(pad(np.concatenate([wc[:, :, 0], wc[:, :, 1]], 1), Rp, 2 * Q).reshape(-1))
+        self.layer_stride = 2 * Dp * 2 * Rp + Rp * Dp + S * Dp
         self.o_layers = sum(len(p) for p in parts)
         for i in range(N):
             wf = sp.conv("dilation_layer_stack.%d.weight" % (4 * i))        # [D,R,2]
             wg = sp.conv("dilation_layer_stack.%d.weight" % (4 * i + 1))
             wd = sp.conv("dilation_layer_stack.%d.weight" % (4 * i + 2))[:, :, 0]
             ws = sp.conv("dilation_layer_stack.%d.weight" % (4 * i + 3))[:, :, 0]
-            fg = np.concatenate([np.concatenate([wf[:, :, 1], wf[:, :, 0]], 1),      # k = [tap1 (cur) | tap0 (old)]
-                                 np.concatenate([wg[:, :, 1], wg[:, :, 0]], 1)], 0)
-            parts += [fg.reshape(-1), wd.reshape(-1), ws.reshape(-1)]
+            blk = lambda a, b: np.concatenate([pad(a, Dp, Rp), pad(b, Dp, Rp)], 1)
+            fg = np.concatenate([blk(wf[:, :, 1], wf[:, :, 0]),                      # k = [tap1 (cur) | tap0 (old)]
+                                 blk(wg[:, :, 1], wg[:, :, 0])], 0)
+            parts += [fg.reshape(-1), pad(wd, Rp, Dp).reshape(-1), pad(ws, S, Dp).reshape(-1)]
+            # the packed forms: [f; g] rows, K = [tap0 | tap1] in natural order; dense in chained order (as wn_resblock_fwd)
+            mats["fg%d" % i] = (np.concatenate([blk(wf[:, :, 0], wf[:, :, 1]), blk(wg[:, :, 0], wg[:, :, 1])], 0), False)
+            mats["d%d" % i] = (pad(wd, Rp, Dp), True)
+            mats.setdefault("skip_cols", []).append(pad(ws, S, Dp))
         self.o_p1 = sum(len(p) for p in parts)
         parts.append(sp.conv("post_process_1.weight")[:, :, 0].reshape(-1))
         self.o_p2 = sum(len(p) for p in parts)
@@ -73,10 +107,10 @@ class _DecodePack:
             self.o_bias = sum(len(p) for p in parts)
             b = lambda n: sp.off[n] + np.arange(sp.shape[n][0])
             self.ob_causal = self.o_bias
-            parts.append(b("causal_layer.bias"))
+            parts.append(padv(b("causal_layer.bias"), Rp))
             self.ob_layers = sum(len(p) for p in parts)
             for i in range(N):
-                parts += [b("dilation_layer_stack.%d.bias" % (4 * i + k)) for k in range(4)]
+                parts += [padv(b("dilation_layer_stack.%d.bias" % (4 * i + k)), n) for k, n in enumerate((Dp, Dp, Rp, S))]
             self.ob_p1 = sum(len(p) for p in parts)
             parts.append(b("post_process_1.bias"))
             self.ob_p2 = sum(len(p) for p in parts)
@@ -85,12 +119,39 @@ class _DecodePack:
         self.idx = torch.from_numpy(idx).to(eng.device)
         self.buf = torch.empty(len(idx), dtype=torch.float32, device=eng.device)
         self.eng = eng
+        self.pk = None
+        if self.mfma:
+            # packed fragments: per block "fg" then "d" at a fixed stride, then skip, p1, p2 (offsets in halfs, hi + lo planes)
+            lst = []
+            for i in range(N):
+                lst += [("fg%d" % i,) + mats["fg%d" % i], ("d%d" % i,) + mats["d%d" % i]]
+            lst += [("skip", np.concatenate(mats["skip_cols"], 1), False),
+                    ("p1", sp.conv("post_process_1.weight")[:, :, 0], False), ("p2", sp.conv("post_process_2.weight")[:, :, 0], False)]
+            offs, o, pidx = {}, 0, []
+            for name, m, chained in lst:
+                offs[name] = 2 * o
+                pi = pack_index(m.astype(np.int64), chained)
+                pidx.append(pi)
+                o += len(pi)
+            self.pk_off = offs
+            self.pk_stride = offs["fg1"] - offs["fg0"] if N > 1 else 0
+            self.pk_idx = torch.from_numpy(np.concatenate(pidx).astype(np.int32)).to(eng.device)
+            self.pk = torch.zeros(2 * o, dtype=torch.int16, device=eng.device)
 
     def refresh(self):
         call("wn_gather_grads", ptr(self.eng.flat), ptr(self.idx), ptr(self.buf), self.idx.numel(), _lib.stream())
+        if self.pk is not None:
+            call("wn_pack_weights", ptr(self.eng.flat), ptr(self.pk_idx), ptr(self.pk), self.pk_idx.numel(), _lib.F16X3, _lib.stream())
 
     def p(self, off):
         return None if off is None else ptr(self.buf, off)
+
+    def chain(self):
+        """(pk pointer, fg offset, d offset, per-block stride, skip, p1, p2 offsets) for wn_decode_batch_pk, or Nones / -1."""
+        if self.pk is None:
+            return None, 0, 0, 0, -1, -1, -1
+        o = self.pk_off
+        return ptr(self.pk), o["fg0"], o["d0"], self.pk_stride, o["skip"], o["p1"], o["p2"]
 
 
 class DecodeState(OrderedDict):
@@ -101,13 +162,14 @@ class DecodeState(OrderedDict):
     def __init__(self, eng, rings, prev, steps=0):
         super().__init__()
         self.eng, self.rings, self.prev, self.steps = eng, rings, prev, steps
-        self.q_off = np.cumsum([0] + [d * eng.R for d in eng.dil[:-1]]).astype(np.int64)
+        self.rw = _ring_width(eng)                # floats per queue column (64 on the matrix-core kernels, zeros beyond eng.R)
+        self.q_off = np.cumsum([0] + [d * self.rw for d in eng.dil[:-1]]).astype(np.int64)
         for k in ["causal_layer"] + ["block_%d" % (i + 1) for i in range(eng.N)]:
             OrderedDict.__setitem__(self, k, None)
 
     def _ring(self, i):
-        d, R = self.eng.dil[i], self.eng.R
-        return self.rings[self.q_off[i]:self.q_off[i] + d * R].view(d, R)
+        d = self.eng.dil[i]
+        return self.rings[self.q_off[i]:self.q_off[i] + d * self.rw].view(d, self.rw)[:, :self.eng.R]
 
     def __getitem__(self, key):
         if key == "causal_layer":
@@ -126,30 +188,11 @@ class DecodeState(OrderedDict):
     @staticmethod
     def from_tensors(eng, queue):
         """Build the ring form from reference-style tensors (time-ordered, oldest first)."""
-        rings = torch.cat([queue["block_%d" % (i + 1)].to(eng.device).float().reshape(eng.R, eng.dil[i]).t().reshape(-1)
-                           for i in range(eng.N)])
+        rw = _ring_width(eng)
+        rings = torch.cat([torch.nn.functional.pad(queue["block_%d" % (i + 1)].to(eng.device).float().reshape(eng.R, eng.dil[i]).t(),
+                                                   (0, rw - eng.R)).reshape(-1) for i in range(eng.N)])
         prev = queue["causal_layer"].to(eng.device).float().reshape(-1).clone()
         return DecodeState(eng, rings.contiguous(), prev, 0)
-
-
-def _packed_chain(eng):
-    """(pk pointer, fg offset, d offset, per-block stride) of the training engine's packed f16x3 forward weights for the
-    matrix-core form of the decode chain (wn_decode_batch_pk), or (None, 0, 0, 0) when it does not apply (64 residual /
-    dilation channels, f16x3 forward mode; biases are fine) or WN_DEC_MFMA=0; plus the fragment bases of the skip and
-    post-processing products (256 skip / quantisation channels), or -1."""
-    import os
-    if (os.environ.get("WN_DEC_MFMA", "1") != "1" or eng.R != 64 or eng.D != 64 or eng.mode_fwd != _lib.F16X3 or
-            "fg0" not in eng.pk_f_off):        # (the general plan's packs have another fragment order: fp32 decode kernel)
-        return None, 0, 0, 0, -1, -1, -1
-    off = eng.pk_f_off
-    fg0, d0 = off["fg0"], off["d0"]
-    stride = off["fg1"] - fg0 if eng.N > 1 else 0
-    for i in range(eng.N):
-        if off["fg%d" % i] != fg0 + i * stride or off["d%d" % i] != d0 + i * stride:
-            return None, 0, 0, 0, -1, -1, -1
-    eng.pack_weights()
-    post = (off["skip"], off["p1"], off["p2"]) if (eng.S == 256 and eng.Q == 256) else (-1, -1, -1)
-    return (ptr(eng.pk_f), fg0, d0, stride) + post
 
 
 def _decode(net, state, note0, n_steps, forced=None, want_probs=False, correct_queue=False, temperature=None, seed=0):
@@ -167,12 +210,12 @@ def _decode(net, state, note0, n_steps, forced=None, want_probs=False, correct_q
     qoff = (ctypes.c_int64 * eng.N)(*[int(v) for v in state.q_off])
     forced_t = forced.to(device=dev, dtype=torch.int32).contiguous() if forced is not None else None
     sync = getattr(net, "_decode_sync", None)
-    n_sync = _lib.decode_sync_granules(eng.N, eng.D, eng.S)
+    n_sync = _lib.decode_sync_granules(eng.N, pack.Dp, eng.S)
     if sync is None or sync.device != dev or sync.numel() != n_sync:
         sync = net._decode_sync = torch.zeros(n_sync, dtype=torch.int64, device=dev)
     bias = pack.o_bias is not None
-    pk = _packed_chain(eng)
-    call("wn_decode_batch_pk", eng.N, eng.R, eng.D, eng.S, eng.Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
+    pk = pack.chain()
+    call("wn_decode_batch_pk", eng.N, pack.Rp, pack.Dp, eng.S, eng.Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
          ptr(state.rings), pack.p(pack.o_causal), pack.p(pack.ob_causal) if bias else None,
          pack.p(pack.o_layers), pack.layer_stride, pack.p(pack.ob_layers) if bias else None,
          pack.p(pack.o_p1), pack.p(pack.ob_p1) if bias else None, pack.p(pack.o_p2), pack.p(pack.ob_p2) if bias else None,
@@ -199,7 +242,9 @@ def predict_next(net, note, state_queue=None, correct_queue=False):
         T, pitch, CH, R = x.size(2), ws["pitch"], eng.CH, eng.R
         X = ws["X"][SLACK:SLACK + (eng.N + 1) * CH * pitch].view(eng.N + 1, CH, pitch)
         # queue of block i = the last d_i columns of that block's INPUT (fast_generate.py:42-47)
-        rings = torch.cat([X[i, :R, T - d:T].t().reshape(-1) for i, d in enumerate(eng.dil)]).contiguous()
+        rw = _ring_width(eng)
+        rings = torch.cat([torch.nn.functional.pad(X[i, :R, T - d:T].t(), (0, rw - R)).reshape(-1)
+                           for i, d in enumerate(eng.dil)]).contiguous()
         state = DecodeState(eng, rings, x[0, :, -1].clone(), 0)
         _, predict = torch.topk(probs.view(-1), 1)
         return predict.to(note.device), state
@@ -246,7 +291,9 @@ def generate_codes_batch(net, start_pieces, note_num, correct_queue=False, tempe
     T, pitch, CH, R, N, Q = x.size(2), ws["pitch"], eng.CH, eng.R, eng.N, eng.Q
     X = ws["X"][SLACK:SLACK + (N + 1) * U * CH * pitch].view(N + 1, U, CH, pitch)
     # ring of block i of utterance u = the last d_i columns of that block's input, time-major
-    rings = torch.cat([X[i, :, :R, T - d:T].transpose(1, 2).reshape(U, d * R) for i, d in enumerate(eng.dil)], 1).contiguous()
+    rw = _ring_width(eng)
+    rings = torch.cat([torch.nn.functional.pad(X[i, :, :R, T - d:T].transpose(1, 2), (0, rw - R)).reshape(U, d * rw)
+                       for i, d in enumerate(eng.dil)], 1).contiguous()
     first = probs.view(U, Q).argmax(1)
     if note_num <= 1:
         return first.view(U, 1)[:, :note_num]
@@ -261,13 +308,13 @@ def generate_codes_batch(net, start_pieces, note_num, correct_queue=False, tempe
     codes = torch.empty(U, n_steps, dtype=torch.int32, device=dev)
     note_out = torch.empty(U, Q, dtype=torch.float32, device=dev)
     prev_out = torch.empty(U, Q, dtype=torch.float32, device=dev)
-    sync = torch.zeros(U * _lib.decode_sync_granules(N, eng.D, eng.S), dtype=torch.int64, device=dev)
+    sync = torch.zeros(U * _lib.decode_sync_granules(N, pack.Dp, eng.S), dtype=torch.int64, device=dev)
     dil = (ctypes.c_int32 * N)(*eng.dil)
-    q_off = np.cumsum([0] + [d * R for d in eng.dil[:-1]]).astype(np.int64)
+    q_off = np.cumsum([0] + [d * rw for d in eng.dil[:-1]]).astype(np.int64)
     qoff = (ctypes.c_int64 * N)(*[int(v) for v in q_off])
     bias = pack.o_bias is not None
-    pk = _packed_chain(eng)
-    call("wn_decode_batch_pk", N, R, eng.D, eng.S, Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
+    pk = pack.chain()
+    call("wn_decode_batch_pk", N, pack.Rp, pack.Dp, eng.S, Q, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p),
          ptr(rings), pack.p(pack.o_causal), pack.p(pack.ob_causal) if bias else None,
          pack.p(pack.o_layers), pack.layer_stride, pack.p(pack.ob_layers) if bias else None,
          pack.p(pack.o_p1), pack.p(pack.ob_p1) if bias else None, pack.p(pack.o_p2), pack.p(pack.ob_p2) if bias else None,

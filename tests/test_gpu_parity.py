@@ -414,6 +414,62 @@ def test_decode_config5_vs_oracle(bias):
         np.testing.assert_allclose(st["block_30"].cpu().numpy(), q_o["block_30"].numpy(), atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize("shape", [(32, 32, 512, False, 12), (24, 20, 512, True, 12), (48, 64, 512, False, 6), (17, 33, 256, True, 36)],
+                         ids=lambda s: "R%d_D%d_S%d_%s_N%d" % (s[0], s[1], s[2], "bias" if s[3] else "nobias", s[4]))
+def test_decode_padded_and_512_skip_channels_vs_oracle(shape):
+    """The matrix-core decode kernels at the reference's SHIPPED widths (32 / 32 / 512, wavenet_params.json) and other models
+    with at most 64 residual / dilation channels: fewer than 64 are padded to 64 with zero rows and columns (64-wide queue
+    columns inside; the state a caller indexes keeps the reference's shapes), 512 skip channels run the S = 512 form of the
+    skip / post-processing workgroup; 36 blocks: without the tap-0 partial sums.  Both queue recurrences against the oracle:
+    argmax ids exact, probabilities within 1e-4, the last block's queue as the reference would hold it."""
+    from music_amd import fast_generate as fg
+    from music_amd.model import wavenet
+    from oracle import intops
+    R, D, S, bias, N = shape
+    dil = ([1, 2, 4, 8, 16, 32] * 6)[:N]
+    cfg = dict(filter_width=2, dilations=dil, dilation_channels=D, residual_channels=R, skip_channels=S,
+               quantization_channels=256, use_bias=bias)
+    torch.manual_seed(61)
+    net = wavenet(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.2)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    rng = np.random.default_rng(62)
+    start = rng.integers(0, 256, size=(net.receptive_field,))
+    forced = rng.integers(0, 256, size=(12,))
+
+    def onehot(ix):
+        return torch.from_numpy(intops.one_hot_proper(np.atleast_1d(ix)))[None]
+    torch.set_num_threads(8)
+    for correct in (False, True):
+        pred_o, q_o, p0 = wo.fast_predict_next(params, dil, onehot(start), None, return_probs=True)
+        want, want_p = [int(pred_o[0])], []
+        for s_ in forced:
+            pred_o, q_o, pr = wo.fast_predict_next(params, dil, onehot(s_), q_o, correct_queue=correct, return_probs=True)
+            want.append(int(pred_o[0]))
+            want_p.append(pr.numpy())
+        pred, st = fg.predict_next(net, onehot(start).cuda(), None)
+        assert fg._mfma_decode(st.eng) and st.rw == 64
+        got = [int(pred[0])]
+        nxt = torch.from_numpy(np.concatenate([forced[1:], [0]]).astype(np.int32))
+        codes, probs, _ = fg._decode(net, st, onehot(forced[0]).reshape(-1).cuda(), len(forced), forced=nxt,
+                                     want_probs=True, correct_queue=correct)
+        got += codes.cpu().tolist()
+        err = np.abs(probs.cpu().numpy() - np.stack(want_p)).max()
+        print("decode R%d D%d S%d (correct_queue=%s): probs err %.2e" % (R, D, S, correct, err))
+        assert got == want and err < 1e-4
+        last = "block_%d" % N
+        assert tuple(st[last].shape) == tuple(q_o[last].shape)
+        np.testing.assert_allclose(st[last].cpu().numpy(), q_o[last].numpy(), atol=1e-4, rtol=0)
+    # batched generation: rows equal the single-stream result
+    starts = torch.cat([onehot(np.roll(start, k)) for k in range(3)]).cuda()
+    rows = fg.generate_codes_batch(net, starts, 24)
+    for k in range(3):
+        assert torch.equal(rows[k], fg.generate_codes(net, starts[k:k + 1], 24))
+
+
 def test_autoencoder_backward_vs_oracle():
     """loss.backward() through the autoencoder (decoder with conditioning, epilogue conditioning,
     pooled encoding, encoder blocks) vs autograd on the CPU oracle, same per-forward projections."""
