@@ -6,6 +6,8 @@ Tolerances (BASELINE.json north_star): integers bit-exact; float logits / probab
 passes).  Gradients: 2e-3 of the tensor's max-abs."""
 from collections import OrderedDict
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -451,7 +453,8 @@ def test_decode_padded_and_512_skip_channels_vs_oracle(shape):
             want.append(int(pred_o[0]))
             want_p.append(pr.numpy())
         pred, st = fg.predict_next(net, onehot(start).cuda(), None)
-        assert fg._mfma_decode(st.eng) and st.rw == 64
+        if os.environ.get("WN_DEC_MFMA", "1") == "1":        # (the switch test re-runs this on the fp32 kernel)
+            assert fg._mfma_decode(st.eng) and st.rw == 64
         got = [int(pred[0])]
         nxt = torch.from_numpy(np.concatenate([forced[1:], [0]]).astype(np.int32))
         codes, probs, _ = fg._decode(net, st, onehot(forced[0]).reshape(-1).cuda(), len(forced), forced=nxt,
