@@ -89,10 +89,48 @@ def shard_bounds(n_items, rank, world):
     return lo, min(lo + c, n_items)
 
 
+class _Stager:
+    """Host -> device for the loader's two small integer tensors without stalling the launch stream: the batch is gathered
+    into one of three rotating PINNED buffers and copied on a copy stream; the caller's stream only waits for that copy's
+    event.  (A `.cuda()` of pageable memory is a synchronous copy queued BEHIND the previous step's kernels: the host then sits
+    out the whole step before it can prepare the next one - 6.1 instead of 4.5 ms per step through train.py at 8 x 16000.)"""
+
+    def __init__(self):
+        self.bufs, self.k, self.stream = {}, 0, None
+
+    def to_device(self, parts, dtype):
+        """parts: list of equally long 1-D CPU tensors -> (len(parts), n) tensor of `dtype` on the device"""
+        n = parts[0].numel()
+        key = (len(parts), n, dtype)
+        ring = self.bufs.get(key)
+        if ring is None:
+            ring = self.bufs[key] = [[torch.empty(len(parts), n, dtype=dtype).pin_memory(), None] for _ in range(3)]
+        slot = ring[self.k % 3]
+        self.k += 1
+        pin, ev = slot
+        if ev is not None:
+            ev.synchronize()                     # the copy that last read this buffer has left it
+        pn = pin.numpy()
+        for i, t in enumerate(parts):            # plain memcpys (numpy): no OpenMP region (DESIGN.md section 7)
+            pn[i] = t.numpy()
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.stream):
+            dev = pin.to("cuda", non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        slot[1] = ev
+        main.wait_event(ev)
+        dev.record_stream(main)
+        return dev
+
+
 class _Collate:
     def __init__(self, q, shard=None):
         self.q = q
         self.shard = shard
+        self.stager = _Stager()
 
     def __call__(self, items):
         scale = 1.0
@@ -107,10 +145,15 @@ class _Collate:
             items = items[lo:hi]
         if not items:
             return {"audio_piece": None, "audio_target": None, "dp_scale": 0.0}
-        codes = torch.stack([it['audio_piece'] for it in items]).to(torch.int32)
-        target = torch.stack([it['audio_target'] for it in items])
-        batch = {"audio_piece": onehot_device(codes, self.q),
-                 "audio_target": target.cuda(non_blocking=True) if torch.cuda.is_available() else target}
+        same = len({it['audio_piece'].numel() for it in items}) == 1 and len({it['audio_target'].numel() for it in items}) == 1
+        if same and torch.cuda.is_available():
+            codes = self.stager.to_device([it['audio_piece'].to(torch.int32) for it in items], torch.int32)
+            target = self.stager.to_device([it['audio_target'] for it in items], torch.int64)
+        else:                                    # (torch.stack raises on ragged items, as in the reference; no device: onehot_device raises)
+            codes = torch.stack([it['audio_piece'] for it in items]).to(torch.int32)
+            target = torch.stack([it['audio_target'] for it in items])
+            target = target.cuda(non_blocking=True) if torch.cuda.is_available() else target
+        batch = {"audio_piece": onehot_device(codes, self.q), "audio_target": target}
         if self.shard is not None:
             batch["dp_scale"] = scale
         return batch
