@@ -924,13 +924,14 @@ def test_clip_pairs_on_the_64_channel_blocks_equal_the_32_channel_kernels(monkey
         assert (outs[0][2] - outs[1][2]).abs().max().item() <= 2e-5 * gmax
 
 
-def test_training_reduces_the_loss_64_channels():
-    """End-to-end sanity of the production kernels (channel-split backward block, fused CE, flat
+@pytest.mark.parametrize("ch", [64, 32], ids=["64ch", "32ch_clip_pairs"])
+def test_training_reduces_the_loss_64_channels(ch):
+    """End-to-end sanity of the production kernels (one-launch backward block, fused CE, flat
     Adam): 60 fused steps on one fixed small batch drive the loss from ln(256) towards its floor.
     The reference applies CrossEntropyLoss to PROBABILITIES, so the loss lives in
-    [log(e + 255) - 1, ...] = [4.552, ...]: memorising the batch means approaching 4.55."""
+    [log(e + 255) - 1, ...] = [4.552, ...]: memorising the batch means approaching 4.55.  32 channels: the same on clip pairs."""
     from music_amd.model import wavenet
-    cfg = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 32], dilation_channels=64, residual_channels=64,
+    cfg = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 32], dilation_channels=ch, residual_channels=ch,
                skip_channels=128, quantization_channels=256, use_bias=False)
     torch.manual_seed(5)
     net = wavenet(**cfg).cuda()
