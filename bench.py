@@ -646,7 +646,8 @@ def main():
     def traffic_of(*prefixes):
         tot = 0.0
         for pre in prefixes:
-            hit = [v["hbm_bytes_per_launch"] for k, v in pmc.items() if k.startswith(pre)]
+            # (entries with a "source" were measured on another workload - the config-4 step - and are not this run's kernels)
+            hit = [v["hbm_bytes_per_launch"] for k, v in pmc.items() if k.startswith(pre) and "source" not in v]
             if not hit:
                 return None
             tot += max(hit)
