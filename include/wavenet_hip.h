@@ -39,7 +39,7 @@ extern "C" {
 
 typedef void* wn_stream_t;                 /* hipStream_t */
 enum { WN_F16X3 = 0, WN_F16X1 = 1, WN_BF16X3 = 2, WN_BF16X1 = 3 };
-#define WN_ABI_VERSION 1
+#define WN_ABI_VERSION 2
 #define WN_CE_NUM_PARTIALS 1024
 
 int wn_version(void);
@@ -173,14 +173,26 @@ int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch);
  * second clip sit that many floats behind the first clip's, the slabs hold the block-diagonal gradients, wn_gather_grads2
  * adds the two copies) - for n_launches block launches in ONE reduce: launch l ran with t_lo[l] (HOST array, as slab_off) and
  * the same t_hi / batch and wrote its slabs at cslab + slab_off[l] floats; out[l][b][2ch rows][cond_le] with the strides
- * given.  More than 32 buckets: wn_resblock_bwd_ms + wn_cond_grad. */
+ * given.  More than 32 buckets: wn_resblock_bwd_ms + wn_cond_grad.
+ * WHOLE forms (ABI 2).  q_in == NULL with p_in != NULL: the block above handed dx_{i+1} on as ONE tensor, p_in, valid on
+ * [p_lo, t_hi).  chain != 0 (unconditioned blocks with d % 32 == 0 and at least d / 32 items of 32 columns per clip:
+ * wn_resblock_bwd_pq_chain_ok): the launch walks its 32-column items in chains of stride d downwards in time, so that the Q
+ * rows of an item are added to the P rows of the next one in registers - dx_i is written WHOLE to p_out on
+ * [t_lo - d, t_hi), q_out is not touched, nothing else changes (same sums per item; the weight-gradient slabs follow the
+ * chain plan: wn_resblock_bwd_pq_slabs(…, d, chain) slabs). */
 #define WN_COND_IDX_PAD 64
 int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, int dn, int p_lo, const float* dz,
                        float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
                        const uint16_t* wdT, const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, int z_lo,
                        float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_le,
-                       const uint8_t* cond_idx, float* cslab, int64_t dz_half_stride, int batch, int mode_fwd, int mode_bwd,
-                       wn_stream_t stream);
+                       const uint8_t* cond_idx, float* cslab, int64_t dz_half_stride, int chain, int batch, int mode_fwd,
+                       int mode_bwd, wn_stream_t stream);
+int wn_resblock_bwd_pq_chain_ok(int t_lo, int t_hi, int batch, int d);
+int wn_resblock_bwd_pq_slabs(int t_lo, int t_hi, int batch, int d, int chain);
+/* Host-only view of the chain plan (what tests check it with; nothing is launched): the items workgroup wg of a chain-form launch
+ * walks, in order, as triples (clip, first column t0, flags: 1 = halo item - recomputed for its Q rows only, 2 = top of its chain,
+ * 4 = bottom) written to out[3 * k ..]; returns the number of items (at most cap are written), -1 when there is no chain form. */
+int wn_resblock_bwd_pq_chain_items(int t_lo, int t_hi, int batch, int d, int wg, int* out, int cap);
 int wn_resblock_bwd_pq_cond_floats(int t_lo, int t_hi, int batch);
 int wn_resblock_bwd_pq_cond_reduce(const float* cslab, const int64_t* slab_off, const int* t_lo, int n_launches, int t_hi, int batch,
                                    int cond_le, float* out, int64_t out_lstride, int64_t out_bstride, int out_pitch,

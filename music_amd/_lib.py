@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("WAVENET_HIP_LIB") or os.path.join(_HERE, "libwavenet_
 F16X3, F16X1, BF16X3, BF16X1 = 0, 1, 2, 3
 MODE_NAMES = {"f16x3": F16X3, "f16x1": F16X1, "bf16x3": BF16X3, "bf16x1": BF16X1}
 CE_NUM_PARTIALS = 1024
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -47,7 +47,10 @@ SIGNATURES = {
                            _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_bwd_ms_slabs": [_i, _i, _i],
     "wn_resblock_bwd_pq": [_p, _p, _p, _i, _i, _p, _p, _p, _l, _l, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p,
-                           _p, _l, _i, _i, _p, _p, _l, _i, _i, _i, _p],
+                           _p, _l, _i, _i, _p, _p, _l, _i, _i, _i, _i, _p],
+    "wn_resblock_bwd_pq_chain_ok": [_i, _i, _i, _i],
+    "wn_resblock_bwd_pq_slabs": [_i, _i, _i, _i, _i],
+    "wn_resblock_bwd_pq_chain_items": [_i, _i, _i, _i, _i, _p, _i],
     "wn_resblock_bwd_pq_cond_floats": [_i, _i, _i],
     "wn_resblock_bwd_pq_cond_reduce": [_p, _p, _p, _i, _i, _i, _i, _p, _l, _l, _i, _p],
     "wn_split16": [_p, _p, _p, _l, _i, _p],
@@ -159,6 +162,16 @@ COND_IDX_PAD = 64       # include/wavenet_hip.h WN_COND_IDX_PAD
 def ms_slabs(t_lo, t_hi, batch):
     """Number of slabs one wn_resblock_bwd_ms call writes (plain int return, not a status)."""
     return load().wn_resblock_bwd_ms_slabs(t_lo, t_hi, batch)
+
+
+def pq_chain_ok(t_lo, t_hi, batch, d):
+    """Can wn_resblock_bwd_pq run this block in its chain form (dx handed on whole)?  (plain int return, not a status)"""
+    return bool(load().wn_resblock_bwd_pq_chain_ok(t_lo, t_hi, batch, d))
+
+
+def pq_slabs(t_lo, t_hi, batch, d, chain):
+    """Number of slabs one wn_resblock_bwd_pq call writes (plain int return, not a status)."""
+    return load().wn_resblock_bwd_pq_slabs(t_lo, t_hi, batch, d, 1 if chain else 0)
 
 
 def enc_slabs(t_lo, t_hi, batch):

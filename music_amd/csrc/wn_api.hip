@@ -229,24 +229,30 @@ int wn_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, 
                        float* p_out, float* q_out, int64_t x_bstride, int64_t dz_bstride, int pitch, const uint16_t* wfg,
                        const uint16_t* wdT, const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, int z_lo,
                        float* slab_fg, float* slab_d, const float* cond, int64_t cond_bstride, int cond_pitch, int cond_le,
-                       const uint8_t* cond_idx, float* cslab, int64_t dz_half_stride, int batch, int mode_fwd, int mode_bwd,
-                       wn_stream_t stream) {
+                       const uint8_t* cond_idx, float* cslab, int64_t dz_half_stride, int chain, int batch, int mode_fwd,
+                       int mode_bwd, wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: pitch must be a multiple of 4");
     if (cond && (!cond_idx || cond_le < 1 || cond_le > 32))
         return wn_set_error_msg(-4, "wn_resblock_bwd_pq: a conditioned block needs cond_idx and 1..32 buckets");
     if (cslab && !cond) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: cslab without cond");
     if (ch != 64) return wn_set_error_msg(-3, "wn_resblock_bwd_pq: 64 padded channels only");
     if (mode_fwd != WN_MODE_F16X3 || mode_bwd != WN_MODE_BF16X3) return wn_set_error_msg(-2, "wn_resblock_bwd_pq: (f16x3, bf16x3) only");
-    if (!x_in || !dz || !p_out || !q_out || !wfg || !wpq || !slab_fg) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: null argument");
-    if ((p_in && (!q_in || !wdT)) || (!p_in && q_in)) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: p_in, q_in and wdT go together");
+    if (!x_in || !dz || !p_out || (!q_out && !chain) || !wfg || !wpq || !slab_fg) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: null argument");
+    if ((p_in && !wdT) || (!p_in && q_in)) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: p_in and wdT go together, q_in needs p_in");
+    if (chain && (cond || dz_half_stride < 0)) return wn_set_error_msg(-4, "wn_resblock_bwd_pq: no chain form of a conditioned block");
     WnResPqArgs a;
     memset(&a, 0, sizeof(a));
     a.x_in = x_in; a.p_in = p_in; a.q_in = q_in; a.dn = dn; a.p_lo = p_lo; a.dz = dz; a.p_out = p_out; a.q_out = q_out;
     a.x_bstride = x_bstride; a.dz_bstride = dz_bstride; a.pitch = pitch; a.wfg = wfg; a.wdT = wdT; a.wpq = wpq;
     a.slab_fg = slab_fg; a.slab_d = p_in ? slab_d : nullptr; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.z_lo = z_lo;
     a.cond = cond; a.cond_bstride = cond_bstride; a.cond_pitch = cond_pitch; a.cond_le = cond_le;
-    a.cond_idx = cond ? cond_idx : nullptr; a.cslab = cslab; a.dz_half = dz_half_stride;
+    a.cond_idx = cond ? cond_idx : nullptr; a.cslab = cslab; a.dz_half = dz_half_stride; a.chain = chain ? 1 : 0;
     return wn_launch_resblock_bwd_pq(a, batch, (hipStream_t)stream);
+}
+int wn_resblock_bwd_pq_chain_ok(int t_lo, int t_hi, int batch, int d) { return wn_pq_chain_ok(t_lo, t_hi, batch, d); }
+int wn_resblock_bwd_pq_slabs(int t_lo, int t_hi, int batch, int d, int chain) { return wn_pq_slabs(t_lo, t_hi, batch, d, chain); }
+int wn_resblock_bwd_pq_chain_items(int t_lo, int t_hi, int batch, int d, int wg, int* out, int cap) {
+    return wn_pq_chain_items(t_lo, t_hi, batch, d, wg, out, cap);
 }
 int wn_resblock_bwd_pq_cond_floats(int t_lo, int t_hi, int batch) { return wn_pq_cond_slab_floats(t_lo, t_hi, batch); }
 int wn_resblock_bwd_pq_cond_reduce(const float* cslab, const int64_t* slab_off, const int* t_lo, int n_launches, int t_hi, int batch,

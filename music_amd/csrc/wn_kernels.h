@@ -114,12 +114,21 @@ struct WnResPqArgs {
     const float* cond; long cond_bstride; int cond_pitch; int cond_le;
     const uint8_t* cond_idx; float* cslab; int cslab_slots;
     long dz_half;                                          // two 32-channel clips side by side: dz rows 32..63 sit dz_half floats behind rows 0..31 (0: 64 rows)
+    // CHAIN form (d a multiple of 32, every chain non-empty: wn_pq_chain_ok): a workgroup walks the 32-column items of ONE residue
+    // class of (item index mod d/32) downwards in time, so the Q half of an item is the carry of the next one and dx_i leaves
+    // the launch WHOLE in p_out (valid on [t_lo - d, t_hi)); q_out is not touched.  Set by the launcher (wn_pq_chain_plan):
+    int chain, ch_s, ch_qn, ch_rm, ch_g, ch_nchain;        // d/32, items per chain (qn, +1 for the first rm chains), segments per chain (0: whole chains per workgroup), chains
 #ifdef PQ_SPAN
     int span_slot;                                      // developer build: slot of this launch in the span log
 #endif
 };
 #define WN_PQ_IDX_PAD 64
 int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st);
+// chain form: can this launch walk chains (d % 32 == 0, at least one item per chain)?  and its plan / slab count
+int wn_pq_chain_ok(int t_lo, int t_hi, int batch, int d);
+void wn_pq_chain_plan(int t_lo, int t_hi, int batch, int d, int& t_base, int& steps, int& s, int& qn, int& rm, int& g, int& nchain, int& nwg);
+int wn_pq_slabs(int t_lo, int t_hi, int batch, int d, int chain);      // slabs (= workgroups) of one launch
+int wn_pq_chain_items(int t_lo, int t_hi, int batch, int d, int wg, int* out, int cap);
 int wn_pq_cond_slots(int t_lo, int t_hi, int batch);       // slots per workgroup of WnResPqArgs::cslab
 int wn_pq_cond_slab_floats(int t_lo, int t_hi, int batch); // floats of the whole cslab of one launch
 int wn_launch_pq_cond_reduce(const float* cslab, const long* off, const int* t_lo, int n, int t_hi, int batch, int le, float* out,

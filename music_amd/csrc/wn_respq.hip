@@ -27,8 +27,15 @@
 // 16-byte row read gives the samples of the lane's two 4-sample groups; the R waves' pair writes, the row reads and the
 // transposed reads are all conflict free / 2-way with the chunk swizzle K[] below (MI355X_MICROARCH.md LDS table).
 //
-// (-DPQ_T_NOQ: neither stores nor loads the Q half - the upper bound of what handing dx on WHOLE could save; -DPQ_T_SC1,
-// -DPQ_GRAD_F16: see below.)
+// CHAIN form (round 4; d a multiple of 32): the pair costs a tensor written and a tensor read per block.  dx_i[t] needs Q of the
+// item d columns ABOVE it, so a workgroup that walks the items of one residue class (item index mod d/32) DOWNWARDS in time
+// has that Q in registers: the (P, Q) product is split by 16-sample halves instead of by P | Q (R waves: samples 0..15, W
+// waves: 16..31, each BOTH weight halves - the same 24 MFMAs per wave), the Q rows of an item stay in the wave that made
+// them (4 registers) and are added to the P rows of the next item: dx_i leaves the launch WHOLE (p_out, valid on
+// [t_lo - d, t_hi); below t_base it is the last carry of each chain), and x(t - d) of an item is x(t) of the next one (an
+// L1 / L2 hit).  A chain is cut into segments for the 256 CUs; a segment that does not start at the top of its chain
+// first recomputes the item above it for its Q rows (HALO item: no stores, no weight gradients).  QIN = false: the block
+// above handed dx on whole (p_in alone).
 // PQ_T_* macros are timing-build switches (remove one ingredient; results are then wrong) used to see what a launch is
 // made of: -DPQ_T_NOREC / NOGATE / NOWG / NOPQ / NOSTORE / NOFILLDY / NOCONV via `make EXTRA=...` (tools/pq_phases.sh); for the
 // conditioned form -DPQ_T_NOCBIAS (no bias k-step), -DPQ_T_NOCSUM (no bucket sums), -DPQ_T_WD2 (rows two items ahead: spills)
@@ -52,30 +59,10 @@ __device__ __forceinline__ f32x2 pq_ld2u(const float* p) {
     f32x2 r = {u.v[0], u.v[1]};
     return r;
 }
-#ifdef PQ_T_SC1
-// TIMING build (results unchanged): every load and store of the (P, Q) pair on the write-through / L2-bypassing `sc1` path, i.e.
-// what a whole-stack persistent kernel would have to use to hand the pair from workgroup to workgroup (cdna_hip_programming.md
-// Guideline 16, R1).  Prices the payload side of that design without building it.
-typedef unsigned int pq_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int pq_u32x2 __attribute__((ext_vector_type(2)));
-#define PQ_RSRC(p) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, 0x7fffffff, 0x00020000)
-#define PQ_LD2(rs, base, off) __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)((off) * 4), 0, 16))
-#define PQ_LD4(rs, base, off) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((off) * 4), 0, 16))
-#else
-#define PQ_RSRC(p) 0
-#define PQ_LD2(rs, base, off) pq_ld2u((base) + (off))
-#define PQ_LD4(rs, base, off) ld4u((base) + (off))
-#endif
-// The 16-bit type of the GRADIENT operands: bf16 (float32's exponent range).  -DPQ_GRAD_F16 is a TIMING build
-// (an unscaled f16 split underflows on real gradients): what the cheaper f16 split (1.5 instead of ~3.5 vector instructions
-// per element) would buy this kernel.
-#ifdef PQ_GRAD_F16
-typedef F16 PQG;
-#define PQ_ONE16 0x3C00u                                   // 1.0 in the gradient operand type
-#else
-typedef BF16 PQG;
-#define PQ_ONE16 0x3F80u
-#endif
+#define PQ_LD2(base, off) pq_ld2u((base) + (off))
+#define PQ_LD4(base, off) ld4u((base) + (off))
+typedef BF16 PQG;                                          // the 16-bit type of the GRADIENT operands (float32's exponent range)
+#define PQ_ONE16 0x3F80u                                   // 1.0 in it
 typedef PQG::vec8 pqg8;
 // (a, b) -> packed 16-bit pairs hi = (cvt(a), cvt(b)) and lo = (cvt(a - hi_a), cvt(b - hi_b))
 __device__ __forceinline__ void pq_split2(float a, float b, uint32_t& hi, uint32_t& lo) { split2<PQG>(a, b, hi, lo); }
@@ -130,10 +117,50 @@ __device__ __forceinline__ void pq_store_frag(uint16_t* base, int idx, int lane,
     p[64] = __builtin_bit_cast(u32x4, f.lo);
 }
 
+// ---- CHAIN plan, shared by the kernel and the host (wn_pq_chain_items: the CPU test of the plan).  Items are the 32-column
+// tiles j = 0 .. steps-1 of a clip (from t_base); chain (clip b, residue r) holds the items j = r (mod s), s = d / 32, walked
+// from the highest j down: qn + 1 items for r < rm, qn otherwise.  Chain order = clips, then residues, then positions.
+struct PqChain { int s, qn, rm, g, nchain, steps; };
+struct PqCS { int b, r, pos, m; };                         // chain state: clip, residue, position from the top, items of the chain
+__host__ __device__ __forceinline__ PqCS pq_cs_next(PqCS c, const PqChain& p) {
+    if (c.pos + 1 < c.m) { c.pos += 1; return c; }
+    c.pos = 0;
+    c.r += 1;
+    if (c.r == p.s) { c.r = 0; c.b += 1; }
+    c.m = p.qn + (c.r < p.rm ? 1 : 0);
+    return c;
+}
+// workgroup wg of nwg: its first item (the halo item, if it has one), the number of items it owns, whether a halo item precedes them
+__host__ __device__ __forceinline__ void pq_chain_start(const PqChain& p, int wg, int nwg, PqCS& c, int& n_real, bool& halo) {
+    int c0, p0;
+    if (p.g > 0) {                                         // g segments per chain, the first (m mod g) one item longer
+        c0 = wg / p.g;
+        const int sg = wg - c0 * p.g;
+        const int r = c0 % p.s;
+        const int m = p.qn + (r < p.rm ? 1 : 0);
+        const int base = m / p.g, ex = m - base * p.g;
+        n_real = base + (sg < ex ? 1 : 0);
+        p0 = sg * base + (sg < ex ? sg : ex);
+    } else {                                               // whole chains per workgroup
+        c0 = (int)((long)wg * p.nchain / nwg);
+        const int c1 = (int)((long)(wg + 1) * p.nchain / nwg);
+        const int b0 = c0 / p.s, r0 = c0 - b0 * p.s, b1 = c1 / p.s, r1 = c1 - b1 * p.s;
+        n_real = (b1 * p.steps + r1 * p.qn + (r1 < p.rm ? r1 : p.rm)) - (b0 * p.steps + r0 * p.qn + (r0 < p.rm ? r0 : p.rm));
+        p0 = 0;
+    }
+    halo = p0 > 0 && n_real > 0;
+    c.b = c0 / p.s;
+    c.r = c0 - c.b * p.s;
+    c.m = p.qn + (c.r < p.rm ? 1 : 0);
+    c.pos = p0 - (halo ? 1 : 0);
+}
+
 // COND: the conditioned form (conditioning table in the recompute, bucket sums of [df;dg]); compiled apart so that the
 // plain form keeps its register budget (242, no spills)
-template <bool HAS_DY, bool COND>
+template <bool HAS_DY, bool COND, bool QIN, bool CHAIN>
 __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
+    static_assert(!(COND && CHAIN), "the conditioned block keeps the (P, Q) form");
+    static_assert(HAS_DY || QIN, "no dy: one form");
     constexpr int CH = PQ_CH;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
 
@@ -146,26 +173,74 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     unsigned long long dbg_acc[16] = {};
 #endif
 
-    // items of this workgroup: the workgroups of an XCD walk one contiguous item range interleaved (wn_resrw.hip)
-    int first, cnt, j;
-    if (a.swz) {
-        const int nwg = gridDim.x, id = blockIdx.x;
-        const int qn = nwg >> 3, rn = nwg & 7, xcd = id & 7;
-        first = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
-        cnt = xcd < rn ? qn + 1 : qn;
-        j = id >> 3;
+    // items of this workgroup.  (P, Q) form: the workgroups of an XCD walk one contiguous item range interleaved (wn_resrw.hip).
+    // CHAIN form: a run of `n_items` items in CHAIN ORDER (clip, residue r of the item index mod s, then downwards in time),
+    // the first of them possibly a halo item; positions are stepped, a window of five (items it-1 .. it+3) lives in scalars.
+    struct Pos { int b, t0; bool live, halo, top, bot; };
+    int first = 0, cnt = 1, j = 0, wgid, total = 0, i_lo = 0, n_items;
+    typedef PqCS CS;
+    const PqChain chp = {a.ch_s, a.ch_qn, a.ch_rm, a.ch_g, a.ch_nchain, a.steps_per_clip};
+    CS cs_front = {0, 0, 0, 1};
+    int k_front = 0;
+    bool has_halo = false;
+    int win_b[5], win_t[5];                                 // the window, packed: clip | t0 (a multiple of 32) + live, halo, top, bot bits
+    auto cs_next = [&](CS c) __attribute__((always_inline)) { return pq_cs_next(c, chp); };
+    auto cs_pos = [&](CS c, int k) __attribute__((always_inline)) {      // -> packed t0 + flags
+        const int t0 = a.t_base + PQ_COLS * (c.r + (c.m - 1 - c.pos) * a.ch_s);
+        return t0 | ((k >= 0 && k < n_items) ? 1 : 0) | ((has_halo && k == 0) ? 2 : 0) | (c.pos == 0 ? 4 : 0) | (c.pos == c.m - 1 ? 8 : 0);
+    };
+    auto win_get = [&](int i) __attribute__((always_inline)) {
+        Pos p;
+        const int v = win_t[i];
+        p.b = win_b[i];
+        p.t0 = v & ~31;
+        p.live = v & 1; p.halo = v & 2; p.top = v & 4; p.bot = v & 8;
+        return p;
+    };
+    if (CHAIN) {
+        wgid = blockIdx.x;
+        int n_real;
+        CS c;
+        pq_chain_start(chp, wgid, gridDim.x, c, n_real, has_halo);
+#ifdef PQ_T_NOHALO
+        if (has_halo) { has_halo = false; c = cs_next(c); }      // TIMING build (wrong results): what the halo items cost
+#endif
+        n_items = n_real + (has_halo ? 1 : 0);
+        win_b[0] = c.b; win_t[0] = cs_pos(c, -1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            win_b[k + 1] = c.b; win_t[k + 1] = cs_pos(c, k);
+            if (k < 3) c = cs_next(c);
+        }
+        cs_front = c;
+        k_front = 3;
     } else {
-        first = 0; cnt = gridDim.x; j = blockIdx.x;
+        if (a.swz) {
+            const int nwg = gridDim.x, id = blockIdx.x;
+            const int qn = nwg >> 3, rn = nwg & 7, xcd = id & 7;
+            first = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+            cnt = xcd < rn ? qn + 1 : qn;
+            j = id >> 3;
+        } else {
+            first = 0; cnt = gridDim.x; j = blockIdx.x;
+        }
+        wgid = first + j;
+        total = a.steps_per_clip * a.batch;
+        i_lo = first * a.items_per_wg + j;
+        int i_hi = (first + cnt) * a.items_per_wg;
+        if (i_hi > total) i_hi = total;
+        n_items = i_lo < i_hi ? (i_hi - i_lo + cnt - 1) / cnt : 0;
     }
-    const int wgid = first + j;
-    const int total = a.steps_per_clip * a.batch;
-    const int i_lo = first * a.items_per_wg + j;
-    int i_hi = (first + cnt) * a.items_per_wg;
-    if (i_hi > total) i_hi = total;
-    const int n_items = i_lo < i_hi ? (i_hi - i_lo + cnt - 1) / cnt : 0;
-
-    struct Pos { int b, t0; bool live; };
-    auto pos_k = [&](int k) {                                  // position of this workgroup's k-th item, clamped
+    auto win_advance = [&]() __attribute__((always_inline)) {
+        if (CHAIN) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { win_b[k] = win_b[k + 1]; win_t[k] = win_t[k + 1]; }
+            cs_front = cs_next(cs_front);
+            k_front += 1;
+            win_b[4] = cs_front.b; win_t[4] = cs_pos(cs_front, k_front);
+        }
+    };
+    auto pos_abs = [&](int k) {                                // (P, Q) form: position of this workgroup's k-th item, clamped
         const bool live = k >= 0 && k < n_items;
         k = k < n_items ? k : n_items - 1;
         int it = i_lo + (k < 0 ? 0 : k) * cnt;
@@ -174,8 +249,11 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         p.b = it / a.steps_per_clip;
         p.t0 = a.t_base + PQ_COLS * (it - p.b * a.steps_per_clip);
         p.live = live;
+        p.halo = p.top = p.bot = false;
         return p;
     };
+    // position of item `it + rel` where `it` is the iteration the window stands at (rel = -1 .. 3, a constant at every call site)
+    auto pos_r = [&](int it, int rel) __attribute__((always_inline)) { return CHAIN ? win_get(rel + 1) : pos_abs(it + rel); };
 
     // the packed [W1^T; W0^T] weights (32 fragments x 2 KB) and zeros in the result tiles of stage 1 (multiplied once
     // before anything was written to them).  (Requested by LDS-DMA from the W waves instead and first used in iteration
@@ -192,11 +270,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     }
 
     const float* p_or_x = HAS_DY ? a.p_in : a.x_in;         // loads stay unconditional
-    const float* q_or_x = HAS_DY ? a.q_in : a.x_in;
-    const auto rs_p = PQ_RSRC(p_or_x);
-    const auto rs_q = PQ_RSRC(q_or_x);
-    const auto rs_po = PQ_RSRC(a.p_out);
-    const auto rs_qo = PQ_RSRC(a.q_out);
+    const float* q_or_x = (HAS_DY && QIN) ? a.q_in : a.x_in;
     // dy rows for the R waves' dz product, as recompute-style fragments: wave g converts rows 4(g&1).. of k-step g>>1
     struct RawD { f32x2 p[4], qq[4]; };
     auto load_dy = [&](RawD& r, Pos ps) {
@@ -206,12 +280,9 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             const int dn = ps.live ? a.dn : 0;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                r.p[jj] = PQ_LD2(rs_p, p_or_x, ro + jj * rp);
-#ifdef PQ_T_NOQ
-                r.qq[jj] = f32x2{0.f, 0.f};
-#else
-                r.qq[jj] = PQ_LD2(rs_q, q_or_x, ro + dn + jj * rp);
-#endif
+                r.p[jj] = PQ_LD2(p_or_x, ro + jj * rp);
+                if (QIN) r.qq[jj] = PQ_LD2(q_or_x, ro + dn + jj * rp);
+                else r.qq[jj] = f32x2{0.f, 0.f};
             }
         }
     };
@@ -290,11 +361,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         acc[1] += acb[1];
 #endif
 #ifndef PQ_T_NOSTORE
-#ifdef PQ_T_NOQ
-        if (ps.live && !sel) {
-#else
         if (ps.live) {
-#endif
             float* out = (sel ? a.q_out : a.p_out) + (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q;
             const bool whole = ps.t0 >= a.t_lo && ps.t0 + PQ_COLS <= a.t_hi;
 #pragma unroll
@@ -304,16 +371,58 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] += dy32[4 * m + i];
                 }
-#ifdef PQ_T_SC1
-                if (whole) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pq_u32x4, v), sel ? rs_qo : rs_po,
-                                                                  (int)((out + 16 * m - (sel ? a.q_out : a.p_out)) * 4), 0, 16);
-#else
                 if (whole) *reinterpret_cast<f32x4*>(out + 16 * m) = v;      // plain: the next launch finds P and Q in L2 (streaming stores: 2.21 vs 2.00 ms for the stack)
-#endif
                 else st4m(out + 16 * m, v, ps.t0 + 16 * m + 4 * q, a.t_lo, a.t_hi);
             }
         }
 #endif
+    };
+    // ---- CHAIN form: the 16-sample half `mt` of the item's 32 columns, BOTH weight halves: dx rows = P rows + the Q rows carried
+    // from the item above (+ the lane's fp32 dy rows, dy4), then this item's Q rows become the carry; the last item of a chain
+    // leaves its carry d columns further down (dx on [t_lo - d, t_base): nothing but Q).  A halo item only makes the carry.
+    auto pq_mt = [&](int stage, int mt, Pos ps, const float* dy4, f32x4& carry) __attribute__((always_inline)) {
+        if (!ps.live) return;
+        const uint16_t* tt = lds + (size_t)stage * PQ_STAGE + PQ_T;
+        const uint16_t* pw = lds + PQ_W;
+        f32x4 ap[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // even / odd k-steps: four chains in flight
+        f32x4 aq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Frag<PQG> w1, w0;
+            load_a<PQG, 3>(w1, pw, g * 4 + s, lane);
+            load_a<PQG, 3>(w0, pw, (4 + g) * 4 + s, lane);
+            const uint16_t* tb = tt + ((s >> 1) * 4 + 2 * (s & 1) + (q >> 1)) * 1024;
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[0] + 4 * mt));
+            s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[1] + 4 * mt));
+            s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[0] + 4 * mt));
+            s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[1] + 4 * mt));
+            s16x8 hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            s16x8 ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            Frag<PQG> ad;
+            ad.hi = __builtin_bit_cast(pqg8, hh);
+            ad.lo = __builtin_bit_cast(pqg8, ll);
+            ap[s & 1] = PQG::mfma(ad.lo, w1.hi, ap[s & 1]);
+            aq[s & 1] = PQG::mfma(ad.lo, w0.hi, aq[s & 1]);
+            ap[s & 1] = PQG::mfma(ad.hi, w1.lo, ap[s & 1]);
+            aq[s & 1] = PQG::mfma(ad.hi, w0.lo, aq[s & 1]);
+            ap[s & 1] = PQG::mfma(ad.hi, w1.hi, ap[s & 1]);
+            aq[s & 1] = PQG::mfma(ad.hi, w0.hi, aq[s & 1]);
+        }
+        if (ps.top) carry = f32x4{0.f, 0.f, 0.f, 0.f};
+        float* out = a.p_out + (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 16 * mt + 4 * q;
+        const int tq = ps.t0 + 16 * mt + 4 * q;
+        if (!ps.halo) {
+            f32x4 v = (ap[0] + ap[1]) + carry;
+            if (dy4 != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += dy4[i];
+            }
+            if (ps.t0 + PQ_COLS <= a.t_hi) *reinterpret_cast<f32x4*>(out) = v;      // (t0 >= t_base > t_lo - d always)
+            else st4m(out, v, tq, a.t_lo - a.d, a.t_hi);
+        }
+        carry = aq[0] + aq[1];
+        if (ps.bot) st4m(out - a.d, carry, tq - a.d, a.t_lo - a.d, a.t_lo);
     };
 
     if (wv < 4) {
@@ -368,18 +477,41 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             for (int i = 0; i < 4; ++i) cr[i] = pq_ld2u(dzc + i * rp);
         };
 
+        // CHAIN: this wave's fp32 dy rows of samples 0..15 of an item (the residual term of its half of dx), one item ahead
+        f32x4 dyrP = {0.f, 0.f, 0.f, 0.f}, dyrQ = {0.f, 0.f, 0.f, 0.f}, carry = {0.f, 0.f, 0.f, 0.f};
+        auto load_dyr = [&](Pos ps) __attribute__((always_inline)) {
+            if (CHAIN && HAS_DY) {
+                const size_t ro = ps.live ? (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q : 0;
+                dyrP = PQ_LD4(p_or_x, ro);
+                if (QIN) dyrQ = PQ_LD4(q_or_x, ro + (ps.live ? a.dn : 0));
+            }
+        };
+        auto pq_r = [&](int stage, Pos ps) __attribute__((always_inline)) {      // the R waves' share of the data gradient of item ps
+            if (CHAIN) {
+                float d4[4];
+                if (HAS_DY) {
+                    const bool fast = interior(ps);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d4[i] = fast ? dyrP[i] + dyrQ[i] : dyv(dyrP[i], dyrQ[i], ps.t0 + 4 * q + i);
+                }
+                pq_mt(stage, 0, ps, HAS_DY ? d4 : nullptr, carry);
+            } else {
+                pq_half(stage, 1, ps, nullptr);                 // Q rows
+            }
+        };
+
         f32x2 crA[4], crB[4];
-        load_cr(crA, pos_k(0));
-        load_cr(crB, pos_k(1));
+        load_cr(crA, pos_r(0, 0));
+        load_cr(crB, pos_r(0, 1));
         RawX x0, x1;                                        // x1 / x0 hold the raw rows of items it+1 / it+2
         RawD rd;                                            // dy rows (as the pair) of item it+1
-        load_x(x0, pos_k(0));
-        load_dy(rd, pos_k(0));
-        load_x(x1, pos_k(1));
+        load_x(x0, pos_r(0, 0));
+        load_dy(rd, pos_r(0, 0));
+        load_x(x1, pos_r(0, 1));
         fill_x(x0, 0);
-        fill_dy(rd, pos_k(0), 0);
-        load_x(x0, pos_k(2));
-        load_dy(rd, pos_k(1));
+        fill_dy(rd, pos_r(0, 0), 0);
+        load_x(x0, pos_r(0, 2));
+        load_dy(rd, pos_r(0, 1));
         __syncthreads();                                    // stage 0 operands of the first item, the weights, the zeros
         if (wv == 0) PQ_STAMP(1);
         // conditioned form with the bucket bytes and <= 32 buckets: the conditioning bias T_b[row][bucket(t)] is one more
@@ -407,7 +539,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             if (it >= n_items) {
                 // the void item that pads an odd count: nothing of its own to do (its result tiles are never multiplied:
                 // the W waves skip a void item's products), only the Q rows of the last real item
-                pq_half((it + 1) & 1, 1, pos_k(it - 1), nullptr);
+                pq_r((it + 1) & 1, pos_r(it, -1));
+                win_advance();
                 __syncthreads();
                 return;
             }
@@ -415,18 +548,19 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             PQ_TICK(k0);
             int cidx[2] = {0, 0};                            // buckets of this lane's two samples (used after the Q rows below)
             if (COND) {
-                const uint8_t* ip = a.cond_idx + (WN_PQ_IDX_PAD + pos_k(it).t0 + 2 * c - a.t_lo);
+                const uint8_t* ip = a.cond_idx + (WN_PQ_IDX_PAD + pos_r(it, 0).t0 + 2 * c - a.t_lo);
                 cidx[0] = ip[0]; cidx[1] = ip[1];
             }
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
-            load_x(rx, pos_k(it + 3));                       // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
+            load_x(rx, pos_r(it, 3));                       // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
 #ifndef PQ_T_NOFILLDY
-            fill_dy(rd, pos_k(it + 1), (it + 1) & 1);        // (the R waves wait at the barrier otherwise: the W waves are the pole)
-            load_dy(rd, pos_k(it + 2));
+            fill_dy(rd, pos_r(it, 1), (it + 1) & 1);        // (the R waves wait at the barrier otherwise: the W waves are the pole)
+            load_dy(rd, pos_r(it, 2));
 #endif
-            pq_half((it + 1) & 1, 1, pos_k(it - 1), nullptr);       // Q rows of the previous item
+            pq_r((it + 1) & 1, pos_r(it, -1));                 // Q rows (CHAIN: the first half of dx) of the previous item
+            load_dyr(pos_r(it, 0));
             PQ_TICK(k1);
-            const Pos p_cur = pos_k(it);
+            const Pos p_cur = pos_r(it, 0);
             const bool live = it < n_items;
             const int tl = p_cur.t0 + 2 * c;
             uint16_t* st = lds + (size_t)(it & 1) * PQ_STAGE;
@@ -528,7 +662,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 put(1, vg);
                 if (HAS_DY) put(2, vz);
             }
-            load_cr(cr, pos_k(it + 2));
+            load_cr(cr, pos_r(it, 2));
+            win_advance();
             PQ_TICK(k3);
             __syncthreads();
             PQ_TICK(k4);
@@ -540,7 +675,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         }
         {
             const int n_even = (n_items + 1) & ~1;
-            if (pos_k(n_even - 1).live) pq_half((n_even - 1) & 1, 1, pos_k(n_even - 1), nullptr);      // Q rows of the last item
+            if (pos_r(n_even, -1).live) pq_r((n_even - 1) & 1, pos_r(n_even, -1));      // Q rows of the last item
         }
         if (wv == 0) PQ_STAMP(2);
         __syncthreads();                                    // the W waves' extra round (products of the last item)
@@ -566,12 +701,9 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         r.x0[0] = ld4u(xr - dd); r.x0[1] = ld4u(xr - dd + h);
         r.x1[0] = ld4u(xr); r.x1[1] = ld4u(xr + h);
         if (HAS_DY) {
-            r.p[0] = PQ_LD4(rs_p, p_or_x, ro); r.p[1] = PQ_LD4(rs_p, p_or_x, ro + h);
-#ifdef PQ_T_NOQ
-            r.qq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; r.qq[1] = r.qq[0];
-#else
-            r.qq[0] = PQ_LD4(rs_q, q_or_x, ro + dn); r.qq[1] = PQ_LD4(rs_q, q_or_x, ro + dn + h);
-#endif
+            r.p[0] = PQ_LD4(p_or_x, ro); r.p[1] = PQ_LD4(p_or_x, ro + h);
+            if (QIN) { r.qq[0] = PQ_LD4(q_or_x, ro + dn); r.qq[1] = PQ_LD4(q_or_x, ro + dn + h); }
+            else { r.qq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; r.qq[1] = r.qq[0]; }
         }
         if (COND && do_c) {                                 // buckets of the lane's 4 + 4 samples
             const uint8_t* ip = a.cond_idx + (WN_PQ_IDX_PAD + ps.t0 + 4 * q - a.t_lo);
@@ -630,11 +762,12 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     // hi S + lo S).  W wave g takes row tiles 2g, 2g+1 of [df;dg]; S is built per item from the buckets of the lane's own 8
     // samples (the k order of the tiles); the sums run over all items of one clip, then go to the workgroup's slot of that
     // clip (plain stores; wn_launch_pq_cond_reduce adds the workgroups in a fixed order: no float atomics, bit-reproducible)
+    f32x4 carry_w = {0.f, 0.f, 0.f, 0.f};                  // CHAIN: Q rows of samples 16..31 of the item above
     f32x4 cacc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) { cacc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; cacc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     int c_b = -1, c_next = 0;
-    const int c_first = pos_k(0).b;
+    const int c_first = pos_r(0, 0).b;
     float* const cs_base = do_c ? a.cslab + (size_t)wgid * a.cslab_slots * (2 * CH * 32) : nullptr;
     auto c_store = [&](int slot, bool zero) __attribute__((always_inline)) {
         float* sp = cs_base + (size_t)slot * (2 * CH * 32);
@@ -662,9 +795,10 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         const uint16_t* tt = lds + (size_t)stage * PQ_STAGE + PQ_T;
         const bool c_item = COND && do_c && ps.live;
         if (COND && c_item && ps.b != c_b) c_flush(ps.b);
-        // ---- weight gradients: rows = all [df;dg] / z tiles, columns = this wave's x / dy rows
+        // ---- weight gradients: rows = all [df;dg] / z tiles, columns = this wave's x / dy rows (not for a halo item: the
+        // workgroup above counts it)
 #ifndef PQ_T_NOWG
-        {
+        if (!(CHAIN && ps.halo)) {
             // the three products of an x3 term are walked across FOUR accumulators (two tiles x two column blocks), so
             // no MFMA waits for the one in front of it; the next pair of tiles is read meanwhile
             auto term = [](f32x4& acc, const Frag<PQG>& wa, const Frag<PQG>& xb, int t) {
@@ -720,7 +854,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         }
 #endif
         PQ_TICK(p1);
-        pq_half(stage, 0, ps, o.dy32);
+        if (CHAIN) pq_mt(stage, 1, ps, HAS_DY ? &o.dy32[4] : nullptr, carry_w);
+        else pq_half(stage, 0, ps, o.dy32);
         PQ_TICK(p2);
         PQ_TICK(p3);
         PQ_ACC(5, p1 - p0); PQ_ACC(6, p2 - p1); PQ_ACC(7, p3 - p2);
@@ -734,9 +869,9 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #else
         constexpr int WD = COND ? 1 : 2;                    // form does that and spends the 32 registers on its bucket sums)
 #endif
-        load_rows(rr, pos_k(0));
-        if (WD == 2) load_rows(rr2, pos_k(1));
-        convert(ops, rr, pos_k(-1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
+        load_rows(rr, pos_r(0, 0));
+        if (WD == 2) load_rows(rr2, pos_r(0, 1));
+        convert(ops, rr, pos_r(0, -1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
         __syncthreads();
         if (wv == 4) PQ_STAMP(3);
         // iteration it: products of item it-1 (result tiles of stage (it-1)&1, operands in `ops`); then the raw rows of
@@ -744,12 +879,13 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         auto w_body = [&](const int it, RawRows& rr) {
             PQ_TICK(k0);
             PQ_TICK(k1);
-            products((it + 1) & 1, ops, pos_k(it - 1));
+            products((it + 1) & 1, ops, pos_r(it, -1));
             PQ_TICK(k2);
 #ifndef PQ_T_NOCONV
-            convert(ops, rr, pos_k(it));
-            load_rows(rr, pos_k(it + WD));
+            convert(ops, rr, pos_r(it, 0));
+            load_rows(rr, pos_r(it, WD));
 #endif
+            win_advance();
             PQ_TICK(k3);
             __syncthreads();
             PQ_TICK(k4);
@@ -757,7 +893,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         };
         const int n_even = (n_items + 1) & ~1;
         for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, WD == 1 ? rr : rr2); }
-        if (pos_k(n_even - 1).live) products((n_even - 1) & 1, ops, pos_k(n_even - 1));    // the last item, unless it is the void one
+        if (pos_r(n_even, -1).live) products((n_even - 1) & 1, ops, pos_r(n_even, -1));    // the last item, unless it is the void one
         __syncthreads();
         if (wv == 4) PQ_STAMP(4);
         PQ_FLUSH(4, 6);
@@ -883,13 +1019,88 @@ int wn_launch_pq_cond_reduce(const float* cslab, const long* off, const int* t_l
     return 0;
 }
 
+// ---- CHAIN plan.  Items are the 32-column tiles j = 0 .. steps-1 of a clip (from t_base); chain (clip b, residue r) holds the
+// items j = r (mod s), s = d / 32, walked from the highest j down: qn + 1 items for r < rm, qn otherwise.  Chain order = clips,
+// then residues, then positions.  With fewer than 256 chains every chain is cut into g segments (the first `m mod g` one item
+// longer), one workgroup each; otherwise a workgroup takes whole chains.  Gradient bits depend on this plan only.
+int wn_pq_chain_ok(int t_lo, int t_hi, int batch, int d) {
+    if (d < PQ_COLS || d % PQ_COLS != 0 || t_hi <= t_lo || batch <= 0) return 0;
+    const int t_base = t_lo & ~(PQ_COLS - 1);
+    const int steps = (t_hi - t_base + PQ_COLS - 1) / PQ_COLS;
+    return steps >= d / PQ_COLS;                           // every chain has an item (its tail is what writes dx below t_base)
+}
+void wn_pq_chain_plan(int t_lo, int t_hi, int batch, int d, int& t_base, int& steps, int& s, int& qn, int& rm, int& g, int& nchain, int& nwg) {
+    t_base = t_lo & ~(PQ_COLS - 1);
+    steps = (t_hi - t_base + PQ_COLS - 1) / PQ_COLS;
+    s = d / PQ_COLS;
+    qn = steps / s;
+    rm = steps % s;
+    nchain = s * batch;
+    if (nchain >= 256) { g = 0; nwg = 256; return; }
+    g = 256 / nchain;
+    const int gmax = qn / 4 > 1 ? qn / 4 : 1;              // segments of at least ~4 items: a halo item costs most of an item
+    if (g > gmax) g = gmax;
+    nwg = nchain * g;
+}
+// test hook: the items workgroup `wg` walks, as (clip, t0, flags: 1 halo | 2 top | 4 bottom) triples; returns their number or -1
+int wn_pq_chain_items(int t_lo, int t_hi, int batch, int d, int wg, int* out, int cap) {
+    if (!wn_pq_chain_ok(t_lo, t_hi, batch, d)) return -1;
+    PqChain p;
+    int t_base, nwg;
+    wn_pq_chain_plan(t_lo, t_hi, batch, d, t_base, p.steps, p.s, p.qn, p.rm, p.g, p.nchain, nwg);
+    if (wg < 0 || wg >= nwg) return -1;
+    PqCS c;
+    int n_real;
+    bool halo;
+    pq_chain_start(p, wg, nwg, c, n_real, halo);
+    const int n = n_real + (halo ? 1 : 0);
+    for (int k = 0; k < n && k < cap; ++k) {
+        out[3 * k] = c.b;
+        out[3 * k + 1] = t_base + PQ_COLS * (c.r + (c.m - 1 - c.pos) * p.s);
+        out[3 * k + 2] = ((halo && k == 0) ? 1 : 0) | (c.pos == 0 ? 2 : 0) | (c.pos == c.m - 1 ? 4 : 0);
+        c = pq_cs_next(c, p);
+    }
+    return n;
+}
+int wn_pq_slabs(int t_lo, int t_hi, int batch, int d, int chain) {
+    if (t_hi <= t_lo || batch <= 0) return 0;
+    int t_base, steps, ipw, nwg;
+    if (chain && wn_pq_chain_ok(t_lo, t_hi, batch, d)) {
+        int s, qn, rm, g, nchain;
+        wn_pq_chain_plan(t_lo, t_hi, batch, d, t_base, steps, s, qn, rm, g, nchain, nwg);
+        return nwg;
+    }
+    wn_resrw_plan(t_lo, t_hi, batch, t_base, steps, ipw, nwg);
+    return nwg;
+}
+
+template <bool HAS_DY, bool COND, bool QIN, bool CHAIN>
+static void pq_launch(const WnResPqArgs& k, int nwg, size_t sh, hipStream_t st) {
+    static unsigned long long done = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((done >> dev) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<HAS_DY, COND, QIN, CHAIN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        done |= 1ull << dev;
+    }
+    hipLaunchKernelGGL((resblock_bwd_pq_k<HAS_DY, COND, QIN, CHAIN>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
+}
+
 int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
     if (a.t_hi <= a.t_lo || batch <= 0) return 0;
     WnResPqArgs k = a;
     int nwg;
-    wn_resrw_plan(a.t_lo, a.t_hi, batch, k.t_base, k.steps_per_clip, k.items_per_wg, nwg);      // same items and slabs as wn_resrw.hip
     k.batch = batch;
     k.swz = wn_xcd_swizzle_enabled();
+    if (k.chain) {
+        if (k.cond) return wn_set_error_msg(-4, "resblock_bwd_pq: the conditioned block has no chain form");
+        if (!wn_pq_chain_ok(a.t_lo, a.t_hi, batch, a.d)) return wn_set_error_msg(-4, "resblock_bwd_pq: chain form needs d % 32 == 0 and an item per chain");
+        wn_pq_chain_plan(a.t_lo, a.t_hi, batch, a.d, k.t_base, k.steps_per_clip, k.ch_s, k.ch_qn, k.ch_rm, k.ch_g, k.ch_nchain, nwg);
+        k.items_per_wg = 0;
+    } else {
+        wn_resrw_plan(a.t_lo, a.t_hi, batch, k.t_base, k.steps_per_clip, k.items_per_wg, nwg);      // same items and slabs as wn_resrw.hip
+    }
     if (k.cond) {
         if (!k.cond_idx || k.cond_le > 32 || k.cond_le < 1)
             return wn_set_error_msg(-4, "resblock_bwd_pq: a conditioned block needs cond_idx and 1..32 buckets");
@@ -901,25 +1112,20 @@ int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
     pq_span_slot = (pq_span_slot + 1) & 63;
 #endif
     const size_t sh = (size_t)PQ_LDS_HALFS * sizeof(uint16_t);
-    static unsigned long long done = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!((done >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<true, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<false, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<true, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<false, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        done |= 1ull << dev;
+    const bool has_dy = k.p_in != nullptr, qin = k.q_in != nullptr, cnd = k.cond != nullptr, chn = k.chain != 0;
+    if (cnd) {
+        if (has_dy && !qin) return wn_set_error_msg(-4, "resblock_bwd_pq: a conditioned block takes the (P, Q) pair");
+        if (has_dy) pq_launch<true, true, true, false>(k, nwg, sh, st);
+        else pq_launch<false, true, true, false>(k, nwg, sh, st);
+    } else if (chn) {
+        if (!has_dy) pq_launch<false, false, true, true>(k, nwg, sh, st);
+        else if (qin) pq_launch<true, false, true, true>(k, nwg, sh, st);
+        else pq_launch<true, false, false, true>(k, nwg, sh, st);
+    } else {
+        if (!has_dy) pq_launch<false, false, true, false>(k, nwg, sh, st);
+        else if (qin) pq_launch<true, false, true, false>(k, nwg, sh, st);
+        else pq_launch<true, false, false, false>(k, nwg, sh, st);
     }
-    const bool has_dy = k.p_in && k.q_in, cnd = k.cond != nullptr;
-    if (has_dy && cnd) hipLaunchKernelGGL((resblock_bwd_pq_k<true, true>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
-    else if (has_dy) hipLaunchKernelGGL((resblock_bwd_pq_k<true, false>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
-    else if (cnd) hipLaunchKernelGGL((resblock_bwd_pq_k<false, true>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
-    else hipLaunchKernelGGL((resblock_bwd_pq_k<false, false>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
     WN_CHECK_LAUNCH();
     return 0;
 }

@@ -473,15 +473,21 @@ class WaveNetEngine:
         if bw["pq"] or pair:
             bw["PQ"] = [(buf(self.CH), buf(self.CH)), (buf(self.CH), buf(self.CH))]
         ops = [("p2", lo, T, 1024), ("p1", lo, T, 1024), ("skip", lo, T, 2048)]
+        # one-launch blocks whose dilation is a multiple of 32 hand dx on WHOLE (chain form of wn_resblock_bwd_pq: the Q rows
+        # of an item are the carry of the next item of its chain); decided here, once per workspace, with the slab counts
+        Bp = B // 2 if pair else B
+        want = os.environ.get("WN_PQ_CHAIN", "1") == "1"       # 0: every block hands the (P, Q) pair on (round 3's form)
+        bw["chain"] = [want and bool(bw["pq"] or pair) and _lib.pq_chain_ok(self.off[i + 1], T, Bp, self.dil[i]) for i in range(self.N)]
         for i in range(self.N):
             if pair:                                          # the 64-channel one-launch block on B / 2 clip pairs
-                ops.append(("fg2_%d" % i, self.off[i + 1], T, -2))
+                ops.append(("fg2_%d" % i, self.off[i + 1], T, (-3, i)))
                 if i < self.N - 1:
-                    ops.append(("d2_%d" % i, self.off[i + 1], T, -2))
+                    ops.append(("d2_%d" % i, self.off[i + 1], T, (-3, i)))
                 continue
-            ops.append(("fg%d" % i, self.off[i + 1], T, -1 if ms else 512))
+            kind = (-3, i) if bw["pq"] else (-1 if ms else 512)
+            ops.append(("fg%d" % i, self.off[i + 1], T, kind))
             if i < self.N - 1:
-                ops.append(("d%d" % i, self.off[i + 1], T, -1 if ms else 512))
+                ops.append(("d%d" % i, self.off[i + 1], T, kind))
         ops.append(("causal", 1, T, 512))
         # the same gradient from integer codes (wn_causal_wgrad_codes) when the input is a one-hot this engine / the
         # loader built: its own slab region and its own reduction table (only the last row differs)
@@ -492,10 +498,10 @@ class WaveNetEngine:
             n = r * c
             if chunk is None:
                 ns = _lib.causal_codes_slabs(T, B)
+            elif isinstance(chunk, tuple):                    # one-launch block (on clips or clip pairs): one slab per workgroup of ITS plan
+                ns = _lib.pq_slabs(t_lo, t_hi, Bp, self.dil[chunk[1]], bw["chain"][chunk[1]])
             elif chunk > 0:
                 ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B)
-            elif chunk == -2:                                 # ... on clip pairs
-                ns = _lib.ms_slabs(t_lo, t_hi, B // 2)
             else:                                             # channel-split block: one slab per workgroup
                 ns = _lib.ms_slabs(t_lo, t_hi, B)
             plan[name] = (so, n, chunk)
@@ -737,9 +743,12 @@ class WaveNetEngine:
                 main.wait_event(ev_w[k])
             if bw["pq"] or bw["pair"]:
                 p_out, q_out = (ptr(t, SLACK) for t in bw["PQ"][i % 2])
+                chain = 1 if bw["chain"][i] else 0
                 if i < N - 1:
                     p_in, q_in = (ptr(t, SLACK) for t in bw["PQ"][(i + 1) % 2])
                     dn, p_lo = self.dil[i + 1], self.off[i + 2]
+                    if bw["chain"][i + 1]:                    # the block above handed dx on whole (valid from ITS t_lo - d = this t_lo)
+                        q_in, dn, p_lo = None, 0, t_lo
                 else:
                     p_in = q_in = None
                     dn = p_lo = 0
@@ -748,14 +757,17 @@ class WaveNetEngine:
                     call("wn_resblock_bwd_pq", self._x(ws, i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CH * pitch),
                          p_out, q_out, 2 * xb, 2 * zb, pitch, fr("fg2_%d" % i), br("dT2_%d" % i), br("pq2_%d" % i), 64, d, t_lo, T, lo,
                          ptr(bw["slab"], plan["fg2_%d" % i][0]), ptr(bw["slab"], plan["d2_%d" % i][0]) if i < N - 1 else None,
-                         None, 0, 0, 0, None, None, zb, B // 2, mf, mb, st)
+                         None, 0, 0, 0, None, None, zb, chain, B // 2, mf, mb, st)
                 else:
                     call("wn_resblock_bwd_pq", self._x(ws, i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CH * pitch),
                          p_out, q_out, xb, zb, pitch, fr("fg%d" % i), br("dT%d" % i), br("pq%d" % i), CH, d, t_lo, T, lo,
                          ptr(bw["slab"], plan["fg%d" % i][0]), ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None,
-                         None, 0, 0, 0, None, None, 0, B, mf, mb, st)
+                         None, 0, 0, 0, None, None, 0, chain, B, mf, mb, st)
                 self.fmark("b_block")
-                if i == 0:
+                if i == 0 and chain:
+                    # (a first block with d >= 32: dx_0 is already whole)
+                    bw["dX"][0].copy_(bw["PQ"][0][0])
+                elif i == 0:
                     # dx_0 for the causal layer: the pair made whole once (19 us; the scatter from codes can also take the
                     # pair as it is - wn_causal_wgrad_codes(dx_q) - but its doubled, masked tile loads cost the same 20 us)
                     call("wn_shift_add", p_out, q_out, ptr(bw["dX"][0], SLACK), xb, pitch, CH, d, t_lo, self.off[0], T, B, st)

@@ -719,12 +719,12 @@ class _AutoencoderEngine:
                     call("wn_resblock_bwd_pq", xd(i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CHd * pitch), p_out, q_out,
                          2 * db, 2 * zb, pitch, fr("de_fg2_%d" % i), br("de_dT2_%d" % i), br("de_pq2_%d" % i), 64, d, t_lo, T, lo,
                          ptr(bw["slab"], plan["de_fg2_%d" % i][0]), ptr(bw["slab"], plan["de_d2_%d" % i][0]) if i < N - 1 else None,
-                         ptr(ws["tab"][i]), 4 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"], bw["cs_off"][i]), zb, Bp, mf, mb, st)
+                         ptr(ws["tab"][i]), 4 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"], bw["cs_off"][i]), zb, 0, Bp, mf, mb, st)
                 else:
                     call("wn_resblock_bwd_pq", xd(i), p_in, q_in, dn, p_lo, ptr(bw["dZ"], SLACK + i * CHd * pitch), p_out, q_out,
                          db, zb, pitch, fr("de_fg%d" % i), br("de_dT%d" % i), br("de_pq%d" % i), CHd, d, t_lo, T, lo,
                          ptr(bw["slab"], plan["de_fg%d" % i][0]), ptr(bw["slab"], plan["de_d%d" % i][0]) if i < N - 1 else None,
-                         ptr(ws["tab"][i]), 2 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"], bw["cs_off"][i]), 0, B, mf, mb, st)
+                         ptr(ws["tab"][i]), 2 * CHd * Le, Le, Le, ptr(ws["cidx"][i]), ptr(bw["cslab"], bw["cs_off"][i]), 0, 0, B, mf, mb, st)
                 if i == 0:
                     call("wn_shift_add", p_out, q_out, ptr(bw["dXd"][0], SLACK), db, pitch, CHd, d, t_lo, self.off[0], T, B, st)
                 continue

@@ -74,3 +74,58 @@ def test_module_without_gpu_raises_not_falls_back():
         assert "no CPU path" in str(e)
     else:
         raise AssertionError("CPU input must raise")
+
+
+def _chain_items(lib, t_lo, t_hi, batch, d, wg):
+    import ctypes
+    out = (ctypes.c_int * (3 * 4096))()
+    n = lib.wn_resblock_bwd_pq_chain_items(t_lo, t_hi, batch, d, wg, out, 4096)
+    return n, [(out[3 * k], out[3 * k + 1], out[3 * k + 2]) for k in range(max(n, 0))]
+
+
+def test_chain_plan_covers_every_item_once():
+    """The chain form of wn_resblock_bwd_pq (host view of its plan, nothing launched): over the workgroups of a launch every
+    32-column item of every clip is owned exactly once, items of a workgroup follow their chain downwards in steps of d,
+    a halo item is the item d columns above the first owned one, the top / bottom flags mark the ends of every chain, and
+    the tails (t0 - d of the bottoms) tile [t_base - d, t_base) once per clip."""
+    from music_amd import _lib
+    lib = _lib.load()
+    cases = [(3071, 16000, 8, 512), (2047, 16000, 8, 256), (1100, 16000, 8, 32), (3071, 16000, 1, 512), (3071, 16000, 64, 512),
+             (40, 16000, 64, 32), (1024, 4000, 1, 512), (1024, 1024 + 16 * 32, 2, 512), (100, 100 + 33, 3, 32), (512, 9000, 5, 64),
+             (77, 3000, 2, 96)]
+    for t_lo, t_hi, batch, d in cases:
+        assert lib.wn_resblock_bwd_pq_chain_ok(t_lo, t_hi, batch, d) == 1, (t_lo, t_hi, batch, d)
+        nwg = lib.wn_resblock_bwd_pq_slabs(t_lo, t_hi, batch, d, 1)
+        assert 1 <= nwg <= 256
+        t_base = t_lo & ~31
+        steps = (t_hi - t_base + 31) // 32
+        owned, tails = {}, {}
+        for wg in range(nwg):
+            n, items = _chain_items(lib, t_lo, t_hi, batch, d, wg)
+            assert n >= 0
+            prev = None
+            for k, (b, t0, fl) in enumerate(items):
+                assert 0 <= b < batch and (t0 - t_base) % 32 == 0 and t_base <= t0 < t_base + 32 * steps
+                halo, top, bot = fl & 1, fl & 2, fl & 4
+                assert bool(halo) == (k == 0 and not top and n > 0 and items[0][2] & 1 == 1)
+                assert bool(top) == (t0 + d >= t_base + 32 * steps)       # nothing above it
+                assert bool(bot) == (t0 - d < t_base)
+                if prev is not None and not top:
+                    assert (b, t0 + d) == prev[:2]                         # the item above it came just before
+                if k == 0 and not top:
+                    assert halo                                            # a segment that starts inside a chain brings the item above it
+                if halo:
+                    assert k == 0 and n > 1
+                else:
+                    assert (b, t0) not in owned
+                    owned[(b, t0)] = wg
+                    if bot:
+                        tails[(b, t0 - d)] = 1
+                prev = (b, t0, fl)
+        assert len(owned) == batch * steps, (t_lo, t_hi, batch, d, len(owned), batch * steps)
+        for b in range(batch):
+            assert sorted(t for (bb, t) in tails if bb == b) == list(range(t_base - d, t_base, 32))
+    # no chain form: d not a multiple of 32, fewer items than chains
+    assert lib.wn_resblock_bwd_pq_chain_ok(100, 16000, 8, 16) == 0
+    assert lib.wn_resblock_bwd_pq_chain_ok(1024, 1024 + 15 * 32, 2, 512) == 0
+    assert _chain_items(lib, 100, 16000, 8, 16, 0)[0] == -1

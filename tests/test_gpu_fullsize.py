@@ -39,7 +39,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import intops
 from oracle import wavenet_oracle as wo
-from tests.helpers import scrambled_input
+from tests.helpers import nonvacuous, scrambled_input
 
 import os
 
@@ -167,7 +167,7 @@ def test_c2_full_length_loss_and_gradients_vs_oracle():
     l_ref, p_ref, g32, l64, g64 = _oracle_grads_f32_f64(params, C2["dilations"], x, target, _c2_dev_pre(eng, eng.workspace(B, T)))
     e_p = (probs - p_ref).abs().max().item()
     assert probs.shape == (B * W, 256) and e_p <= LOGIT_TOL, e_p
-    assert p_ref.max().item() > 0.5                       # non-vacuous
+    nonvacuous(p_ref, "c2 at 2 x 16000", 0.5)            # 
     assert abs(loss.item() - l_ref.item()) < 1e-4 and abs(loss.item() - l64.item()) < 1e-4
     worst, name, cpu = _check_grads(got, g64, g32)
     print("c2 full length (2 x 16000): probs err %.2e, loss %.7f (oracle f32 %.7f, f64 %.7f), worst grad err vs f64 %.2e "
@@ -260,7 +260,13 @@ def test_c4_full_size_autoencoder_vs_oracle():
                de_dilation_channel=64, de_skip_channel=256, use_bias=False)
     torch.manual_seed(5)
     net = wavenet_autoencoder(**cfg)
-    params = _scaled(net, 1.6)
+    _scaled(net, 1.6)
+    # 60 gated blocks in a row: a uniform gain makes the float32 reference itself irreproducible (at gain 3 float32 and float64
+    # differ by 8e-3 on the probabilities, with max p still 0.06) long before the output becomes confident, so the last 1x1
+    # conv alone takes the extra gain that makes the 1e-3 bar on the probabilities mean something (max p > 0.5, asserted below)
+    with torch.no_grad():
+        net.connection_2.weight.mul_(12.0)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
     net = net.cuda()
     rng = np.random.default_rng(51)
     B, T = 2, 16000
@@ -301,6 +307,7 @@ def test_c4_full_size_autoencoder_vs_oracle():
     e_enc = (net.last_encoding.cpu() - enc_ref.detach()).abs().max().item()
     e_p = (probs.detach().cpu() - p_ref.detach()).abs().max().item()
     assert e_enc < 1e-4 and e_p <= LOGIT_TOL, (e_enc, e_p)
+    nonvacuous(p_ref.detach(), "c4 at 2 x 16000", 0.5)
     assert abs(loss.item() - l_ref.item()) < 1e-4
     got = {name: p.grad for name, p in net.named_parameters()}
     assert list(got.keys()) == list(g64.keys())
@@ -419,7 +426,8 @@ def test_shipped_config_forward_and_gradients_vs_oracle():
     got = {n: eng.param_view(n, grad=True).clone() for n in eng.param_names}
     l_ref, p_ref, g32, l64, g64 = _oracle_grads_f32_f64(params, SHIPPED["dilations"], x, target, _c2_dev_pre(eng, eng.workspace(B, T)))
     e_p = (probs - p_ref).abs().max().item()
-    assert e_p <= LOGIT_TOL and p_ref.max().item() > 0.3, (e_p, p_ref.max().item())
+    assert e_p <= LOGIT_TOL, e_p
+    nonvacuous(p_ref, "shipped 40-block model", 0.3)
     assert abs(loss.item() - l_ref.item()) < 1e-4
     worst, name, cpu = _check_grads(got, g64, g32)
     print("shipped config (40 blocks, 32/32/512, 2 x %d): probs err %.2e (max p %.3f), worst grad err vs f64 %.2e "
@@ -454,6 +462,7 @@ def test_shipped_config_shipped_batch_window_vs_oracle():
     err = (got - want).abs().max().item()
     print("shipped config at 4 x %d: window probs err %.2e" % (T, err))
     assert err <= LOGIT_TOL
+    nonvacuous(want, "shipped model, window of the shipped batch", 0.3)
     # a full training step at this shape runs and is bit-reproducible
     target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).cuda()
     l1 = eng.loss_and_grad(x, target).item()

@@ -74,6 +74,8 @@ def test_general_plan_forward_and_gradients_vs_oracle(case):
     o_dev = eng.workspace(B, T)["O"][:B * Q * W].view(B, Q, W).cpu()
     e_o = (o_dev - inter["pre_softmax"].detach()).abs().max().item()
     assert probs.shape == (B * W, Q) and e_p <= LOGIT_TOL and e_o <= LOGIT_TOL, (e_p, e_o)
+    from tests.helpers import nonvacuous
+    nonvacuous(p_ref, "general plan " + name, 10.0 / Q)
     assert abs(loss.item() - l_ref.item()) < 1e-4
     worst = 0.0
     gmax = max(g.abs().max().item() for g in g_ref.values())

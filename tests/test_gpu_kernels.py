@@ -497,7 +497,7 @@ def test_conditioned_block_entry_points_refuse_bad_arguments():
     pk = torch.zeros(1 << 16, dtype=torch.int16, device=DEV)
     pq = lambda cond, le, idx, cslab: call(
         "wn_resblock_bwd_pq", ptr(buf), None, None, 0, 0, ptr(buf), ptr(buf), ptr(buf), 64 * 256, 64 * 256, 256, ptr(pk), ptr(pk), ptr(pk),
-        64, 1, 8, 200, 8, ptr(buf), ptr(buf), cond, 128 * 8, 8, le, idx, cslab, 0, 1, _lib.F16X3, _lib.BF16X3, _lib.stream())
+        64, 1, 8, 200, 8, ptr(buf), ptr(buf), cond, 128 * 8, 8, le, idx, cslab, 0, 0, 1, _lib.F16X3, _lib.BF16X3, _lib.stream())
     for args, what in (((ptr(buf), 8, None, None), "cond_idx"), ((ptr(buf), 33, ptr(i8), None), "buckets"),
                        ((None, 8, ptr(i8), ptr(buf)), "cslab without cond")):
         with pytest.raises(_lib.WavenetHipError, match=what):

@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import wavenet_oracle as wo
-from tests.helpers import scrambled_input
+from tests.helpers import nonvacuous, scrambled_input
 
 LOGIT_TOL = 1e-3
 GRAD_RTOL = 2e-3
@@ -75,6 +75,7 @@ def test_ragged_shapes_vs_oracle(case):
     e_pre = (pre - pre_ref.reshape(B, 256, W)).abs().max().item()
     assert e_pre <= LOGIT_TOL, e_pre
     assert e_p <= LOGIT_TOL, e_p
+    nonvacuous(p_ref, "sweep")
     loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
     assert abs(loss.item() - l_ref.item()) < 1e-4
     loss.backward()

@@ -18,6 +18,7 @@ SWITCHES = [
     {"WN_GEMM_RW": "0"},           # one-pass narrow product (chan_gemm_k) for the per-layer data gradient (what other shapes run)
     {"WN_TALIGN": "4"},            # tile origins at t_lo & ~3 instead of 64-sample lines (also disables the two-role narrow product)
     {"WN_XCD": "0"},               # no XCD-aware block remap
+    {"WN_PQ_CHAIN": "0"},          # every one-launch block hands the (P, Q) pair on (no chain walk: what d < 32 and short clips run)
 ]
 
 
@@ -156,3 +157,50 @@ def test_forward_epilogue_chains_give_the_same_bits(bias, monkeypatch):
     for split in ("2", "3"):
         for a, b in zip(got["1"], got[split]):
             assert torch.equal(a, b), split
+
+
+def test_chain_form_equals_pair_form(monkeypatch):
+    """Blocks with d % 32 == 0 hand dx on whole (chain walk, Q rows carried in registers); WN_PQ_CHAIN=0 makes every block hand
+    the (P, Q) pair on.  Same products per item, another summation order of the weight-gradient slabs and of P + Q + dy:
+    loss bit-identical (the forward is the same), every gradient within 2e-5 of its max-abs; a second run of either
+    form reproduces its bits.  Shapes: a ragged one with short chains (segments + halo items, chains of 1-3 items at d = 512)
+    and a batch of 3 with whole chains per workgroup."""
+    import numpy as np
+    import torch
+    from music_amd.model import wavenet
+    for dil, B, extra, seed in (([1, 2, 4, 8, 16, 32, 64, 128, 256, 512], 2, 1700, 5), ([32, 64, 1, 2, 32, 128], 3, 2100, 6),
+                                ([1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 2, 16, 600, 7)):
+        cfg = dict(filter_width=2, dilations=dil, dilation_channels=64, residual_channels=64, skip_channels=64,
+                   quantization_channels=256, use_bias=False)
+        torch.manual_seed(seed)
+        net = wavenet(**cfg)
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(2.5)
+        net = net.cuda()
+        eng = net._engine_for(torch.device("cuda", 0))
+        rng = np.random.default_rng(seed)
+        T = net.receptive_field + extra
+        codes = torch.from_numpy(rng.integers(0, 256, size=(B, T)).astype(np.int32)).cuda()
+        target = torch.from_numpy(rng.integers(0, 256, size=(B * (extra + 1),)).astype(np.int64)).cuda()
+        got = {}
+        for form in ("1", "0", "1b", "0b"):
+            monkeypatch.setenv("WN_PQ_CHAIN", form[0])
+            eng._ws.clear()
+            loss = eng.loss_and_grad_codes(codes, target)
+            torch.cuda.synchronize()
+            ws = eng.workspace(B, T)
+            assert any(ws["bwd"]["chain"]) == (form[0] == "1")
+            got[form] = (loss.clone(), eng.flat_grad.clone())
+        assert torch.equal(got["1"][0], got["0"][0])
+        assert torch.equal(got["1"][1], got["1b"][1]) and torch.equal(got["0"][1], got["0b"][1])
+        worst = 0.0
+        for name in eng.param_names:
+            o, shp = eng.spec.off[name], eng.spec.shape[name]
+            n = int(np.prod(shp))
+            a, b = got["1"][1][o:o + n], got["0"][1][o:o + n]
+            worst = max(worst, ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item())
+        print("chain vs pair form: worst gradient difference %.2e of max-abs (dilations %s, batch %d)" % (worst, dil[:10], B))
+        assert worst < 2e-5, worst
+    monkeypatch.delenv("WN_PQ_CHAIN")
+    eng._ws.clear()
