@@ -34,8 +34,7 @@ def _self_launch():
     # can lose it to another process in between)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
            "--nproc-per-node", str(known.gpus), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this host driver)
+    env = dict(os.environ)                                  # (inherited as is: the pool exports what RCCL needs across processes)
     env.setdefault("OMP_NUM_THREADS", "8")
     sys.exit(subprocess.call(cmd, env=env))
 
@@ -53,7 +52,7 @@ MARK_EVERY = int(os.environ.get("WN_BENCH_MARK_EVERY", "4"))             # timed
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec); 6.29e12 measured copy
 MFMA_PEAK = 2.5e15         # FLOP/s, dense bf16 / f16 MFMA (same guide)
 BWD_KERNELS = "resblock_bwd_pq_k"
-BWD_PMC = ("resblock_bwd_pq_k<true",)
+BWD_PMC = "resblock_bwd_pq_k<"                       # every form of the backward block (pair / chain, with / without dy)
 
 
 def synth_codes(rank, b, t):
@@ -421,6 +420,18 @@ def surface_benchmarks(net, eng, piece, target):
     return out
 
 
+def csrc_sha():
+    """sha256[:16] over the kernel sources (music_amd/csrc/*.hip, *.h and the public header), in name order."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "music_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))) + [os.path.join(ROOT, "include", "wavenet_hip.h")]:
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_copy_gbs():
     """Device-to-device copy rate (read + write bytes / time) of a 1 GiB buffer, best of 5."""
     n = 1 << 28
@@ -566,8 +577,16 @@ def main():
     # marks included, and are discarded; the contract's W untimed + K timed steps follow unchanged.
     state["sampled"], state["k0"] = [], state["k"]
     eng.mark_only = {"step_begin", "causal_fwd", "stack_fwd", "epilogue_bwd", "stack_bwd"}
-    for _ in range(args.settle):
+    # ... but the one-time cost stays visible: the first window of the process (min(25, settle) steps, wall clock) is reported
+    first_n = min(25, args.settle)
+    first_ms = None
+    torch.cuda.synchronize()
+    t_first = time.perf_counter()
+    for i_ in range(args.settle):
         loss = step()
+        if i_ + 1 == first_n:
+            torch.cuda.synchronize()
+            first_ms = (time.perf_counter() - t_first) / first_n * 1e3
     barrier()
     state["sampled"], eng.marks, eng.mark_only = None, None, None
     for _ in range(args.warmup):
@@ -579,11 +598,16 @@ def main():
     # steps afterwards.
     state["sampled"], state["k0"] = [], state["k"]
     eng.mark_only = {"step_begin", "causal_fwd", "stack_fwd", "epilogue_bwd", "stack_bwd"}
+    # one event per step end (enable_timing): median / min / max of the per-step GPU time
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev[0].record()
+    for i_ in range(args.steps):
         loss = step()
+        step_ev[i_ + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    per_step = sorted(step_ev[i_].elapsed_time(step_ev[i_ + 1]) for i_ in range(args.steps))
     marks, eng.marks, eng.mark_only = state["sampled"], None, None
     state["sampled"] = None
     n_sampled = (args.steps + MARK_EVERY - 1) // MARK_EVERY
@@ -643,15 +667,29 @@ def main():
         except Exception:
             pmc = {}
 
+    # the committed PMC summary belongs to the kernel sources it was measured on: a hash of music_amd/csrc travels with it,
+    # and a figure measured on other sources is dropped (traffic: null) instead of being carried along
+    src_sha = csrc_sha()
+    pmc_stale = bool(pmc) and pmc.get("_csrc_sha16") not in (None, src_sha)
+    if pmc_stale:
+        pmc = {}
+
     def traffic_of(*prefixes):
         tot = 0.0
         for pre in prefixes:
             # (entries with a "source" were measured on another workload - the config-4 step - and are not this run's kernels)
-            hit = [v["hbm_bytes_per_launch"] for k, v in pmc.items() if k.startswith(pre) and "source" not in v]
+            hit = [v["hbm_bytes_per_launch"] for k, v in pmc.items() if k.startswith(pre) and isinstance(v, dict) and "source" not in v]
             if not hit:
                 return None
             tot += max(hit)
         return tot
+
+    def traffic_mean(prefix):
+        """launch-weighted mean over every instantiation of a kernel (the backward block runs in several forms per step)"""
+        hit = [(v["hbm_bytes_per_launch"], v.get("launches_per_step", 1)) for k, v in pmc.items()
+               if k.startswith(prefix) and isinstance(v, dict) and "source" not in v]
+        n = sum(c for _, c in hit)
+        return sum(b * c for b, c in hit) / n if n else None
 
     copy_gbs = measured_copy_gbs() if rank == 0 else None
     # Per-kernel split of the backward stack, from 3 extra (untimed) steps with one HIP event per launch
@@ -705,10 +743,14 @@ def main():
         "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
         "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step_stats": {"median": per_step[len(per_step) // 2], "min": per_step[0], "max": per_step[-1],
+                              "note": "GPU time between the end-of-step HIP events of consecutive timed steps (rank 0)"} if per_step else None,
+        "first_window": {"steps": first_n, "ms_per_step": first_ms,
+                         "note": "the first steps of this process (one-time costs included), before the settle / warm-up steps are discarded"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (forward + recompute: f16 2-term split operands, 2^-22 per element; backward products: bf16 2-term split, 2^-17 per element, f32 range; 3 MFMA per product, f32 accumulate)" if x3 else args.precision,
         "data": "synthetic",
-        "rccl_ranks": world if use_dist else 0, "backend": (dist.get_backend() if use_dist else "none"),
+        "rccl_ranks": world if (use_dist and dist.get_backend() == "nccl") else 0, "backend": (dist.get_backend() if use_dist else "none"),
         "config": {"workload": "BASELINE configs[1]: 30-layer (3x dilations 1..512) WaveNet, 64 res/dil, 256 skip, "
                                "batch 8x16000 per GPU, full train step (H2D of codes and targets, prefetched one step ahead on a copy stream, + fwd on the loader-layout one-hot of the codes (never materialised) + CE + bwd + all-reduce + Adam)",
                    "global_batch": world * B_LOCAL, "seq_len": T, "parallelism": "dp%d" % world,
@@ -717,9 +759,11 @@ def main():
         # time of the backward stack inside the timed region / its 30 blocks)
         "roofline": roof(bwd_b / n_layers, bwd_launch_ms,
                          kernel="%s: backward of one residual block, %d per step" % (BWD_KERNELS, n_layers),
-                         traffic=traffic_of(*BWD_PMC),
-                         traffic_source="profiles/pmc_kernels.json: the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an EARLIER run of "
-                                        "this command (committed summary), corrected per MI355X_MICROARCH.md; not measured in this run",
+                         traffic=traffic_mean(BWD_PMC),
+                         traffic_source=("profiles/pmc_kernels.json was measured on other kernel sources (hash mismatch): dropped" if pmc_stale else
+                                         "profiles/pmc_kernels.json: the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an EARLIER run of "
+                                         "this command on these kernel sources (committed summary, source hash checked), corrected per "
+                                         "MI355X_MICROARCH.md; not measured in this run; mean over the step's %d launches" % n_layers),
                          algorithmic_bytes_per_launch=bwd_b / n_layers,
                          avg_launch_ms=bwd_launch_ms, measured_copy_GBs=copy_gbs,
                          frac_of_measured_copy=(gbs(bwd_b / n_layers, bwd_launch_ms) / copy_gbs) if copy_gbs and bwd_ms == bwd_ms else None),

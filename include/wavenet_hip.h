@@ -309,6 +309,10 @@ int wn_onehot(const int32_t* codes, float* out, int batch, int q, int t, int scr
  * canonical encoder (bit-exact); decode through the 256-entry table. */
 int wn_mulaw_encode_tbl(const float* audio, const float* thresholds, uint8_t* codes, int64_t n, wn_stream_t stream);
 int wn_mulaw_decode_lut(const uint8_t* codes, const float* table, float* audio, int64_t n, wn_stream_t stream);
+/* The same for any number q >= 2 of quantisation channels (the argument of audio_func.py:5,24): q - 1 ascending float32
+ * thresholds (code = number of thresholds <= the sample), a q-entry decode table (codes clamped to [0, q)), int32 codes. */
+int wn_mulaw_encode_q(const float* audio, const float* thresholds, int q, int32_t* codes, int64_t n, wn_stream_t stream);
+int wn_mulaw_decode_q(const int32_t* codes, const float* table, int q, float* audio, int64_t n, wn_stream_t stream);
 
 /* Cached-queue greedy decode, n_steps samples in one persistent launch
  * (wavenet/fast_generate.py:66-141 per sample; :166-172 loop).  All weights fp32 in "decode

@@ -74,6 +74,8 @@ SIGNATURES = {
     "wn_onehot": [_p, _p, _i, _i, _i, _i, _p],
     "wn_mulaw_encode_tbl": [_p, _p, _p, _l, _p],
     "wn_mulaw_decode_lut": [_p, _p, _p, _l, _p],
+    "wn_mulaw_encode_q": [_p, _p, _i, _p, _l, _p],
+    "wn_mulaw_decode_q": [_p, _p, _i, _p, _l, _p],
     "wn_decode": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l,
                   _i, _i, _p, _p],
     "wn_decode_batch": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l,
@@ -94,13 +96,13 @@ def cpu_quota():
     """CPUs this process may use per its cgroup's bandwidth limit (cpu.max / cfs_quota_us), or None without one."""
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        return None if q == "max" else max(1, int(q) // int(per))
+        return None if q == "max" else max(1, -(-int(q) // int(per)))        # ceil: a quota of 1.5 CPUs keeps two threads
     except (OSError, ValueError):
         pass
     try:
         q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
         per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-        return None if q <= 0 else max(1, q // per)
+        return None if q <= 0 else max(1, -(-q // per))
     except (OSError, ValueError):
         return None
 
@@ -110,12 +112,16 @@ def respect_cpu_quota():
     container's CPU quota; an OpenMP region then wakes all of them, they spin, and the scheduler throttles the WHOLE process
     for the rest of the period - host code that feeds a GPU loses 80 ms out of every 100 (measured: the autoencoder with the
     reference's shipped parameters, 68 instead of 10 ms per step).  Called once when the library is loaded: the pool is
-    cut to the quota.  WN_KEEP_TORCH_THREADS=1 leaves it alone."""
+    cut to the quota (rounded up), and the change is REPORTED once on stderr, because it changes the host application's
+    intra-op thread count too.  WN_KEEP_TORCH_THREADS=1 leaves the pool alone."""
+    import sys
     import torch
     if os.environ.get("WN_KEEP_TORCH_THREADS", "0") == "1":
         return
     q = cpu_quota()
     if q is not None and torch.get_num_threads() > q:
+        print("music_amd: torch intra-op threads %d -> %d (the container's CPU quota; WN_KEEP_TORCH_THREADS=1 keeps torch's own setting)"
+              % (torch.get_num_threads(), q), file=sys.stderr)
         torch.set_num_threads(q)
 
 
@@ -219,5 +225,5 @@ def side_stream(device):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("WN_SIDE_PRIO", "-1")))
+        st = _side_streams[key] = torch.cuda.Stream(device=dev, priority=-1)
     return st

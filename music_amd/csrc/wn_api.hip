@@ -176,6 +176,14 @@ int wn_mulaw_encode_tbl(const float* audio, const float* thresholds, uint8_t* co
 int wn_mulaw_decode_lut(const uint8_t* codes, const float* table, float* audio, int64_t n, wn_stream_t stream) {
     return wn_launch_mulaw_decode(codes, table, audio, n, (hipStream_t)stream);
 }
+int wn_mulaw_encode_q(const float* audio, const float* thresholds, int q, int32_t* codes, int64_t n, wn_stream_t stream) {
+    if (q < 2 || (n > 0 && (!audio || !thresholds || !codes))) return wn_set_error_msg(-4, "wn_mulaw_encode_q: bad argument");
+    return wn_launch_mulaw_encode_q(audio, thresholds, q - 1, codes, n, (hipStream_t)stream);
+}
+int wn_mulaw_decode_q(const int32_t* codes, const float* table, int q, float* audio, int64_t n, wn_stream_t stream) {
+    if (q < 2 || (n > 0 && (!audio || !table || !codes))) return wn_set_error_msg(-4, "wn_mulaw_decode_q: bad argument");
+    return wn_launch_mulaw_decode_q(codes, table, q, audio, n, (hipStream_t)stream);
+}
 
 int wn_resblock_bwd_ms(const float* x_in, const float* dy, const float* dz, float* dfg, int64_t x_bstride,
                        int64_t dz_bstride, int64_t dfg_bstride, int pitch, const uint16_t* wfg, const uint16_t* wdT,

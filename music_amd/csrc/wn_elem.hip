@@ -260,6 +260,45 @@ __global__ void mulaw_decode_k(const uint8_t* __restrict__ codes, const float* _
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < n; i += stride) audio[i] = table[codes[i]];
 }
+// any number of quantisation channels (wavenet/audio_func.py takes it as an argument): n_thr = q - 1 thresholds in global memory
+// (L1 / L2 resident), int32 codes
+__global__ void mulaw_encode_q_k(const float* __restrict__ audio, const float* __restrict__ thr, int n_thr,
+                                 int32_t* __restrict__ codes, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float a = audio[i];
+        int lo = 0, hi = n_thr;               // count of thresholds <= a
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (thr[mid] <= a) lo = mid + 1; else hi = mid;
+        }
+        codes[i] = lo;
+    }
+}
+__global__ void mulaw_decode_q_k(const int32_t* __restrict__ codes, const float* __restrict__ table, int q,
+                                 float* __restrict__ audio, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int c = codes[i];
+        audio[i] = table[c < 0 ? 0 : (c >= q ? q - 1 : c)];
+    }
+}
+int wn_launch_mulaw_encode_q(const float* audio, const float* thr, int n_thr, int32_t* codes, long n, hipStream_t st) {
+    if (n <= 0) return 0;
+    long grid = (n + 255) / 256; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(mulaw_encode_q_k, dim3((int)grid), dim3(256), 0, st, audio, thr, n_thr, codes, n);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+int wn_launch_mulaw_decode_q(const int32_t* codes, const float* table, int q, float* audio, long n, hipStream_t st) {
+    if (n <= 0) return 0;
+    long grid = (n + 255) / 256; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(mulaw_decode_q_k, dim3((int)grid), dim3(256), 0, st, codes, table, q, audio, n);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
 int wn_launch_mulaw_encode(const float* audio, const float* thr, uint8_t* codes, long n, hipStream_t st) {
     if (n <= 0) return 0;
     long grid = (n + 255) / 256; if (grid > 2048) grid = 2048;

@@ -188,6 +188,8 @@ int wn_launch_gather_grads2(const float* packed, const int32_t* idx, const int32
 int wn_launch_onehot(const int32_t* idx, float* out, int batch, int q, int t, int scrambled, hipStream_t st);
 int wn_launch_mulaw_encode(const float* audio, const float* thr, uint8_t* codes, long n, hipStream_t st);
 int wn_launch_mulaw_decode(const uint8_t* codes, const float* table, float* audio, long n, hipStream_t st);
+int wn_launch_mulaw_encode_q(const float* audio, const float* thr, int n_thr, int32_t* codes, long n, hipStream_t st);
+int wn_launch_mulaw_decode_q(const int32_t* codes, const float* table, int q, float* audio, long n, hipStream_t st);
 int wn_launch_bias_grad(const float* a, long a_bstride, int a_pitch, int a_shift, int rows, int t_lo,
                         int t_hi, int batch, float* out, hipStream_t st);
 

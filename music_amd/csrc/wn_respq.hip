@@ -74,7 +74,6 @@ __device__ __forceinline__ void pq_split2(float a, float b, uint32_t& hi, uint32
 #define PQ_STAGE 24576
 #define PQ_W (2 * PQ_STAGE)
 #define PQ_LDS_HALFS (PQ_W + 32768)
-
 #ifdef PQ_SPAN
 // developer build (tools/pq_spans.py): realtime-clock (100 MHz) stamps of every workgroup of the last 64 launches:
 // [start, R first barrier, R loop end, W first barrier, W loop end, end (slab stores issued), n_items, -]
@@ -172,7 +171,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #ifdef PQ_DBG
     unsigned long long dbg_acc[16] = {};
 #endif
-
     // items of this workgroup.  (P, Q) form: the workgroups of an XCD walk one contiguous item range interleaved (wn_resrw.hip).
     // CHAIN form: a run of `n_items` items in CHAIN ORDER (clip, residue r of the item index mod s, then downwards in time),
     // the first of them possibly a halo item; positions are stepped, a window of five (items it-1 .. it+3) lives in scalars.
@@ -505,12 +503,15 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         load_cr(crB, pos_r(0, 1));
         RawX x0, x1;                                        // x1 / x0 hold the raw rows of items it+1 / it+2
         RawD rd;                                            // dy rows (as the pair) of item it+1
+        // XD: items the raw x rows are requested ahead.  The chain form that is fed by a pair (the first chain block under a
+        // (P, Q) block: 2 launches of 30) holds the dy rows twice more (dyrP, dyrQ) and keeps ONE set of x rows: no spills
+        constexpr int XD = (CHAIN && QIN && HAS_DY) ? 1 : 2;
         load_x(x0, pos_r(0, 0));
         load_dy(rd, pos_r(0, 0));
-        load_x(x1, pos_r(0, 1));
+        if (XD == 2) load_x(x1, pos_r(0, 1));
         fill_x(x0, 0);
         fill_dy(rd, pos_r(0, 0), 0);
-        load_x(x0, pos_r(0, 2));
+        load_x(x0, pos_r(0, XD));
         load_dy(rd, pos_r(0, 1));
         __syncthreads();                                    // stage 0 operands of the first item, the weights, the zeros
         if (wv == 0) PQ_STAMP(1);
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 cidx[0] = ip[0]; cidx[1] = ip[1];
             }
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
-            load_x(rx, pos_r(it, 3));                       // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
+            load_x(rx, pos_r(it, XD + 1));                  // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
 #ifndef PQ_T_NOFILLDY
             fill_dy(rd, pos_r(it, 1), (it + 1) & 1);        // (the R waves wait at the barrier otherwise: the W waves are the pole)
             load_dy(rd, pos_r(it, 2));
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             PQ_ACC(0, k1 - k0); PQ_ACC(1, k2 - k1); PQ_ACC(2, k3 - k2); PQ_ACC(3, k4 - k3);
         };
         for (int it = 0; it < n_items; it += 2) {
-            r_body(it, crA, x1);
+            r_body(it, crA, XD == 2 ? x1 : x0);
             r_body(it + 1, crB, x0);
         }
         {

@@ -493,18 +493,22 @@ class WaveNetEngine:
         # loader built: its own slab region and its own reduction table (only the last row differs)
         ops.append(("causal_codes", 1, T, None))
         plan, desc, so, vs = {}, [], 0, 0
+        nslab = {}
+        for name, t_lo, t_hi, chunk in ops:
+            if isinstance(chunk, tuple):
+                nslab[name] = _lib.pq_slabs(t_lo, t_hi, Bp, self.dil[chunk[1]], bw["chain"][chunk[1]])
         for name, t_lo, t_hi, chunk in ops:
             go, r, c = self.gp_off["causal" if name == "causal_codes" else name]
             n = r * c
             if chunk is None:
                 ns = _lib.causal_codes_slabs(T, B)
             elif isinstance(chunk, tuple):                    # one-launch block (on clips or clip pairs): one slab per workgroup of ITS plan
-                ns = _lib.pq_slabs(t_lo, t_hi, Bp, self.dil[chunk[1]], bw["chain"][chunk[1]])
+                ns = nslab[name]
             elif chunk > 0:
                 ns = _lib.wgrad_slabs(t_lo, t_hi, chunk, B)
             else:                                             # channel-split block: one slab per workgroup
                 ns = _lib.ms_slabs(t_lo, t_hi, B)
-            plan[name] = (so, n, chunk)
+            plan[name] = (so, n, chunk, ns, go)
             if name == "causal_codes":
                 desc_codes = desc[:-1] + [[desc[-1][0], so, ns, n, go, n]]
             else:
@@ -673,7 +677,7 @@ class WaveNetEngine:
 
         def wgrad(name, *args):
             """args = everything of wn_wgrad up to and including relu_b, then ldc, t_lo, t_hi"""
-            so, n, chunk = plan[name]
+            so, n, chunk = plan[name][:3]
             head, (ldc, t_lo, t_hi) = args[:-3], args[-3:]
             call("wn_wgrad", *head, ptr(bw["slab"], so), ldc, n, t_lo, t_hi, chunk, B, mb, st)
         dO, dH, dU, dZ = ptr(bw["dO"]), ptr(bw["dH"], SLACK), ptr(bw["dU"], SLACK), ptr(bw["dZ"], SLACK)
@@ -697,7 +701,7 @@ class WaveNetEngine:
                 fn(_lib.stream())
 
         def wgrad_s(name, *args):
-            so, n, chunk = plan[name]
+            so, n, chunk = plan[name][:3]
             head, (ldc, t_lo, t_hi) = args[:-3], args[-3:]
             on_side(lambda s2: call("wn_wgrad", *head, ptr(bw["slab"], so), ldc, n, t_lo, t_hi, chunk, B, mb, s2))
 
@@ -805,11 +809,11 @@ class WaveNetEngine:
                 side.wait_event(ev_r)
             with torch.cuda.stream(side):
                 st2 = _lib.stream()
-                so, n, chunk = plan["fg%d" % i]
+                so, n, chunk = plan["fg%d" % i][:3]
                 call("wn_wgrad", dfg, 2 * CH * pitch, pitch, 0, pitch, self._x(ws, i), self._x(ws, i), xb, pitch, -d, 0, pitch,
                      CH // 16, 2 * CH // 16, 0, ptr(bw["slab"], so), 2 * CH, n, t_lo, T, chunk, B, mb, st2)
                 if i < N - 1:
-                    so, n, chunk = plan["d%d" % i]
+                    so, n, chunk = plan["d%d" % i][:3]
                     zsrc, zstr = (ptr(ws["Z"], SLACK + i * CH * pitch), zb) if self.z_from_fwd else (zs, xb)
                     call("wn_wgrad", dy, xb, pitch, 0, pitch, zsrc, None, zstr, pitch, 0, 0, pitch, CH // 16, CH // 16, 0,
                          ptr(bw["slab"], so), CH, n, t_lo, T, chunk, B, mb, st2)

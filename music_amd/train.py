@@ -48,6 +48,84 @@ def get_arguments():
             get_params('./params/dataset_params.json'))
 
 
+class FlatAdam(optim.Adam):
+    """``torch.optim.Adam`` whose ``step()`` is ONE ``wn_adam_flat`` launch when it can be.
+
+    The module's parameters are views of one flat buffer (music_amd/engine.py) and the gradients autograd hands to them
+    are views of one flat buffer too (``_WaveNetFunction.backward``), so the 123 per-tensor updates of the reference's
+    ``optim.Adam(model.parameters(), lr)`` (wavenet/train.py:39-42) are one elementwise pass.  The optimizer state is
+    torch's own - per parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` - with the two moment tensors being VIEWS of two flat
+    buffers: ``state_dict()`` / ``load_state_dict()`` interchange with ``torch.optim.Adam``, and any step the fast path
+    does not cover (parameters not on the flat buffer yet, gradients that are not one flat tensor, weight decay /
+    amsgrad / maximize / closures, several parameter groups) falls through to ``torch.optim.Adam.step`` on the same state."""
+
+    def __init__(self, model, lr):
+        super().__init__(model.parameters(), lr=lr)
+        self._model = model
+        self._flat = None            # (engine, m, v, steps): flat moments of that engine's flat parameter buffer
+
+    def _fast_state(self):
+        eng = getattr(self._model, "_engine", None)
+        if eng is None or getattr(eng, "flat", None) is None or len(self.param_groups) != 1:
+            return None
+        g = self.param_groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+            return None
+        params = g["params"]
+        named = [p for _, p in self._model.named_parameters()]
+        if len(params) != len(named) or any(a is not b for a, b in zip(params, named)):
+            return None
+        base = eng.flat.data_ptr()
+        if any(p.data_ptr() != base + 4 * eng.spec.off[n] for n, p in zip(eng.param_names, params)):
+            return None                                   # (the module was moved: its parameters left the flat buffer)
+        if self._flat is not None and self._flat[0] is eng:
+            return self._flat
+        # adopt whatever per-parameter state exists (a loaded state_dict, earlier torch steps) into flat moment buffers
+        m, v = torch.zeros_like(eng.flat), torch.zeros_like(eng.flat)
+        steps = []
+        for n, p in zip(eng.param_names, params):
+            o, k = eng.spec.off[n], p.numel()
+            st = self.state[p]
+            if "exp_avg" in st:
+                m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+            step = st.get("step")
+            step = torch.zeros((), dtype=torch.float32) if step is None else torch.as_tensor(step, dtype=torch.float32).detach().cpu().reshape(())
+            st["step"], st["exp_avg"], st["exp_avg_sq"] = step, m[o:o + k].view(p.shape), v[o:o + k].view(p.shape)
+            steps.append(step)
+        if any(float(s) != float(steps[0]) for s in steps):
+            return None                                   # parameters at different step counts: torch's per-tensor path
+        self._flat = (eng, m, v, steps)
+        return self._flat
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._flat = None                                 # re-adopt the loaded tensors at the next step
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        fast = self._fast_state() if closure is None else None
+        if fast is not None:
+            eng, m, v, steps = fast
+            params = self.param_groups[0]["params"]
+            g0 = params[0].grad
+            ok = g0 is not None and g0.dtype == torch.float32
+            if ok:
+                gbase = g0.data_ptr() - 4 * eng.spec.off[eng.param_names[0]]
+                ok = all(p.grad is not None and p.grad.is_contiguous() and p.grad.data_ptr() == gbase + 4 * eng.spec.off[n]
+                         for n, p in zip(eng.param_names, params))
+            if ok:
+                from music_amd import _lib
+                grp = self.param_groups[0]
+                torch._foreach_add_(steps, 1.0)
+                t = float(steps[0])
+                b1, b2 = grp["betas"]
+                _lib.call("wn_adam_flat", eng.flat.data_ptr(), gbase, m.data_ptr(), v.data_ptr(), eng.spec.total,
+                          float(grp["lr"]), b1, b2, grp["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t, 1.0, _lib.stream())
+                return None
+        return super().step(closure)
+
+
 def get_optimizer(model, optimizer_type, learning_rate, momentum):
     """wavenet/train.py:28-42 — 'sgd' / 'rmsprop' (with momentum) / 'adam'; anything else -> None."""
     if optimizer_type == 'sgd':
@@ -55,7 +133,7 @@ def get_optimizer(model, optimizer_type, learning_rate, momentum):
     if optimizer_type == 'rmsprop':
         return optim.RMSprop(model.parameters(), lr=learning_rate, momentum=momentum)
     if optimizer_type == 'adam':
-        return optim.Adam(model.parameters(), lr=learning_rate)
+        return FlatAdam(model, lr=learning_rate)          # an optim.Adam (same state_dict); one launch per step on the flat buffers
 
 
 def save_model(model, num_iter, path):

@@ -33,6 +33,25 @@ def mu_law_encode_table(audio, thresholds):
     return np.searchsorted(thresholds, a, side="right").astype(np.int64)
 
 
+def mu_law_encode_torch(audio, q=256):
+    """audio_func.py:16-22 with the ATen float32 ops the reference itself calls, op for op (torch is imported here only):
+    the same bits as the reference on the same torch build, for ANY q - what the table form is checked against for
+    quantization_channels other than 256 (tests/golden/g5q_mulaw.npz pins it to the reference's own outputs)."""
+    import torch
+    a = torch.as_tensor(np.asarray(audio, dtype=np.float32))
+    mu = torch.Tensor([q - 1]).float()
+    magnitude = torch.log1p(mu * torch.abs(torch.clamp(a, -1.0, 1.0))) / torch.log1p(mu)
+    return ((torch.sign(a) * magnitude + 1) / 2 * mu + 0.5).long().numpy()
+
+
+def mu_law_decode_torch(codes, q=256):
+    """audio_func.py:35-39 with torch float32 ops, op for op."""
+    import torch
+    mu = torch.Tensor([q - 1]).float()
+    signal = 2.0 * (torch.as_tensor(np.asarray(codes)).float() / mu) - 1.0
+    return (torch.sign(signal) * ((1.0 / mu) * ((1.0 + mu) ** torch.abs(signal) - 1.0))).numpy()
+
+
 def mu_law_decode(codes, q=256):
     """audio_func.py:24-39: s = 2*k/mu - 1 ; sign(s) * ((1+mu)^|s| - 1)/mu  in float32."""
     mu = np.float32(q - 1)

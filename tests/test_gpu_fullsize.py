@@ -190,6 +190,58 @@ def test_c2_full_length_loss_and_gradients_vs_oracle():
         assert (a1 - a2).abs().max().item() <= 1e-4 * max(a1.abs().max().item(), 1e-30), n
 
 
+def test_c2_bench_geometry_gradients_vs_oracle():
+    """Config 2 at the BENCHMARK's geometry, 8 x 16000 through eng.loss_and_grad_codes (what bench.py times): loss,
+    probabilities and EVERY gradient against the oracle.  The persistent backward's item ranges, chain segments, slab
+    counts and XCD walks depend on the batch; the 2-clip tests above do not reach this partition.  The oracle runs clip by
+    clip (chunk-softmax rows never cross clips, SURVEY Q2, and all clips have W rows, so the batch loss is the mean of the
+    clip losses and the batch gradient the mean of the clip gradients): float32 for loss / probabilities, float64 with the
+    device's sign at near-zero ReLU pre-activations for the gradients (module docstring), 3 GB of host memory at a time."""
+    from music_amd.model import wavenet
+    torch.manual_seed(3)
+    net = wavenet(**C2)
+    params = _scaled(net, 2.5)
+    net = net.cuda()
+    rng = np.random.default_rng(33)
+    B, T = 8, 16000
+    W = T - net.receptive_field + 1
+    codes = rng.integers(0, 256, size=(B, T))
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64))
+    eng = net._engine_for(torch.device("cuda", 0))
+    loss = eng.loss_and_grad_codes(torch.from_numpy(codes.astype(np.int32)).cuda(), target.cuda(), scrambled=True, want_probs=True)
+    ws = eng.workspace(B, T)
+    assert any(ws["bwd"]["chain"]) and ws["bwd"]["pq"]          # the default kernels: one-launch blocks, chain form for d >= 32
+    probs = ws["probs"].cpu()
+    got = {n: eng.param_view(n, grad=True).clone() for n in eng.param_names}
+    dev_pre = _c2_dev_pre(eng, ws)
+    torch.set_num_threads(ORACLE_THREADS)
+    p64 = {k: v.double() for k, v in params.items()}
+    g64 = {k: torch.zeros_like(v) for k, v in p64.items()}
+    l32 = l64 = 0.0
+    e_p = p_max = 0.0
+    near = flips = 0
+    for b in range(B):
+        xb = scrambled_input(codes[b:b + 1])
+        tb = target[b * W:(b + 1) * W]
+        with torch.no_grad():
+            pb = wo.wavenet_forward(params, C2["dilations"], xb)
+        l32 += torch.nn.functional.cross_entropy(pb, tb).item() / B
+        e_p = max(e_p, (probs[b * W:(b + 1) * W] - pb).abs().max().item())
+        p_max = max(p_max, pb.max().item())
+        relu, stats = _device_relu({k: v[b:b + 1] for k, v in dev_pre.items()})
+        lb, _, gb = wo.loss_and_grads(p64, C2["dilations"], xb.double(), tb, relu=relu)
+        l64 += lb.item() / B
+        near, flips = near + stats["near"], flips + stats["flips"]
+        for k in g64:
+            g64[k] += gb[k] / B
+    assert e_p <= LOGIT_TOL, e_p
+    nonvacuous(torch.tensor(p_max), "c2 at 8 x 16000", 0.5)
+    assert abs(loss.item() - l32) < 1e-4 and abs(loss.item() - l64) < 1e-4, (loss.item(), l32, l64)
+    worst, name, _ = _check_grads(got, g64, {})
+    print("c2 at the bench geometry (8 x 16000, codes path): probs err %.2e, loss %.7f (oracle f32 %.7f, f64 %.7f), worst grad err vs f64 "
+          "%.2e (%s); %d ReLU pre-activations inside the tolerance band, device sign differs at %d" % (e_p, loss.item(), l32, l64, worst, name, near, flips))
+
+
 def _aligned_batch(B, T, W):
     """structured clip (period-7 pattern, a different phase per clip) + constant target: the terms of every gradient
     sum line up instead of cancelling, so the comparison resolves 2^-17 from 2^-22 arithmetic (tools/diag_fullsize.py)"""

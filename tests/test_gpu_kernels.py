@@ -421,6 +421,25 @@ def test_onehot_and_mulaw():
     assert torch.equal(c2, ks)
 
 
+def test_mulaw_other_channel_counts_on_device():
+    """audio_func.mu_law_encode / mu_law_decode with quantization_channels = 64 / 100 / 512 (the reference takes any,
+    audio_func.py:5,24): bit-exact against the reference's own known answers (tests/golden/g5q_mulaw.npz), code boundaries
+    included; encode(decode(k)) == k; tensors of any shape and device come back on their device."""
+    from music_amd import audio_func as af
+    d = load_npz("g5q_mulaw.npz")
+    for q in (64, 100, 512):
+        x = torch.from_numpy(d["x%d" % q])
+        c = af.mu_law_encode(x.to(DEV), q)
+        assert c.dtype == torch.int64 and c.is_cuda and np.array_equal(c.cpu().numpy(), d["codes%d" % q])
+        a = af.mu_law_decode(torch.arange(q), q)
+        assert not a.is_cuda and np.array_equal(a.numpy(), d["decode%d" % q])
+        assert torch.equal(af.mu_law_encode(a, q), torch.arange(q))
+        c2 = af.mu_law_encode(x.view(-1, 1)[:100].expand(100, 3), q)            # non-contiguous, 2-D
+        assert c2.shape == (100, 3) and torch.equal(c2[:, 0], c[:100].cpu())
+    with pytest.raises(ValueError):
+        af.mu_law_encode(torch.zeros(4), 1)
+
+
 def test_adam_flat_matches_torch():
     n = 100003
     g = torch.Generator().manual_seed(1)

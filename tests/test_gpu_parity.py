@@ -168,6 +168,62 @@ def test_fused_train_step_matches_autograd_path_and_oracle():
         assert (a - b).abs().max().item() < 5e-3 * max(1e-3, b.abs().max().item()), name
 
 
+def test_flat_adam_is_torch_adam_on_the_drop_in_surface():
+    """train.get_optimizer(net, 'adam', lr, momentum) returns a torch.optim.Adam whose step() is one wn_adam_flat launch on
+    the flat parameter / gradient buffers (wavenet/train.py:39-42 builds optim.Adam(model.parameters(), lr)): the reference's
+    loop (zero_grad, net(x), CrossEntropyLoss, backward, step) gives the same parameters as torch.optim.Adam stepping the
+    same module, the fast path is the one that runs, state_dict() loads into a torch.optim.Adam and back, a step with
+    foreign gradients (not one flat tensor) and a step with a closure fall through to torch's own path on the same state."""
+    from music_amd import train as T
+    from music_amd.model import wavenet
+    meta = [m for m in g1_meta() if m["name"] == "tiny_s0_g3_w130"][0]
+    d = load_npz("g1_%s.npz" % meta["name"])
+    x = g1_input(d, meta).cuda()
+    target = torch.from_numpy(d["target"]).cuda()
+    ce = torch.nn.CrossEntropyLoss()
+    nets, opts = [], []
+    for kind in ("flat", "torch"):
+        net = build(meta["cfg"], params_from(d))
+        opt = T.get_optimizer(net, "adam", 1e-3, 0.9) if kind == "flat" else torch.optim.Adam(net.parameters(), lr=1e-3)
+        nets.append(net)
+        opts.append(opt)
+    assert isinstance(opts[0], torch.optim.Adam) and type(opts[0]).__name__ == "FlatAdam"
+    calls = []
+    from music_amd import _lib
+    real_call = _lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real_call(name, *a)
+    _lib.call = spy
+    try:
+        for step in range(4):
+            for net, opt in zip(nets, opts):
+                opt.zero_grad()
+                loss = ce(net(x), target)
+                loss.backward()
+                if step == 2 and opt is opts[0]:
+                    for p in net.parameters():              # foreign gradient tensors: torch's per-tensor path, same state
+                        p.grad = p.grad.clone()
+                opt.step()
+    finally:
+        _lib.call = real_call
+    assert calls.count("wn_adam_flat") == 3                    # steps 0, 1, 3 of the flat optimizer
+    for (n, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), n
+    sd = opts[0].state_dict()
+    assert float(sd["state"][0]["step"]) == 4.0
+    plain = torch.optim.Adam(nets[1].parameters(), lr=1e-3)
+    plain.load_state_dict(sd)                                   # torch's Adam takes it ...
+    opts[0].load_state_dict(opts[1].state_dict())               # ... and the flat one takes torch's
+    opts[0].zero_grad()
+    ce(nets[0](x), target).backward()
+    opts[0].step()
+    assert float(opts[0].state_dict()["state"][0]["step"]) == 5.0
+    m0 = opts[0].state_dict()["state"][0]["exp_avg"]
+    assert m0.shape == next(nets[0].parameters()).shape and torch.isfinite(m0).all()
+
+
 def test_full_size_c2_properties():
     """BASELINE config 2 (30 layers, 64/64/256, batch 8 x 16000): size-independent properties."""
     from music_amd.model import wavenet

@@ -75,7 +75,10 @@ def test_ragged_shapes_vs_oracle(case):
     e_pre = (pre - pre_ref.reshape(B, 256, W)).abs().max().item()
     assert e_pre <= LOGIT_TOL, e_pre
     assert e_p <= LOGIT_TOL, e_p
-    nonvacuous(p_ref, "sweep")
+    # shallow ragged models: what the absolute 1e-3 bar bites on here is the PRE-SOFTMAX (|max| 0.8 ... 34 over the cases), the
+    # probabilities only have to be off the uniform distribution (2 / 256)
+    assert pre_ref.abs().max().item() > 0.5
+    nonvacuous(p_ref, "sweep, |pre-softmax| up to %.2f" % pre_ref.abs().max().item(), 2.0 / 256)
     loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
     assert abs(loss.item() - l_ref.item()) < 1e-4
     loss.backward()

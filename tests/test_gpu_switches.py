@@ -184,7 +184,7 @@ def test_chain_form_equals_pair_form(monkeypatch):
         codes = torch.from_numpy(rng.integers(0, 256, size=(B, T)).astype(np.int32)).cuda()
         target = torch.from_numpy(rng.integers(0, 256, size=(B * (extra + 1),)).astype(np.int64)).cuda()
         got = {}
-        for form in ("1", "0", "1b", "0b"):
+        for form in ("1", "0", "1b", "0b"):                       # b: the same again
             monkeypatch.setenv("WN_PQ_CHAIN", form[0])
             eng._ws.clear()
             loss = eng.loss_and_grad_codes(codes, target)

@@ -129,6 +129,24 @@ def test_g5_mulaw():
     assert np.array_equal(intops.mu_law_encode_table(d["decode_table"], thr), np.arange(256))
 
 
+def test_g5q_mulaw_other_channel_counts():
+    """quantization_channels = 64 / 100 / 512 (audio_func.py:5,24 take it as an argument): the oracle's op-for-op torch
+    restatement against the reference's own known answers, boundary neighbourhoods included, and its decode tables."""
+    d = load_npz("g5q_mulaw.npz")
+    for q in (64, 100, 512):
+        assert np.array_equal(intops.mu_law_encode_torch(d["x%d" % q], q), d["codes%d" % q].astype(np.int64))
+        assert np.array_equal(intops.mu_law_decode_torch(np.arange(q), q), d["decode%d" % q])
+        assert d["codes%d" % q].min() == 0 and d["codes%d" % q].max() == q - 1
+        # the table builder of the product side (a table of constants; samples are encoded on the device) reproduces them
+        from music_amd import audio_func as af
+        thr, tab = af.build_tables(q)
+        assert np.array_equal(np.searchsorted(thr.numpy(), d["x%d" % q], side="right"), d["codes%d" % q])
+        assert np.array_equal(tab.numpy(), d["decode%d" % q])
+    thr, tab = af.build_tables(256)                               # ... and the committed 256-channel tables bit for bit
+    g5 = load_npz("g5_mulaw.npz")
+    assert np.array_equal(thr.numpy(), g5["thresholds"]) and np.array_equal(tab.numpy(), g5["decode_table"])
+
+
 @pytest.mark.parametrize("tag,correct", [("asis", False), ("fixed", True)])
 def test_g6_fast_generate(tag, correct):
     d = load_npz("g6_fastgen.npz")

@@ -23,9 +23,9 @@ if [ "$STAGE" = "all" ] || [ "$STAGE" = "prof" ]; then
   rm -rf gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $REPO/gpurun_out/prof.log 2>&1)
   echo "prof exit $?" | tee -a gpurun_out/summary.txt
-  (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $REPO/gpurun_out/pmc_fetch.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --settle 0 --no-cpu-baseline --no-extras > $REPO/gpurun_out/pmc_fetch.log 2>&1)
   echo "pmc fetch exit $?" | tee -a gpurun_out/summary.txt
-  (cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_write -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $REPO/gpurun_out/pmc_write.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_write -- python3 $REPO/bench.py --steps 2 --warmup 1 --settle 0 --no-cpu-baseline --no-extras > $REPO/gpurun_out/pmc_write.log 2>&1)
   echo "pmc write exit $?" | tee -a gpurun_out/summary.txt
   python3 tools/prof_summary.py gpurun_out > gpurun_out/prof_summary.md 2>&1
   # keep only the small files (the raw traces can be large)

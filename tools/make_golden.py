@@ -291,6 +291,35 @@ def g5_mulaw(af):
              decode_table=dec.astype(np.float32))
 
 
+def g5q_mulaw(af):
+    """audio_func.mu_law_encode / mu_law_decode with quantization_channels other than 256 (the argument of audio_func.py:5,24):
+    known answers of the reference itself for q = 64, 100, 512 - random inputs, the neighbourhood of every code boundary
+    (found by bisection on the reference) and the special values - plus its decode tables."""
+    out = {}
+    rng = np.random.default_rng(55)
+    for q in (64, 100, 512):
+        def enc(a):
+            return af.mu_law_encode(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)), q).numpy()
+        ks = np.arange(1, q)
+        lo = np.full(q - 1, _f32_to_ordered(np.array([-1.0], dtype=np.float32))[0], dtype=np.int64)
+        hi = np.full(q - 1, _f32_to_ordered(np.array([1.0], dtype=np.float32))[0], dtype=np.int64)
+        while (hi - lo > 1).any():
+            mid = (lo + hi) // 2
+            ge = enc(_ordered_to_f32(mid)) >= ks
+            hi = np.where(ge, mid, hi)
+            lo = np.where(ge, lo, mid)
+        thr = _ordered_to_f32(hi)
+        xs = np.concatenate([(0.3 * rng.standard_normal(6000)).astype(np.float32), rng.uniform(-1.2, 1.2, 3000).astype(np.float32),
+                             thr, np.nextafter(thr, np.float32(-2)), np.nextafter(thr, np.float32(2)),
+                             np.array([0.0, -0.0, 1.0, -1.0, 5.0, -5.0, 1e-30, -1e-30, np.inf, -np.inf], dtype=np.float32)])
+        ys = enc(xs)
+        assert (np.searchsorted(thr, xs, side="right") == ys).all(), "reference encoder is not monotone at q = %d" % q
+        dec = af.mu_law_decode(torch.arange(q), q).numpy().astype(np.float32)
+        assert (enc(dec) == np.arange(q)).all()
+        out["x%d" % q], out["codes%d" % q], out["decode%d" % q] = xs, ys.astype(np.int32), dec
+    np.savez_compressed(os.path.join(OUT, "g5q_mulaw.npz"), **out)
+
+
 def load_fast_predict_next(correct=False):
     """Appendix A.3: AST-extract predict_next from fast_generate.py with the two torch>=0.4
     substitutions; never executes the module-level generate() call."""
@@ -578,6 +607,7 @@ def main():
     g3_softmax(model)
     g4_data(fad)
     g5_mulaw(af)
+    g5q_mulaw(af)
     g6_fastgen(model)
     g7_train()
     g8_autoencoder()

@@ -37,6 +37,10 @@ def main():
                                                   float(r["AverageNs"]) / 1e3, r["Percentage"]))
         print()
     pmc = {}
+    launches = {}
+    # steps of the profiled command: the PMC passes run `bench.py --steps 2 --warmup 1 --settle 0` + its 3 phase-table and 3
+    # per-kernel steps (tools/gpu_check.sh); PMC_STEPS overrides.  launches per step = launches / steps.
+    n_steps = float(os.environ.get("PMC_STEPS", "9"))
     for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         files = find(os.path.join(root, tag), "*counter_collection.csv")
         if not files:
@@ -54,14 +58,19 @@ def main():
         for k, (n, v) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:20]:
             print("| %s | %d | %.1f |" % (k, n, v / n))
             pmc.setdefault(k, {})[counter] = v / n
+            launches[k] = n
         print()
     # HBM bytes per launch of the dominant kernel, corrected as MI355X_MICROARCH.md prescribes for gfx950:
     # FETCH_SIZE (KiB) counts 128-B wide reads at 64 B -> x2; WRITE_SIZE (KiB) is exact.
     import json
     allk = {k: {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"],
-                "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024}
+                "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
+                "launches_per_step": round(launches.get(k, 0) / n_steps, 3)}
             for k, v in pmc.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
     if allk:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import csrc_sha
+        allk["_csrc_sha16"] = csrc_sha()                     # the kernel sources these figures belong to (bench.py checks it)
         # bench.py reads this one (copied to profiles/pmc_kernels.json): HBM bytes per launch of every kernel
         json.dump(allk, open(os.path.join(root, "pmc_kernels.json"), "w"), indent=1)
     for k, v in pmc.items():
