@@ -357,7 +357,10 @@ def surface_benchmarks(net, eng, piece, target):
     out = {}
     B, W = piece.shape[0], target.numel() // piece.shape[0]
     ce = torch.nn.CrossEntropyLoss()
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    # the reference builds its optimizer through train.get_optimizer (wavenet/train.py:28-42,138-139); so does this loop, through
+    # the drop-in module's: a torch.optim.Adam whose step() is one launch on the flat buffers (music_amd/train.py FlatAdam)
+    from music_amd import train as wtrain
+    opt = wtrain.get_optimizer(net, "adam", 1e-4, 0.9)
     x_tag = eng.onehot(piece, scrambled=True)
     x_plain = x_tag.clone()                                    # a copy loses the tag: the dense path
 
@@ -378,7 +381,8 @@ def surface_benchmarks(net, eng, piece, target):
         dt = (time.perf_counter() - t0) / 10
         out[name] = {"ms_per_step": dt * 1e3, "samples_per_s": B * piece.shape[1] / dt, "loss": float(loss.item())}
     out["workload"] = ("the reference's own training loop (wavenet/train.py:171-182: zero_grad, net(x), CrossEntropyLoss on the "
-                       "probabilities, backward, torch.optim.Adam) on this nn.Module at 8 x 16000, input resident, 10 steps after 3")
+                       "probabilities, backward, step of train.get_optimizer(net, 'adam', ..)) on this nn.Module at 8 x 16000, input "
+                       "resident, 10 steps after 3; torch's own CrossEntropyLoss kernels are ~0.42 ms of it (kernel trace, DESIGN.md)")
     del x_tag, x_plain, opt
 
     def fused():

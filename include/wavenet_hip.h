@@ -360,7 +360,11 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
  * sync here holds wn_decode_sync_granules(n_layers, D, S) uint64 PER UTTERANCE (error flag = the last word of an
  * utterance's region).  Eight utterances share a workgroup pair, one pair of MFMA result columns each (n_utt <= 1024
  * on this path; when fewer than eight are left for a pair the spare columns mirror the last utterance; same arithmetic
- * per utterance, so rows are bit-identical whatever the batch). */
+ * per utterance, so rows are bit-identical whatever the batch).
+ * With 512 skip channels (and room: at most 24 pairs per launch, else the form above) the skip sum and the post-processing of a
+ * pair are split over S / 64 workgroups, one 16-row tile per wave, their post-processing tiles register-resident, the
+ * S-vectors exchanged as tagged granules through the hand-off area (decode): same sums per row, same codes.
+ * Models deeper than 32 blocks keep the tap-0 partial sums of a sample in the pair's hand-off area instead of LDS. */
 int64_t wn_decode_sync_granules(int n_layers, int D, int S);
 int wn_decode_batch_pk(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
                        float* queues, const float* w_causal, const float* b_causal, const float* w_layers,

@@ -395,8 +395,7 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
 }
 
 int64_t wn_decode_sync_granules(int n_layers, int D, int S) {
-    (void)S;
-    return (int64_t)n_layers * D + 2;          // z hand-offs of every block + the code granule + the error flag
+    return (int64_t)wn_decode_granules(n_layers, D, S);      // z of every block, the split form's vectors, the tap-0 table, code, error flag
 }
 
 int wn_decode_batch_pk(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,

@@ -322,14 +322,27 @@ __device__ __forceinline__ bool dec_poll2(const unsigned long long* p, unsigned 
 // thread and block) take the place of the split queue columns in LDS (n_layers x 4 KB; chosen when that fits: <= 32 blocks).
 #define DEC_T0_CHUNK 4
 // S = 256 or 512 skip channels (the reference's shipped parameters have 512): MS = S / 64 row tiles of an S-vector per wave.
-template <bool BIAS, bool T0, int S = 256>
+//
+// T0 = 2: the tap-0 partial sums of more than 32 blocks do not fit LDS (4 KB per block) - they live in the pair's hand-off area
+// in global memory instead (L2 resident; written a sample ahead, read back one block ahead of their use).
+//
+// KS > 1 (round 4): the skip sum and the post-processing are the work of KS = S / 64 workgroups per pair instead of one.  With 512
+// skip channels ONE workgroup streams 128 KB of skip weights per block and 1.5 MB of post-processing weights per sample from
+// L2 - 6.6 MB per sample at the ~65 GB/s a single CU gets from L2 is 100 us: the skip workgroup, not the chain, set the pace
+// (9.5 k samples/s for the reference's shipped 40-block 32 / 32 / 512 model).  Part j takes rows 64 j .. 64 j + 63 of every
+// S-vector - ONE 16-row tile per wave: 16 KB of skip weights per block, and its tiles of post_process_1 / post_process_2 stay in
+// REGISTERS for the whole launch (2 x 128) - so the tail behind the last block has no weight traffic at all.  The S-vectors
+// (skip sum, post_process_1 output) are exchanged between the parts as tagged granules like z (all-gather: every part
+// publishes its 64 rows and polls the others'), the logits go to part 0, which chooses the codes.
+template <bool BIAS, int T0, int S = 256, int KS = 1>
 __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
     constexpr int NU = 8, R = 64, D = 64, Q = 256, MS = S / 64;
+    static_assert(KS == 1 || KS == S / 64, "one row tile per wave in the split form");
     // LDS strides between utterances (halfs): the eight utterances of a 16-lane group read 16-byte pieces at the same offset of
     // their own vectors - with the natural strides (256 B, 1 KB) all of them in the same banks.  +16 B per utterance spreads the
     // group over all 64 banks (hi | lo halves are 128 B apart for the 64-vectors; 640 B for the 256-vectors)
     constexpr int VS = 2 * R + 8, WLO = S + 64, WS = 2 * WLO + 8;       // (S = 256: 320 and 648)
-    const int pair = blockIdx.x >> 1, role = blockIdx.x & 1;
+    const int pair = blockIdx.x / (1 + KS), role = blockIdx.x - pair * (1 + KS);
     const size_t ubase = (size_t)pair * NU;
     // a pair with fewer than eight utterances left (n_utt not a multiple of 8; a single utterance): the spare columns MIRROR the
     // last real one - same inputs, same arithmetic, same addresses, so their stores only repeat identical values
@@ -340,7 +353,12 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ int s_code[NU], s_pc[NU], s_nc[NU];
     __shared__ int slots[WN_DEC_MAX_LAYERS];
+    // hand-off area of an utterance (8-byte granules): z [n_layers][D] | skip vector [S] | post_process_1 output [S] | logits [Q] |
+    // (first utterance of a pair, T0 = 2: tap-0 table [n_layers][256] x 16 bytes) | code | error flag
     auto zg_of = [&](int uu) { return a.sync + ux(uu) * (size_t)a.sync_ustride; };
+    auto sv_of = [&](int uu) { return zg_of(uu) + (size_t)a.n_layers * D; };
+    auto hv_of = [&](int uu) { return sv_of(uu) + S; };
+    auto lg_of = [&](int uu) { return hv_of(uu) + S; };
     auto cg_of = [&](int uu) { return a.sync + (ux(uu) + 1) * (size_t)a.sync_ustride - 2; };
     unsigned long long* const zg = zg_of(u);                 // [n_layers][D] z granules of this lane's utterance
 
@@ -357,7 +375,8 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
         uint16_t* xh1 = xh0 + NU * VS;
         uint16_t* zh = xh1 + NU * VS;                    // [NU][hi D | lo D], chained k order
         uint16_t* oldh = zh + NU * VS;                   // [n_layers][NU][hi R | lo R] queue columns of this sample (T0: of DEC_T0_CHUNK blocks)
-        f32x4* part = reinterpret_cast<f32x4*>(oldh + (size_t)DEC_T0_CHUNK * NU * VS);      // T0: [n_layers][256] tap-0 partial sums (f0, f1, g0, g1)
+        // T0: [n_layers][256] tap-0 partial sums (f0, f1, g0, g1): in LDS (T0 = 1) or in the pair's hand-off area (T0 = 2)
+        f32x4* part = T0 == 2 ? reinterpret_cast<f32x4*>(lg_of(0) + Q) : reinterpret_cast<f32x4*>(oldh + (size_t)DEC_T0_CHUNK * NU * VS);
         for (int i = tid; i < NU * Q; i += 256) { const int uu = i / Q, e = i - uu * Q; note[i] = a.note0[ux(uu) * Q + e]; prev[i] = a.prev0[ux(uu) * Q + e]; }
         if (BIAS && a.b_layers && !T0) for (int i = tid; i < a.n_layers * BL; i += 256) { const int l = i / BL, e = i - l * BL; bias[i] = a.b_layers[(size_t)l * (BL + S) + e]; }
         if (tid < a.n_layers) slots[tid] = (int)(a.step0 % a.dil[tid]);
@@ -464,12 +483,18 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                 }
                 dec_sync();                                  // the chunk's halfs are consumed: the next chunk may overwrite them
             }
+            if (T0 == 2) {                                   // the table's stores have left this CU before anybody reads it back
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                dec_sync();
+            }
         };
         if (T0) tap0_ahead();
         else load_queues();
         float bdn0 = 0.f, bdn1 = 0.f;                        // T0: the next block's dense bias (two rows of this thread)
+        f32x4 t0n = {0.f, 0.f, 0.f, 0.f};                    // T0 = 2: the next block's partial sums, fetched a block ahead (L2 round trip)
         for (int step = 0; step < a.n_steps; ++step) {
             const unsigned tag = (unsigned)step + 1u;
+            if (T0 == 2) t0n = __builtin_nontemporal_load(part + tid);
             // weight fragments: two register sets, each re-armed two blocks ahead (as in decode_duo_mfma_k)
             Frag<F16> wfA[4], wgA[4], wdA[2], wfB[4], wgB[4], wdB[2];
             const size_t lb1 = a.n_layers > 1 ? (size_t)a.pk_lstride : 0;
@@ -532,7 +557,13 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                 }
                 float f0, f1, g0, g1;
                 if (T0) {
-                    const f32x4 t0 = part[(size_t)l * 256 + tid];                  // W_tap0 x(t - d), formed a sample ahead
+                    f32x4 t0;                                                       // W_tap0 x(t - d), formed a sample ahead
+                    if (T0 == 2) {
+                        t0 = t0n;
+                        t0n = __builtin_nontemporal_load(part + (size_t)(l + 1 < a.n_layers ? l + 1 : l) * 256 + tid);
+                    } else {
+                        t0 = part[(size_t)l * 256 + tid];
+                    }
                     const f32x4 af = dec_pairsum(pf[2] + pf[3]), ag = dec_pairsum(pg[2] + pg[3]);
                     f0 = (h ? af[2] : af[0]) + t0[0]; f1 = (h ? af[3] : af[1]) + t0[1];
                     g0 = (h ? ag[2] : ag[0]) + t0[2]; g1 = (h ? ag[3] : ag[1]) + t0[3];
@@ -602,6 +633,156 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
             dec_sync();
         }
         for (int i = tid; i < NU * Q; i += 256) { const int uu = i / Q, e = i - uu * Q; a.prev_out[ux(uu) * Q + e] = prev[i]; a.note_out[ux(uu) * Q + e] = note[i]; }
+    } else if (KS > 1) {
+        // ------------------------------------------------------------------ skip sum + post-processing, part j of KS: one row tile per wave
+        constexpr int KP = S / 32;                           // k-steps of a product over an S-vector
+        const int jpart = role - 1;
+        const int tile = 4 * jpart + w;                      // this wave's 16 rows of the skip sum and of post_process_1
+        const bool has_p2 = tile < Q / 16;                   // ... and of post_process_2 (Q / 16 tiles: the first waves)
+        uint16_t* zz0 = reinterpret_cast<uint16_t*>(sm);     // [2][NU][hi D | lo D]
+        uint16_t* skip = zz0 + 2 * NU * VS;                  // [NU][hi S | lo S]: the WHOLE vector (own rows + the other parts')
+        uint16_t* h1 = skip + NU * WS;                       // [NU][hi S | lo S]
+        float* logit = reinterpret_cast<float*>(h1 + NU * WS);   // [NU][Q] (part 0)
+        float* bsk = logit + NU * Q;                         // [S] summed skip biases, [S] post_process_1 bias, [Q] post_process_2 bias
+        if (BIAS && a.b_layers) {
+            for (int r = tid; r < S; r += 256) {
+                float t = 0.f;
+                for (int l = 0; l < a.n_layers; ++l) t += a.b_layers[(size_t)l * (2 * D + R + S) + 2 * D + R + r];
+                bsk[r] = t;
+            }
+        }
+        if (BIAS && a.b_p1) for (int r = tid; r < S; r += 256) bsk[S + r] = a.b_p1[r];
+        if (BIAS && a.b_p2) bsk[2 * S + tid] = a.b_p2[tid];
+        dec_sync();
+        const int KSS = a.n_layers * D / 32;
+        const uint16_t* skb = a.pk + a.pk_skip;
+        // this wave's tiles of post_process_1 and post_process_2: 2 x KP fragments, in registers for the whole launch
+        Frag<F16> wp1[KP], wp2[KP];
+#pragma unroll
+        for (int ks = 0; ks < KP; ++ks) {
+            load_a<F16, 3>(wp1[ks], a.pk + a.pk_p1, tile * KP + ks, lane);
+            load_a<F16, 3>(wp2[ks], a.pk + a.pk_p2, (has_p2 ? tile : 0) * KP + ks, lane);
+        }
+        const int row = 16 * tile + 4 * q + 2 * h;           // this lane's two rows (of utterance u): row, row + 1
+        // all-gather of an S-vector (or of the logits): thread (utterance uu = tid >> 5, i = tid & 31) polls the granule pairs
+        // i, i + 32, .. of that utterance - own rows included (they come back from L2 like everybody else's) - until every tag
+        // is this sample's, and leaves the values split in LDS (vector) or as floats (logits)
+        auto gather_rows = [&](const unsigned long long* base, const int n_rows, uint16_t* vec, float* flt, const unsigned tag, unsigned long long* err) __attribute__((always_inline)) {
+            constexpr int NLMAX = S / 64;                    // pairs per thread of an S-vector (logits: Q / 64)
+            const int nl = n_rows / 64;
+            const int uu = tid >> 5, i = tid & 31;
+            unsigned long long g[2 * NLMAX];
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < NLMAX; ++k) {
+                    const unsigned long long* p = base + 2 * (size_t)(i + 32 * (k < nl ? k : 0));
+                    g[2 * k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g[2 * k + 1] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < NLMAX; ++k)
+                    if (k < nl) ok = ok && (unsigned)(g[2 * k] >> 32) == tag && (unsigned)(g[2 * k + 1] >> 32) == tag;
+                if (ok) break;
+                if ((spin & 255) == 255 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (spin == (1 << 22) - 1) __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int k = 0; k < NLMAX; ++k) {
+                if (k < nl) {
+                    const int r2 = 2 * (i + 32 * k);
+                    const float v0 = __uint_as_float((unsigned)g[2 * k]), v1 = __uint_as_float((unsigned)g[2 * k + 1]);
+                    if (vec) dec_put2(vec + uu * WS, WLO, r2, v0, v1);
+                    else { flt[uu * Q + r2] = v0; flt[uu * Q + r2 + 1] = v1; }
+                }
+            }
+        };
+        const unsigned long long* const zmine = zg_of(tid >> 5) + (tid & 31) * 2;       // this thread's two granules of block 0
+        unsigned long long* const errp = cg_of(tid >> 5) + 1;
+        unsigned long long pa = 0, pb = 0;                                               // prefetched pair (tag 0 = nothing yet)
+        for (int step = 0; step < a.n_steps; ++step) {
+            const unsigned tag = (unsigned)step + 1u;
+            f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            Frag<F16> ws[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) load_a<F16, 3>(ws[s2], skb, tile * KSS + s2, lane);
+            for (int l = 0; l < a.n_layers; ++l) {
+                uint16_t* zz = zz0 + (l & 1) * NU * VS;
+                {   // z of block l (asked for one block earlier), as in the one-workgroup form
+                    float za, zb;
+                    if ((unsigned)(pa >> 32) == tag && (unsigned)(pb >> 32) == tag) { za = __uint_as_float((unsigned)pa); zb = __uint_as_float((unsigned)pb); }
+                    else dec_poll2(zmine + (size_t)l * D, tag, za, zb, errp);
+                    const unsigned long long* nx = zmine + (size_t)(l + 1 < a.n_layers ? l + 1 : 0) * D;      // (block 0: the next sample's)
+                    pa = __hip_atomic_load(nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pb = __hip_atomic_load(nx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dec_put2(zz + (tid >> 5) * VS, D, (tid & 31) * 2, za, zb);
+                }
+                dec_sync();
+                const int ln = l + 1 < a.n_layers ? l + 1 : l;
+                const f16x8 bz[2] = {*reinterpret_cast<const f16x8*>(zz + u * VS + h * D + 8 * q),
+                                     *reinterpret_cast<const f16x8*>(zz + u * VS + h * D + 32 + 8 * q)};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) acc2[s2] = F16::mfma(ws[s2].hi, bz[s2], acc2[s2]);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) acc2[s2] = F16::mfma(ws[s2].lo, bz[s2], acc2[s2]);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) load_a<F16, 3>(ws[s2], skb, tile * KSS + 2 * ln + s2, lane);      // next block (unconditional)
+            }
+            {   // this wave's rows of relu(skip sum): published, then the whole vector gathered
+                const f32x4 t = dec_pairsum(acc2[0] + acc2[1]);
+                float v0 = h ? t[2] : t[0], v1 = h ? t[3] : t[1];
+                if (BIAS && a.b_layers) { v0 += bsk[row]; v1 += bsk[row + 1]; }
+                dec_send2(sv_of(u) + row, fmaxf(v0, 0.f), fmaxf(v1, 0.f), tag);
+            }
+            gather_rows(sv_of(tid >> 5), S, skip, nullptr, tag, errp);
+            dec_sync();
+            {   // post_process_1: this wave's tile
+                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int ks = 0; ks < KP; ++ks) {
+                    const f16x8 bx = *reinterpret_cast<const f16x8*>(skip + u * WS + h * WLO + 32 * ks + 8 * q);
+                    acc[ks & 1] = F16::mfma(wp1[ks].hi, bx, acc[ks & 1]);
+                    acc[ks & 1] = F16::mfma(wp1[ks].lo, bx, acc[ks & 1]);
+                }
+                const f32x4 t = dec_pairsum(acc[0] + acc[1]);
+                float v0 = h ? t[2] : t[0], v1 = h ? t[3] : t[1];
+                if (BIAS && a.b_p1) { v0 += bsk[S + row]; v1 += bsk[S + row + 1]; }
+                dec_send2(hv_of(u) + row, fmaxf(v0, 0.f), fmaxf(v1, 0.f), tag);
+            }
+            gather_rows(hv_of(tid >> 5), S, h1, nullptr, tag, errp);
+            dec_sync();
+            if (has_p2) {   // post_process_2: the first Q / 16 waves of the pair's parts hold a tile each
+                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int ks = 0; ks < KP; ++ks) {
+                    const f16x8 bx = *reinterpret_cast<const f16x8*>(h1 + u * WS + h * WLO + 32 * ks + 8 * q);
+                    acc[ks & 1] = F16::mfma(wp2[ks].hi, bx, acc[ks & 1]);
+                    acc[ks & 1] = F16::mfma(wp2[ks].lo, bx, acc[ks & 1]);
+                }
+                const f32x4 t = dec_pairsum(acc[0] + acc[1]);
+                float v0 = h ? t[2] : t[0], v1 = h ? t[3] : t[1];
+                if (BIAS && a.b_p2) { v0 += bsk[2 * S + row]; v1 += bsk[2 * S + row + 1]; }
+                dec_send2(lg_of(u) + row, v0, v1, tag);
+            }
+            if (jpart == 0) {   // part 0 chooses: the logits of all parts, then as the one-workgroup form
+                gather_rows(lg_of(tid >> 5), Q, nullptr, logit, tag, errp);
+                dec_sync();
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {          // wave w chooses for utterances 2w and 2w + 1
+                    const int uu = 2 * w + e;
+                    const size_t ug = ux(uu);
+                    const float ur = a.sample ? dec_uniform(a.seed, (unsigned long long)(a.step0 + step), ug) : 0.f;
+                    float* pdst = a.probs_out ? a.probs_out + (ug * (size_t)a.n_steps + step) * Q : nullptr;
+                    const int bi = dec_choose(logit + uu * Q, lane, pdst, a.inv_temp, a.sample != 0, ur);
+                    if (lane == 0) {
+                        a.codes_out[ug * a.n_steps + step] = bi;
+                        __hip_atomic_store(cg_of(uu), dec_pack((float)bi, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            dec_sync();
+        }
     } else {
         // ------------------------------------------------------------------ skip sum + post-processing
         uint16_t* zz0 = reinterpret_cast<uint16_t*>(sm);        // [2][NU][hi D | lo D]
@@ -737,6 +918,12 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
     }
 }
 
+// granules of one utterance's hand-off area: z of every block | skip vector | post_process_1 output | logits | the pair's tap-0
+// table (deeper than 32 blocks: it does not fit LDS) | code | error flag
+long wn_decode_granules(int n_layers, int D, int S) {
+    return (long)n_layers * D + 2 * (long)S + 256 + (n_layers > 32 ? (long)n_layers * 512 : 0) + 2;
+}
+
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
     if (a.n_steps <= 0) return 0;
     if (a.n_layers > WN_DEC_MAX_LAYERS) return wn_set_error_msg(-4, "decode: too many layers");
@@ -755,39 +942,45 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
         if (e != hipSuccess) return wn_set_error(e, __FILE__, __LINE__);
         const size_t s80_f = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R + (a.b_layers ? a.n_layers * (2 * a.D + a.R) : 0));
         const size_t s80 = s80_f + sizeof(uint16_t) * (size_t)(8 * 136 * (3 + (size_t)a.n_layers));
-        // tap 0 ahead (decode_duo_mfma8_k<.., true>): split queue columns of DEC_T0_CHUNK blocks + 4 KB of partial sums per block
-        const size_t s80_t0 = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R) + sizeof(uint16_t) * (size_t)(8 * 136 * (3 + DEC_T0_CHUNK)) +
-                              (size_t)a.n_layers * 256 * sizeof(f32x4);
+        // tap 0 ahead (decode_duo_mfma8_k<.., 1 | 2>): split queue columns of DEC_T0_CHUNK blocks (+ 4 KB of partial sums per block in LDS: T0 = 1)
+        const size_t s80_t2 = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R) + sizeof(uint16_t) * (size_t)(8 * 136 * (3 + DEC_T0_CHUNK));
+        const size_t s80_t0 = s80_t2 + (size_t)a.n_layers * 256 * sizeof(f32x4);
         const size_t ws_h = 2 * ((size_t)a.S + 64) + 8;               // halfs of one utterance's split S-vector (the kernel's WS)
         const size_t s81 = sizeof(uint16_t) * (size_t)(2 * 8 * 136 + 2 * 8 * ws_h) + sizeof(float) * (size_t)(8 * a.Q + 2 * a.S + a.Q);
-        static int t0_env = -1;
+        static int t0_env = -1, ks_env = -2;
         if (t0_env < 0) { const char* e = getenv("WN_DEC_T0"); t0_env = e ? atoi(e) : 1; }
-        const bool t0 = t0_env && s80_t0 + 1024 <= 160 * 1024;
-        const size_t sh = t0 ? (s80_t0 > s81 ? s80_t0 : s81) : (s80 > s81 ? s80 : s81);
+        if (ks_env < -1) { const char* e = getenv("WN_DEC_KS"); ks_env = e ? atoi(e) : -1; }
+        // tap-0 table: in LDS when it fits (<= 32 blocks), else in the pair's hand-off area (wn_decode_sync_granules leaves room)
+        const long need_tab = wn_decode_granules(a.n_layers, a.D, a.S);
+        const int t0 = !t0_env ? 0 : (s80_t0 + 1024 <= 160 * 1024 ? 1 : (a.sync_ustride >= need_tab ? 2 : 0));
+        // split skip / post-processing (KS = S / 64 workgroups + the chain per pair): the default while every workgroup of every
+        // pair is resident at once (they spin on each other: at most 224 workgroups per launch); WN_DEC_KS=1 forces the
+        // one-workgroup form (what larger batches run).  Measured (round 4): the reference's shipped 40-block 32 / 32 / 512 model
+        // 9.4 -> 17.3 k samples/s single stream, config 5 (30 blocks, 256 skip channels) 26.9 -> 27.4 k
+        const int pairs = (nu + 7) / 8, ks_full = a.S / 64;
+        const bool fits = (long)pairs * (1 + ks_full) <= 224 && a.sync_ustride >= need_tab;
+        const int ks = (ks_env == 0 || ks_env == 1 || !fits) ? 1 : ks_full;
+        const size_t s_chain = t0 == 1 ? s80_t0 : (t0 == 2 ? s80_t2 : s80);
+        const size_t sh = s_chain > s81 ? s_chain : s81;
         if (sh + 1024 > 160 * 1024) return wn_set_error_msg(-4, "decode: this many blocks do not fit the matrix-core kernel's LDS");
-        if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core pairs x 8 utterances: %d utterances, %d steps, %d skip channels, biases %d, tap-0 ahead %d\n", nu, a.n_steps, a.S, any_bias ? 1 : 0, t0 ? 1 : 0);
-        static unsigned long long attr_done = 0;
+        if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] matrix-core, 8 utterances per pair: %d utterances, %d steps, %d skip channels, biases %d, tap-0 ahead %d, skip parts %d\n", nu, a.n_steps, a.S, any_bias ? 1 : 0, t0, ks);
         int dev = 0;
         (void)hipGetDevice(&dev);
         const int mx = 160 * 1024 - 1024;           // (the kernel also has ~350 bytes of static LDS)
-#define DEC_ATTR(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, mx)
-        if (!((attr_done >> dev) & 1ull)) {
-            DEC_ATTR((decode_duo_mfma8_k<true, true, 256>)); DEC_ATTR((decode_duo_mfma8_k<false, true, 256>));
-            DEC_ATTR((decode_duo_mfma8_k<true, false, 256>)); DEC_ATTR((decode_duo_mfma8_k<false, false, 256>));
-            DEC_ATTR((decode_duo_mfma8_k<true, true, 512>)); DEC_ATTR((decode_duo_mfma8_k<false, true, 512>));
-            DEC_ATTR((decode_duo_mfma8_k<true, false, 512>)); DEC_ATTR((decode_duo_mfma8_k<false, false, 512>));
-            attr_done |= 1ull << dev;
-        }
-#undef DEC_ATTR
-        const dim3 gr(2 * ((nu + 7) / 8)), bl(DEC_MT);
-#define DEC_GO(SS) do { \
-        if (any_bias && t0) hipLaunchKernelGGL((decode_duo_mfma8_k<true, true, SS>), gr, bl, sh, st, a); \
-        else if (any_bias) hipLaunchKernelGGL((decode_duo_mfma8_k<true, false, SS>), gr, bl, sh, st, a); \
-        else if (t0) hipLaunchKernelGGL((decode_duo_mfma8_k<false, true, SS>), gr, bl, sh, st, a); \
-        else hipLaunchKernelGGL((decode_duo_mfma8_k<false, false, SS>), gr, bl, sh, st, a); } while (0)
-        if (a.S == 512) DEC_GO(512);
-        else DEC_GO(256);
+        const dim3 gr((1 + ks) * pairs), bl(DEC_MT);
+#define DEC_GO3(BB, TT, SS, KK) do { \
+        static unsigned long long done_ = 0; \
+        if (!((done_ >> dev) & 1ull)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_duo_mfma8_k<BB, TT, SS, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, mx); done_ |= 1ull << dev; } \
+        hipLaunchKernelGGL((decode_duo_mfma8_k<BB, TT, SS, KK>), gr, bl, sh, st, a); } while (0)
+#define DEC_GO2(BB, SS, KK) do { if (t0 == 2) DEC_GO3(BB, 2, SS, KK); else if (t0 == 1) DEC_GO3(BB, 1, SS, KK); else DEC_GO3(BB, 0, SS, KK); } while (0)
+#define DEC_GO(SS, KK) do { if (any_bias) DEC_GO2(true, SS, KK); else DEC_GO2(false, SS, KK); } while (0)
+        if (a.S == 512 && ks > 1) DEC_GO(512, 8);
+        else if (a.S == 512) DEC_GO(512, 1);
+        else if (ks > 1) DEC_GO(256, 4);
+        else DEC_GO(256, 1);
 #undef DEC_GO
+#undef DEC_GO2
+#undef DEC_GO3
     } else {
         if (getenv("WN_DEC_VERBOSE")) fprintf(stderr, "[wn_decode] generic fp32 kernel: %d utterances, %d steps\n", nu, a.n_steps);
         size_t sh = sizeof(float) * (size_t)(3 * a.Q + 3 * a.R + 3 * a.D + 2 * a.S + 64);

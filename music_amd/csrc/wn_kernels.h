@@ -242,3 +242,4 @@ struct WnDecodeArgs {
     long pk_skip, pk_p1, pk_p2;          // "skip" ([S/16][n_layers*D/32]), "p1" ([S/16][S/32]), "p2" ([Q/16][S/32]) fragment bases, natural k order (S = Q = 256)
 };
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st);
+long wn_decode_granules(int n_layers, int D, int S);      // 8-byte granules of one utterance's hand-off area (matrix-core kernels)

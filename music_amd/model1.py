@@ -953,7 +953,19 @@ class wavenet_autoencoder(nn.Module):
         if eng is None or eng.device != device or p0.data_ptr() != eng.flat.data_ptr():
             if any(p.device != device for p in self.parameters()):
                 raise RuntimeError("music_amd.wavenet_autoencoder: parameters and input are on different devices")
-            eng = self._engine = _AutoencoderEngine(self, device)
+            # the specialised kernels cover filter_width 2, 256 quantisation channels and up to 64 residual / dilation channels on
+            # both sides (what the reference ships and BASELINE.json names); any other constructor argument takes the general plan
+            fast = (self.filter_width == 2 and self.quantization_channel == 256 and
+                    max(self.en_residual_channel, self.en_dilation_channel, self.de_residual_channel, self.de_dilation_channel) <= 64)
+            if fast:
+                eng = _AutoencoderEngine(self, device)
+            else:
+                try:
+                    from .ae_generic import GenericAutoencoderEngine
+                except ImportError:
+                    from music_amd.ae_generic import GenericAutoencoderEngine
+                eng = GenericAutoencoderEngine(self, device)
+            self._engine = eng
         return eng
 
     def forward(self, wave_sample):

@@ -98,7 +98,9 @@ def test_bench_two_ranks_on_this_box(tmp_path):
     lines = r.stdout.strip().split("\n")
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout          # ONE JSON line on stdout, nothing else
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak"
+    # rccl_ranks counts ranks whose collective really is RCCL: 0 when the two ranks share the device over gloo
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["rccl_ranks"] == (2 if out["backend"] == "nccl" else 0)
+    assert out["backend"] == ("gloo" if torch.cuda.device_count() < 2 else "nccl")
     assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
     assert "allreduce" in out["phase_ms_per_step"] and out["value"] > 0
     assert abs(out["value"] - 2 * 8 * 16000 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]

@@ -75,7 +75,7 @@ def test_general_plan_forward_and_gradients_vs_oracle(case):
     e_o = (o_dev - inter["pre_softmax"].detach()).abs().max().item()
     assert probs.shape == (B * W, Q) and e_p <= LOGIT_TOL and e_o <= LOGIT_TOL, (e_p, e_o)
     from tests.helpers import nonvacuous
-    nonvacuous(p_ref, "general plan " + name, 10.0 / Q)
+    nonvacuous(p_ref, "general plan " + name, 6.0 / Q)         # at least six times the uniform probability (Q = 64 ... 512)
     assert abs(loss.item() - l_ref.item()) < 1e-4
     worst = 0.0
     gmax = max(g.abs().max().item() for g in g_ref.values())
@@ -155,3 +155,86 @@ def test_cached_queue_decode_on_the_general_plan_with_64_channels():
         pred, st = fg.predict_next(net, onehot[:, :, t:t + 1].cuda(), st)
         pred_o, q_o = wo.fast_predict_next(params, cfg["dilations"], onehot[:, :, t:t + 1], q_o, quantization_channels=128)
         assert int(pred[0]) == int(pred_o[0]), t
+
+
+AE_CASES = [
+    # (name, filter_width, dilations, en R / D, bottleneck, pool, de R / D / S, Q, bias, B, W)
+    ("ae_fw3", 3, [1, 2, 4], 24, 20, 10, 40, 32, 28, 48, 256, False, 2, 320),
+    ("ae_q64_bias", 2, [1, 2, 4, 3], 16, 24, 6, 25, 24, 16, 40, 64, True, 2, 150),
+    ("ae_ch96_80", 2, [1, 2, 4, 8], 72, 96, 12, 50, 96, 80, 112, 256, True, 1, 400),
+    ("ae_fw4_q100", 4, [2, 1], 33, 17, 5, 9, 20, 36, 33, 100, False, 3, 137),
+]
+
+
+@pytest.mark.parametrize("case", AE_CASES, ids=[c[0] for c in AE_CASES])
+def test_general_plan_autoencoder_vs_oracle(case):
+    """wavenet_autoencoder with constructor arguments the specialised kernels do not cover (model1.py:14-31 takes any): other
+    filter widths, quantisation widths, more than 64 channels - through music_amd/ae_generic.py.  Encoding, probabilities,
+    loss and EVERY gradient (bias gradients included) against autograd on the CPU oracle with the same per-forward conditioning
+    projections; both branches of _conditon occur; the fused step gives the same gradients and is bit-reproducible."""
+    from music_amd.model1 import wavenet_autoencoder
+    from music_amd.ae_generic import GenericAutoencoderEngine
+    from oracle import intops
+    name, fw, dil, eR, eD, bw_, pool, dR, dD, dS, Q, bias, B, W = case
+    cfg = dict(filter_width=fw, quantization_channel=Q, dilations=dil, en_residual_channel=eR, en_dilation_channel=eD,
+               en_bottleneck_width=bw_, en_pool_kernel_size=pool, de_residual_channel=dR, de_dilation_channel=dD,
+               de_skip_channel=dS, use_bias=bias)
+    torch.manual_seed(200 + len(name))
+    net = wavenet_autoencoder(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+        net.connection_2.weight.mul_(6.0)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    rf = net.receptive_field
+    assert rf == wo.receptive_field(fw, dil)
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, Q, size=(B, rf + W - 1))
+    x = torch.from_numpy(np.stack([intops.one_hot_proper(r, Q) for r in idx]))
+    target = torch.from_numpy(rng.integers(0, Q, size=(B * W,)).astype(np.int64))
+    Le = W // pool
+    T = rf + W - 1
+    L, stretch = T - (fw - 1), []
+    for d in dil:
+        L -= (fw - 1) * d
+        stretch.append(L % Le == 0)
+    torch.manual_seed(91)
+    net.zero_grad()
+    probs = net(x.cuda())
+    assert isinstance(net._engine, GenericAutoencoderEngine)
+    loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
+    loss.backward()
+    torch.manual_seed(91)
+    cond = wo.draw_conditioning(len(dil), bw_, dD, dS)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    p_ref, enc_ref = wo.autoencoder_forward(leaf, dil, x, pool, cond, filter_width=fw, q=Q)
+    l_ref = torch.nn.functional.cross_entropy(p_ref, target)
+    g_ref = torch.autograd.grad(l_ref, list(leaf.values()), allow_unused=True)
+    e_enc = (net.last_encoding.cpu() - enc_ref.detach()).abs().max().item()
+    e_p = (probs.detach().cpu() - p_ref.detach()).abs().max().item()
+    assert probs.shape == (B * W, Q) and e_enc < 1e-4 and e_p <= LOGIT_TOL, (e_enc, e_p)
+    from tests.helpers import nonvacuous
+    nonvacuous(p_ref.detach(), "general plan " + name, 6.0 / Q)
+    assert abs(loss.item() - l_ref.item()) < 1e-4
+    gs = [torch.zeros_like(leaf[n]) if g is None else g for (n, _), g in zip(net.named_parameters(), g_ref)]
+    gmax = max(g.abs().max().item() for g in gs)
+    worst = 0.0
+    for (n, p), want in zip(net.named_parameters(), gs):
+        got = torch.zeros_like(want) if p.grad is None else p.grad.cpu()
+        err = (got - want).abs().max().item() / max(want.abs().max().item(), 1e-3 * gmax)
+        worst = max(worst, err)
+        assert err <= GRAD_RTOL, (n, err)
+    # the fused step with the same projections: same loss and gradients, bit-reproducible
+    eng = net._engine
+    l2 = eng.loss_and_grad(x.cuda(), target.cuda(), cond)
+    assert abs(l2.item() - l_ref.item()) < 1e-4
+    g1 = eng.flat_grad.clone()
+    for (n, p), want in zip(net.named_parameters(), gs):
+        o = eng.spec.off[n]
+        err = (g1[o:o + p.numel()].view(p.shape).cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-3 * gmax)
+        assert err <= GRAD_RTOL, (n, err)
+    eng.loss_and_grad(x.cuda(), target.cuda(), cond)
+    assert torch.equal(g1, eng.flat_grad)
+    print("%s: fw %d Q %d encoder %d/%d decoder %d/%d/%d bias %d, %d stretch / %d tile layers: enc err %.1e probs err %.1e worst grad err %.1e" %
+          (name, fw, Q, eR, eD, dR, dD, dS, bias, sum(stretch), len(stretch) - sum(stretch), e_enc, e_p, worst))

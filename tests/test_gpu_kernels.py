@@ -426,6 +426,7 @@ def test_mulaw_other_channel_counts_on_device():
     audio_func.py:5,24): bit-exact against the reference's own known answers (tests/golden/g5q_mulaw.npz), code boundaries
     included; encode(decode(k)) == k; tensors of any shape and device come back on their device."""
     from music_amd import audio_func as af
+    from tests.helpers import load_npz
     d = load_npz("g5q_mulaw.npz")
     for q in (64, 100, 512):
         x = torch.from_numpy(d["x%d" % q])

@@ -742,6 +742,7 @@ def test_autoencoder_backward_64_channels_vs_oracle(pool):
     with torch.no_grad():
         for p in net.parameters():
             p.mul_(2.0)
+        net.connection_2.weight.mul_(10.0)          # peaked outputs (max p 0.4): the 1e-3 bar on the probabilities means something
     params = {k: v.clone() for k, v in net.state_dict().items()}
     net = net.cuda()
     rng = np.random.default_rng(42)
@@ -792,6 +793,7 @@ def test_autoencoder_backward_with_bias_vs_oracle(width):
     with torch.no_grad():
         for p in net.parameters():
             p.mul_(2.0)
+        net.connection_2.weight.mul_(10.0)          # peaked outputs (max p 0.24 / 0.30)
     params = {k: v.clone() for k, v in net.state_dict().items()}
     assert any(k.endswith(".bias") for k in params)
     net = net.cuda()

@@ -91,9 +91,22 @@ def test_decode_without_tap0_ahead_stays_correct():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize("env,expr", [({"WN_DEC_KS": "1"}, "decode or generat")], ids=["one_skip_workgroup"])
+def test_decode_skip_forms_stay_correct(env, expr):
+    """The skip sum + post-processing of a pair of eight utterances runs as S / 64 workgroups (one row tile per wave, the
+    S-vectors exchanged as tagged granules) while all workgroups of a launch are resident, and as ONE workgroup beyond that
+    (more than 24 / 44 pairs per launch at 512 / 256 skip channels).  WN_DEC_KS=1 forces the one-workgroup form: every decode
+    and generation test against the oracle on it."""
+    e = dict(os.environ, **env)
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", expr]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+
+
 def test_decode_deeper_than_the_tap0_table_matches_the_oracle():
-    """36 blocks: the tap-0 partial sums (4 KB per block) no longer fit beside the rest of the chain's LDS, the launcher
-    falls back to the kernel that multiplies both taps in the block; ids and probabilities against the oracle."""
+    """36 blocks: the tap-0 partial sums (4 KB per block) no longer fit beside the rest of the chain's LDS: they live in the
+    pair's hand-off area in global memory (read back a block ahead); ids and probabilities against the oracle."""
     import numpy as np
     import torch
     from music_amd import fast_generate as fg
