@@ -48,7 +48,7 @@ import torch  # noqa: E402
 CFG = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 3, dilation_channels=64,
            residual_channels=64, skip_channels=256, quantization_channels=256, use_bias=False)
 B_LOCAL, T = 8, 16000
-MARK_EVERY = int(os.environ.get("WN_BENCH_MARK_EVERY", "4"))             # timed region: HIP events of the stack kernels on every 4th step (an event costs a marker packet)
+MARK_EVERY = 4             # timed region: HIP events of the stack kernels on every 4th step (an event costs a marker packet)
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec); 6.29e12 measured copy
 MFMA_PEAK = 2.5e15         # FLOP/s, dense bf16 / f16 MFMA (same guide)
 BWD_KERNELS = "resblock_bwd_pq_k"

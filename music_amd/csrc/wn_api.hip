@@ -13,21 +13,9 @@ int wn_set_error(hipError_t e, const char* file, int line) {
     snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
     return -1;
 }
-int wn_tile_origin(int t_lo) {
-    static int align = -1;
-    if (align < 0) {
-        const char* e = getenv("WN_TALIGN");
-        align = e ? atoi(e) : 64;
-        if (align < 4 || (align & (align - 1))) align = 4;
-    }
-    return t_lo & ~(align - 1);
-}
+int wn_tile_origin(int t_lo) { return t_lo & ~63; }       // 64 samples = two 128-byte lines of a row (29.7 -> 27.3 us per forward block)
 
-int wn_xcd_swizzle_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("WN_XCD"); on = e ? atoi(e) : 1; }
-    return on;
-}
+int wn_xcd_swizzle_enabled() { return 1; }                 // the XCD-aware block remap is always on (speed only: wn_common.h)
 
 int wn_set_error_msg(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -432,7 +420,7 @@ static int decode_impl(int n_layers, int R, int D, int S, int Q, const int32_t* 
     a.b_layers = b_layers; a.w_p1 = w_p1; a.b_p1 = b_p1; a.w_p2 = w_p2; a.b_p2 = b_p2;
     a.note0 = note0; a.prev0 = prev0; a.note_out = note_out; a.prev_out = prev_out; a.forced = forced;
     a.codes_out = codes_out; a.probs_out = probs_out; a.step0 = step0; a.n_steps = n_steps; a.push_input = push_input;
-    { const char* e = getenv("WN_DEC_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = 0;
     a.sync = reinterpret_cast<unsigned long long*>(sync);
     a.sync_ustride = sync_ustride;
     a.n_utt = n_utt; a.queues_ustride = queues_ustride;

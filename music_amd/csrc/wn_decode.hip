@@ -955,11 +955,15 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
         const int t0 = !t0_env ? 0 : (s80_t0 + 1024 <= 160 * 1024 ? 1 : (a.sync_ustride >= need_tab ? 2 : 0));
         // split skip / post-processing (KS = S / 64 workgroups + the chain per pair): the default while every workgroup of every
         // pair is resident at once (they spin on each other: at most 224 workgroups per launch); WN_DEC_KS=1 forces the
-        // one-workgroup form (what larger batches run).  Measured (round 4): the reference's shipped 40-block 32 / 32 / 512 model
-        // 9.4 -> 17.3 k samples/s single stream, config 5 (30 blocks, 256 skip channels) 26.9 -> 27.4 k
+        // one-workgroup form (what larger batches run), any other value the split form wherever it fits.  Measured (round 4): the
+        // reference's shipped 40-block 32 / 32 / 512 model 9.4 -> 17.3 k samples/s single stream and 0.96 -> 1.40 M at 128
+        // utterances; config 5 (30 blocks, 256 skip channels) 27.0 -> 27.6 k single stream, but 1.59 -> 1.41 M at 64 utterances and
+        // 3.14 -> 2.82 M at 128 (one workgroup keeps pace there, the extra pollers only cost): at 256 skip channels the split
+        // form is the default for ONE pair (up to eight utterances) only
         const int pairs = (nu + 7) / 8, ks_full = a.S / 64;
         const bool fits = (long)pairs * (1 + ks_full) <= 224 && a.sync_ustride >= need_tab;
-        const int ks = (ks_env == 0 || ks_env == 1 || !fits) ? 1 : ks_full;
+        const bool want = ks_env > 1 || (ks_env < 0 && (a.S == 512 || pairs <= 1));
+        const int ks = (fits && want) ? ks_full : 1;
         const size_t s_chain = t0 == 1 ? s80_t0 : (t0 == 2 ? s80_t2 : s80);
         const size_t sh = s_chain > s81 ? s_chain : s81;
         if (sh + 1024 > 160 * 1024) return wn_set_error_msg(-4, "decode: this many blocks do not fit the matrix-core kernel's LDS");

@@ -232,15 +232,8 @@ __global__ __launch_bounds__(GR_THREADS, 2) void chan_gemm_rw_k(WnGemmArgs a, Gr
     }
 }
 
-static int gr_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("WN_GEMM_RW"); v = e ? (atoi(e) != 0) : 1; }
-    return v;
-}
-
 // returns 1 if the launch was taken, 0 if the arguments are outside this kernel's preconditions
 int wn_launch_gemm_rw(const WnGemmArgs& k, int batch, int mode, hipStream_t st) {
-    if (!gr_enabled()) return 0;
     if (mode != WN_MODE_BF16X3 && mode != WN_MODE_F16X3) return 0;
     const int ks = k.ks0 + k.ks1;
     if (k.mt != 4 || (ks != 8 && ks != 4) || (k.ks1 > 0 && !k.in1) || k.relu_in || k.out_shift != 0) return 0;

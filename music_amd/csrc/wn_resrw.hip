@@ -537,9 +537,7 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
 void wn_resrw_plan(int t_lo, int t_hi, int batch, int& t_base, int& steps, int& ipw, int& nwg) {
     // items start on multiples of 32 samples of absolute time = 128-byte lines of every row (pitch and bases
     // are multiples of 128 B): each 32-sample row segment an item reads or writes is exactly ONE cache line
-    static int align = -1;
-    if (align < 0) { const char* e = getenv("WN_RW_ALIGN"); align = e ? atoi(e) : 32; if (align < 4) align = 4; }
-    t_base = t_lo & ~(align - 1);
+    t_base = t_lo & ~(RW_COLS - 1);
     steps = (t_hi - t_base + RW_COLS - 1) / RW_COLS;
     const int total = steps * batch;
     ipw = (total + 255) / 256;

@@ -177,6 +177,9 @@ class WaveNetEngine:
         # epilogue's three (2 rounds of workgroups at 80 % fill each) then pack into the data-gradient GEMMs'
         # idle CUs (epilogue backward 1.25 -> 1.00 ms)
         self.overlap_wgrad = True
+        # the forward epilogue's three products as this many per-clip-group chains, every second one on the side stream (1 = one
+        # chain on the main stream; bit-identical results: tests/test_gpu_switches.py)
+        self.epi_chains = 2
         # Channel-split backward block with both weight gradients in the launch (wn_resblock_bwd_ms):
         # 64 padded channels, (f16x3, bf16x3) only; None = whenever it applies (WN_MS_BWD=0 turns it off)
         self.ms_bwd = None
@@ -447,8 +450,7 @@ class WaveNetEngine:
         ws["pair"] = self.pair_ok and B % 2 == 0
         # the FORWARD block of the 64-channel form takes 512 columns per workgroup: below ~200 workgroups (B / 2 pairs x T / 512)
         # the 32-channel forward fills the chip better (same X / Z layout either way; the backward pairs regardless)
-        fw = os.environ.get("WN_PAIR32_FWD", "auto")
-        ws["pair_fwd"] = ws["pair"] and (fw == "1" or (fw == "auto" and (B // 2) * ((T + 511) // 512) >= 200))
+        ws["pair_fwd"] = ws["pair"] and (B // 2) * ((T + 511) // 512) >= 200
         return ws
 
     def _bwd_workspace(self, ws):
@@ -567,7 +569,7 @@ class WaveNetEngine:
         # tensor has not been written to since)
         tag = getattr(x, "_wn_codes", None) if x is not None else None
         ws["x_codes"] = (codes[0], bool(codes[1])) if x is None else None
-        if tag is not None and os.environ.get("WN_CAUSAL_CODES", "1") == "1":
+        if tag is not None:
             codes, scrambled, version, cversion = tag
             if (x._version == version and codes._version == cversion and codes.is_cuda and codes.dtype == torch.int32 and codes.is_contiguous() and
                     tuple(codes.shape) == (B, T)):
@@ -624,7 +626,7 @@ class WaveNetEngine:
             call("wn_chan_gemm", ptr(ws["H"], SLACK + b0 * SP * pitch), None, SP * pitch, pitch, lo, T, 0, 0, SP // 32, 0, fr("p2"), Q // 16, Q,
                  ptr(ws["O"], b0 * Q * W), Q * W, W, -lo, self._bias_ptr("post_process_2.bias"),
                  None, 0, 0, 0, None, 0, 0, lo, T, 1, nb, mf, s_)
-        nsplit = min(int(os.environ.get("WN_EPI_SPLIT", "2")), B)
+        nsplit = min(int(self.epi_chains), B)
         if nsplit >= 2:
             # the three products of each part of the clips as a chain of its own, every second chain on the side stream: a
             # product's half-empty last round of workgroups (408 tiles of 256 columns on 256 CUs) then packs into the other

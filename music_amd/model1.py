@@ -83,7 +83,7 @@ class _AutoencoderEngine:
         self._gen = 0
         self.marks = None            # list of (name, torch.cuda.Event) when phase timing is on (bench.py)
         self._side = None            # second HIP stream for the epilogue's weight gradients (as music_amd/engine.py)
-        self.overlap_wgrad = os.environ.get("WN_AE_OVERLAP", "1") == "1"
+        self.overlap_wgrad = True
 
     def mark(self, name):
         if self.marks is not None:
@@ -311,13 +311,12 @@ class _AutoencoderEngine:
         ws["gen"], ws["x_in"], ws["Le"] = self._gen, x, Le
         pair = ws["pair"] = self.pair_ok and B % 2 == 0 and Le <= 32      # decided per workspace shape (B, T fix Le)
         # the forward blocks pair only when that fills the chip (music_amd/engine.py); the backward blocks always
-        fw = os.environ.get("WN_PAIR32_FWD", "auto")
-        pair_f = pair and (fw == "1" or (fw == "auto" and (B // 2) * ((T + 511) // 512) >= 200))
+        pair_f = pair and (B // 2) * ((T + 511) // 512) >= 200
         # a one-hot built from integer codes (engine.onehot / the loader) carries them: both causal layers then run on the
         # codes (gather forward, scatter backward), as in music_amd/engine.py
         ws["x_codes"] = None
         tag = getattr(x, "_wn_codes", None)
-        if tag is not None and os.environ.get("WN_CAUSAL_CODES", "1") == "1":
+        if tag is not None:
             codes, scrambled, version, cversion = tag
             if (x._version == version and codes._version == cversion and codes.is_cuda and codes.dtype == torch.int32 and
                     codes.is_contiguous() and tuple(codes.shape) == (B, T)):
@@ -463,8 +462,8 @@ class _AutoencoderEngine:
             g_("c2", ptr(ws["R1"], SLACK + o), None, sb, pitch, lo, T, 0, 0, SP // 32, 0, Q // 16, Q,
                ptr(ws["O"], b0 * Q * W), Q * W, W, -lo, self._bias("connection_2"), NONE3, NONE3, lo, T, 1)
         # two per-clip-group chains, the second on the side stream: a product's half-empty last round of workgroups packs into
-        # the other chain's launches (music_amd/engine.py, WN_EPI_SPLIT; bit-identical results)
-        nsplit = min(int(os.environ.get("WN_EPI_SPLIT", "2")), B)
+        # the other chain's launches (music_amd/engine.py epi_chains; bit-identical results)
+        nsplit = min(2, B)
         if nsplit >= 2 and self.overlap_wgrad:
             main = torch.cuda.current_stream()
             if self._side is None:
@@ -513,16 +512,15 @@ class _AutoencoderEngine:
                       and os.environ.get("WN_MS_BWD", "1") == "1")
         bw["ms"] = ms
         # ... and the data gradient inside the same launch, as the (P, Q) pair (wn_resblock_bwd_pq), without biases
-        # (the conditioning gradient too, as bucket sums on the matrix cores: at most 32 pooled frames; WN_AE_COND_FUSED=0
-        # keeps the blocks on wn_resblock_bwd_ms + wn_cond_grad, what longer encodings run)
-        bw["pq"] = pair or (ms and not self.use_bias and os.environ.get("WN_PQ_BWD", "1") == "1" and "cidx" in ws
-                            and os.environ.get("WN_AE_COND_FUSED", "1") == "1")
+        # (the conditioning gradient too, as bucket sums on the matrix cores: at most 32 pooled frames - the forward built the
+        # bucket bytes then; longer encodings, and WN_AE_COND_MFMA=0, keep wn_resblock_bwd_ms + wn_cond_grad)
+        bw["pq"] = pair or (ms and not self.use_bias and os.environ.get("WN_PQ_BWD", "1") == "1" and "cidx" in ws)
         if bw["pq"]:
             bw["PQ"] = [(buf(self.CHd), buf(self.CHd)), (buf(self.CHd), buf(self.CHd))]
         else:
             bw["dfg"] = buf(2 * self.CHd)               # [df;dg] in HBM: only the other block kernels write it
         # encoder blocks: wn_enc_resblock_bwd (dh + both weight gradients in one launch) where it applies
-        enc_fused = pair or (self.CHe == 64 and self.mode_b == _lib.BF16X3 and os.environ.get("WN_AE_FUSED_ENC_BWD", "1") == "1")
+        enc_fused = pair or (self.CHe == 64 and self.mode_b == _lib.BF16X3 and self.fused_encoder)
         bw["enc_fused"] = enc_fused
         # ... and the data gradient inside the same launch, as the (P, Q) pair (wn_enc_resblock_bwd_pq), without biases
         bw["enc_pq"] = pair or (enc_fused and not self.use_bias and os.environ.get("WN_AE_ENC_PQ", "1") == "1")

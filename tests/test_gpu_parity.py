@@ -1155,11 +1155,9 @@ def test_code_aware_causal_gradient_equals_dense_path(scrambled, monkeypatch):
     eng.loss_and_grad(x, target)
     assert eng.workspace(B, T)["x_codes"] is not None
     g_codes = eng.flat_grad.clone()
-    monkeypatch.setenv("WN_CAUSAL_CODES", "0")
-    eng.loss_and_grad(x, target)
+    eng.loss_and_grad(x.clone(), target)                  # a copy carries no codes: the dense path
     assert eng.workspace(B, T)["x_codes"] is None
     g_dense = eng.flat_grad.clone()
-    monkeypatch.delenv("WN_CAUSAL_CODES")
     # both the forward (gather of exact fp32 weights instead of the f16 split product: x0 moves by ~2e-7) and the causal
     # weight gradient (scatter) differ in rounding only
     o = eng.spec.off["causal_layer.weight"]
@@ -1190,11 +1188,9 @@ def test_code_aware_causal_gradient_equals_dense_path(scrambled, monkeypatch):
     assert eng.workspace(B, T)["x_codes"] is None
     # the codes alone (no one-hot tensor at all): same loss, probabilities and gradients
     x = eng.onehot(codes, scrambled=scrambled)
-    monkeypatch.setenv("WN_CAUSAL_CODES", "0")
-    l_dense = eng.loss_and_grad(x, target, want_probs=True).item()
+    l_dense = eng.loss_and_grad(x.clone(), target, want_probs=True).item()      # (a copy: the dense path)
     p_dense = eng.workspace(B, T)["probs"].clone()
     g_dense = eng.flat_grad.clone()
-    monkeypatch.delenv("WN_CAUSAL_CODES")
     l_codes = eng.loss_and_grad_codes(codes, target, scrambled=scrambled, want_probs=True).item()
     assert abs(l_codes - l_dense) < 1e-6
     assert (eng.workspace(B, T)["probs"] - p_dense).abs().max().item() < 1e-4
@@ -1232,8 +1228,7 @@ def test_autoencoder_causal_layers_on_codes_equal_dense_path(scrambled, monkeypa
     l1 = eng.loss_and_grad(x, target, cond).item()
     assert eng.workspace(B, T)["x_codes"] is not None
     g1 = eng.flat_grad.clone()
-    monkeypatch.setenv("WN_CAUSAL_CODES", "0")
-    l0 = eng.loss_and_grad(x, target, cond).item()
+    l0 = eng.loss_and_grad(x.clone(), target, cond).item()      # a copy carries no codes: both causal layers on the dense tensor
     assert eng.workspace(B, T)["x_codes"] is None
     g0 = eng.flat_grad.clone()
     assert abs(l1 - l0) < 1e-6
@@ -1241,7 +1236,6 @@ def test_autoencoder_causal_layers_on_codes_equal_dense_path(scrambled, monkeypa
         o = eng.spec.off[name]
         u, v = g1[o:o + p.numel()], g0[o:o + p.numel()]
         assert (u - v).abs().max().item() <= 1e-2 * max(v.abs().max().item(), 1e-30), name
-    monkeypatch.delenv("WN_CAUSAL_CODES")
     # bit-reproducible, and through autograd the tag survives detach()
     eng.loss_and_grad(x, target, cond)
     assert torch.equal(g1, eng.flat_grad)

@@ -15,9 +15,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SWITCHES = [
     {"WN_PQ_BWD": "0"},            # resblock_bwd_rw_k + chan_gemm_rw_k instead of the one-launch block (what biased / conditioned blocks run)
     {"WN_MS_BWD": "0"},            # resblock_bwd_k + 2 x wgrad_k instead of the two-role block (what 32 padded channels / x1 modes run)
-    {"WN_GEMM_RW": "0"},           # one-pass narrow product (chan_gemm_k) for the per-layer data gradient (what other shapes run)
-    {"WN_TALIGN": "4"},            # tile origins at t_lo & ~3 instead of 64-sample lines (also disables the two-role narrow product)
-    {"WN_XCD": "0"},               # no XCD-aware block remap
     {"WN_PQ_CHAIN": "0"},          # every one-launch block hands the (P, Q) pair on (no chain walk: what d < 32 and short clips run)
 ]
 
@@ -32,14 +29,14 @@ def test_alternative_paths_stay_correct(env):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
-@pytest.mark.parametrize("env", [{"WN_AE_FUSED_ENC": "0"}, {"WN_AE_FUSED_ENC_BWD": "0"}, {"WN_PQ_BWD": "0"}, {"WN_AE_COND_FUSED": "0"}, {"WN_AE_COND_MFMA": "0"}, {"WN_AE_ENC_PQ": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+@pytest.mark.parametrize("env", [{"WN_AE_FUSED_ENC": "0"}, {"WN_PQ_BWD": "0"}, {"WN_AE_COND_MFMA": "0"}, {"WN_AE_ENC_PQ": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_autoencoder_alternative_paths_stay_correct(env):
-    """The autoencoder with its encoder blocks as two channel GEMMs (instead of wn_enc_resblock_fwd) / its encoder
-    blocks' backward as GEMM + weight-gradient launches (the paths 32-channel encoders run) / its decoder blocks on
-    wn_resblock_bwd_ms + the data-gradient GEMM (what biased decoders run) / the conditioning gradient as bucket sums of a
-    written [df;dg] (wn_cond_grad: what more than 32 pooled frames run) / the conditioning bias gathered in the forward block
-    instead of multiplied (same) / the encoder blocks' data gradient as a launch of its own on a written dh (what biased
-    encoders run): the G8 forward fixture and the 64-channel backward parity test."""
+    """The autoencoder with its encoder blocks as two channel GEMMs forward and GEMM + weight-gradient launches backward
+    (WN_AE_FUSED_ENC=0: the paths 32-channel encoders run) / its decoder blocks on wn_resblock_bwd_ms + the data-gradient
+    GEMM (what biased decoders run) / the conditioning bias gathered in the forward block instead of multiplied and its
+    gradient as bucket sums of a written [df;dg] (WN_AE_COND_MFMA=0, wn_cond_grad: what more than 32 pooled frames run) /
+    the encoder blocks' data gradient as a launch of its own on a written dh (what biased encoders run): the G8 forward
+    fixture and the 64-channel backward parity test."""
     e = dict(os.environ, **env)
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", "g8_autoencoder_forward or autoencoder_backward_64"]
@@ -91,12 +88,14 @@ def test_decode_without_tap0_ahead_stays_correct():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
-@pytest.mark.parametrize("env,expr", [({"WN_DEC_KS": "1"}, "decode or generat")], ids=["one_skip_workgroup"])
+@pytest.mark.parametrize("env,expr", [({"WN_DEC_KS": "1"}, "decode or generat"), ({"WN_DEC_KS": "8"}, "decode or generat")],
+                         ids=["one_skip_workgroup", "split_skip_parts"])
 def test_decode_skip_forms_stay_correct(env, expr):
     """The skip sum + post-processing of a pair of eight utterances runs as S / 64 workgroups (one row tile per wave, the
-    S-vectors exchanged as tagged granules) while all workgroups of a launch are resident, and as ONE workgroup beyond that
-    (more than 24 / 44 pairs per launch at 512 / 256 skip channels).  WN_DEC_KS=1 forces the one-workgroup form: every decode
-    and generation test against the oracle on it."""
+    S-vectors exchanged as tagged granules) at 512 skip channels and for a single pair at 256, and as ONE workgroup otherwise
+    (batches at 256 skip channels; more than 24 pairs per launch at 512).  WN_DEC_KS=1 forces the one-workgroup form, any
+    larger value the split form wherever all workgroups of the launch are resident: every decode and generation test against
+    the oracle on both."""
     e = dict(os.environ, **env)
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", expr]
@@ -144,7 +143,7 @@ def test_decode_deeper_than_the_tap0_table_matches_the_oracle():
 
 @pytest.mark.parametrize("bias", [False, True])
 def test_forward_epilogue_chains_give_the_same_bits(bias, monkeypatch):
-    """The skip product and the two post-processing products run as per-clip-group chains on two streams (WN_EPI_SPLIT,
+    """The skip product and the two post-processing products run as per-clip-group chains on two streams (engine.epi_chains,
     default 2; read at every call): every clip goes through the same tiles whatever the grouping, so probabilities, loss
     and gradients must be bit-identical for 1 chain, 2, and 3 (ragged groups of a batch of 3)."""
     import numpy as np
@@ -160,8 +159,9 @@ def test_forward_epilogue_chains_give_the_same_bits(bias, monkeypatch):
     x = scrambled_input(rng.integers(0, 256, size=(3, T))).cuda()
     target = torch.from_numpy(rng.integers(0, 256, size=(3 * 701,)).astype(np.int64)).cuda()
     got = {}
+    net(x)
     for split in ("1", "2", "3"):
-        monkeypatch.setenv("WN_EPI_SPLIT", split)
+        net._engine.epi_chains = int(split)
         probs = net(x).detach().clone()
         eng = net._engine
         loss = eng.loss_and_grad(x, target)
