@@ -555,7 +555,9 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
             load_x(rx, pos_r(it, XD + 1));                  // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
 #ifndef PQ_T_NOFILLDY
-            fill_dy(rd, pos_r(it, 1), (it + 1) & 1);        // (the R waves wait at the barrier otherwise: the W waves are the pole)
+            // (on the W waves instead - they wait 15 % of their time at the barrier in the chain form, the R waves 3.5 % - the stack
+            // got SLOWER, 1.99-2.02 vs 1.93-1.97 ms same box, round 4: their loads of the same rows then queue behind each other)
+            fill_dy(rd, pos_r(it, 1), (it + 1) & 1);
             load_dy(rd, pos_r(it, 2));
 #endif
             pq_r((it + 1) & 1, pos_r(it, -1));                 // Q rows (CHAIN: the first half of dx) of the previous item
@@ -886,6 +888,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             convert(ops, rr, pos_r(it, 0));
             load_rows(rr, pos_r(it, WD));
 #endif
+
             win_advance();
             PQ_TICK(k3);
             __syncthreads();
@@ -913,10 +916,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     if (HAS_DY && a.slab_d) {
         float* sd = a.slab_d + (size_t)wgid * (CH * CH);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_nontemporal_store(cd[m][i], &sd[(size_t)(16 * g + c) * CH + 16 * m + 4 * q + i]);
+        for (int m = 0; m < 4; ++m)            // 4 consecutive floats of a row per lane: one 16-byte store
+            __builtin_nontemporal_store(cd[m], reinterpret_cast<f32x4*>(&sd[(size_t)(16 * g + c) * CH + 16 * m + 4 * q]));
     }
     if (wv == 4) {
         PQ_STAMP(5);

@@ -86,8 +86,15 @@ class WorkspacePool:
                 self._last[key] = ws
                 return ws
         if len(lst) >= self.MAX_PER_SHAPE:
-            raise RuntimeError("music_amd: %d forwards of shape %s are waiting for their backward; run backward() (or drop "
-                               "the outputs) before another forward of this shape" % (len(lst), key))
+            # the reference never runs out (autograd just keeps allocating): take the OLDEST waiting forward's workspace over, say
+            # so once, and let a backward that still arrives for it fail loudly (its generation no longer matches)
+            import warnings
+            warnings.warn("music_amd: %d forwards of shape %s are waiting for their backward; the oldest one's activations are "
+                          "reused (run backward(), drop the outputs, or use torch.no_grad() for inference)" % (len(lst), key))
+            ws = min(lst, key=lambda w: w.get("gen", 0))
+            ws["held"] = False
+            self._last[key] = ws
+            return ws
         ws = self._make(B, T)
         lst.append(ws)
         self._last[key] = ws

@@ -43,9 +43,15 @@ except ImportError:
 def _mfma_decode(eng):
     """True when the matrix-core decode kernels serve this model (wn_decode_batch_pk): up to 64 residual / dilation channels -
     fewer are PADDED to 64 with zero rows and columns (the decoder is bound by latency, not traffic: the padding is free) -,
-    256 or 512 skip channels, 256 quantisation channels, f16x3 forward mode; biases are fine.  WN_DEC_MFMA=0: never."""
-    return (os.environ.get("WN_DEC_MFMA", "1") == "1" and getattr(eng, "k", 2) == 2 and eng.R <= 64 and eng.D <= 64 and
-            eng.S in (256, 512) and eng.Q == 256 and eng.mode_fwd == _lib.F16X3 and "fg0" in getattr(eng, "pk_f_off", {}))
+    256 or 512 skip channels, 256 quantisation channels, f16x3 forward mode; biases are fine.  WN_DEC_MFMA=0: never.
+    Decided ONCE per engine (the queue column width of every DecodeState and the layout of the weight pack follow from it:
+    a switch flipped inside a process must not make them disagree)."""
+    v = getattr(eng, "_dec_mfma", None)
+    if v is None:
+        v = eng._dec_mfma = bool(os.environ.get("WN_DEC_MFMA", "1") == "1" and getattr(eng, "k", 2) == 2 and eng.R <= 64 and
+                                 eng.D <= 64 and eng.S in (256, 512) and eng.Q == 256 and eng.mode_fwd == _lib.F16X3 and
+                                 "fg0" in getattr(eng, "pk_f_off", {}))
+    return v
 
 
 def _ring_width(eng):
@@ -200,6 +206,9 @@ def _decode(net, state, note0, n_steps, forced=None, want_probs=False, correct_q
     pack = getattr(net, "_decode_pack", None)
     if pack is None or pack.eng is not eng:
         pack = net._decode_pack = _DecodePack(eng)
+    if state.rw != pack.Rp:
+        raise RuntimeError("music_amd.fast_generate: this DecodeState holds %d floats per queue column, the weight pack is laid "
+                           "out for %d (built for another engine or decode kernel form)" % (state.rw, pack.Rp))
     pack.refresh()
     dev = eng.device
     codes = torch.empty(n_steps, dtype=torch.int32, device=dev)

@@ -22,7 +22,7 @@ except ImportError:                      # imported as a bare module (`from mode
 
 class _WaveNetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, wave_sample, *params):
+    def forward(ctx, net, grad_on, wave_sample, *params):
         eng = net._engine_for(wave_sample.device)
         x = wave_sample.detach()
         if x.dtype != torch.float32 or not x.is_contiguous():
@@ -33,9 +33,11 @@ class _WaveNetFunction(torch.autograd.Function):
                 x._wn_codes = (tag[0], tag[1], x._version, tag[3])
         probs, ws = eng.forward(x)
         ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
-        # a forward that some backward may follow keeps its workspace: the next forward of this shape gets another
-        # one (several micro-batches in flight, as the reference's autograd allows)
-        ctx.hold = WorkspaceHold(ws) if any(ctx.needs_input_grad) else None
+        # a forward that some backward may follow keeps its workspace: the next forward of this shape gets another one (several
+        # micro-batches in flight, as the reference's autograd allows).  `grad_on` is torch.is_grad_enabled() as the caller saw
+        # it (inside Function.forward it is always off, and needs_input_grad is True for parameters even under no_grad): an
+        # inference forward holds nothing
+        ctx.hold = WorkspaceHold(ws) if (grad_on and any(ctx.needs_input_grad)) else None
         # a fresh alias goes out: the workspace keeps `probs` for the backward, and the tensor autograd hangs this node on
         # must not be the one the workspace holds (workspace -> output -> node -> hold -> workspace would never die)
         return probs.detach()
@@ -57,7 +59,7 @@ class _WaveNetFunction(torch.autograd.Function):
             for s in shp:
                 n *= s
             grads.append(g[o:o + n].view(shp))
-        return (None, None) + tuple(grads)
+        return (None, None, None) + tuple(grads)
 
 
 class wavenet(nn.Module):
@@ -134,7 +136,7 @@ class wavenet(nn.Module):
         if output_width <= 0:
             raise ValueError("wave sample not long enough")
         params = [p for _, p in self._named_ref_params()]
-        return _WaveNetFunction.apply(self, wave_sample, *params)
+        return _WaveNetFunction.apply(self, torch.is_grad_enabled(), wave_sample, *params)
 
 
 def predict_next(model, wave_var, quantization_channels=256):

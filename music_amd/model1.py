@@ -848,7 +848,7 @@ class _AutoencoderEngine:
 
 class _AutoencoderFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, wave_sample, cond, *params):
+    def forward(ctx, net, grad_on, wave_sample, cond, *params):
         eng = net._engine_for(wave_sample.device)
         x = wave_sample.detach()
         if x.dtype != torch.float32 or not x.is_contiguous():
@@ -860,7 +860,7 @@ class _AutoencoderFunction(torch.autograd.Function):
         probs, enc, ws = eng.forward(x, cond)
         net.last_encoding = enc
         ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
-        ctx.hold = WorkspaceHold(ws) if any(ctx.needs_input_grad) else None      # see music_amd/model.py
+        ctx.hold = WorkspaceHold(ws) if (grad_on and any(ctx.needs_input_grad)) else None      # see music_amd/model.py
         return probs.detach()            # (an alias: the workspace's own reference must not carry the autograd node)
 
     @staticmethod
@@ -876,7 +876,7 @@ class _AutoencoderFunction(torch.autograd.Function):
         for name in eng.param_names:
             o, shp = eng.spec.off[name], eng.spec.shape[name]
             grads.append(g[o:o + int(np.prod(shp))].view(shp))
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
 class wavenet_autoencoder(nn.Module):
@@ -973,4 +973,4 @@ class wavenet_autoencoder(nn.Module):
             raise ValueError("wave sample not long enough")
         self._engine_for(wave_sample.device)
         cond = self._draw_conditioning()
-        return _AutoencoderFunction.apply(self, wave_sample, cond, *list(self.parameters()))
+        return _AutoencoderFunction.apply(self, torch.is_grad_enabled(), wave_sample, cond, *list(self.parameters()))
