@@ -364,7 +364,7 @@ int wn_decode_batch(int n_layers, int R, int D, int S, int Q, const int32_t* dil
  * With 512 skip channels (and room: at most 24 pairs per launch, else the form above) the skip sum and the post-processing of a
  * pair are split over S / 64 workgroups, one 16-row tile per wave, their post-processing tiles register-resident, the
  * S-vectors exchanged as tagged granules through the hand-off area (decode): same sums per row, same codes.
- * Models deeper than 32 blocks keep the tap-0 partial sums of a sample in the pair's hand-off area instead of LDS. */
+ * Models deeper than 31 blocks keep the tap-0 partial sums of a sample in the pair's hand-off area instead of LDS. */
 int64_t wn_decode_sync_granules(int n_layers, int D, int S);
 int wn_decode_batch_pk(int n_layers, int R, int D, int S, int Q, const int32_t* dilations_host, const int64_t* q_off_host,
                        float* queues, const float* w_causal, const float* b_causal, const float* w_layers,

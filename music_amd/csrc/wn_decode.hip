@@ -319,11 +319,11 @@ __device__ __forceinline__ bool dec_poll2(const unsigned long long* p, unsigned 
 // partial sums for ALL blocks of the next sample in the window in which it otherwise only waits for the other workgroup's
 // code (skip sum + post-processing of the current sample, ~5 us), and a block's critical path keeps the tap-1 half only:
 // 8 instead of 16 f / g MFMAs, half the LDS operand reads, half the weight re-arm loads.  The partial sums (4 floats per
-// thread and block) take the place of the split queue columns in LDS (n_layers x 4 KB; chosen when that fits: <= 32 blocks).
+// thread and block) take the place of the split queue columns in LDS (n_layers x 4 KB; chosen when that fits: <= 31 blocks).
 #define DEC_T0_CHUNK 4
 // S = 256 or 512 skip channels (the reference's shipped parameters have 512): MS = S / 64 row tiles of an S-vector per wave.
 //
-// T0 = 2: the tap-0 partial sums of more than 32 blocks do not fit LDS (4 KB per block) - they live in the pair's hand-off area
+// T0 = 2: the tap-0 partial sums of more than 31 blocks do not fit LDS (4 KB per block) - they live in the pair's hand-off area
 // in global memory instead (L2 resident; written a sample ahead, read back one block ahead of their use).
 //
 // KS > 1 (round 4): the skip sum and the post-processing are the work of KS = S / 64 workgroups per pair instead of one.  With 512
@@ -919,9 +919,14 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
 }
 
 // granules of one utterance's hand-off area: z of every block | skip vector | post_process_1 output | logits | the pair's tap-0
-// table (deeper than 32 blocks: it does not fit LDS) | code | error flag
+// table (deeper than 31 blocks: it does not fit LDS) | code | error flag
+// LDS bytes of the chain workgroup with the tap-0 table in LDS (T0 = 1; the matrix-core path has Q = 256, R = 64 inside)
+static size_t dec_t0_lds_bytes(int n_layers) {
+    return sizeof(float) * (size_t)(16 * 256 + 16 * 64) + sizeof(uint16_t) * (size_t)(8 * 136 * (3 + DEC_T0_CHUNK)) + (size_t)n_layers * 256 * sizeof(f32x4);
+}
+static bool dec_t0_fits_lds(int n_layers) { return dec_t0_lds_bytes(n_layers) + 1024 <= 160 * 1024; }      // up to 31 blocks
 long wn_decode_granules(int n_layers, int D, int S) {
-    return (long)n_layers * D + 2 * (long)S + 256 + (n_layers > 32 ? (long)n_layers * 512 : 0) + 2;
+    return (long)n_layers * D + 2 * (long)S + 256 + (dec_t0_fits_lds(n_layers) ? 0 : (long)n_layers * 512) + 2;
 }
 
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
@@ -944,15 +949,15 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
         const size_t s80 = s80_f + sizeof(uint16_t) * (size_t)(8 * 136 * (3 + (size_t)a.n_layers));
         // tap 0 ahead (decode_duo_mfma8_k<.., 1 | 2>): split queue columns of DEC_T0_CHUNK blocks (+ 4 KB of partial sums per block in LDS: T0 = 1)
         const size_t s80_t2 = sizeof(float) * (size_t)(16 * a.Q + 16 * a.R) + sizeof(uint16_t) * (size_t)(8 * 136 * (3 + DEC_T0_CHUNK));
-        const size_t s80_t0 = s80_t2 + (size_t)a.n_layers * 256 * sizeof(f32x4);
+        const size_t s80_t0 = dec_t0_lds_bytes(a.n_layers);
         const size_t ws_h = 2 * ((size_t)a.S + 64) + 8;               // halfs of one utterance's split S-vector (the kernel's WS)
         const size_t s81 = sizeof(uint16_t) * (size_t)(2 * 8 * 136 + 2 * 8 * ws_h) + sizeof(float) * (size_t)(8 * a.Q + 2 * a.S + a.Q);
         static int t0_env = -1, ks_env = -2;
         if (t0_env < 0) { const char* e = getenv("WN_DEC_T0"); t0_env = e ? atoi(e) : 1; }
         if (ks_env < -1) { const char* e = getenv("WN_DEC_KS"); ks_env = e ? atoi(e) : -1; }
-        // tap-0 table: in LDS when it fits (<= 32 blocks), else in the pair's hand-off area (wn_decode_sync_granules leaves room)
+        // tap-0 table: in LDS when it fits (<= 31 blocks), else in the pair's hand-off area (wn_decode_sync_granules leaves room)
         const long need_tab = wn_decode_granules(a.n_layers, a.D, a.S);
-        const int t0 = !t0_env ? 0 : (s80_t0 + 1024 <= 160 * 1024 ? 1 : (a.sync_ustride >= need_tab ? 2 : 0));
+        const int t0 = !t0_env ? 0 : (dec_t0_fits_lds(a.n_layers) ? 1 : (a.sync_ustride >= need_tab ? 2 : 0));
         // split skip / post-processing (KS = S / 64 workgroups + the chain per pair): the default while every workgroup of every
         // pair is resident at once (they spin on each other: at most 224 workgroups per launch); WN_DEC_KS=1 forces the
         // one-workgroup form (what larger batches run), any other value the split form wherever it fits.  Measured (round 4): the

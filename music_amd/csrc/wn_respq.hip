@@ -87,7 +87,8 @@ extern "C" int wn_pq_span_read(unsigned long long* out) {
 #define PQ_STAMP(i)
 #endif
 #ifdef PQ_DBG
-// phase clock sums (developer build, tools/pq_clocks.py): [R: fill_x, recompute, gate+put, barrier | W: fill_dy, wgrad, pq, store, convert, barrier]
+// phase clock sums (developer build, tools/pq_clocks.py): [R: fill_x, recompute, gate+put, barrier | W: fill_dy, wgrad, pq, store, convert, barrier |
+// R's first phase apart: x fill + loads, dy fill + loads, its share of the dx product, dy row loads]
 __device__ unsigned long long pq_dbg[16];
 #define PQ_TICK(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
 #define PQ_ACC(slot, dt) dbg_acc[(slot)] += (unsigned long long)(dt)
@@ -554,15 +555,19 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             }
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
             load_x(rx, pos_r(it, XD + 1));                  // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
+            PQ_TICK(ka);
 #ifndef PQ_T_NOFILLDY
             // (on the W waves instead - they wait 15 % of their time at the barrier in the chain form, the R waves 3.5 % - the stack
             // got SLOWER, 1.99-2.02 vs 1.93-1.97 ms same box, round 4: their loads of the same rows then queue behind each other)
             fill_dy(rd, pos_r(it, 1), (it + 1) & 1);
             load_dy(rd, pos_r(it, 2));
 #endif
+            PQ_TICK(kb);
             pq_r((it + 1) & 1, pos_r(it, -1));                 // Q rows (CHAIN: the first half of dx) of the previous item
+            PQ_TICK(kc);
             load_dyr(pos_r(it, 0));
             PQ_TICK(k1);
+            PQ_ACC(10, ka - k0); PQ_ACC(11, kb - ka); PQ_ACC(12, kc - kb); PQ_ACC(13, k1 - kc);
             const Pos p_cur = pos_r(it, 0);
             const bool live = it < n_items;
             const int tl = p_cur.t0 + 2 * c;
@@ -683,6 +688,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         if (wv == 0) PQ_STAMP(2);
         __syncthreads();                                    // the W waves' extra round (products of the last item)
         PQ_FLUSH(0, 4);
+        PQ_FLUSH(10, 4);
         return;
     }
 

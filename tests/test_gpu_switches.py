@@ -79,7 +79,7 @@ def test_decode_generic_kernel_stays_correct():
 
 def test_decode_without_tap0_ahead_stays_correct():
     """The matrix-core decoder forms the tap-0 half of every block's f / g product a sample ahead (WN_DEC_T0, default 1, when
-    its partial sums fit LDS: <= 32 blocks); WN_DEC_T0=0 is the kernel deeper models run: the config-5 oracle tests, the
+    its partial sums fit LDS: <= 31 blocks); WN_DEC_T0=0 is the kernel deeper models run: the config-5 oracle tests, the
     batched / sampling tests and the autoencoder's cached generation on it."""
     e = dict(os.environ, WN_DEC_T0="0")
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
@@ -103,18 +103,21 @@ def test_decode_skip_forms_stay_correct(env, expr):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
-def test_decode_deeper_than_the_tap0_table_matches_the_oracle():
-    """36 blocks: the tap-0 partial sums (4 KB per block) no longer fit beside the rest of the chain's LDS: they live in the
-    pair's hand-off area in global memory (read back a block ahead); ids and probabilities against the oracle."""
+@pytest.mark.parametrize("blocks,skip,bias", [(31, 256, False), (32, 256, False), (32, 512, True), (36, 256, False), (41, 512, True)])
+def test_decode_deeper_than_the_tap0_table_matches_the_oracle(blocks, skip, bias):
+    """The tap-0 partial sums (4 KB per block) fit beside the rest of the chain's LDS up to 31 blocks; from 32 on they live in
+    the pair's hand-off area in global memory (read back a block ahead; `wn_decode_sync_granules` leaves room for them from
+    exactly that depth on - round 4's first cut reserved it from 33 and a 32-block model timed out, found by
+    tools/fuzz_decode.py --shapes); ids and probabilities against the oracle on both sides of the boundary."""
     import numpy as np
     import torch
     from music_amd import fast_generate as fg
     from music_amd.model import wavenet
     from oracle import intops
     from oracle import wavenet_oracle as wo
-    dil = [1, 2, 4, 8] * 9
-    cfg = dict(filter_width=2, dilations=dil, dilation_channels=64, residual_channels=64, skip_channels=256,
-               quantization_channels=256, use_bias=False)
+    dil = ([1, 2, 4, 8] * 11)[:blocks]
+    cfg = dict(filter_width=2, dilations=dil, dilation_channels=64, residual_channels=64, skip_channels=skip,
+               quantization_channels=256, use_bias=bias)
     torch.manual_seed(41)
     net = wavenet(**cfg)
     with torch.no_grad():

@@ -25,3 +25,6 @@ names = ["R fill_x", "R recompute", "R gate+put", "R barrier", "W fill_dy", "W w
 for lo, hi in ((0, 4), (4, 10)):
     tot = sum(v[lo:hi]) or 1
     print(", ".join("%s %.1f%%" % (names[i], 100.0 * v[i] / tot) for i in range(lo, hi)), " total clocks", tot)
+tot = sum(v[0:4]) or 1
+print("R first phase apart (share of the R loop): " + ", ".join("%s %.1f%%" % (n, 100.0 * v[10 + i] / tot) for i, n in enumerate(
+    ["x fill + loads", "dy fill + loads", "dx product half", "dy row loads"])))
