@@ -553,6 +553,9 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 const uint8_t* ip = a.cond_idx + (WN_PQ_IDX_PAD + pos_r(it, 0).t0 + 2 * c - a.t_lo);
                 cidx[0] = ip[0]; cidx[1] = ip[1];
             }
+            // (x operands written by the W waves instead - they hold the same rows for the weight gradients; f16 hi/lo [channel][time]
+            // tiles read here with transposed reads, no x loads or conversions in the R waves - is correct and SLOWER, round 4: stack
+            // 1.89-1.92 vs 1.85-1.87 ms same box; the R waves then wait 14-16 % at the barrier and the W waves set the pace)
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
             load_x(rx, pos_r(it, XD + 1));                  // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
             PQ_TICK(ka);
@@ -634,6 +637,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #endif
             PQ_TICK(k2);
             uint16_t* tt = st + PQ_T;
+            // (mask-free copies of this phase for items inside [t_lo, t_hi) and on one side of z_lo - a fifth of the R waves' vector
+            // instructions are compares and selects - change nothing, round 4: 1.858 vs 1.858 ms chain form, 1.897 vs 1.910 pair form)
             const bool ok0 = live && tl >= a.t_lo && tl < a.t_hi, ok1 = live && tl + 1 >= a.t_lo && tl + 1 < a.t_hi;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

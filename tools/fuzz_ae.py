@@ -78,6 +78,35 @@ def one_case(rng, k, general=False):
         if err > worst:
             worst, wname = err, name
     ok = e_p <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and worst <= 2e-3
+    if not ok and e_p <= 1e-3 and general:
+        # general plan: every ReLU's pre-activation (encoder x_i / h_i, skip sum, connection_1 output) as the device holds it
+        # against the oracle's: opposite signs within rounding of 0 make the gradients differ legitimately
+        from music_amd.engine import SLACK
+        eng = net._engine
+        T = idx.shape[1]
+        ws = eng.workspace(B, T)
+        pitch = ws["pitch"]
+        inter = {}
+        with torch.no_grad():
+            wo.autoencoder_forward(params, dil, x, cfg["en_pool_kernel_size"], cond, filter_width=fw, q=Q, intermediates=inter)
+        ties, near = 0, 0.0
+
+        def cmp(key, i, rows_p, rows, ref):
+            buf = ws[key][SLACK + i * B * rows_p * pitch:SLACK + (i + 1) * B * rows_p * pitch].view(B, rows_p, pitch)
+            gpu = buf[:, :rows, T - ref.size(2):T].cpu()
+            diff = (gpu > 0) != (ref > 0)
+            return int(diff.sum()), (float(ref[diff].abs().max() / ref.abs().max()) if diff.any() else 0.0)
+        for i in range(n):
+            for key, nm, rp, r in (("Xe", "en_x%d" % i, eng.ReP, eng.Re), ("He", "en_h%d" % i, eng.DeP, eng.De)):
+                t_, m_ = cmp(key, i, rp, r, inter[nm])
+                ties, near = ties + t_, max(near, m_)
+        for key, nm in (("U", "de_skip"), ("R1", "de_conn")):
+            t_, m_ = cmp(key, 0, eng.SP, eng.Sd, inter[nm])
+            ties, near = ties + t_, max(near, m_)
+        if ties and near < 1e-5:
+            print("tie  case %3d  %d ReLU pre-activation(s) within %.1e of 0 (relative) with opposite signs; grad %.1e (%s) not judged"
+                  % (k, ties, near, worst, wname), flush=True)
+            return True
     if not ok and e_p <= 1e-3 and not general:
         # ReLU ties in the encoder (its ReLUs sit on x_i and h_i): a pre-activation within rounding of 0 with opposite
         # signs on the two sides makes the gradients differ legitimately
