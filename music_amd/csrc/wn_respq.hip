@@ -566,9 +566,13 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             load_dy(rd, pos_r(it, 2));
 #endif
             PQ_TICK(kb);
+#ifndef PQ_T_RLATE
             pq_r((it + 1) & 1, pos_r(it, -1));                 // Q rows (CHAIN: the first half of dx) of the previous item
+#endif
             PQ_TICK(kc);
+#ifndef PQ_T_RLATE
             load_dyr(pos_r(it, 0));
+#endif
             PQ_TICK(k1);
             PQ_ACC(10, ka - k0); PQ_ACC(11, kb - ka); PQ_ACC(12, kc - kb); PQ_ACC(13, k1 - kc);
             const Pos p_cur = pos_r(it, 0);
@@ -675,6 +679,10 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 put(1, vg);
                 if (HAS_DY) put(2, vz);
             }
+#ifdef PQ_T_RLATE
+            pq_r((it + 1) & 1, pos_r(it, -1));                 // timing build: the R waves' share of the dx product behind the gate
+            load_dyr(pos_r(it, 0));
+#endif
             load_cr(cr, pos_r(it, 2));
             win_advance();
             PQ_TICK(k3);
@@ -868,11 +876,15 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         }
 #endif
         PQ_TICK(p1);
-        if (CHAIN) pq_mt(stage, 1, ps, HAS_DY ? &o.dy32[4] : nullptr, carry_w);
-        else pq_half(stage, 0, ps, o.dy32);
+        PQ_ACC(5, p1 - p0);
+    };
+    // the W waves' share of the data gradient of item ps (result tiles in `stage`); dyk = the lane's fp32 dy rows of that item
+    auto pq_w = [&](int stage, const float* dyk, Pos ps) __attribute__((always_inline)) {
+        PQ_TICK(p1);
+        if (CHAIN) pq_mt(stage, 1, ps, HAS_DY ? dyk + 4 : nullptr, carry_w);
+        else pq_half(stage, 0, ps, dyk);
         PQ_TICK(p2);
-        PQ_TICK(p3);
-        PQ_ACC(5, p1 - p0); PQ_ACC(6, p2 - p1); PQ_ACC(7, p3 - p2);
+        PQ_ACC(6, p2 - p1);
     };
 
     {
@@ -890,25 +902,48 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         if (wv == 4) PQ_STAMP(3);
         // iteration it: products of item it-1 (result tiles of stage (it-1)&1, operands in `ops`); then the raw rows of
         // item it become `ops` and the rows of item it+2 are requested (loop unrolled by two: no register copies)
+#ifdef PQ_T_WORDER
+        constexpr bool WMID = false;                        // A/B build
+#else
+        constexpr bool WMID = !COND && !(CHAIN && QIN && HAS_DY);     // (the conditioned form and the pair-fed chain form have no registers for it)
+#endif
         auto w_body = [&](const int it, RawRows& rr) {
             PQ_TICK(k0);
             PQ_TICK(k1);
             products((it + 1) & 1, ops, pos_r(it, -1));
-            PQ_TICK(k2);
-#ifndef PQ_T_NOCONV
-            convert(ops, rr, pos_r(it, 0));
-            load_rows(rr, pos_r(it, WD));
-#endif
+            if (!WMID) {
+                pq_w((it + 1) & 1, ops.dy32, pos_r(it, -1));      // rounds 2-4's order: weight gradients, dx product, conversion
+                PQ_TICK(k2);
+                convert(ops, rr, pos_r(it, 0));
+                load_rows(rr, pos_r(it, WD));
+                PQ_TICK(k3);
+                PQ_ACC(8, k3 - k2);
+            } else {
+                // the row conversion BETWEEN the weight gradients and the dx product: vector work beside the R waves' recompute MFMAs,
+                // the product's MFMAs beside their gate phase (the other order pairs matrix with matrix and vector with vector)
+                float dyk[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) dyk[jj] = (jj >= (CHAIN ? 4 : 0)) ? ops.dy32[jj] : 0.f;
+                PQ_TICK(k2);
+                convert(ops, rr, pos_r(it, 0));
+                load_rows(rr, pos_r(it, WD));
+                PQ_TICK(k2b);
+                pq_w((it + 1) & 1, dyk, pos_r(it, -1));
+                PQ_ACC(8, k2b - k2);
+            }
 
             win_advance();
-            PQ_TICK(k3);
+            PQ_TICK(k3b);
             __syncthreads();
             PQ_TICK(k4);
-            PQ_ACC(4, k1 - k0); PQ_ACC(8, k3 - k2); PQ_ACC(9, k4 - k3);
+            PQ_ACC(4, k1 - k0); PQ_ACC(9, k4 - k3b);
         };
         const int n_even = (n_items + 1) & ~1;
         for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, WD == 1 ? rr : rr2); }
-        if (pos_r(n_even, -1).live) products((n_even - 1) & 1, ops, pos_r(n_even, -1));    // the last item, unless it is the void one
+        if (pos_r(n_even, -1).live) {                        // the last item, unless it is the void one
+            products((n_even - 1) & 1, ops, pos_r(n_even, -1));
+            pq_w((n_even - 1) & 1, ops.dy32, pos_r(n_even, -1));
+        }
         __syncthreads();
         if (wv == 4) PQ_STAMP(4);
         PQ_FLUSH(4, 6);
