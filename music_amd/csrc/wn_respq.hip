@@ -324,41 +324,41 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) tr_off[h] = (16 * p + ((8 * (q & 1) + 4 * h + qp) ^ pq_k(p))) * 8;
     }
-    auto pq_half = [&](int stage, int sel, Pos ps, const float* dy32) {
+    struct PqAcc { f32x4 a[2], b[2]; };                       // pair form: even / odd k-steps of the two 16-sample tiles; chain form: P | Q rows
+    auto pq_zero = [&](PqAcc& r) __attribute__((always_inline)) {
+        r.a[0] = r.a[1] = r.b[0] = r.b[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto pq_half_step = [&](int stage, int sel, int s, PqAcc& r) __attribute__((always_inline)) {
         const uint16_t* tt = lds + (size_t)stage * PQ_STAGE + PQ_T;
         const uint16_t* pw = lds + PQ_W;
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        f32x4 acb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // odd k-steps: four chains in flight
 #ifndef PQ_T_NOPQ
+        Frag<PQG> w;
+        load_a<PQG, 3>(w, pw, (sel * 4 + g) * 4 + s, lane);
+        const uint16_t* tb = tt + ((s >> 1) * 4 + 2 * (s & 1) + (q >> 1)) * 1024;
+        Frag<PQG> ad[2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            Frag<PQG> w;
-            load_a<PQG, 3>(w, pw, (sel * 4 + g) * 4 + s, lane);
-            const uint16_t* tb = tt + ((s >> 1) * 4 + 2 * (s & 1) + (q >> 1)) * 1024;
-            Frag<PQG> ad[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[0] + 4 * m));
-                s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[1] + 4 * m));
-                s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[0] + 4 * m));
-                s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[1] + 4 * m));
-                s16x8 hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                s16x8 ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-                ad[m].hi = __builtin_bit_cast(pqg8, hh);
-                ad[m].lo = __builtin_bit_cast(pqg8, ll);
-            }
-            f32x4* ac = (s & 1) ? acb : acc;
-            ac[0] = PQG::mfma(ad[0].lo, w.hi, ac[0]);
-            ac[1] = PQG::mfma(ad[1].lo, w.hi, ac[1]);
-            ac[0] = PQG::mfma(ad[0].hi, w.lo, ac[0]);
-            ac[1] = PQG::mfma(ad[1].hi, w.lo, ac[1]);
-            ac[0] = PQG::mfma(ad[0].hi, w.hi, ac[0]);
-            ac[1] = PQG::mfma(ad[1].hi, w.hi, ac[1]);
+        for (int m = 0; m < 2; ++m) {
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[0] + 4 * m));
+            s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[1] + 4 * m));
+            s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[0] + 4 * m));
+            s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[1] + 4 * m));
+            s16x8 hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            s16x8 ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            ad[m].hi = __builtin_bit_cast(pqg8, hh);
+            ad[m].lo = __builtin_bit_cast(pqg8, ll);
         }
-        acc[0] += acb[0];
-        acc[1] += acb[1];
+        f32x4* ac = (s & 1) ? r.b : r.a;                      // odd k-steps: four chains in flight
+        ac[0] = PQG::mfma(ad[0].lo, w.hi, ac[0]);
+        ac[1] = PQG::mfma(ad[1].lo, w.hi, ac[1]);
+        ac[0] = PQG::mfma(ad[0].hi, w.lo, ac[0]);
+        ac[1] = PQG::mfma(ad[1].hi, w.lo, ac[1]);
+        ac[0] = PQG::mfma(ad[0].hi, w.hi, ac[0]);
+        ac[1] = PQG::mfma(ad[1].hi, w.hi, ac[1]);
 #endif
+    };
+    auto pq_half_tail = [&](int sel, Pos ps, const float* dy32, PqAcc& r) __attribute__((always_inline)) {
+        f32x4 acc[2] = {r.a[0] + r.b[0], r.a[1] + r.b[1]};
 #ifndef PQ_T_NOSTORE
         if (ps.live) {
             float* out = (sel ? a.q_out : a.p_out) + (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q;
@@ -376,43 +376,47 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         }
 #endif
     };
+    auto pq_half = [&](int stage, int sel, Pos ps, const float* dy32) __attribute__((always_inline)) {
+        PqAcc r;
+        pq_zero(r);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pq_half_step(stage, sel, s, r);
+        pq_half_tail(sel, ps, dy32, r);
+    };
     // ---- CHAIN form: the 16-sample half `mt` of the item's 32 columns, BOTH weight halves: dx rows = P rows + the Q rows carried
     // from the item above (+ the lane's fp32 dy rows, dy4), then this item's Q rows become the carry; the last item of a chain
     // leaves its carry d columns further down (dx on [t_lo - d, t_base): nothing but Q).  A halo item only makes the carry.
-    auto pq_mt = [&](int stage, int mt, Pos ps, const float* dy4, f32x4& carry) __attribute__((always_inline)) {
-        if (!ps.live) return;
+    auto pq_mt_step = [&](int stage, int mt, int s, PqAcc& r) __attribute__((always_inline)) {      // r.a = P rows, r.b = Q rows (even / odd k-steps)
         const uint16_t* tt = lds + (size_t)stage * PQ_STAGE + PQ_T;
         const uint16_t* pw = lds + PQ_W;
-        f32x4 ap[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // even / odd k-steps: four chains in flight
-        f32x4 aq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            Frag<PQG> w1, w0;
-            load_a<PQG, 3>(w1, pw, g * 4 + s, lane);
-            load_a<PQG, 3>(w0, pw, (4 + g) * 4 + s, lane);
-            const uint16_t* tb = tt + ((s >> 1) * 4 + 2 * (s & 1) + (q >> 1)) * 1024;
-            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-            s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[0] + 4 * mt));
-            s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[1] + 4 * mt));
-            s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[0] + 4 * mt));
-            s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[1] + 4 * mt));
-            s16x8 hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-            s16x8 ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-            Frag<PQG> ad;
-            ad.hi = __builtin_bit_cast(pqg8, hh);
-            ad.lo = __builtin_bit_cast(pqg8, ll);
-            ap[s & 1] = PQG::mfma(ad.lo, w1.hi, ap[s & 1]);
-            aq[s & 1] = PQG::mfma(ad.lo, w0.hi, aq[s & 1]);
-            ap[s & 1] = PQG::mfma(ad.hi, w1.lo, ap[s & 1]);
-            aq[s & 1] = PQG::mfma(ad.hi, w0.lo, aq[s & 1]);
-            ap[s & 1] = PQG::mfma(ad.hi, w1.hi, ap[s & 1]);
-            aq[s & 1] = PQG::mfma(ad.hi, w0.hi, aq[s & 1]);
-        }
+        Frag<PQG> w1, w0;
+        load_a<PQG, 3>(w1, pw, g * 4 + s, lane);
+        load_a<PQG, 3>(w0, pw, (4 + g) * 4 + s, lane);
+        const uint16_t* tb = tt + ((s >> 1) * 4 + 2 * (s & 1) + (q >> 1)) * 1024;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[0] + 4 * mt));
+        s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[1] + 4 * mt));
+        s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[0] + 4 * mt));
+        s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[1] + 4 * mt));
+        s16x8 hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        s16x8 ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        Frag<PQG> ad;
+        ad.hi = __builtin_bit_cast(pqg8, hh);
+        ad.lo = __builtin_bit_cast(pqg8, ll);
+        r.a[s & 1] = PQG::mfma(ad.lo, w1.hi, r.a[s & 1]);
+        r.b[s & 1] = PQG::mfma(ad.lo, w0.hi, r.b[s & 1]);
+        r.a[s & 1] = PQG::mfma(ad.hi, w1.lo, r.a[s & 1]);
+        r.b[s & 1] = PQG::mfma(ad.hi, w0.lo, r.b[s & 1]);
+        r.a[s & 1] = PQG::mfma(ad.hi, w1.hi, r.a[s & 1]);
+        r.b[s & 1] = PQG::mfma(ad.hi, w0.hi, r.b[s & 1]);
+    };
+    auto pq_mt_tail = [&](int mt, Pos ps, const float* dy4, f32x4& carry, PqAcc& r) __attribute__((always_inline)) {
+        if (!ps.live) return;
         if (ps.top) carry = f32x4{0.f, 0.f, 0.f, 0.f};
         float* out = a.p_out + (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 16 * mt + 4 * q;
         const int tq = ps.t0 + 16 * mt + 4 * q;
         if (!ps.halo) {
-            f32x4 v = (ap[0] + ap[1]) + carry;
+            f32x4 v = (r.a[0] + r.a[1]) + carry;
             if (dy4 != nullptr) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] += dy4[i];
@@ -420,12 +424,23 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             if (ps.t0 + PQ_COLS <= a.t_hi) *reinterpret_cast<f32x4*>(out) = v;      // (t0 >= t_base > t_lo - d always)
             else st4m(out, v, tq, a.t_lo - a.d, a.t_hi);
         }
-        carry = aq[0] + aq[1];
+        carry = r.b[0] + r.b[1];
         if (ps.bot) st4m(out - a.d, carry, tq - a.d, a.t_lo - a.d, a.t_lo);
+    };
+    auto pq_mt = [&](int stage, int mt, Pos ps, const float* dy4, f32x4& carry) __attribute__((always_inline)) {
+        if (!ps.live) return;
+        PqAcc r;
+        pq_zero(r);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pq_mt_step(stage, mt, s, r);
+        pq_mt_tail(mt, ps, dy4, carry, r);
     };
 
     if (wv < 4) {
         // =========================== R waves: recompute, dz, gate ===========================
+#ifdef PQ_T_RPRIO
+        __builtin_amdgcn_s_setprio(PQ_T_RPRIO);
+#endif
         struct RawX { f32x2 x[8]; };
         // recompute operands ("time on lanes"; lane (c, q) of N-tile n holds sample t0 + 2c + n): wave g converts
         // k-step g = (tap g>>1, channel half g&1) of x, both N-tiles
@@ -499,6 +514,23 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             }
         };
 
+        auto pq_r_step = [&](int stage, int s, PqAcc& r) __attribute__((always_inline)) {
+            if (CHAIN) pq_mt_step(stage, 0, s, r);
+            else pq_half_step(stage, 1, s, r);
+        };
+        auto pq_r_tail = [&](Pos ps, PqAcc& r) __attribute__((always_inline)) {
+            if (CHAIN) {
+                float d4[4];
+                if (HAS_DY) {
+                    const bool fast = interior(ps);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d4[i] = fast ? dyrP[i] + dyrQ[i] : dyv(dyrP[i], dyrQ[i], ps.t0 + 4 * q + i);
+                }
+                pq_mt_tail(0, ps, HAS_DY ? d4 : nullptr, carry, r);
+            } else {
+                pq_half_tail(1, ps, nullptr, r);
+            }
+        };
         f32x2 crA[4], crB[4];
         load_cr(crA, pos_r(0, 0));
         load_cr(crB, pos_r(0, 1));
@@ -507,6 +539,11 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         // XD: items the raw x rows are requested ahead.  The chain form that is fed by a pair (the first chain block under a
         // (P, Q) block: 2 launches of 30) holds the dy rows twice more (dyrP, dyrQ) and keeps ONE set of x rows: no spills
         constexpr int XD = (CHAIN && QIN && HAS_DY) ? 1 : 2;
+#if defined(PQ_T_NORMIX) || defined(PQ_T_RLATE) || defined(PQ_T_RMID) || defined(PQ_T_RFIRST)
+        constexpr bool RMIX = false;
+#else
+        constexpr bool RMIX = !CHAIN && !COND;
+#endif
         load_x(x0, pos_r(0, 0));
         load_dy(rd, pos_r(0, 0));
         if (XD == 2) load_x(x1, pos_r(0, 1));
@@ -556,8 +593,20 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             // (x operands written by the W waves instead - they hold the same rows for the weight gradients; f16 hi/lo [channel][time]
             // tiles read here with transposed reads, no x loads or conversions in the R waves - is correct and SLOWER, round 4: stack
             // 1.89-1.92 vs 1.85-1.87 ms same box; the R waves then wait 14-16 % at the barrier and the W waves set the pace)
+#ifdef PQ_T_RFIRST
+            pq_r((it + 1) & 1, pos_r(it, -1));                 // timing build: the R waves' share of the dx product in front of the fills
+            load_dyr(pos_r(it, 0));
+#endif
+            // RMIX (pair form): the k-steps of the R waves' share of the dx product woven into the operand fills (1.81 vs 1.83 ms for
+            // the stack, round 4; the chain form, at its register limit, gains nothing: 1.823 vs 1.829 with one set of x rows)
+            PqAcc pa;
+            if (RMIX) {
+                pq_zero(pa);
+                pq_r_step((it + 1) & 1, 0, pa);
+            }
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
             load_x(rx, pos_r(it, XD + 1));                  // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
+            if (RMIX) pq_r_step((it + 1) & 1, 1, pa);
             PQ_TICK(ka);
 #ifndef PQ_T_NOFILLDY
             // (on the W waves instead - they wait 15 % of their time at the barrier in the chain form, the R waves 3.5 % - the stack
@@ -565,13 +614,19 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             fill_dy(rd, pos_r(it, 1), (it + 1) & 1);
             load_dy(rd, pos_r(it, 2));
 #endif
+            if (RMIX) {
+                pq_r_step((it + 1) & 1, 2, pa);
+                pq_r_step((it + 1) & 1, 3, pa);
+                pq_r_tail(pos_r(it, -1), pa);
+                load_dyr(pos_r(it, 0));
+            }
             PQ_TICK(kb);
-#ifndef PQ_T_RLATE
-            pq_r((it + 1) & 1, pos_r(it, -1));                 // Q rows (CHAIN: the first half of dx) of the previous item
+#if !defined(PQ_T_RLATE) && !defined(PQ_T_RMID) && !defined(PQ_T_RFIRST)
+            if (!RMIX) pq_r((it + 1) & 1, pos_r(it, -1));                 // Q rows (CHAIN: the first half of dx) of the previous item
 #endif
             PQ_TICK(kc);
-#ifndef PQ_T_RLATE
-            load_dyr(pos_r(it, 0));
+#if !defined(PQ_T_RLATE) && !defined(PQ_T_RMID) && !defined(PQ_T_RFIRST)
+            if (!RMIX) load_dyr(pos_r(it, 0));
 #endif
             PQ_TICK(k1);
             PQ_ACC(10, ka - k0); PQ_ACC(11, kb - ka); PQ_ACC(12, kc - kb); PQ_ACC(13, k1 - kc);
@@ -638,6 +693,10 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                     ag[n] = F16::mfma(tcg.hi, e, ag[n]);
                 }
             }
+#endif
+#ifdef PQ_T_RMID
+            pq_r((it + 1) & 1, pos_r(it, -1));                 // timing build: the R waves' share of the dx product between recompute and gate
+            load_dyr(pos_r(it, 0));
 #endif
             PQ_TICK(k2);
             uint16_t* tt = st + PQ_T;
@@ -706,6 +765,9 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     }
 
     // =========================== W waves: weight gradients and the (P, Q) product ===========================
+#ifdef PQ_T_WPRIO
+    __builtin_amdgcn_s_setprio(PQ_T_WPRIO);               // timing build: static priority for the younger half of the workgroup
+#endif
     f32x4 cfg[8][2], cd[4];
 #pragma unroll
     for (int m = 0; m < 8; ++m) { cfg[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; cfg[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
