@@ -411,6 +411,8 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         __syncthreads();
         // iteration it: products of item it-1 (result tiles of stage (it-1)&1, operands in `ops`); then the raw rows of
         // item it become `ops` and the rows of item it+2 are requested (loop unrolled by two: no register copies)
+        // (the row conversion between the weight gradients and the dx product - what pays in wn_respq.hip, whose R waves have a long
+        // vector phase - is SLOWER here, round 4: encoder stack backward 1.64 against 1.57 ms at config 4, three alternations)
         auto w_body = [&](const int it, RawRows& r) {
             products((it + 1) & 1, ops, pos_k(it - 1));
             convert(ops, r, pos_k(it));
