@@ -39,7 +39,10 @@
 // PQ_T_* macros are timing-build switches (remove one ingredient; results are then wrong) used to see what a launch is
 // made of: -DPQ_T_NOREC / NOGATE / NOWG / NOPQ / NOSTORE / NOFILLDY / NOCONV via `make EXTRA=...` (tools/pq_phases.sh); for the
 // conditioned form -DPQ_T_NOCBIAS (no bias k-step), -DPQ_T_NOCSUM (no bucket sums), -DPQ_T_WD2 (rows two items ahead: spills)
-// with tools/ae_variant.sh.
+// with tools/ae_variant.sh.  Phase-order builds (correct results; tools/r4_abn.sh times them against the shipped order):
+// -DPQ_T_WORDER (W waves: weight gradients, dx product, conversion - rounds 2-4's order), -DPQ_T_RLATE / RMID / RFIRST (the R waves'
+// share of the dx product behind the gate / between recompute and gate / in front of the fills), -DPQ_T_FDLATE (dy fill behind that
+// share), -DPQ_T_NORMIX (pair form without the woven k-steps), -DPQ_T_WPRIO=n / -DPQ_T_RPRIO=n (static s_setprio of a role).
 #include <stdlib.h>
 #include <string.h>
 #include "wn_common.h"
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             load_x(rx, pos_r(it, XD + 1));                  // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
             if (RMIX) pq_r_step((it + 1) & 1, 1, pa);
             PQ_TICK(ka);
-#ifndef PQ_T_NOFILLDY
+#if !defined(PQ_T_NOFILLDY) && !defined(PQ_T_FDLATE)
             // (on the W waves instead - they wait 15 % of their time at the barrier in the chain form, the R waves 3.5 % - the stack
             // got SLOWER, 1.99-2.02 vs 1.93-1.97 ms same box, round 4: their loads of the same rows then queue behind each other)
             fill_dy(rd, pos_r(it, 1), (it + 1) & 1);
@@ -627,6 +630,10 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             PQ_TICK(kc);
 #if !defined(PQ_T_RLATE) && !defined(PQ_T_RMID) && !defined(PQ_T_RFIRST)
             if (!RMIX) load_dyr(pos_r(it, 0));
+#endif
+#ifdef PQ_T_FDLATE
+            fill_dy(rd, pos_r(it, 1), (it + 1) & 1);         // timing build: the dy fill behind the R waves' share of the dx product
+            load_dy(rd, pos_r(it, 2));
 #endif
             PQ_TICK(k1);
             PQ_ACC(10, ka - k0); PQ_ACC(11, kb - ka); PQ_ACC(12, kc - kb); PQ_ACC(13, k1 - kc);
