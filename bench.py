@@ -604,6 +604,12 @@ def main():
     eng.mark_only = {"step_begin", "causal_fwd", "stack_fwd", "epilogue_bwd", "stack_bwd"}
     # one event per step end (enable_timing): median / min / max of the per-step GPU time
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # the host issues ~110 launches per step a few hundred microseconds ahead of the device: a collector pause of the interpreter
+    # inside the timed region shows up as one long step (5.9 ms among twenty of 4.28 in one run); collect before, not during
+    import gc
+    gc.collect()
+    gc.disable()
+    barrier()
     t0 = time.perf_counter()
     step_ev[0].record()
     for i_ in range(args.steps):
@@ -611,6 +617,7 @@ def main():
         step_ev[i_ + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     per_step = sorted(step_ev[i_].elapsed_time(step_ev[i_ + 1]) for i_ in range(args.steps))
     marks, eng.marks, eng.mark_only = state["sampled"], None, None
     state["sampled"] = None
@@ -748,7 +755,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
         "ms_per_step": dt / args.steps * 1e3,
         "ms_per_step_stats": {"median": per_step[len(per_step) // 2], "min": per_step[0], "max": per_step[-1],
-                              "note": "GPU time between the end-of-step HIP events of consecutive timed steps (rank 0)"} if per_step else None,
+                              "note": "GPU time between the end-of-step HIP events of consecutive timed steps (rank 0); the interpreter's garbage collector runs before the timed region, not inside it"} if per_step else None,
         "first_window": {"steps": first_n, "ms_per_step": first_ms,
                          "note": "the first steps of this process (one-time costs included), before the settle / warm-up steps are discarded"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
