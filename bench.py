@@ -584,6 +584,10 @@ def main():
     # ... but the one-time cost stays visible: the first window of the process (min(25, settle) steps, wall clock) is reported
     first_n = min(25, args.settle)
     first_ms = None
+    import gc
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    gc.collect()
+    gc.disable()
     torch.cuda.synchronize()
     t_first = time.perf_counter()
     for i_ in range(args.settle):
@@ -593,6 +597,10 @@ def main():
             first_ms = (time.perf_counter() - t_first) / first_n * 1e3
     barrier()
     state["sampled"], eng.marks, eng.mark_only = None, None, None
+    # everything the host has to do besides launching went IN FRONT of the settle steps (above): a device left idle for milliseconds between
+    # the warm-up and the timed steps lowers its clock and takes ~7 steps to raise it again (5.19, 4.80, 4.63, 4.56, 4.49, 4.39, 4.36, then
+    # 4.25 ms in one run whose collector pass sat between the two).  The interpreter's collector runs here, not inside the timed region
+    # (the host issues ~110 launches per step, 0.74 ms of its time per 4.3 ms step: a collector pause shows up as one long step)
     for _ in range(args.warmup):
         loss = step()
     barrier()
@@ -603,13 +611,6 @@ def main():
     state["sampled"], state["k0"] = [], state["k"]
     eng.mark_only = {"step_begin", "causal_fwd", "stack_fwd", "epilogue_bwd", "stack_bwd"}
     # one event per step end (enable_timing): median / min / max of the per-step GPU time
-    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    # the host issues ~110 launches per step a few hundred microseconds ahead of the device: a collector pause of the interpreter
-    # inside the timed region shows up as one long step (5.9 ms among twenty of 4.28 in one run); collect before, not during
-    import gc
-    gc.collect()
-    gc.disable()
-    barrier()
     t0 = time.perf_counter()
     step_ev[0].record()
     for i_ in range(args.steps):
@@ -618,7 +619,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
-    per_step = sorted(step_ev[i_].elapsed_time(step_ev[i_ + 1]) for i_ in range(args.steps))
+    per_step_order = [round(step_ev[i_].elapsed_time(step_ev[i_ + 1]), 3) for i_ in range(args.steps)]
+    per_step = sorted(per_step_order)
     marks, eng.marks, eng.mark_only = state["sampled"], None, None
     state["sampled"] = None
     n_sampled = (args.steps + MARK_EVERY - 1) // MARK_EVERY
@@ -637,6 +639,14 @@ def main():
     # epilogue forward + softmax/CE + epilogue backward; stack_fwd / stack_bwd are exact
     timed = {"stack_fwd": phase.get("stack_fwd"), "stack_bwd": phase.get("stack_bwd"),
              "begin_to_stack": phase.get("causal_fwd"), "between_stacks": phase.get("epilogue_bwd")}
+    # how long the HOST takes to enqueue a step (device idle at the start, nothing waited for inside): the margin by which the
+    # interpreter runs ahead of the device.  Timed steps that take longer than the median are host stalls when this is close to it
+    barrier()
+    t_h = time.perf_counter()
+    for _ in range(8):
+        step()
+    host_enqueue_ms = (time.perf_counter() - t_h) / 8 * 1e3
+    barrier()
     # full phase table: 3 untimed steps with every mark
     eng.marks = []
     for _ in range(3):
@@ -755,7 +765,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
         "ms_per_step": dt / args.steps * 1e3,
         "ms_per_step_stats": {"median": per_step[len(per_step) // 2], "min": per_step[0], "max": per_step[-1],
+                              "p90": per_step[min(len(per_step) - 1, (len(per_step) * 9) // 10)], "first_10_in_order": per_step_order[:10],
                               "note": "GPU time between the end-of-step HIP events of consecutive timed steps (rank 0); the interpreter's garbage collector runs before the timed region, not inside it"} if per_step else None,
+        "host_enqueue_ms_per_step": host_enqueue_ms,
         "first_window": {"steps": first_n, "ms_per_step": first_ms,
                          "note": "the first steps of this process (one-time costs included), before the settle / warm-up steps are discarded"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
