@@ -14,11 +14,11 @@
  *     every call only enqueues work on `stream` (safe under hipGraph stream capture);
  *   - re-entrant across devices/streams and threads: no global mutable state; the last-error text is
  *     thread-local (wn_last_error() returns the calling thread's);
- *   - no collective is exported.  SURVEY 8(b) sketched a `wn_allreduce_flat(ncclComm_t, ...)` wrapper; it is left
- *     out on purpose: the RCCL communicator belongs to torch.distributed (ProcessGroupNCCL owns its creation, streams
- *     and teardown and does not hand the ncclComm_t out), and a second communicator created behind its back would
- *     duplicate the xGMI rings and the bootstrap for one 5 MB all-reduce per step.  The data-parallel exchange is
- *     `torch.distributed.all_reduce(flat_grad)` on the buffer these kernels fill (music_amd/dist.py).
+ *   - the one collective of the path (the data-parallel gradient sum) is `wn_allreduce_flat` on a communicator
+ *     the CALLER owns; RCCL is resolved at first use from the process image (or librccl.so), not linked.  The Python host keeps
+ *     `torch.distributed.all_reduce(flat_grad)` (music_amd/dist.py): ProcessGroupNCCL owns its communicator and does not hand
+ *     the ncclComm_t out, and a second communicator behind its back would duplicate the xGMI rings and the bootstrap for one
+ *     5 MB all-reduce per step; a host without torch uses the entry points below.
  *
  * Data layout: activations are float32 [clip][channel][time] with time
  * contiguous, in ABSOLUTE time (column t = index of the newest input sample the value depends
@@ -275,6 +275,18 @@ int wn_chunk_softmax256_ce(const float* x, const int64_t* target, float* probs, 
 int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, float bias_corr1, float bias_corr2, float gscale,
                  wn_stream_t stream);
+/* The reference's nn.DataParallel gradient reduction (wavenet/train.py:116-122) as ONE in-place sum over the ranks of the flat
+ * fp32 gradient buffer: ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum, comm, stream) on the caller's RCCL communicator
+ * (`comm` = an ncclComm_t).  The 1 / world_size of the mean goes into wn_adam_flat's gscale.  Returns -5 when RCCL is neither
+ * loaded in the process nor on the loader path (wn_coll_available() == 0), -6 with RCCL's error text when RCCL fails.
+ * wn_comm_unique_id / wn_comm_create / wn_comm_destroy are ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy for a host that
+ * does not link RCCL itself: rank 0 makes the 128-byte id, every rank gets it by the host's own means and creates its
+ * communicator on its current device (collective: returns when all ranks have called). */
+int wn_coll_available(void);
+int wn_comm_unique_id(char* id128);
+int wn_comm_create(int nranks, int rank, const char* id128, void** comm);
+int wn_comm_destroy(void* comm);
+int wn_allreduce_flat(void* comm, float* buf, int64_t n, wn_stream_t stream);
 /* flat_grad[i] = packed[idx[i]] (idx<0 -> 0): dense wgrad results -> state_dict (out,in,k) layout. */
 int wn_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, wn_stream_t stream);
 /* ... with two sources per element, flat_grad[i] = packed[idx[i]] + packed[idx2[i]] (< 0: nothing): the gradient of a weight

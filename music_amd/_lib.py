@@ -69,6 +69,11 @@ SIGNATURES = {
     "wn_chunk_softmax_bwd": [_p, _p, _p, _l, _i, _p],
     "wn_chunk_softmax_ce": [_p, _p, _p, _p, _p, _l, _i, _f, _p],
     "wn_adam_flat": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p],
+    "wn_coll_available": [],
+    "wn_comm_unique_id": [_p],
+    "wn_comm_create": [_i, _i, _p, _p],
+    "wn_comm_destroy": [_p],
+    "wn_allreduce_flat": [_p, _p, _l, _p],
     "wn_gather_grads": [_p, _p, _p, _i, _p],
     "wn_gather_grads2": [_p, _p, _p, _p, _i, _p],
     "wn_onehot": [_p, _p, _i, _i, _i, _i, _p],

@@ -148,6 +148,13 @@ int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float beta2, float eps, float bias_corr1, float bias_corr2, float gscale, wn_stream_t stream) {
     return wn_launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, bias_corr1, bias_corr2, gscale, (hipStream_t)stream);
 }
+int wn_coll_available(void) { return wn_coll_loaded(); }
+int wn_comm_unique_id(char* id128) { return wn_coll_unique_id(id128); }
+int wn_comm_create(int nranks, int rank, const char* id128, void** comm) { return wn_coll_create(nranks, rank, id128, comm); }
+int wn_comm_destroy(void* comm) { return wn_coll_destroy(comm); }
+int wn_allreduce_flat(void* comm, float* buf, int64_t n, wn_stream_t stream) {
+    return wn_coll_allreduce_flat(comm, buf, n, (hipStream_t)stream);
+}
 int wn_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, wn_stream_t stream) {
     return wn_launch_gather_grads(packed, idx, flat_grad, n, (hipStream_t)stream);
 }

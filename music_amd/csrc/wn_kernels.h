@@ -243,3 +243,10 @@ struct WnDecodeArgs {
 };
 int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st);
 long wn_decode_granules(int n_layers, int D, int S);      // 8-byte granules of one utterance's hand-off area (matrix-core kernels)
+
+// wn_coll.hip
+int wn_coll_loaded();
+int wn_coll_unique_id(char* id128);
+int wn_coll_create(int nranks, int rank, const char* id128, void** comm);
+int wn_coll_destroy(void* comm);
+int wn_coll_allreduce_flat(void* comm, float* buf, int64_t n, hipStream_t st);

@@ -129,3 +129,22 @@ def test_chain_plan_covers_every_item_once():
     assert lib.wn_resblock_bwd_pq_chain_ok(100, 16000, 8, 16) == 0
     assert lib.wn_resblock_bwd_pq_chain_ok(1024, 1024 + 15 * 32, 2, 512) == 0
     assert _chain_items(lib, 100, 16000, 8, 16, 0)[0] == -1
+
+
+def test_collective_entry_points_check_their_arguments_without_a_device():
+    """wn_allreduce_flat / wn_comm_* (the thin ncclAllReduce wrapper on the caller's communicator): RCCL is resolved
+    at first use from the process image, not linked; bad arguments come back as -4 before RCCL is touched, and the error text
+    names the function.  (The 1-rank collective itself runs in tests/test_gpu_dist.py.)"""
+    import ctypes
+    from music_amd import _lib
+    lib = _lib.load()
+    if not lib.wn_coll_available():
+        assert lib.wn_allreduce_flat(None, None, 0, None) == -5 and b"RCCL" in lib.wn_last_error()
+        return
+    assert lib.wn_allreduce_flat(None, None, 16, None) == -4
+    assert b"wn_allreduce_flat" in lib.wn_last_error()
+    comm = ctypes.c_void_p()
+    assert lib.wn_comm_create(0, 0, b"\0" * 128, ctypes.byref(comm)) == -4
+    assert lib.wn_comm_create(2, 2, b"\0" * 128, ctypes.byref(comm)) == -4
+    assert lib.wn_comm_destroy(None) == 0
+

@@ -122,3 +122,35 @@ def test_bench_under_launcher_prints_one_json_line_with_rccl():
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["backend"] == "nccl" and "allreduce" in out["phase_ms_per_step"]
+
+
+def test_allreduce_flat_through_the_c_abi_one_rank():
+    """wn_comm_unique_id / wn_comm_create / wn_allreduce_flat / wn_comm_destroy on this process's RCCL (the copy torch has loaded:
+    the library resolves it from the process image): a one-rank communicator on the current device, the in-place sum of a flat
+    fp32 buffer on a side stream (an identity for one rank, bit for bit), then the flat Adam step with gscale = 1 / world as
+    music_amd/dist.py applies it.  More ranks need more GPUs: the N-rank arithmetic is tests/test_dist_cpu.py's (gloo)."""
+    import ctypes
+    from music_amd import _lib
+    lib = _lib.load()
+    assert lib.wn_coll_available() == 1
+    torch.cuda.set_device(0)
+    ident = ctypes.create_string_buffer(128)
+    assert lib.wn_comm_unique_id(ident) == 0, lib.wn_last_error()
+    comm = ctypes.c_void_p()
+    assert lib.wn_comm_create(1, 0, ident, ctypes.byref(comm)) == 0, lib.wn_last_error()
+    try:
+        g = torch.randn(1_270_000, device="cuda")
+        want = g.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            assert lib.wn_allreduce_flat(comm, g.data_ptr(), g.numel(), side.cuda_stream) == 0, lib.wn_last_error()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(g, want)
+        assert lib.wn_allreduce_flat(comm, g.data_ptr(), 0, None) == 0          # empty buffer: nothing to do
+        mapped = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "rccl" in ln})
+        assert len(mapped) == 1, mapped                                          # ONE copy of RCCL in the process
+    finally:
+        assert lib.wn_comm_destroy(comm) == 0
+
