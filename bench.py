@@ -384,7 +384,8 @@ def surface_benchmarks(net, eng, piece, target):
         out[name] = {"ms_per_step": dt * 1e3, "samples_per_s": B * piece.shape[1] / dt, "loss": float(loss.item())}
     out["workload"] = ("the reference's own training loop (wavenet/train.py:171-182: zero_grad, net(x), CrossEntropyLoss on the "
                        "probabilities, backward, step of train.get_optimizer(net, 'adam', ..)) on this nn.Module at 8 x 16000, input "
-                       "resident, 10 steps after 0.3 s of warm-up steps; torch's own CrossEntropyLoss kernels are ~0.42 ms of it (kernel trace, DESIGN.md)")
+                       "resident, 10 steps after 0.3 s of warm-up steps; the CrossEntropyLoss call is intercepted on the module's output and runs as the "
+                       "engine's fused softmax + CE pass (net.fuse_loss; torch's own kernels: +0.45 ms per step, DESIGN.md)")
     del x_tag, x_plain, opt
 
     def fused():

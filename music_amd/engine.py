@@ -154,6 +154,7 @@ class WaveNetEngine:
         self.dil = [int(d) for d in dilations]
         self.N = len(self.dil)
         self.R, self.D, self.S, self.Q = residual_channels, dilation_channels, skip_channels, quantization_channels
+        self.fused_loss_ok = True           # model.py: nn.CrossEntropyLoss on the module's output may run as wn_chunk_softmax256_ce (Q = 256 here)
         self.use_bias = bool(use_bias)
         self.CH = _pad(max(self.R, self.D), 32)
         if self.CH not in (32, 64):

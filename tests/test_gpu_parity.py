@@ -210,7 +210,8 @@ def test_flat_adam_is_torch_adam_on_the_drop_in_surface():
         _lib.call = real_call
     assert calls.count("wn_adam_flat") == 3                    # steps 0, 1, 3 of the flat optimizer
     for (n, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
-        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), n
+        # (four float32 Adam updates of lr = 1e-3: two correct implementations differ by a few ulp of a step)
+        assert (a - b).abs().max().item() <= 4e-6 * max(1.0, b.abs().max().item()), n
     sd = opts[0].state_dict()
     assert float(sd["state"][0]["step"]) == 4.0
     plain = torch.optim.Adam(nets[1].parameters(), lr=1e-3)
@@ -1339,3 +1340,75 @@ def test_in_place_write_to_a_tagged_input_is_reported_at_backward():
     x.mul_(1.0)
     with pytest.raises(RuntimeError, match="modified in place"):
         ce(out, target).backward()
+
+
+def _small_net(bias=False, seed=5):
+    from music_amd.model import wavenet
+    torch.manual_seed(seed)
+    net = wavenet(filter_width=2, dilations=[1, 2, 4, 8, 16, 32, 64], dilation_channels=64, residual_channels=64, skip_channels=256,
+                  quantization_channels=256, use_bias=bias)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.5)
+    return net.cuda()
+
+
+def test_cross_entropy_on_the_module_output_runs_fused_and_equals_torchs():
+    """`nn.CrossEntropyLoss()(net(x), target)` - the reference's own loss call (wavenet/train.py:146,179) - is intercepted on the
+    module's output (a Tensor subclass) and runs as the engine's one-pass softmax + CE + backward; loss and EVERY parameter gradient
+    must equal what torch's own CrossEntropyLoss gives on the same module (`fuse_loss = False`), including: a scaled loss, a loss
+    that uses the probabilities a second time, non-default arguments (torch's path), an in-place change of the output (torch's
+    path), and inference under no_grad."""
+    import numpy as np
+    from music_amd import model as mm
+    from tests.helpers import scrambled_input
+    net = _small_net()
+    rng = np.random.default_rng(3)
+    B, W = 3, 700
+    T = net.receptive_field + W - 1
+    x = scrambled_input(rng.integers(0, 256, size=(B, T))).cuda()
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).cuda()
+    crit = torch.nn.CrossEntropyLoss()
+
+    def run(fuse, loss_fn):
+        net.fuse_loss = fuse
+        net.zero_grad()
+        out = net(x)
+        loss = loss_fn(out)
+        loss.backward()
+        return float(loss.detach()), [p.grad.clone() for p in net.parameters()], out
+
+    cases = {
+        "plain": lambda o: crit(o, target),
+        "scaled": lambda o: 3.0 * crit(o, target),
+        "second use": lambda o: crit(o, target) + 0.25 * (o * o).sum() / o.numel(),
+        "functional": lambda o: torch.nn.functional.cross_entropy(o, target),
+        "sum reduction (torch's path)": lambda o: torch.nn.CrossEntropyLoss(reduction="sum")(o, target) / target.numel(),
+        "smoothing (torch's path)": lambda o: torch.nn.CrossEntropyLoss(label_smoothing=0.1)(o, target),
+    }
+    for name, fn in cases.items():
+        l0, g0, _ = run(False, fn)
+        l1, g1, out = run(True, fn)
+        assert type(out) is mm._Probs and out.shape == (B * W, 256)
+        assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)), (name, l0, l1)
+        gmax = max(g.abs().max().item() for g in g0)
+        for a, b in zip(g0, g1):
+            assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1e-3 * gmax), name
+    # the fused pass really ran in the plain case (and only there among the torch-path cases)
+    net.fuse_loss = True
+    net.zero_grad()
+    out = net(x)
+    hook = out._wn_hook
+    loss = crit(out, target)
+    assert hook.fused and loss.grad_fn is not None and type(loss) is torch.Tensor
+    assert crit(out, target).grad_fn is not None and hook.fused          # a second loss on the same output: torch's path
+    loss.backward()
+    out = net(x)
+    out.mul_(1.0)                                                       # modified in place: torch's path
+    assert not (crit(out, target), out._wn_hook.fused)[1]
+    with torch.no_grad():
+        o2 = net(x)
+        assert type(o2) is torch.Tensor and abs(float(crit(o2, target)) - float(loss)) < 1e-5
+    # everything else sees an ordinary tensor
+    assert type(out + 1) is torch.Tensor and type(out.view(-1)) is torch.Tensor and type(out.detach()) is torch.Tensor
+
