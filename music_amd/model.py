@@ -11,89 +11,17 @@ implementation: calling ``forward`` without a ROCm device raises.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 try:
-    from . import _lib
+    from . import _losshook
     from .engine import WaveNetEngine, WorkspaceHold
     from .engine_generic import GenericWaveNetEngine
 except ImportError:                      # imported as a bare module (`from model import wavenet`)
-    from music_amd import _lib
+    from music_amd import _losshook
     from music_amd.engine import WaveNetEngine, WorkspaceHold
     from music_amd.engine_generic import GenericWaveNetEngine
 
-
-class _LossHook(object):
-    """What `nn.CrossEntropyLoss` on this forward's output needs to run as ONE pass over the pre-softmax buffer (the engine's
-    fused chunk softmax + cross entropy + both backward steps, wn_chunk_softmax256_ce) instead of torch's five kernels over the
-    probabilities (0.42 ms of a 4.7 ms step at 8 x 16000)."""
-    __slots__ = ("eng", "ws", "gen", "version", "fused", "dloss")
-
-    def __init__(self, eng, ws, gen):
-        self.eng, self.ws, self.gen = eng, ws, gen
-        self.version, self.fused, self.dloss = None, False, None
-
-
-_ZERO = {}
-
-
-def _zero_token(like):
-    """A gradient of zeros for `probs` that occupies four bytes (expanded with stride 0): what the fused loss hands autograd.  Its own
-    contribution travels through the hook; any OTHER use of the probabilities in the user's loss adds its dense gradient to these
-    zeros, and the result is then no longer this buffer."""
-    key = (like.device, like.dtype)
-    if key not in _ZERO:
-        _ZERO[key] = torch.zeros(1, dtype=like.dtype, device=like.device)
-    return _ZERO[key]
-
-
-class _FusedCE(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, probs, target, hook):
-        eng, ws = hook.eng, hook.ws
-        n = ws["B"] * ws["W"]
-        bw = eng._bwd_workspace(ws) if ctx.needs_input_grad[0] else None
-        if "loss_part" not in ws:
-            ws["loss_part"] = torch.zeros(_lib.CE_NUM_PARTIALS, dtype=torch.float32, device=eng.device)
-        _lib.call("wn_chunk_softmax256_ce", _lib.ptr(ws["O"]), _lib.ptr(target), None, _lib.ptr(bw["dO"]) if bw else None,
-                  _lib.ptr(ws["loss_part"]), n, 1.0 / n, _lib.stream())
-        hook.fused = bw is not None
-        ctx.hook, ctx.shape = hook, probs.shape
-        return ws["loss_part"].sum()
-
-    @staticmethod
-    def backward(ctx, dloss):
-        ctx.hook.dloss = dloss
-        return _zero_token(dloss).expand(ctx.shape), None, None
-
-
-class _Probs(torch.Tensor):
-    """The module's output while a backward may follow: an ordinary tensor for every operation but one - the reference's own
-    `nn.CrossEntropyLoss()(net(x), target)` (wavenet/train.py:146,179: mean reduction, no weights, no smoothing) runs fused."""
-
-    @classmethod
-    def __torch_function__(cls, func, types, args=(), kwargs=None):
-        kwargs = kwargs or {}
-        if func is F.cross_entropy:
-            out = _fused_cross_entropy(*args, **kwargs)
-            if out is not NotImplemented:
-                return out
-        with torch._C.DisableTorchFunctionSubclass():
-            return func(*args, **kwargs)
-
-
-def _fused_cross_entropy(input, target, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean",
-                         label_smoothing=0.0):
-    hook = getattr(input, "_wn_hook", None)
-    if (hook is None or hook.fused or weight is not None or size_average is not None or reduce is not None or
-            reduction != "mean" or label_smoothing != 0.0 or ignore_index != -100 or type(target) is not torch.Tensor):
-        return NotImplemented
-    ws = hook.ws
-    if (ws.get("gen") != hook.gen or input._version != hook.version or target.dtype != torch.int64 or not target.is_cuda or
-            target.dim() != 1 or target.numel() != ws["B"] * ws["W"]):
-        return NotImplemented
-    with torch._C.DisableTorchFunctionSubclass():
-        return _FusedCE.apply(input, target.contiguous(), hook)
+_Probs = _losshook.Probs                 # the type of the module's output while a backward may follow
 
 
 class _WaveNetFunction(torch.autograd.Function):
@@ -109,7 +37,7 @@ class _WaveNetFunction(torch.autograd.Function):
                 x._wn_codes = (tag[0], tag[1], x._version, tag[3])
         probs, ws = eng.forward(x)
         ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
-        ctx.loss_hook = net._last_hook = _LossHook(eng, ws, ws["gen"]) if (grad_on and getattr(eng, "fused_loss_ok", False)) else None
+        ctx.loss_hook = net._last_hook = _losshook.make(eng, ws, grad_on)
         # a forward that some backward may follow keeps its workspace: the next forward of this shape gets another one (several
         # micro-batches in flight, as the reference's autograd allows).  `grad_on` is torch.is_grad_enabled() as the caller saw
         # it (inside Function.forward it is always off, and needs_input_grad is True for parameters even under no_grad): an
@@ -125,23 +53,7 @@ class _WaveNetFunction(torch.autograd.Function):
         if ws.get("gen") != ctx.gen:
             raise RuntimeError("music_amd.wavenet: the activations of this forward were overwritten by a later "
                                "forward of the same module before backward() ran")
-        hook = ctx.loss_hook
-        if hook is not None and hook.fused and hook.dloss is not None:
-            # the loss ran fused: d loss / d pre-softmax is in the workspace already (for d loss = 1; gradients are linear in it).
-            # `dprobs` is the zero token unless the user's loss uses the probabilities elsewhere too
-            tok = _zero_token(dprobs)
-            if dprobs.data_ptr() == tok.data_ptr() and not any(dprobs.stride()):
-                eng.backward_from_dlogits(ws)
-                eng.flat_grad.mul_(hook.dloss)
-            else:
-                n = ws["B"] * ws["W"]
-                bw = eng._bwd_workspace(ws)
-                extra = torch.empty(n * eng.Q, dtype=torch.float32, device=eng.device)
-                _lib.call("wn_chunk_softmax256_bwd", _lib.ptr(ws["probs"]), _lib.ptr(dprobs.contiguous()), _lib.ptr(extra), n, _lib.stream())
-                bw["dO"][:n * eng.Q].mul_(hook.dloss).add_(extra)
-                eng.backward_from_dlogits(ws)
-            hook.fused, hook.dloss = False, None
-        else:
+        if not _losshook.backward(ctx.loss_hook, eng, ws, dprobs):          # (the loss ran fused: see _losshook.py)
             eng.backward(ws, dprobs)
         if ctx.hold is not None:
             ctx.hold.release()           # (retain_graph + a second backward still works until the next forward reuses it)
@@ -237,10 +149,7 @@ class wavenet(nn.Module):
         self._last_hook = None
         out = _WaveNetFunction.apply(self, torch.is_grad_enabled(), wave_sample, *params)
         hook, self._last_hook = self._last_hook, None
-        if hook is not None and self.fuse_loss and out.requires_grad:
-            out = out.as_subclass(_Probs)
-            hook.version = out._version
-            out._wn_hook = hook
+        return _losshook.wrap(out, hook) if self.fuse_loss else out
         return out
 
 

@@ -27,11 +27,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 try:
-    from . import _lib
+    from . import _lib, _losshook
     from ._lib import call, ptr
     from .engine import SLACK, PAD_BACK, _Spec, _pad, pack_index, pack_positions, WorkspacePool, WorkspaceHold
 except ImportError:
-    from music_amd import _lib
+    from music_amd import _lib, _losshook
     from music_amd._lib import call, ptr
     from music_amd.engine import SLACK, PAD_BACK, _Spec, _pad, pack_index, pack_positions, WorkspacePool, WorkspaceHold
 
@@ -47,6 +47,7 @@ class _AutoencoderEngine:
         self.dil = [int(d) for d in net.dilations]
         self.N = len(self.dil)
         self.Q = net.quantization_channel
+        self.fused_loss_ok = True           # _losshook.py: nn.CrossEntropyLoss on the module's output may run as wn_chunk_softmax256_ce
         if net.filter_width != 2 or self.Q != 256:
             raise NotImplementedError("HIP path implements filter_width == 2 and quantization_channel == 256")
         self.Re, self.De, self.Bw, self.pool = net.en_residual_channel, net.en_dilation_channel, net.en_bottleneck_width, net.en_pool_kernel_size
@@ -590,6 +591,9 @@ class _AutoencoderEngine:
         call("wn_adam_flat", ptr(self.flat), ptr(self.flat_grad), ptr(s["m"]), ptr(s["v"]), self.spec.total,
              s["lr"], s["b1"], s["b2"], s["eps"], 1.0 - s["b1"] ** s["t"], 1.0 - s["b2"] ** s["t"], gscale, _lib.stream())
 
+    def backward_from_dlogits(self, ws):
+        self.backward(ws, None)
+
     def backward(self, ws, dprobs):
         """Fills self.flat_grad from d loss / d probabilities (B*W, Q); dprobs None = bw["dO"] already holds
         d loss / d logits (loss_and_grad)."""
@@ -860,6 +864,7 @@ class _AutoencoderFunction(torch.autograd.Function):
         probs, enc, ws = eng.forward(x, cond)
         net.last_encoding = enc
         ctx.eng, ctx.ws, ctx.gen = eng, ws, ws["gen"]
+        ctx.loss_hook = net._last_hook = _losshook.make(eng, ws, grad_on)
         ctx.hold = WorkspaceHold(ws) if (grad_on and any(ctx.needs_input_grad)) else None      # see music_amd/model.py
         return probs.detach()            # (an alias: the workspace's own reference must not carry the autograd node)
 
@@ -868,7 +873,8 @@ class _AutoencoderFunction(torch.autograd.Function):
         eng, ws = ctx.eng, ctx.ws
         if ws.get("gen") != ctx.gen:
             raise RuntimeError("music_amd.wavenet_autoencoder: activations were overwritten by a later forward")
-        eng.backward(ws, dprobs)
+        if not _losshook.backward(ctx.loss_hook, eng, ws, dprobs):          # (the loss ran fused: see _losshook.py)
+            eng.backward(ws, dprobs)
         if ctx.hold is not None:
             ctx.hold.release()
         g = eng.flat_grad.clone()
@@ -973,4 +979,7 @@ class wavenet_autoencoder(nn.Module):
             raise ValueError("wave sample not long enough")
         self._engine_for(wave_sample.device)
         cond = self._draw_conditioning()
-        return _AutoencoderFunction.apply(self, torch.is_grad_enabled(), wave_sample, cond, *list(self.parameters()))
+        self._last_hook = None
+        out = _AutoencoderFunction.apply(self, torch.is_grad_enabled(), wave_sample, cond, *list(self.parameters()))
+        hook, self._last_hook = self._last_hook, None
+        return _losshook.wrap(out, hook) if getattr(self, "fuse_loss", True) else out

@@ -1412,3 +1412,44 @@ def test_cross_entropy_on_the_module_output_runs_fused_and_equals_torchs():
     # everything else sees an ordinary tensor
     assert type(out + 1) is torch.Tensor and type(out.view(-1)) is torch.Tensor and type(out.detach()) is torch.Tensor
 
+
+def test_cross_entropy_on_the_autoencoder_output_runs_fused_and_equals_torchs():
+    """The same interception on `wavenet_autoencoder` (its train loop applies nn.CrossEntropyLoss to the output as well): loss and
+    every gradient against the unfused module, with the same per-forward conditioning projections (same torch seed)."""
+    import numpy as np
+    from music_amd import _losshook
+    from music_amd.model1 import wavenet_autoencoder
+    from oracle import intops
+    torch.manual_seed(11)
+    net = wavenet_autoencoder(filter_width=2, quantization_channel=256, dilations=[1, 2, 4, 8, 16], en_residual_channel=64,
+                              en_dilation_channel=64, en_bottleneck_width=16, en_pool_kernel_size=50, de_residual_channel=64,
+                              de_dilation_channel=64, de_skip_channel=256, use_bias=False)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+        net.connection_2.weight.mul_(6.0)
+    net = net.cuda()
+    rng = np.random.default_rng(12)
+    B, W = 2, 400
+    idx = rng.integers(0, 256, size=(B, net.receptive_field + W - 1))
+    x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx])).cuda()
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).cuda()
+    crit = torch.nn.CrossEntropyLoss()
+    res = []
+    for fuse in (False, True):
+        net.fuse_loss = fuse
+        net.zero_grad()
+        torch.manual_seed(77)
+        out = net(x)
+        assert (type(out) is _losshook.Probs) == fuse
+        loss = 2.0 * crit(out, target)
+        if fuse:
+            assert out._wn_hook.fused
+        loss.backward()
+        res.append((float(loss.detach()), [p.grad.clone() for p in net.parameters()]))
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)), (l0, l1)
+    gmax = max(g.abs().max().item() for g in g0)
+    for a, b in zip(g0, g1):
+        assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1e-3 * gmax)
+
