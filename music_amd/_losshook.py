@@ -122,11 +122,13 @@ def backward(hook, eng, ws, dprobs):
         eng.flat_grad.mul_(hook.dloss)
     else:                                                   # the probabilities are used elsewhere in the loss too
         n = ws["B"] * ws["W"]
-        bw = eng._bwd_workspace(ws)
+        d_o = eng._bwd_workspace(ws)["dO"][:n * eng.Q]
+        keep = d_o.clone()                                  # (a second backward through a retained graph finds it unchanged)
         extra = torch.empty(n * eng.Q, dtype=torch.float32, device=eng.device)
         _lib.call("wn_chunk_softmax256_bwd", _lib.ptr(ws["probs"]), _lib.ptr(dprobs.contiguous()), _lib.ptr(extra), n, _lib.stream())
-        bw["dO"][:n * eng.Q].mul_(hook.dloss).add_(extra)
+        d_o.mul_(hook.dloss).add_(extra)
         eng.backward_from_dlogits(ws)
-    hook.fused, hook.dloss = False, None
+        d_o.copy_(keep)
+    hook.dloss = None
     return True
 

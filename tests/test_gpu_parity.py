@@ -1394,6 +1394,16 @@ def test_cross_entropy_on_the_module_output_runs_fused_and_equals_torchs():
         gmax = max(g.abs().max().item() for g in g0)
         for a, b in zip(g0, g1):
             assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1e-3 * gmax), name
+    # a retained graph: a second backward through the fused loss gives the same gradients again (accumulated: twice)
+    net.fuse_loss = True
+    net.zero_grad()
+    out = net(x)
+    loss = crit(out, target) + 0.25 * (out * out).sum() / out.numel()
+    loss.backward(retain_graph=True)
+    first = [p.grad.clone() for p in net.parameters()]
+    loss.backward()
+    for a, p in zip(first, net.parameters()):
+        assert (p.grad - 2.0 * a).abs().max().item() <= 1e-6 * max(a.abs().max().item(), 1e-30) + 1e-12
     # the fused pass really ran in the plain case (and only there among the torch-path cases)
     net.fuse_loss = True
     net.zero_grad()
