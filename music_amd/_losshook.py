@@ -88,7 +88,7 @@ def _fused_cross_entropy(input, target, weight=None, size_average=None, ignore_i
             reduction != "mean" or label_smoothing != 0.0 or ignore_index != -100 or type(target) is not torch.Tensor):
         return NotImplemented
     ws = hook.ws
-    if (ws.get("gen") != hook.gen or input._version != hook.version or target.dtype != torch.int64 or not target.is_cuda or
+    if (ws.get("gen") != hook.gen or input._version != hook.version or target.dtype != torch.int64 or target.device != input.device or
             target.dim() != 1 or target.numel() != ws["B"] * ws["W"]):
         return NotImplemented
     with torch._C.DisableTorchFunctionSubclass():
