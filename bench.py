@@ -465,6 +465,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)          # discard 10 warm-up steps, time >= 50
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--settle", type=int, default=60, help="discarded steps before the warm-up (one-time costs of a fresh box)")
+    ap.add_argument("--dump-steps", action="store_true", help="every timed step's GPU time in the line (ms_per_step_stats.all_in_order)")
     ap.add_argument("--precision", default="f16x3,bf16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-4 / config-5 sub-benchmarks")
@@ -768,7 +769,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
         "ms_per_step": dt / args.steps * 1e3,
         "ms_per_step_stats": {"median": per_step[len(per_step) // 2], "min": per_step[0], "max": per_step[-1],
-                              "p90": per_step[min(len(per_step) - 1, (len(per_step) * 9) // 10)], "first_10_in_order": per_step_order[:10],
+                              "p90": per_step[min(len(per_step) - 1, (len(per_step) * 9) // 10)], "first_10_in_order": per_step_order[:10], **({"all_in_order": per_step_order} if args.dump_steps else {}),
                               "note": "GPU time between the end-of-step HIP events of consecutive timed steps (rank 0); the interpreter's garbage collector runs before the timed region, not inside it"} if per_step else None,
         "host_enqueue_ms_per_step": host_enqueue_ms,
         "first_window": {"steps": first_n, "ms_per_step": first_ms,
