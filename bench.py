@@ -35,7 +35,10 @@ def _self_launch():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
            "--nproc-per-node", str(known.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)                                  # (inherited as is: the pool exports what RCCL needs across processes)
-    env.setdefault("OMP_NUM_THREADS", "8")
+    # host threads per rank = this host's CPU quota shared by the ranks (music_amd/_lib.py: thread_budget; torchrun's own default
+    # is 1).  _lib imports neither torch nor the library at module level: the parent stays off the GPU
+    from music_amd import _lib as _wl
+    env.setdefault("OMP_NUM_THREADS", str(min(8, _wl.thread_budget(_wl.cpu_quota(), known.gpus))))
     sys.exit(subprocess.call(cmd, env=env))
 
 
@@ -498,7 +501,8 @@ def main():
         os.dup2(stdout_fd, 1)
         os.close(stdout_fd)
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": t.item()}), flush=True)
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": t.item(), "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}),
+                  flush=True)
         return
     backend = os.environ.get("WN_DIST_BACKEND", "nccl")       # gloo: several ranks on one GPU (tests on a 1-GPU box)
     n_dev = max(1, torch.cuda.device_count())
@@ -628,8 +632,13 @@ def main():
     marks, eng.marks, eng.mark_only = state["sampled"], None, None
     state["sampled"] = None
     n_sampled = (args.steps + MARK_EVERY - 1) // MARK_EVERY
+    dt_ranks = [dt]
     if use_dist:
+        # every rank's own wall time over the K steps (what a straggler looks like in the line), then the contract's MAX over ranks
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tg = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(tg, tt)
+        dt_ranks = [float(t.item()) for t in tg]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
 
@@ -771,7 +780,12 @@ def main():
         "ms_per_step_stats": {"median": per_step[len(per_step) // 2], "min": per_step[0], "max": per_step[-1],
                               "p90": per_step[min(len(per_step) - 1, (len(per_step) * 9) // 10)], "first_10_in_order": per_step_order[:10], **({"all_in_order": per_step_order} if args.dump_steps else {}),
                               "note": "GPU time between the end-of-step HIP events of consecutive timed steps (rank 0); the interpreter's garbage collector runs before the timed region, not inside it"} if per_step else None,
+        "ms_per_step_ranks": {"min": min(dt_ranks) / args.steps * 1e3, "max": max(dt_ranks) / args.steps * 1e3,
+                              "all": [round(v / args.steps * 1e3, 4) for v in dt_ranks],
+                              "note": "each rank's wall time over the K timed steps / K; ms_per_step is the max (the contract)"},
         "host_enqueue_ms_per_step": host_enqueue_ms,
+        "host_threads": {"torch_intra_op": torch.get_num_threads(), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
+                         "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))},
         "first_window": {"steps": first_n, "ms_per_step": first_ms,
                          "note": "the first steps of this process (one-time costs included), before the settle / warm-up steps are discarded"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

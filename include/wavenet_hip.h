@@ -39,7 +39,7 @@ extern "C" {
 
 typedef void* wn_stream_t;                 /* hipStream_t */
 enum { WN_F16X3 = 0, WN_F16X1 = 1, WN_BF16X3 = 2, WN_BF16X1 = 3 };
-#define WN_ABI_VERSION 2
+#define WN_ABI_VERSION 3
 #define WN_CE_NUM_PARTIALS 1024
 
 int wn_version(void);
@@ -275,6 +275,15 @@ int wn_chunk_softmax256_ce(const float* x, const int64_t* target, float* probs, 
 int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, float bias_corr1, float bias_corr2, float gscale,
                  wn_stream_t stream);
+/* torch.optim.SGD(params, lr, momentum) / torch.optim.RMSprop(params, lr, momentum) steps on a flat buffer - the other two
+ * optimizers wavenet/train.py:28-38 constructs (every further argument at torch's default: no dampening / Nesterov / weight
+ * decay; RMSprop not centered, alpha and eps passed in).  g is multiplied by gscale.  SGD: first_step != 0 sets the momentum
+ * buffer to the gradient (torch's first step); momentum == 0 needs no buffer (NULL).  RMSprop: momentum_buf may be NULL when
+ * momentum == 0. */
+int wn_sgd_flat(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum, float gscale,
+                int first_step, wn_stream_t stream);
+int wn_rmsprop_flat(float* p, const float* g, float* square_avg, float* momentum_buf, int64_t n, float lr, float alpha,
+                    float eps, float momentum, float gscale, wn_stream_t stream);
 /* The reference's nn.DataParallel gradient reduction (wavenet/train.py:116-122) as ONE in-place sum over the ranks of the flat
  * fp32 gradient buffer: ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum, comm, stream) on the caller's RCCL communicator
  * (`comm` = an ncclComm_t).  The 1 / world_size of the mean goes into wn_adam_flat's gscale.  Returns -5 when RCCL is neither

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("WAVENET_HIP_LIB") or os.path.join(_HERE, "libwavenet_
 F16X3, F16X1, BF16X3, BF16X1 = 0, 1, 2, 3
 MODE_NAMES = {"f16x3": F16X3, "f16x1": F16X1, "bf16x3": BF16X3, "bf16x1": BF16X1}
 CE_NUM_PARTIALS = 1024
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -69,6 +69,8 @@ SIGNATURES = {
     "wn_chunk_softmax_bwd": [_p, _p, _p, _l, _i, _p],
     "wn_chunk_softmax_ce": [_p, _p, _p, _p, _p, _l, _i, _f, _p],
     "wn_adam_flat": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p],
+    "wn_sgd_flat": [_p, _p, _p, _l, _f, _f, _f, _i, _p],
+    "wn_rmsprop_flat": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p],
     "wn_coll_available": [],
     "wn_comm_unique_id": [_p],
     "wn_comm_create": [_i, _i, _p, _p],
@@ -112,22 +114,45 @@ def cpu_quota():
         return None
 
 
+def local_world_size(env=None):
+    """Ranks the launcher started on THIS host (torchrun exports LOCAL_WORLD_SIZE; 1 without a launcher)."""
+    env = os.environ if env is None else env
+    try:
+        return max(1, int(env.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        return 1
+
+
+def thread_budget(quota, local_world, cpus=None):
+    """Host threads ONE rank may run: the container's CPU quota (or, without one, the host's CPUs) shared by the ranks of
+    this host, rounded up, at least 1.  8 ranks on a 16-CPU quota -> 2 each (not 16 each: 128 runnable threads on 16 CPUs
+    is the throttling stall of DESIGN_HISTORY.md, 68 instead of 10 ms per step)."""
+    total = quota if quota is not None else (cpus if cpus is not None else (os.cpu_count() or 1))
+    return max(1, -(-int(total) // max(1, int(local_world))))
+
+
 def respect_cpu_quota():
     """torch sizes its intra-op thread pool by the machine's cores (128 on an MI355X host) and does not look at the
     container's CPU quota; an OpenMP region then wakes all of them, they spin, and the scheduler throttles the WHOLE process
     for the rest of the period - host code that feeds a GPU loses 80 ms out of every 100 (measured: the autoencoder with the
     reference's shipped parameters, 68 instead of 10 ms per step).  Called once when the library is loaded: the pool is
-    cut to the quota (rounded up), and the change is REPORTED once on stderr, because it changes the host application's
-    intra-op thread count too.  WN_KEEP_TORCH_THREADS=1 leaves the pool alone."""
+    cut to this rank's SHARE of the quota - quota / LOCAL_WORLD_SIZE, rounded up (one process per GPU: eight ranks share the
+    host) - and the change is REPORTED once on stderr, because it changes the host application's intra-op thread count too.
+    Without a quota nothing is cut for a single process; under a launcher the share of the host's CPUs applies.
+    WN_KEEP_TORCH_THREADS=1 leaves the pool alone."""
     import sys
     import torch
     if os.environ.get("WN_KEEP_TORCH_THREADS", "0") == "1":
         return
-    q = cpu_quota()
-    if q is not None and torch.get_num_threads() > q:
-        print("music_amd: torch intra-op threads %d -> %d (the container's CPU quota; WN_KEEP_TORCH_THREADS=1 keeps torch's own setting)"
-              % (torch.get_num_threads(), q), file=sys.stderr)
-        torch.set_num_threads(q)
+    q, lw = cpu_quota(), local_world_size()
+    if q is None and lw == 1:
+        return
+    n = thread_budget(q, lw)
+    if torch.get_num_threads() > n:
+        print("music_amd: torch intra-op threads %d -> %d (%s shared by %d rank(s) of this host; WN_KEEP_TORCH_THREADS=1 keeps torch's "
+              "own setting)" % (torch.get_num_threads(), n, "the container's CPU quota of %d" % q if q is not None else
+                                "%d CPUs" % (os.cpu_count() or 1), lw), file=sys.stderr)
+        torch.set_num_threads(n)
 
 
 def load():

@@ -7,12 +7,21 @@ the whole thing as one kernel (wn_chunk_softmax256_ce: loss, and d loss / d pre-
 module's OUTPUT can carry the knowledge: `forward` returns a `torch.Tensor` subclass whose `__torch_function__` lets every operation
 through to torch except `F.cross_entropy` with default arguments on the unmodified output of the latest forward.
 
-Autograd stays exact.  The fused node hands `probs` a gradient of zeros that occupies four bytes (expanded, stride 0); its own
-contribution - d loss / d pre-softmax for an upstream gradient of 1, already in the workspace - is picked up by the module's backward
-through the hook and scaled by the upstream gradient (the backward is linear in it).  If the user's loss uses the probabilities
-elsewhere too, autograd adds that dense gradient to the zeros; the module's backward then sees a tensor that is not the token, runs
-its softmax backward on it and adds the fused part.  One documented difference from torch: a target equal to `ignore_index` (-100)
-makes the fused loss NaN instead of being skipped."""
+The PARAMETER gradients autograd delivers are exact.  The fused node hands `probs` a gradient of zeros that occupies four bytes
+(expanded, stride 0); its own contribution - d loss / d pre-softmax for an upstream gradient of 1, already in the workspace - is picked
+up by the module's backward through the hook and scaled by the upstream gradient (the backward is linear in it).  If the user's loss
+uses the probabilities elsewhere too, autograd adds that dense gradient to the zeros; the module's backward then sees a tensor that is
+not the token, runs its softmax backward on it and adds the fused part.  Any order of backward passes over the same forward is
+handled: a backward of ANOTHER loss on the output that runs before the fused loss's own (retain_graph) overwrites the workspace's
+d loss / d pre-softmax, which the hook notices (`do_valid`) and re-forms from the kept target before it is used; an upstream gradient
+that no module backward consumed (`torch.autograd.grad(loss, out)`) is dropped when that backward pass ends, not carried into the next.
+
+Limits next to torch's own criterion (`net.fuse_loss = False` gives torch's behaviour in every one of them):
+  * what autograd REPORTS for the probabilities themselves is the zero token: `out.retain_grad()`, tensor hooks on `out` and
+    `torch.autograd.grad(loss, out)` see zeros, not d loss / d probs (parameter gradients are unaffected);
+  * a target equal to `ignore_index` (-100) makes the fused loss NaN instead of being skipped, and a target outside [0, 256) makes the
+    loss and that row's gradient NaN where torch raises a device assert (the kernel never indexes with it: wn_elem.hip);
+  * `create_graph=True` (double backward) is not supported through the fused node."""
 import torch
 import torch.nn.functional as F
 
@@ -26,11 +35,14 @@ class LossHook(object):
     """What `nn.CrossEntropyLoss` on this forward's output needs to run as ONE pass over the pre-softmax buffer (the engine's
     fused chunk softmax + cross entropy + both backward steps, wn_chunk_softmax256_ce) instead of torch's five kernels over the
     probabilities (0.42 ms of a 4.7 ms step at 8 x 16000)."""
-    __slots__ = ("eng", "ws", "gen", "version", "fused", "dloss")
+    __slots__ = ("eng", "ws", "gen", "version", "fused", "dloss", "target", "do_valid")
 
     def __init__(self, eng, ws, gen):
         self.eng, self.ws, self.gen = eng, ws, gen
         self.version, self.fused, self.dloss = None, False, None
+        # target: what the fused loss was taken against (kept so that d loss / d pre-softmax can be formed again);
+        # do_valid: the workspace's dO still holds it (an ordinary backward on the same forward overwrites dO)
+        self.target, self.do_valid = None, False
 
 
 _ZERO = {}
@@ -56,13 +68,21 @@ class _FusedCE(torch.autograd.Function):
             ws["loss_part"] = torch.zeros(_lib.CE_NUM_PARTIALS, dtype=torch.float32, device=eng.device)
         _lib.call("wn_chunk_softmax256_ce", _lib.ptr(ws["O"]), _lib.ptr(target), None, _lib.ptr(bw["dO"]) if bw else None,
                   _lib.ptr(ws["loss_part"]), n, 1.0 / n, _lib.stream())
-        hook.fused = bw is not None
+        hook.fused = hook.do_valid = bw is not None
+        hook.target = target if bw is not None else None
         ctx.hook, ctx.shape = hook, probs.shape
         return ws["loss_part"].sum()
 
     @staticmethod
     def backward(ctx, dloss):
-        ctx.hook.dloss = dloss
+        hook = ctx.hook
+        hook.dloss = dloss
+        # the module's backward of THIS pass consumes it; if none runs (torch.autograd.grad(loss, out)) it must not survive
+        # into a later, unrelated backward: dropped when the pass ends
+        def _drop(h=hook, d=dloss):
+            if h.dloss is d:
+                h.dloss = None
+        torch.autograd.Variable._execution_engine.queue_callback(_drop)
         return _zero_token(dloss).expand(ctx.shape), None, None
 
 
@@ -114,8 +134,20 @@ def wrap(out, hook):
 def backward(hook, eng, ws, dprobs):
     """Called first thing in the module's autograd Function backward.  True: the gradients are in eng.flat_grad (the loss ran fused);
     False: nothing was done, run the ordinary backward from `dprobs`."""
-    if hook is None or not hook.fused or hook.dloss is None:
+    if hook is None or not hook.fused:
         return False
+    if hook.dloss is None:
+        # an ordinary backward (another loss on the same output) while the fused loss is pending: eng.backward() is about to
+        # overwrite the workspace's dO, which the fused loss's own backward will need
+        hook.do_valid = False
+        return False
+    if not hook.do_valid:
+        if ws.get("gen") != hook.gen:
+            raise RuntimeError("music_amd: the activations of this forward were overwritten before the fused loss's backward")
+        n = ws["B"] * ws["W"]
+        _lib.call("wn_chunk_softmax256_ce", _lib.ptr(ws["O"]), _lib.ptr(hook.target), None, _lib.ptr(eng._bwd_workspace(ws)["dO"]),
+                  None, n, 1.0 / n, _lib.stream())
+        hook.do_valid = True
     tok = _zero_token(dprobs)
     if dprobs.data_ptr() == tok.data_ptr() and not any(dprobs.stride()):
         eng.backward_from_dlogits(ws)                       # d loss / d pre-softmax is in the workspace (for an upstream gradient of 1)

@@ -148,6 +148,16 @@ int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float beta2, float eps, float bias_corr1, float bias_corr2, float gscale, wn_stream_t stream) {
     return wn_launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, bias_corr1, bias_corr2, gscale, (hipStream_t)stream);
 }
+int wn_sgd_flat(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum, float gscale, int first_step,
+                wn_stream_t stream) {
+    if (momentum != 0.f && !momentum_buf) return wn_set_error_msg(-4, "wn_sgd_flat: momentum needs its buffer");
+    return wn_launch_sgd(p, g, momentum_buf, n, lr, momentum, gscale, first_step, (hipStream_t)stream);
+}
+int wn_rmsprop_flat(float* p, const float* g, float* square_avg, float* momentum_buf, int64_t n, float lr, float alpha, float eps,
+                    float momentum, float gscale, wn_stream_t stream) {
+    if (!square_avg || (momentum > 0.f && !momentum_buf)) return wn_set_error_msg(-4, "wn_rmsprop_flat: missing state buffer");
+    return wn_launch_rmsprop(p, g, square_avg, momentum_buf, n, lr, alpha, eps, momentum, gscale, (hipStream_t)stream);
+}
 int wn_coll_available(void) { return wn_coll_loaded(); }
 int wn_comm_unique_id(char* id128) { return wn_coll_unique_id(id128); }
 int wn_comm_create(int nranks, int rank, const char* id128, void** comm) { return wn_coll_create(nranks, rank, id128, comm); }

@@ -147,13 +147,13 @@ int wn_launch_causal_wgrad_codes(const int32_t* codes, int scrambled, const floa
     static_assert(CW_THREADS == 2 * CW_Q, "one thread per slab column in the read-out");
     const size_t sh = sizeof(float) * ((size_t)2 * CW_Q * CW_ACC_LD + (size_t)ch * (CW_TC + 1)) + sizeof(int) * 2 * CW_Q;
     const size_t sh_max = sizeof(float) * ((size_t)2 * CW_Q * CW_ACC_LD + (size_t)64 * (CW_TC + 1)) + sizeof(int) * 2 * CW_Q;
-    static unsigned long long done = 0;
+    static WnDevOnce done;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((done >> dev) & 1ull)) {
+    if (done.need(dev)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&causal_wgrad_codes_k<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&causal_wgrad_codes_k<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max);
-        done |= 1ull << dev;
+        done.done(dev);
     }
     if (ch == 32) hipLaunchKernelGGL(causal_wgrad_codes_k<32>, dim3(nwg), dim3(CW_THREADS), sh, st, codes, scrambled, dx, dxq, dn, p_lo, dx_bstride, pitch, T, batch, slab);
     else hipLaunchKernelGGL(causal_wgrad_codes_k<64>, dim3(nwg), dim3(CW_THREADS), sh, st, codes, scrambled, dx, dxq, dn, p_lo, dx_bstride, pitch, T, batch, slab);

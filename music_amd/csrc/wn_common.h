@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -221,6 +222,15 @@ int wn_xcd_swizzle_enabled();      // host: 1 (a switch until round 4)
 // the 256-byte row segment of a 64-column wave tile is exactly two 128-byte lines (pitch and bases are
 // multiples of 128 B); columns in front of t_lo are masked.  Must stay a multiple of 4 (float4 lanes).
 int wn_tile_origin(int t_lo);
+
+// "this kernel instantiation has its dynamic-LDS attribute set on device d": one object per instantiation.  The C ABI promises
+// re-entrancy across host threads (include/wavenet_hip.h), so the mask is atomic; two threads that race on a first launch both
+// set the attribute (idempotent).  Device ordinals >= 64 have no bit: the attribute is set on every launch there.
+struct WnDevOnce {
+    std::atomic<unsigned long long> mask{0};
+    bool need(int dev) const { return dev < 0 || dev >= 64 || !((mask.load(std::memory_order_acquire) >> dev) & 1ull); }
+    void done(int dev) { if (dev >= 0 && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release); }
+};
 
 #define WN_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return wn_set_error(e_, __FILE__, __LINE__); } while (0)
 int wn_set_error(hipError_t e, const char* file, int line);

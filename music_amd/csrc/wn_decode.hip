@@ -978,8 +978,8 @@ int wn_launch_decode(const WnDecodeArgs& a, hipStream_t st) {
         const int mx = 160 * 1024 - 1024;           // (the kernel also has ~350 bytes of static LDS)
         const dim3 gr((1 + ks) * pairs), bl(DEC_MT);
 #define DEC_GO3(BB, TT, SS, KK) do { \
-        static unsigned long long done_ = 0; \
-        if (!((done_ >> dev) & 1ull)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_duo_mfma8_k<BB, TT, SS, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, mx); done_ |= 1ull << dev; } \
+        static WnDevOnce done_; \
+        if (done_.need(dev)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_duo_mfma8_k<BB, TT, SS, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, mx); done_.done(dev); } \
         hipLaunchKernelGGL((decode_duo_mfma8_k<BB, TT, SS, KK>), gr, bl, sh, st, a); } while (0)
 #define DEC_GO2(BB, SS, KK) do { if (t0 == 2) DEC_GO3(BB, 2, SS, KK); else if (t0 == 1) DEC_GO3(BB, 1, SS, KK); else DEC_GO3(BB, 0, SS, KK); } while (0)
 #define DEC_GO(SS, KK) do { if (any_bias) DEC_GO2(true, SS, KK); else DEC_GO2(false, SS, KK); } while (0)

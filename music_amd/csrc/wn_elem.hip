@@ -180,6 +180,61 @@ int wn_launch_adam(float* p, const float* g, float* m, float* v, long n, float l
     return 0;
 }
 
+// Flat SGD with momentum and flat RMSprop (torch.optim.SGD / torch.optim.RMSprop semantics as wavenet/train.py:28-38 constructs them:
+// lr + momentum, every other argument at its default - no dampening, no Nesterov, no weight decay, RMSprop alpha / eps given, not
+// centered).  g is pre-scaled by gscale (1 / world_size after the all-reduce).
+//   SGD      buf = first ? g : momentum * buf + g ;  p -= lr * buf            (momentum == 0: p -= lr * g, buf untouched)
+//   RMSprop  sq = alpha * sq + (1 - alpha) * g * g ; avg = sqrt(sq) + eps ;
+//            momentum > 0: buf = momentum * buf + g / avg ; p -= lr * buf     else  p -= lr * g / avg
+__global__ void sgd_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n, float lr, float momentum,
+                      float gscale, int first) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float gi = g[i] * gscale;
+        if (momentum != 0.f) {
+            gi = first ? gi : buf[i] * momentum + gi;
+            buf[i] = gi;
+        }
+        p[i] += -lr * gi;
+    }
+}
+int wn_launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float gscale, int first, hipStream_t st) {
+    if (n <= 0) return 0;
+    long grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(sgd_k, dim3((int)grid), dim3(256), 0, st, p, g, buf, n, lr, momentum, gscale, first);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+__global__ void rmsprop_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, float* __restrict__ buf, long n,
+                          float lr, float alpha, float eps, float momentum, float gscale) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float gi = g[i] * gscale;
+        const float s = sq[i] * alpha + ((1.0f - alpha) * gi) * gi;
+        sq[i] = s;
+        const float avg = sqrtf(s) + eps;
+        if (momentum > 0.f) {
+            const float b = buf[i] * momentum + gi / avg;
+            buf[i] = b;
+            p[i] += -lr * b;
+        } else {
+            p[i] += -lr * (gi / avg);
+        }
+    }
+}
+int wn_launch_rmsprop(float* p, const float* g, float* sq, float* buf, long n, float lr, float alpha, float eps, float momentum,
+                      float gscale, hipStream_t st) {
+    if (n <= 0) return 0;
+    long grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(rmsprop_k, dim3((int)grid), dim3(256), 0, st, p, g, sq, buf, n, lr, alpha, eps, momentum, gscale);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
 // flat_grad[i] = packed[idx[i]]  (idx < 0: structural zero).  Maps the dense C matrices written
 // by wgrad into the reference's (out, in, k) state_dict layout.
 __global__ void gather_grads_k(const float* __restrict__ packed, const int32_t* __restrict__ idx,

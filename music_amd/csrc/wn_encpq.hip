@@ -452,13 +452,13 @@ int wn_launch_enc_bwd_pq(const WnEncPqArgs& a, int ch, int batch, int mode_bwd, 
     k.batch = batch;
     k.swz = wn_xcd_swizzle_enabled();
     const size_t sh = (size_t)EP_LDS_HALFS * sizeof(uint16_t);
-    static unsigned long long done = 0;
+    static WnDevOnce done;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((done >> dev) & 1ull)) {
+    if (done.need(dev)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        done |= 1ull << dev;
+        done.done(dev);
     }
     if (k.q_in) hipLaunchKernelGGL(enc_bwd_pq_k<true>, dim3(nwg), dim3(EP_THREADS), sh, st, k);
     else hipLaunchKernelGGL(enc_bwd_pq_k<false>, dim3(nwg), dim3(EP_THREADS), sh, st, k);

@@ -297,12 +297,12 @@ int wn_launch_enc_bwd_rw(const WnResMsArgs& a, int ch, int batch, int mode_bwd, 
     k.batch = batch;
     k.swz = wn_xcd_swizzle_enabled();
     const size_t sh = (size_t)2 * ER_STAGE * sizeof(uint16_t);
-    static unsigned long long done = 0;
+    static WnDevOnce done;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((done >> dev) & 1ull)) {
+    if (done.need(dev)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_rw_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        done |= 1ull << dev;
+        done.done(dev);
     }
     hipLaunchKernelGGL(enc_bwd_rw_k, dim3(nwg), dim3(ER_THREADS), sh, st, k);
     WN_CHECK_LAUNCH();

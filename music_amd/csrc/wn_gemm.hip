@@ -481,13 +481,13 @@ static int launch_gemm(const WnGemmArgs& k, int batch, hipStream_t st) {
     } else {                             // wide: 256 rows x 256 columns per workgroup
         dim3 g((ncol + 255) / 256, (k.mt + 15) / 16, batch), b(512);
         const size_t sh = (size_t)2 * 32 * (NS == 3 ? 1024 : 512) * sizeof(uint16_t);
-        static unsigned long long done = 0;
+        static WnDevOnce done;
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (!((done >> dev) & 1ull)) {
+        if (done.need(dev)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_gemm_wide2_k<T, NS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            done |= 1ull << dev;
+            done.done(dev);
         }
         hipLaunchKernelGGL((chan_gemm_wide2_k<T, NS>), g, b, sh, st, k);
     }
@@ -499,7 +499,7 @@ int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st) {
     WnGemmArgs k = a;
     k.t_base = wn_tile_origin(a.t_lo);
     k.swz = wn_xcd_swizzle_enabled();
-    if (wn_launch_gemm_rw(k, batch, mode, st)) {
+    if (wn_launch_gemm_rw(k, batch, mode, st) || wn_launch_gemm_dma(k, batch, mode, st)) {
         WN_CHECK_LAUNCH();
         return 0;
     }

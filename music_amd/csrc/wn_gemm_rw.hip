@@ -247,15 +247,15 @@ int wn_launch_gemm_rw(const WnGemmArgs& k, int batch, int mode, hipStream_t st) 
     if (pl.items_per_wg < 1) pl.items_per_wg = 1;
     const int nwg = (total + pl.items_per_wg - 1) / pl.items_per_wg;
     const size_t sh = (size_t)2 * 2 * ks * 1024 * sizeof(uint16_t);
-    static unsigned long long done = 0;
+    static WnDevOnce done;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((done >> dev) & 1ull)) {
+    if (done.need(dev)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_gemm_rw_k<BF16, 8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chan_gemm_rw_k<F16, 8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        done |= 1ull << dev;
+        done.done(dev);
     }
     const dim3 gr(nwg), bl(GR_THREADS);
     if (mode == WN_MODE_BF16X3) {

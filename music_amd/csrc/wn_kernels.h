@@ -27,6 +27,8 @@ struct WnGemmArgs {
 int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 // two-role persistent form of the narrow product (wn_gemm_rw.hip); 1 = launched, 0 = arguments not covered
 int wn_launch_gemm_rw(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
+// LDS-DMA form of the wide product (wn_gemm_dma.hip: >= 256 rows, one tap, x3 modes); 1 = launched, 0 = arguments not covered
+int wn_launch_gemm_dma(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 struct WnResArgs;
 int wn_launch_enc_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);   // wn_resblock2.hip (ENC)
 int wn_launch_pack(const float* flat, const int32_t* idx, uint16_t* out, int n, int is_bf16, int ns,
@@ -183,6 +185,9 @@ int wn_launch_softmax_ce(const float* x, const int64_t* target, float* probs, fl
                          float* loss_part, long nrows, float inv_n, hipStream_t st);
 int wn_launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                    float eps, float bc1, float bc2, float gscale, hipStream_t st);
+int wn_launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float gscale, int first, hipStream_t st);
+int wn_launch_rmsprop(float* p, const float* g, float* sq, float* buf, long n, float lr, float alpha, float eps, float momentum,
+                      float gscale, hipStream_t st);
 int wn_launch_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, hipStream_t st);
 int wn_launch_gather_grads2(const float* packed, const int32_t* idx, const int32_t* idx2, float* flat_grad, int n, hipStream_t st);
 int wn_launch_onehot(const int32_t* idx, float* out, int batch, int q, int t, int scrambled, hipStream_t st);

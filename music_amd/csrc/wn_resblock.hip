@@ -204,13 +204,13 @@ static int launch_bwd(const WnResBwdArgs& a, int ch, int batch, hipStream_t st) 
         hipLaunchKernelGGL((resblock_bwd_k<TF, NSF, TB, NSB, 32>), g, b, sh, st, k);
     } else if (ch == 64) {
         size_t sh = 32 * frf + 8 * frb;
-        static unsigned long long done = 0;
+        static WnDevOnce done;
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (!((done >> dev) & 1ull)) {
+        if (done.need(dev)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_k<TF, NSF, TB, NSB, 64>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            done |= 1ull << dev;
+            done.done(dev);
         }
         hipLaunchKernelGGL((resblock_bwd_k<TF, NSF, TB, NSB, 64>), g, b, sh, st, k);
     } else {

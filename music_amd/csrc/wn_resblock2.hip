@@ -95,10 +95,23 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
     fvec raw[8];
     auto issue = [&](int s) {
         const int tap = s / KT, ch = (s % KT) * 32 + 8 * q;
+#ifdef FW_T_L2X
+        // TIMING build (wrong results): every x read lands in the clip's first 512 columns (served by L2 / the Infinity Cache) -
+        // what the block costs when its input never comes from HBM (halo-recompute fusion of the small dilations, priced)
+        const float* p = xin + (size_t)ch * a.pitch + ((tap == 0 ? colm : tl) & 511);
+#else
         const float* p = xin + (size_t)ch * a.pitch + (tap == 0 ? colm : tl);
+#endif
         // the shifted tap is always loaded with the alignment-free form: choosing between the two forms
         // at run time would merge the loaded registers across a branch, which the compiler implements as
         // load -> wait -> copy, i.e. no prefetch at all
+#ifdef FW_T_NOXLOAD
+        // TIMING build (wrong results): no x loads at all (finite constants instead) - the block whose input is already on the CU
+        // (halo-recompute fusion of the small dilations, priced: tools/exp/README.md)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[j] = fvec{0.01f * (float)(j + 1), -0.02f, 0.03f, 0.015f} + (p == nullptr ? 1.f : 0.f);
+        return;
+#endif
         if (tap == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[j] = VecN<NT>::ldu(p + (size_t)j * a.pitch);
@@ -207,10 +220,25 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
         Frag<T> bf[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
+#ifdef FW_T_NOCONV
+            // TIMING build (wrong results): the loaded bits ARE the fragment (x stored MFMA-ready: same bytes, no vector work)
+            const u32x4 h_ = {__builtin_bit_cast(uint32_t, raw[0][n]), __builtin_bit_cast(uint32_t, raw[1][n]), __builtin_bit_cast(uint32_t, raw[2][n]), __builtin_bit_cast(uint32_t, raw[3][n])};
+            const u32x4 l_ = {__builtin_bit_cast(uint32_t, raw[4][n]), __builtin_bit_cast(uint32_t, raw[5][n]), __builtin_bit_cast(uint32_t, raw[6][n]), __builtin_bit_cast(uint32_t, raw[7][n])};
+#ifdef FW_T_NOCONV_MASK
+            // ... kept FINITE (f16 values below 2 / below 2^-10): garbage operands turn into NaN within a layer and a chip fed NaNs clocks
+            // higher in EVERY kernel of the step; the 8 ANDs per fragment are also what a packed (hi | lo) word layout would pay in v_perm
+            bf[n].hi = __builtin_bit_cast(typename T::vec8, h_ & 0x3BFF3BFFu);
+            if (NS == 3) bf[n].lo = __builtin_bit_cast(typename T::vec8, l_ & 0x13FF13FFu);
+#else
+            bf[n].hi = __builtin_bit_cast(typename T::vec8, h_);
+            if (NS == 3) bf[n].lo = __builtin_bit_cast(typename T::vec8, l_);
+#endif
+#else
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = ENC ? fmaxf(raw[j][n], 0.f) : raw[j][n];
             split8<T, NS>(bf[n], v);
+#endif
         }
         if (s + 1 < KS) issue(s + 1);
         stage_ld(s + 1);
@@ -300,7 +328,11 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
         for (int m = 0; m < MT2; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
+#ifdef FW_T_NORES
+                res[m][i] = fvec{1.f, 2.f, 3.f, 4.f};      // TIMING build (wrong results): no residual re-read (the tap-1 operand would serve)
+#else
                 res[m][i] = VecN<NT>::ld(xin + (size_t)(16 * m + 4 * q + i) * a.pitch + tl);
+#endif
     }
 
     // gate: z tile m = tanh(f tile m) * sigmoid(g tile m)
@@ -446,22 +478,22 @@ static int launch_fwd_nt(const WnResArgs& a, int ch, int batch, hipStream_t st) 
         hipLaunchKernelGGL((resblock_fwd_nt_k<T, NS, 32, NT>), g, b, (size_t)(4 * 2 + 2 * 1) * fr, st, k);
     } else if (ch == 64) {
         const size_t sh = (size_t)(8 * 4 + 4 * 2) * fr;
-        static unsigned long long done = 0;
+        static WnDevOnce done;
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (!((done >> dev) & 1ull)) {
+        if (done.need(dev)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_fwd_nt_k<T, NS, 64, NT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            done |= 1ull << dev;
+            done.done(dev);
         }
         if constexpr (NS == 3 && NT == 4 && std::is_same<T, F16>::value) {
             if (k.cond && k.cond_pack && k.cond_idx && k.cond_le <= 32) {       // conditioning bias on the matrix cores
                 if (a.t_lo - k.t_base > WN_PQ_IDX_PAD) return wn_set_error_msg(-4, "resblock_fwd: tile origin beyond the cond_idx pad");
-                static unsigned long long done_c = 0;
-                if (!((done_c >> dev) & 1ull)) {
+                static WnDevOnce done_c;
+                if (done_c.need(dev)) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_fwd_nt_k<T, NS, 64, NT, false, NtCfg<NT>::WAVES, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-                    done_c |= 1ull << dev;
+                    done_c.done(dev);
                 }
                 hipLaunchKernelGGL((resblock_fwd_nt_k<T, NS, 64, NT, false, NtCfg<NT>::WAVES, true>), g, b, sh, st, k);
                 WN_CHECK_LAUNCH();

@@ -452,18 +452,32 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             const float* xin = a.x_in + (size_t)ps.b * a.x_bstride;
             const float* p = ps.live ? xin + (size_t)(32 * (g & 1) + 8 * q) * a.pitch + ((g >> 1) == 0 ? tl - a.d : tl) : a.x_in;
             const size_t rp = ps.live ? (size_t)a.pitch : 0;
+#ifdef PQ_T_NOXR
+            return;
+#endif
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) r.x[jj] = pq_ld2u(p + jj * rp);
         };
         auto fill_x = [&](const RawX& r, int stage) {
+#ifdef PQ_T_NOXR
+            return;                                         // TIMING build (wrong results): x fragments arrive "by DMA" - the R waves neither load nor fill them
+#endif
             uint16_t* xf = lds + (size_t)stage * PQ_STAGE + PQ_XF;
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
+                Frag<F16> f;
+#ifdef PQ_T_NOCONVR
+                // TIMING build (wrong results): the loaded bits ARE the fragment (x stored MFMA-ready: same bytes, no vector work)
+                const u32x4 h_ = {__builtin_bit_cast(uint32_t, r.x[0][n]), __builtin_bit_cast(uint32_t, r.x[1][n]), __builtin_bit_cast(uint32_t, r.x[2][n]), __builtin_bit_cast(uint32_t, r.x[3][n])};
+                const u32x4 l_ = {__builtin_bit_cast(uint32_t, r.x[4][n]), __builtin_bit_cast(uint32_t, r.x[5][n]), __builtin_bit_cast(uint32_t, r.x[6][n]), __builtin_bit_cast(uint32_t, r.x[7][n])};
+                f.hi = __builtin_bit_cast(F16::vec8, h_ & 0x3BFF3BFFu);      // (kept finite: see wn_resblock2.hip)
+                f.lo = __builtin_bit_cast(F16::vec8, l_ & 0x13FF13FFu);
+#else
                 float v[8];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) v[jj] = r.x[jj][n];
-                Frag<F16> f;
                 split8<F16, 3>(f, v);
+#endif
                 pq_store_frag<F16>(xf, g * 2 + n, lane, f);
             }
         };
@@ -820,12 +834,21 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     auto convert = [&](Ops& o, const RawRows& r, Pos ps) {
         float w[8];
         if (COND) { o.bk[0] = r.bk[0]; o.bk[1] = r.bk[1]; }
+#ifdef PQ_T_NOCONVW
+        // TIMING build (wrong results): the W waves' x rows as loaded are their MFMA operands (x stored split: same bytes)
+        {   // (kept finite: bf16 values below 2 / below 2^-8)
+            const u32x4 mh = {0x3FFF3FFFu, 0x3FFF3FFFu, 0x3FFF3FFFu, 0x3FFF3FFFu}, ml = {0x3BFF3BFFu, 0x3BFF3BFFu, 0x3BFF3BFFu, 0x3BFF3BFFu};
+            o.x0.hi = __builtin_bit_cast(pqg8, __builtin_bit_cast(u32x4, r.x0[0]) & mh); o.x0.lo = __builtin_bit_cast(pqg8, __builtin_bit_cast(u32x4, r.x0[1]) & ml);
+            o.x1.hi = __builtin_bit_cast(pqg8, __builtin_bit_cast(u32x4, r.x1[0]) & mh); o.x1.lo = __builtin_bit_cast(pqg8, __builtin_bit_cast(u32x4, r.x1[1]) & ml);
+        }
+#else
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) w[jj] = ps.live ? r.x0[jj >> 2][jj & 3] : 0.f;
         to_frag(o.x0, w);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) w[jj] = ps.live ? r.x1[jj >> 2][jj & 3] : 0.f;
         to_frag(o.x1, w);
+#endif
         if (HAS_DY) {
             if (interior(ps)) {
 #pragma unroll
@@ -1195,13 +1218,13 @@ int wn_pq_slabs(int t_lo, int t_hi, int batch, int d, int chain) {
 
 template <bool HAS_DY, bool COND, bool QIN, bool CHAIN>
 static void pq_launch(const WnResPqArgs& k, int nwg, size_t sh, hipStream_t st) {
-    static unsigned long long done = 0;
+    static WnDevOnce done;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((done >> dev) & 1ull)) {
+    if (done.need(dev)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_pq_k<HAS_DY, COND, QIN, CHAIN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        done |= 1ull << dev;
+        done.done(dev);
     }
     hipLaunchKernelGGL((resblock_bwd_pq_k<HAS_DY, COND, QIN, CHAIN>), dim3(nwg), dim3(PQ_THREADS), sh, st, k);
 }

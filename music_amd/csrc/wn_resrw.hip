@@ -553,15 +553,15 @@ int wn_launch_resblock_bwd_rw(const WnResMsArgs& a, int batch, hipStream_t st) {
     k.batch = batch;
     k.swz = wn_xcd_swizzle_enabled();
     const size_t sh = (size_t)2 * RW_STAGE * sizeof(uint16_t);
-    static unsigned long long done = 0;
+    static WnDevOnce done;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((done >> dev) & 1ull)) {
+    if (done.need(dev)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_rw_k<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_rw_k<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        done |= 1ull << dev;
+        done.done(dev);
     }
     if (k.dy && k.slab_d) hipLaunchKernelGGL(resblock_bwd_rw_k<true>, dim3(nwg), dim3(RW_THREADS), sh, st, k);
     else hipLaunchKernelGGL(resblock_bwd_rw_k<false>, dim3(nwg), dim3(RW_THREADS), sh, st, k);

@@ -372,12 +372,12 @@ int wn_launch_wgrad2(const WnWgradArgs* a1, const WnWgradArgs* a2, int batch, in
             dim3 g(nch[0], ((k.mt + 15) / 16) * ((nt_total + 15) / 16), batch), b(512);
             int dev = 0;
             (void)hipGetDevice(&dev);
-            static unsigned long long done[4] = {0, 0, 0, 0};
+            static WnDevOnce done[4];
 #define WN_BIG(TT, NN, slot) do { \
-                if (!((done[slot] >> dev) & 1ull)) { \
+                if (done[slot].need(dev)) { \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_k<TT, NN>), \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-                    done[slot] |= 1ull << dev; } \
+                    done[slot].done(dev); } \
                 hipLaunchKernelGGL((wgrad_big_k<TT, NN>), g, b, sh, st, k); } while (0)
             switch (mode) {
                 case WN_MODE_BF16X3: WN_BIG(BF16, 3, 0); break;

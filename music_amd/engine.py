@@ -758,6 +758,10 @@ class WaveNetEngine:
             if bw["pq"] or bw["pair"]:
                 p_out, q_out = (ptr(t, SLACK) for t in bw["PQ"][i % 2])
                 chain = 1 if bw["chain"][i] else 0
+                if i == 0 and chain:
+                    # a first block in chain form (d_0 a multiple of 32) hands dx_0 on WHOLE: straight into the buffer the causal
+                    # layer's weight gradient reads (same layout and stride as the (P, Q) buffers)
+                    p_out = ptr(bw["dX"][0], SLACK)
                 if i < N - 1:
                     p_in, q_in = (ptr(t, SLACK) for t in bw["PQ"][(i + 1) % 2])
                     dn, p_lo = self.dil[i + 1], self.off[i + 2]
@@ -778,10 +782,7 @@ class WaveNetEngine:
                          ptr(bw["slab"], plan["fg%d" % i][0]), ptr(bw["slab"], plan["d%d" % i][0]) if i < N - 1 else None,
                          None, 0, 0, 0, None, None, 0, chain, B, mf, mb, st)
                 self.fmark("b_block")
-                if i == 0 and chain:
-                    # (a first block with d >= 32: dx_0 is already whole)
-                    bw["dX"][0].copy_(bw["PQ"][0][0])
-                elif i == 0:
+                if i == 0 and not chain:
                     # dx_0 for the causal layer: the pair made whole once (19 us; the scatter from codes can also take the
                     # pair as it is - wn_causal_wgrad_codes(dx_q) - but its doubled, masked tile loads cost the same 20 us)
                     call("wn_shift_add", p_out, q_out, ptr(bw["dX"][0], SLACK), xb, pitch, CH, d, t_lo, self.off[0], T, B, st)

@@ -150,7 +150,6 @@ class wavenet(nn.Module):
         out = _WaveNetFunction.apply(self, torch.is_grad_enabled(), wave_sample, *params)
         hook, self._last_hook = self._last_hook, None
         return _losshook.wrap(out, hook) if self.fuse_loss else out
-        return out
 
 
 def predict_next(model, wave_var, quantization_channels=256):

@@ -126,12 +126,146 @@ class FlatAdam(optim.Adam):
         return super().step(closure)
 
 
+def _flat_layout(opt, model, plain_group):
+    """(engine, params, flat gradient base pointer) when `opt` can take its step as ONE launch on the engine's flat buffers: one
+    parameter group holding exactly the module's parameters in order, every parameter a view of the flat parameter buffer, every
+    gradient a contiguous fp32 view of ONE flat gradient buffer at the same offsets (what the module's backward hands autograd),
+    and `plain_group(group)` true (no option the kernel does not implement).  None otherwise: torch's own step runs."""
+    eng = getattr(model, "_engine", None)
+    if eng is None or getattr(eng, "flat", None) is None or len(opt.param_groups) != 1:
+        return None
+    grp = opt.param_groups[0]
+    if not plain_group(grp):
+        return None
+    params = grp["params"]
+    named = [p for _, p in model.named_parameters()]
+    if len(params) != len(named) or any(a is not b for a, b in zip(params, named)):
+        return None
+    base = eng.flat.data_ptr()
+    if any(p.data_ptr() != base + 4 * eng.spec.off[n] for n, p in zip(eng.param_names, params)):
+        return None                                       # (the module was moved: its parameters left the flat buffer)
+    g0 = params[0].grad
+    if g0 is None or g0.dtype != torch.float32:
+        return None
+    gbase = g0.data_ptr() - 4 * eng.spec.off[eng.param_names[0]]
+    if not all(p.grad is not None and p.grad.is_contiguous() and p.grad.data_ptr() == gbase + 4 * eng.spec.off[n]
+               for n, p in zip(eng.param_names, params)):
+        return None
+    return eng, params, gbase
+
+
+def _flat_views(opt, eng, params, key, cache):
+    """One flat buffer for the per-parameter state tensors `key`, the state entries being VIEWS of it (so `state_dict()` /
+    `load_state_dict()` interchange with torch's optimizer).  Existing per-parameter tensors (a loaded state_dict, earlier torch
+    steps) are adopted.  Returns (flat buffer, how many parameters had the entry before)."""
+    hit = cache.get(key)
+    if hit is not None and hit[0] is eng and all(opt.state[p].get(key) is v for p, v in zip(params, hit[2])):
+        return hit[1], len(params)
+    flat = torch.zeros_like(eng.flat)
+    had, views = 0, []
+    for n, p in zip(eng.param_names, params):
+        o, k = eng.spec.off[n], p.numel()
+        st = opt.state[p]
+        old = st.get(key)
+        view = flat[o:o + k].view(p.shape)
+        if old is not None:
+            view.copy_(old)
+            had += 1
+        st[key] = view
+        views.append(view)
+    cache[key] = (eng, flat, views)
+    return flat, had
+
+
+class FlatSGD(optim.SGD):
+    """``torch.optim.SGD(model.parameters(), lr, momentum)`` (wavenet/train.py:28-31) whose ``step()`` is ONE ``wn_sgd_flat``
+    launch when it can be (see FlatAdam): same state (``momentum_buffer`` per parameter, views of one flat buffer), same
+    ``state_dict``; anything the kernel does not cover (dampening, Nesterov, weight decay, maximize, closures, parameters or
+    gradients off the flat buffers, parameters with and without a momentum buffer mixed) falls through to torch's own step."""
+
+    def __init__(self, model, lr, momentum):
+        super().__init__(model.parameters(), lr=lr, momentum=momentum)
+        self._model, self._cache = model, {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._cache = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        lay = None
+        if closure is None:
+            lay = _flat_layout(self, self._model, lambda g: (g.get("dampening", 0) == 0 and not g.get("nesterov") and g.get("weight_decay", 0) == 0
+                                                           and not g.get("maximize") and not g.get("differentiable")))
+        if lay is not None:
+            eng, params, gbase = lay
+            grp = self.param_groups[0]
+            mom = float(grp["momentum"])
+            buf, first = None, 0
+            if mom != 0.0:
+                have = sum(1 for p in params if self.state[p].get("momentum_buffer") is not None)
+                if have not in (0, len(params)):
+                    return super().step(closure)
+                flat, _ = _flat_views(self, eng, params, "momentum_buffer", self._cache)
+                buf, first = flat.data_ptr(), 1 if have == 0 else 0
+            from music_amd import _lib
+            _lib.call("wn_sgd_flat", eng.flat.data_ptr(), gbase, buf, eng.spec.total, float(grp["lr"]), mom, 1.0, first, _lib.stream())
+            return None
+        return super().step(closure)
+
+
+class FlatRMSprop(optim.RMSprop):
+    """``torch.optim.RMSprop(model.parameters(), lr, momentum=momentum)`` (wavenet/train.py:32-37) whose ``step()`` is ONE
+    ``wn_rmsprop_flat`` launch when it can be (see FlatAdam): torch's own state (``step``, ``square_avg``, ``momentum_buffer``; the
+    tensors are views of flat buffers), same ``state_dict``; centered / weight decay / maximize / closures fall through to torch."""
+
+    def __init__(self, model, lr, momentum):
+        super().__init__(model.parameters(), lr=lr, momentum=momentum)
+        self._model, self._cache = model, {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._cache = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        lay = None
+        if closure is None:
+            lay = _flat_layout(self, self._model, lambda g: (not g.get("centered") and g.get("weight_decay", 0) == 0 and not g.get("maximize")
+                                                           and not g.get("capturable") and not g.get("differentiable")))
+        if lay is not None:
+            eng, params, gbase = lay
+            grp = self.param_groups[0]
+            mom = float(grp["momentum"])
+            sq, _ = _flat_views(self, eng, params, "square_avg", self._cache)
+            buf = None
+            if mom > 0.0:
+                buf = _flat_views(self, eng, params, "momentum_buffer", self._cache)[0].data_ptr()
+            steps = self._cache.get("step")                   # torch's step counters (a 0-d tensor per parameter), bumped in one call
+            if steps is None or any(self.state[p].get("step") is not t for p, t in zip(params, steps)):
+                steps = []
+                for p in params:
+                    st = self.state[p]
+                    step = st.get("step")
+                    st["step"] = (torch.zeros((), dtype=torch.float32) if step is None else
+                                  torch.as_tensor(step, dtype=torch.float32).detach().cpu().reshape(()).clone())
+                    steps.append(st["step"])
+                self._cache["step"] = steps
+            torch._foreach_add_(steps, 1.0)
+            from music_amd import _lib
+            _lib.call("wn_rmsprop_flat", eng.flat.data_ptr(), gbase, sq.data_ptr(), buf, eng.spec.total, float(grp["lr"]), float(grp["alpha"]),
+                      float(grp["eps"]), mom, 1.0, _lib.stream())
+            return None
+        return super().step(closure)
+
+
 def get_optimizer(model, optimizer_type, learning_rate, momentum):
-    """wavenet/train.py:28-42 — 'sgd' / 'rmsprop' (with momentum) / 'adam'; anything else -> None."""
+    """wavenet/train.py:28-42 — 'sgd' / 'rmsprop' (with momentum) / 'adam'; anything else -> None.  Each is torch's own optimizer class
+    (same hyper-parameters, same state_dict) whose step() is one launch on the module's flat buffers when it can be."""
     if optimizer_type == 'sgd':
-        return optim.SGD(model.parameters(), lr=learning_rate, momentum=momentum)
+        return FlatSGD(model, lr=learning_rate, momentum=momentum)
     if optimizer_type == 'rmsprop':
-        return optim.RMSprop(model.parameters(), lr=learning_rate, momentum=momentum)
+        return FlatRMSprop(model, lr=learning_rate, momentum=momentum)
     if optimizer_type == 'adam':
         return FlatAdam(model, lr=learning_rate)          # an optim.Adam (same state_dict); one launch per step on the flat buffers
 

@@ -26,7 +26,7 @@ def _free_port():
 
 
 def _launch(nproc, mode, workdir):
-    env = dict(os.environ, OMP_NUM_THREADS="2", PYTHONPATH=ROOT)
+    env = dict(os.environ, OMP_NUM_THREADS="2" if nproc <= 2 else "1", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(workdir)]
@@ -95,6 +95,59 @@ def test_train_two_ranks_equals_one_rank(tmp_path, lens):
         assert (ca[k] - cb[k]).abs().max().item() < 1e-5, k
 
 
+def test_train_eight_ranks_equals_one_rank(tmp_path):
+    """The 8-GPU job's host logic (BASELINE configs[2]: DP over 8 ranks) on CPU: 8 gloo ranks, global batch 8, 15 pieces - a whole
+    batch (one item per rank) and a ragged one of 7 (rank 7 gets an EMPTY shard and must still join the all-reduce) - write the
+    same loss log, store log and checkpoint as ONE rank with the same global batch (wavenet/train.py:116-122: DataParallel's
+    global-batch mean)."""
+    a, b = tmp_path / "one", tmp_path / "eight"
+    os.makedirs(a), os.makedirs(b)
+    _write_run(a, 8, (917, 617))
+    _write_run(b, 8, (917, 617))
+    _launch(1, "train", a)
+    _launch(8, "train", b)
+    la = open(a / "log" / "loss_log.log").read().strip().split("\n")
+    lb = open(b / "log" / "loss_log.log").read().strip().split("\n")
+    assert len(la) == len(lb) and len(la) >= 4
+    for x, y in zip(la, lb):
+        assert x.split("Average")[0] == y.split("Average")[0]
+        assert abs(float(x.split(' ')[-1]) - float(y.split(' ')[-1])) < 2e-6
+    assert open(a / "log" / "store_log.log").read() == open(b / "log" / "store_log.log").read()
+    ca, cb = torch.load(a / "restore" / "wavenet2.model"), torch.load(b / "restore" / "wavenet2.model")
+    for k in ca:
+        assert (ca[k] - cb[k]).abs().max().item() < 1e-5, k
+
+
+def test_thread_budget_per_rank(monkeypatch):
+    """Host threads per rank = ceil(CPU quota / ranks of this host) (VERDICT r4 #4a): 8 ranks on the GPU box's 16-CPU quota get 2
+    each - 8 x 16 runnable threads on 16 CPUs was the 68-ms-per-step throttling stall of DESIGN_HISTORY.md."""
+    from music_amd import _lib
+    assert _lib.thread_budget(16, 8) == 2 and _lib.thread_budget(16, 1) == 16 and _lib.thread_budget(16, 3) == 6
+    assert _lib.thread_budget(4, 8) == 1 and _lib.thread_budget(None, 8, cpus=256) == 32 and _lib.thread_budget(None, 1, cpus=8) == 8
+    assert _lib.local_world_size({"LOCAL_WORLD_SIZE": "8"}) == 8 and _lib.local_world_size({}) == 1
+    assert _lib.local_world_size({"LOCAL_WORLD_SIZE": "x"}) == 1
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setattr(_lib, "cpu_quota", lambda: 16)
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+        monkeypatch.delenv("WN_KEEP_TORCH_THREADS", raising=False)
+        torch.set_num_threads(8)
+        _lib.respect_cpu_quota()
+        assert torch.get_num_threads() == 2
+        torch.set_num_threads(8)
+        monkeypatch.setenv("WN_KEEP_TORCH_THREADS", "1")
+        _lib.respect_cpu_quota()
+        assert torch.get_num_threads() == 8
+        # no quota, one process: torch's own setting stays
+        monkeypatch.delenv("WN_KEEP_TORCH_THREADS", raising=False)
+        monkeypatch.setattr(_lib, "cpu_quota", lambda: None)
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+        _lib.respect_cpu_quota()
+        assert torch.get_num_threads() == 8
+    finally:
+        torch.set_num_threads(before)
+
+
 def test_collate_shards_like_dataparallel_scatter():
     """_Collate's shard=(r, w) slices are torch.chunk's (DataParallel scatter) for every batch length, and the
     dp_scale weights sum to world (so the weighted mean over ranks is the global-batch mean)."""
@@ -127,7 +180,8 @@ def test_bench_self_launches_its_ranks():
     a torch.distributed.run child before anything touches the GPU and relays rank 0's JSON line and the exit code."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "2"
-    for n in (1, 2, 3):
+    env.pop("OMP_NUM_THREADS")          # the parent sets the per-rank budget itself (quota / ranks, at most 8)
+    for n in (1, 2, 3, 8):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-run"], env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-3000:]
@@ -135,3 +189,6 @@ def test_bench_self_launches_its_ranks():
         assert len(lines) == 1, r.stdout
         out = json.loads(lines[0])
         assert out["n_gpus"] == n and out["rank_sum"] == n * (n + 1) / 2
+        if n > 1:
+            from music_amd import _lib
+            assert out["omp_num_threads"] == str(min(8, _lib.thread_budget(_lib.cpu_quota(), n))), out

@@ -104,6 +104,16 @@ def test_bench_two_ranks_on_this_box(tmp_path):
     assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
     assert "allreduce" in out["phase_ms_per_step"] and out["value"] > 0
     assert abs(out["value"] - 2 * 8 * 16000 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    # what the first real N-GPU line must carry (VERDICT r4 #4c): every rank's own time (min / max / all), the max being the
+    # contract's ms_per_step, and the host-thread budget each rank ran with (quota / ranks of this host, music_amd/_lib.py)
+    pr = out["ms_per_step_ranks"]
+    assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - out["ms_per_step"]) < 1e-6 * pr["max"]
+    ht = out["host_threads"]
+    assert ht["local_world_size"] == 2 and ht["torch_intra_op"] >= 1
+    from music_amd import _lib
+    q = _lib.cpu_quota()
+    if q is not None:
+        assert ht["torch_intra_op"] <= _lib.thread_budget(q, 2)
 
 
 def test_bench_under_launcher_prints_one_json_line_with_rccl():

@@ -383,6 +383,78 @@ def test_c4_full_size_autoencoder_vs_oracle():
         assert (a1 - a2).abs().max().item() <= 1e-4 * max(a1.abs().max().item(), 1e-30), name
 
 
+def test_c4_bench_geometry_vs_oracle():
+    """Config 4 at the BENCHMARK's geometry: autoencoder 30 + 30 blocks, 8 x 16000 - what bench.py's
+    extra.c4_autoencoder times - loss, encoding, probabilities and EVERY gradient against the oracle.  The conditioned backward's
+    per-clip bucket-sum slabs, pq_cond_reduce_k's slot order and the encoder's item ranges all depend on the batch; the 2-clip
+    test above does not reach this partition.  The oracle runs clip by clip with the batch's ONE set of 31 conditioning draws
+    (drawn once per forward, applied to every clip's encoding): chunk-softmax rows and the pooled encoding never cross
+    clips and every clip has W rows, so the batch loss / gradient is the mean of the clip losses / gradients.  float32 for the
+    probabilities and the encoding, float64 with the device's sign at near-zero ReLU pre-activations for the gradients."""
+    from music_amd.model1 import wavenet_autoencoder
+    cfg = dict(filter_width=2, quantization_channel=256, dilations=C2["dilations"], en_residual_channel=64,
+               en_dilation_channel=64, en_bottleneck_width=64, en_pool_kernel_size=512, de_residual_channel=64,
+               de_dilation_channel=64, de_skip_channel=256, use_bias=False)
+    torch.manual_seed(6)
+    net = wavenet_autoencoder(**cfg)
+    _scaled(net, 1.6)
+    with torch.no_grad():
+        net.connection_2.weight.mul_(12.0)                    # (see test_c4_full_size_autoencoder_vs_oracle)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    rng = np.random.default_rng(61)
+    B, T = 8, 16000
+    W = T - net.receptive_field + 1
+    idx = rng.integers(0, 256, size=(B, T))
+    x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx]))
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64))
+    torch.manual_seed(78)
+    net.zero_grad()
+    probs = net(x.cuda())
+    loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
+    loss.backward()
+    aeng = net._engine_for(torch.device("cuda", 0))
+    dev_pre = _c4_dev_pre(aeng, B, T)
+    probs = probs.detach().cpu()
+    enc_dev = net.last_encoding.cpu()
+    got = {name: p.grad for name, p in net.named_parameters()}
+    torch.set_num_threads(ORACLE_THREADS)
+    torch.manual_seed(78)
+    cond = wo.draw_conditioning(len(cfg["dilations"]), cfg["en_bottleneck_width"], cfg["de_dilation_channel"], cfg["de_skip_channel"])
+    cond64 = [(w.double(), b.double()) for w, b in cond]
+    p64 = {k: v.double() for k, v in params.items()}
+    g64 = {k: None for k in p64}
+    l32 = l64 = e_p = e_enc = p_max = 0.0
+    near = flips = 0
+    for b in range(B):
+        xb, tb = x[b:b + 1], target[b * W:(b + 1) * W]
+        with torch.no_grad():
+            pb, eb = wo.autoencoder_forward(params, cfg["dilations"], xb, cfg["en_pool_kernel_size"], cond)
+        l32 += torch.nn.functional.cross_entropy(pb, tb).item() / B
+        e_p = max(e_p, (probs[b * W:(b + 1) * W] - pb).abs().max().item())
+        e_enc = max(e_enc, (enc_dev[b:b + 1] - eb).abs().max().item())
+        p_max = max(p_max, pb.max().item())
+        leaf = {k: v.clone().requires_grad_(True) for k, v in p64.items()}
+        relu, stats = _device_relu({k: v[b:b + 1] for k, v in dev_pre.items()})
+        pq, _ = wo.autoencoder_forward(leaf, cfg["dilations"], xb.double(), cfg["en_pool_kernel_size"], cond64, relu=relu)
+        lb = torch.nn.functional.cross_entropy(pq, tb)
+        gb = dict(zip(leaf.keys(), torch.autograd.grad(lb, list(leaf.values()), allow_unused=True)))
+        l64 += lb.item() / B
+        near, flips = near + stats["near"], flips + stats["flips"]
+        for k, g in gb.items():
+            if g is not None:
+                g64[k] = g / B if g64[k] is None else g64[k] + g / B
+        del leaf, pq, lb, gb
+    assert e_enc < 1e-4 and e_p <= LOGIT_TOL, (e_enc, e_p)
+    nonvacuous(torch.tensor(p_max), "c4 at 8 x 16000", 0.5)
+    assert abs(loss.item() - l32) < 1e-4 and abs(loss.item() - l64) < 1e-4, (loss.item(), l32, l64)
+    assert list(got.keys()) == list(g64.keys())
+    worst, name, _ = _check_grads(got, g64, {})
+    print("c4 at the bench geometry (8 x 16000): enc err %.2e, probs err %.2e (max p %.3f), loss %.7f (oracle f32 %.7f, f64 %.7f), worst grad "
+          "err vs f64 %.2e (%s); %d ReLU pre-activations inside the tolerance band, device sign differs at %d" %
+          (e_enc, e_p, p_max, loss.item(), l32, l64, worst, name, near, flips))
+
+
 def _onehot(ix):
     return torch.from_numpy(intops.one_hot_proper(np.atleast_1d(ix)))[None]
 

@@ -225,6 +225,66 @@ def test_flat_adam_is_torch_adam_on_the_drop_in_surface():
     assert m0.shape == next(nets[0].parameters()).shape and torch.isfinite(m0).all()
 
 
+@pytest.mark.parametrize("kind,momentum", [("sgd", 0.9), ("sgd", 0.0), ("rmsprop", 0.9), ("rmsprop", 0.0)])
+def test_flat_sgd_and_rmsprop_are_torchs_on_the_drop_in_surface(kind, momentum):
+    """train.get_optimizer(net, 'sgd' | 'rmsprop', lr, momentum) (wavenet/train.py:28-38) returns torch's own optimizer class whose
+    step() is ONE wn_sgd_flat / wn_rmsprop_flat launch on the flat buffers: over four steps of the reference's loop the parameters
+    equal those of torch.optim.SGD / RMSprop stepping the same module (a few ulp of a step), the fast path is the one that runs,
+    a step with foreign gradient tensors falls through to torch's path on the SAME state, and state_dict() interchanges."""
+    from music_amd import train as T
+    from music_amd import _lib
+    meta = [m for m in g1_meta() if m["name"] == "tiny_s0_g3_w130"][0]
+    d = load_npz("g1_%s.npz" % meta["name"])
+    x = g1_input(d, meta).cuda()
+    target = torch.from_numpy(d["target"]).cuda()
+    ce = torch.nn.CrossEntropyLoss()
+    cls = torch.optim.SGD if kind == "sgd" else torch.optim.RMSprop
+    lr = 1e-2 if kind == "sgd" else 1e-3
+    nets, opts = [], []
+    for flat in (True, False):
+        net = build(meta["cfg"], params_from(d))
+        nets.append(net)
+        opts.append(T.get_optimizer(net, kind, lr, momentum) if flat else cls(net.parameters(), lr=lr, momentum=momentum))
+    assert isinstance(opts[0], cls) and type(opts[0]).__name__ == ("FlatSGD" if kind == "sgd" else "FlatRMSprop")
+    calls, real_call = [], _lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real_call(name, *a)
+    _lib.call = spy
+    def both_step(step):
+        # the SAME gradients go to both optimizers (the flat module's own; the torch-stepped module gets copies): RMSprop divides
+        # by sqrt(E[g^2]), so an element whose gradient is rounding noise moves by a full lr either way and two separately trained
+        # replicas drift apart by construction - what is compared is the UPDATE arithmetic on equal inputs
+        opts[0].zero_grad()
+        ce(nets[0](x), target).backward()
+        for p0, p1 in zip(nets[0].parameters(), nets[1].parameters()):
+            p1.grad = None if p0.grad is None else p0.grad.clone()
+        if step == 2:
+            for p in nets[0].parameters():                  # foreign gradient tensors: torch's per-tensor path, same state
+                p.grad = p.grad.clone()
+        for opt in opts:
+            opt.step()
+    try:
+        for step in range(4):
+            both_step(step)
+    finally:
+        _lib.call = real_call
+    assert calls.count("wn_sgd_flat" if kind == "sgd" else "wn_rmsprop_flat") == 3       # steps 0, 1, 3
+    for (n, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        assert (a - b).abs().max().item() <= 4e-6 * max(1.0, b.abs().max().item()), n
+    # the state is torch's: it loads into the plain optimizer and back, and the next flat step continues from it
+    sd = opts[0].state_dict()
+    plain = cls(nets[1].parameters(), lr=lr, momentum=momentum)
+    plain.load_state_dict(sd)
+    opts[0].load_state_dict(opts[1].state_dict())
+    both_step(4)
+    for (n, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        assert (a - b).abs().max().item() <= 6e-6 * max(1.0, b.abs().max().item()), n
+    if kind == "rmsprop":
+        assert float(opts[0].state_dict()["state"][0]["step"]) == 5.0
+
+
 def test_full_size_c2_properties():
     """BASELINE config 2 (30 layers, 64/64/256, batch 8 x 16000): size-independent properties."""
     from music_amd.model import wavenet
@@ -1421,6 +1481,53 @@ def test_cross_entropy_on_the_module_output_runs_fused_and_equals_torchs():
         assert type(o2) is torch.Tensor and abs(float(crit(o2, target)) - float(loss)) < 1e-5
     # everything else sees an ordinary tensor
     assert type(out + 1) is torch.Tensor and type(out.view(-1)) is torch.Tensor and type(out.detach()) is torch.Tensor
+
+
+def test_fused_loss_survives_other_backward_passes_on_the_same_output():
+    """Backward passes in any order over one forward: (a) ANOTHER loss on the output is back-propagated on its own
+    (retain_graph) before the fused loss - that ordinary backward overwrites the workspace's d loss / d pre-softmax, which the fused
+    loss's backward must re-form; (b) `torch.autograd.grad(loss, out)` runs the fused node's backward without the module's - its
+    upstream gradient must not leak into the next, unrelated backward.  Reference: the same sequence with `fuse_loss = False`."""
+    import numpy as np
+    from tests.helpers import scrambled_input
+    net = _small_net()
+    rng = np.random.default_rng(4)
+    B, W = 2, 500
+    T = net.receptive_field + W - 1
+    x = scrambled_input(rng.integers(0, 256, size=(B, T))).cuda()
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).cuda()
+    crit = torch.nn.CrossEntropyLoss()
+
+    def seq_a(fuse):
+        net.fuse_loss = fuse
+        net.zero_grad()
+        out = net(x)
+        loss = 1.5 * crit(out, target)
+        aux = (out * out).sum() / out.numel()
+        aux.backward(retain_graph=True)
+        g_aux = [p.grad.clone() for p in net.parameters()]
+        loss.backward()
+        return g_aux, [p.grad.clone() for p in net.parameters()]
+
+    def seq_b(fuse):
+        net.fuse_loss = fuse
+        net.zero_grad()
+        out = net(x)
+        loss = 1.5 * crit(out, target)
+        torch.autograd.grad(loss, out, retain_graph=True)        # the fused node's backward alone (its result: the zero token)
+        aux = (out * out).sum() / out.numel()
+        aux.backward(retain_graph=True)                          # must be aux's gradient only
+        g_aux = [p.grad.clone() for p in net.parameters()]
+        loss.backward()
+        return g_aux, [p.grad.clone() for p in net.parameters()]
+
+    for seq in (seq_a, seq_b):
+        ref_aux, ref_all = seq(False)
+        got_aux, got_all = seq(True)
+        for ref, got in ((ref_aux, got_aux), (ref_all, got_all)):
+            gmax = max(g.abs().max().item() for g in ref)
+            for a, b in zip(ref, got):
+                assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1e-3 * gmax), seq.__name__
 
 
 def test_cross_entropy_on_the_autoencoder_output_runs_fused_and_equals_torchs():
