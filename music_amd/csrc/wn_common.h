@@ -90,20 +90,11 @@ template <class T> __device__ __forceinline__ void split2(float a, float b, uint
 typedef _Float16 wn_f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 wn_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float wn_f32x2 __attribute__((ext_vector_type(2)));
-#ifdef WN_SPLIT_PLAIN      // timing builds: the same arithmetic left to the compiler
-template <> __device__ __forceinline__ void split2<F16>(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const wn_f16x2 h = {(_Float16)a, (_Float16)b};
-    const wn_f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
-#else
 template <> __device__ __forceinline__ void split2<F16>(float a, float b, uint32_t& hi, uint32_t& lo) {
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
 }
-#endif
 // bf16 has no mixed form: hi back to f32 by shift / mask, six instructions per pair, and here the compiler's own code is
 // the faster one (the same six written as instructions: backward stack 1.998 vs 1.963 ms on one box)
 template <> __device__ __forceinline__ void split2<BF16>(float a, float b, uint32_t& hi, uint32_t& lo) {

@@ -16,19 +16,10 @@
 #include "wn_kernels.h"
 
 #define DEC_THREADS 1024
-#ifdef DEC_CLK
-__device__ unsigned long long dec_clk[16];
-extern "C" int wn_dec_clk_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dec_clk), 128); }
-#define DCLK(v) const unsigned long long v = __builtin_readcyclecounter()
-#define DACC(i, d) dacc[i] += (d)
-#define DINIT unsigned long long dacc[16] = {}
-#define DFLUSH do { if (tid == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&dec_clk[i_], dacc[i_]); } while (0)
-#else
 #define DCLK(v)
 #define DACC(i, d)
 #define DINIT
 #define DFLUSH
-#endif
 
 // out[o] = epi( bias[o] + sum_k W[o*ldw + k] * x[k] ), o < M.  `parts` lanes share one output.
 // W rows are read as contiguous slices (coalesced across the lanes of an output group).
@@ -867,12 +858,7 @@ __global__ __launch_bounds__(DEC_MT) void decode_duo_mfma8_k(WnDecodeArgs a) {
                     dec_put2(zz + (tid >> 5) * VS, D, (tid & 31) * 2, za, zb);
                 }
                 dec_sync();
-#ifdef DEC_T_HALFSKIP          // TIMING build (wrong results): the skip product of every second block only - what a second skip workgroup would leave to this one
-                if (l & 1) continue;
-                const int ln = l + 2 < a.n_layers ? l + 2 : l;
-#else
                 const int ln = l + 1 < a.n_layers ? l + 1 : l;
-#endif
                 const f16x8 bz[2] = {*reinterpret_cast<const f16x8*>(zz + u * VS + h * D + 8 * q),
                                      *reinterpret_cast<const f16x8*>(zz + u * VS + h * D + 32 + 8 * q)};
 #pragma unroll

@@ -227,20 +227,6 @@ __global__ __launch_bounds__(512) void chan_gemm_k(WnGemmArgs a) {
 // what sets its speed).  LDS: 2 stages x (16 A + 16 B fragments) = 128 KB in the x3 modes.
 // 256 rows x 256 columns per workgroup, 8 waves = 2 (rows) x 4 (column groups of 64).
 // ---------------------------------------------------------------------------------------------
-#ifdef GW_DBG
-// phase clock sums of the wide GEMM's k-step (developer build, tools/gw_clocks.py): per wave half [0-3 | 4-7]:
-// reads + first MFMAs, wait for the global loads, convert + LDS fill, issue next loads, last MFMAs, barrier
-__device__ unsigned long long gw_dbg[16];
-#define GW_TICK(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
-extern "C" int wn_gw_dbg_read(unsigned long long* out, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(gw_dbg), sizeof(unsigned long long) * 16);
-    if (reset) {
-        unsigned long long z[16] = {};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(gw_dbg), z, sizeof(z));
-    }
-    return (int)e;
-}
-#endif
 template <class T, int NS>
 __global__ __launch_bounds__(512) void chan_gemm_wide2_k(WnGemmArgs a) {
     constexpr int MTW = 8, WN = 4;
@@ -337,9 +323,6 @@ __global__ __launch_bounds__(512) void chan_gemm_wide2_k(WnGemmArgs a) {
         for (int i = 0; i < PER_A; ++i) d[threadIdx.x + i * 512] = wreg[i];
     };
     f32x4 raw0[4], raw1[4];
-#ifdef GW_DBG
-    unsigned long long dbg_acc[6] = {};
-#endif
     load_w(0);
     load_b(raw0, 0);
     if (KS > 1) load_b(raw1, 1);
@@ -353,68 +336,31 @@ __global__ __launch_bounds__(512) void chan_gemm_wide2_k(WnGemmArgs a) {
     // (Tidier forms of this loop - branch-free k-steps, the fill spread over the row tiles, a
     // duplicated loop for edge waves - all measured SLOWER: 405-418 us against 355 us for the skip
     // product)
-    // timing builds (-DGW_T=n, results are wrong): 1 no MFMAs, 2 no conversion + LDS fill of the activations, 3 no activation
-    // loads after the prologue, 4 no weight path (loads + LDS fill), 5 no barrier, 6 no LDS fragment reads
-#ifndef GW_T
-#define GW_T 0
-#endif
     auto step = [&](int s, f32x4* rnext) {
-#ifdef GW_DBG
-        GW_TICK(c0s);
-        unsigned long long c0 = c0s;
-#endif
         const uint16_t* la = l_s + (size_t)(s & 1) * STAGE;
         const uint16_t* lb = la + (size_t)(16 + wn * 4) * FR;
         Frag<T> bf[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) load_a<T, NS>(bf[n], GW_T == 6 ? l_s + (size_t)(16 + wn * 4) * FR : lb, n, lane);
+        for (int n = 0; n < 4; ++n) load_a<T, NS>(bf[n], lb, n, lane);
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             Frag<T> af;
-            load_a<T, NS>(af, GW_T == 6 ? l_s : la, wm * MTW + m, lane);
-            if (GW_T == 1) {
-                asm volatile("" :: "v"(af.hi), "v"(af.lo), "v"(bf[m & 3].hi), "v"(bf[m & 3].lo));
-            } else {
+            load_a<T, NS>(af, la, wm * MTW + m, lane);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
-            }
+            for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
             if (m == 3 && s + 1 < KS) {
-#ifdef GW_DBG
-                GW_TICK(c1);
-                asm volatile("s_waitcnt vmcnt(0)");
-                GW_TICK(c2);
-#endif
-                if (GW_T != 2) store_b(rnext, (s + 1) & 1);
-                else asm volatile("" :: "v"(rnext[0]), "v"(rnext[1]), "v"(rnext[2]), "v"(rnext[3]));
-                if (GW_T != 4) store_w((s + 1) & 1);
-#ifdef GW_DBG
-                GW_TICK(c3);
-#endif
-                if (GW_T != 3 && s + 3 < KS) load_b(rnext, s + 3);
-                if (GW_T != 4 && s + 2 < KS) load_w(s + 2);
-#ifdef GW_DBG
-                GW_TICK(c4);
-                dbg_acc[0] += c1 - c0; dbg_acc[1] += c2 - c1; dbg_acc[2] += c3 - c2; dbg_acc[3] += c4 - c3;
-                c0 = c4;
-#endif
+                store_b(rnext, (s + 1) & 1);
+                store_w((s + 1) & 1);
+                if (s + 3 < KS) load_b(rnext, s + 3);
+                if (s + 2 < KS) load_w(s + 2);
             }
         }
-#ifdef GW_DBG
-        GW_TICK(c5);
-#endif
-        if (GW_T != 5) __syncthreads();
-#ifdef GW_DBG
-        GW_TICK(c6);
-        dbg_acc[4] += c5 - c0; dbg_acc[5] += c6 - c5;
-#endif
+        __syncthreads();
     };
     for (int s = 0; s < KS; s += 2) {
         step(s, raw1);
         if (s + 1 < KS) step(s + 1, raw0);
     }
-#ifdef GW_DBG
-    if (lane == 0) for (int z_ = 0; z_ < 6; ++z_) atomicAdd(&gw_dbg[(wave >> 2) * 8 + z_], dbg_acc[z_]);
-#endif
     if (t0 >= a.t_hi || m0 >= a.mt) return;
 
     float* out = a.out + (size_t)b * a.out_bstride;
@@ -499,7 +445,7 @@ int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st) {
     WnGemmArgs k = a;
     k.t_base = wn_tile_origin(a.t_lo);
     k.swz = wn_xcd_swizzle_enabled();
-    if (wn_launch_gemm_rw(k, batch, mode, st) || wn_launch_gemm_dma(k, batch, mode, st)) {
+    if (wn_launch_gemm_rw(k, batch, mode, st)) {
         WN_CHECK_LAUNCH();
         return 0;
     }

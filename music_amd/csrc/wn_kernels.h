@@ -27,8 +27,6 @@ struct WnGemmArgs {
 int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 // two-role persistent form of the narrow product (wn_gemm_rw.hip); 1 = launched, 0 = arguments not covered
 int wn_launch_gemm_rw(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
-// LDS-DMA form of the wide product (wn_gemm_dma.hip: >= 256 rows, one tap, x3 modes); 1 = launched, 0 = arguments not covered
-int wn_launch_gemm_dma(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 struct WnResArgs;
 int wn_launch_enc_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);   // wn_resblock2.hip (ENC)
 int wn_launch_pack(const float* flat, const int32_t* idx, uint16_t* out, int n, int is_bf16, int ns,
@@ -42,9 +40,6 @@ struct WnResArgs {
     int n_f, n_d;                                       // real dilation / residual channel counts
     int d, t_lo, t_hi, z_lo, t_base;                    // outputs valid on [t_lo,t_hi); z stored for t >= z_lo
     int write_x;                                        // 0 for the last block (its x is unused)
-#ifdef FW_DBG
-    int n_d_dbg;                                        // developer build: slot of this launch in the span log
-#endif
     // optional conditioning (wavenet_autoencoder/model1.py:183,227-247): [f;g] += cond[b][row][idx(t)]
     const float* cond; long cond_bstride; int cond_pitch;   // [B][2CH][cond_pitch]
     int cond_mode, cond_le, cond_q;                     // 1: idx = (t-t_lo)/cond_q (stretch); 2: idx = (t-t_lo) % cond_le (tile)
@@ -120,9 +115,6 @@ struct WnResPqArgs {
     // class of (item index mod d/32) downwards in time, so the Q half of an item is the carry of the next one and dx_i leaves
     // the launch WHOLE in p_out (valid on [t_lo - d, t_hi)); q_out is not touched.  Set by the launcher (wn_pq_chain_plan):
     int chain, ch_s, ch_qn, ch_rm, ch_g, ch_nchain;        // d/32, items per chain (qn, +1 for the first rm chains), segments per chain (0: whole chains per workgroup), chains
-#ifdef PQ_SPAN
-    int span_slot;                                      // developer build: slot of this launch in the span log
-#endif
 };
 #define WN_PQ_IDX_PAD 64
 int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st);

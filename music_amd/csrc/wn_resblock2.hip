@@ -46,25 +46,9 @@ template <int NT> struct NtCfg { static constexpr int WAVES = NT == 4 ? 8 : 16; 
 // ENC = the autoencoder's ENCODER block (wavenet_autoencoder/model1.py:137-152) on the same skeleton:
 //   h = Wdil [relu x(t-d); relu x(t)] (+ bias) ; x_out = Wd relu(h) (+ bias) + x(t) ; h (pre-activation) is stored where
 //   the decoder block stores z.  One row group (no gate), ReLU on load and in front of the dense product.
-#ifdef FW_DBG
-// developer build (tools/fw_spans.py): start / end of every workgroup of the last 64 launches on the 100 MHz realtime clock
-__device__ unsigned long long fw_dbg[64 * 256 * 8];
-__device__ unsigned long long fw_clk[64 * 256 * 2];      // shader clock (s_memtime) at the f/g phase's start and end
-static int fw_dbg_slot = 0;
-extern "C" int wn_fw_clk_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fw_clk), sizeof(unsigned long long) * 64 * 256 * 2);
-}
-extern "C" int wn_fw_dbg_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fw_dbg), sizeof(unsigned long long) * 64 * 256 * 8);
-}
-#endif
 template <class T, int NS, int CH, int NT, bool ENC = false, int WV = NtCfg<NT>::WAVES, bool CND = false>
 __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
     static_assert(!CND || (NT == 4 && NS == 3 && !ENC), "conditioning k-step: 4 samples per lane, x3 packs");
-#ifdef FW_DBG
-    const int dbg_wg = blockIdx.y * gridDim.x + blockIdx.x;
-    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8] = __builtin_amdgcn_s_memrealtime();
-#endif
     typedef typename VecN<NT>::t fvec;
     constexpr int THREADS = 64 * WV;
     constexpr int COLS = WV * 16 * NT;
@@ -95,23 +79,10 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
     fvec raw[8];
     auto issue = [&](int s) {
         const int tap = s / KT, ch = (s % KT) * 32 + 8 * q;
-#ifdef FW_T_L2X
-        // TIMING build (wrong results): every x read lands in the clip's first 512 columns (served by L2 / the Infinity Cache) -
-        // what the block costs when its input never comes from HBM (halo-recompute fusion of the small dilations, priced)
-        const float* p = xin + (size_t)ch * a.pitch + ((tap == 0 ? colm : tl) & 511);
-#else
         const float* p = xin + (size_t)ch * a.pitch + (tap == 0 ? colm : tl);
-#endif
         // the shifted tap is always loaded with the alignment-free form: choosing between the two forms
         // at run time would merge the loaded registers across a branch, which the compiler implements as
         // load -> wait -> copy, i.e. no prefetch at all
-#ifdef FW_T_NOXLOAD
-        // TIMING build (wrong results): no x loads at all (finite constants instead) - the block whose input is already on the CU
-        // (halo-recompute fusion of the small dilations, priced: tools/exp/README.md)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = fvec{0.01f * (float)(j + 1), -0.02f, 0.03f, 0.015f} + (p == nullptr ? 1.f : 0.f);
-        return;
-#endif
         if (tap == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[j] = VecN<NT>::ldu(p + (size_t)j * a.pitch);
@@ -133,7 +104,7 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
     // The packed weights go to LDS one k-step at a time: only the MT fragments of k-step 0 are waited for before the first
     // MFMA; the fragments of k-step s + 1 (after the last one: the dense product's) are fetched from L2 while k-step s is
     // multiplied and written behind it, one workgroup barrier per k-step.  (All 80 KB up front held every wave at the first
-    // barrier for 4 of the launch's 24 us: in-kernel stamps, tools/fw_spans.sh.)
+    // barrier for 4 of the launch's 24 us: in-kernel stamps, tools/fw_spans.py on a -DFW_DBG build.)
     constexpr int FRV = FR / 8;                               // u32x4 per fragment
     constexpr int WPT = (MT * FRV + THREADS - 1) / THREADS;   // u32x4 per thread for one k-step's fg fragments
     constexpr int DPT = (ND * FRV + THREADS - 1) / THREADS;   // ... for the dense product's fragments
@@ -208,37 +179,16 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
         for (int n = 0; n < NT; ++n) acc[m][n] = init;
     }
     __syncthreads();
-#ifdef FW_DBG
-    __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && dbg_wg < 256) fw_clk[((size_t)a.n_d_dbg * 256 + dbg_wg) * 2] = __builtin_readcyclecounter();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
 
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         Frag<T> bf[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-#ifdef FW_T_NOCONV
-            // TIMING build (wrong results): the loaded bits ARE the fragment (x stored MFMA-ready: same bytes, no vector work)
-            const u32x4 h_ = {__builtin_bit_cast(uint32_t, raw[0][n]), __builtin_bit_cast(uint32_t, raw[1][n]), __builtin_bit_cast(uint32_t, raw[2][n]), __builtin_bit_cast(uint32_t, raw[3][n])};
-            const u32x4 l_ = {__builtin_bit_cast(uint32_t, raw[4][n]), __builtin_bit_cast(uint32_t, raw[5][n]), __builtin_bit_cast(uint32_t, raw[6][n]), __builtin_bit_cast(uint32_t, raw[7][n])};
-#ifdef FW_T_NOCONV_MASK
-            // ... kept FINITE (f16 values below 2 / below 2^-10): garbage operands turn into NaN within a layer and a chip fed NaNs clocks
-            // higher in EVERY kernel of the step; the 8 ANDs per fragment are also what a packed (hi | lo) word layout would pay in v_perm
-            bf[n].hi = __builtin_bit_cast(typename T::vec8, h_ & 0x3BFF3BFFu);
-            if (NS == 3) bf[n].lo = __builtin_bit_cast(typename T::vec8, l_ & 0x13FF13FFu);
-#else
-            bf[n].hi = __builtin_bit_cast(typename T::vec8, h_);
-            if (NS == 3) bf[n].lo = __builtin_bit_cast(typename T::vec8, l_);
-#endif
-#else
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = ENC ? fmaxf(raw[j][n], 0.f) : raw[j][n];
             split8<T, NS>(bf[n], v);
-#endif
         }
         if (s + 1 < KS) issue(s + 1);
         stage_ld(s + 1);
@@ -251,7 +201,6 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) mma<T, NS>(acc[m][n], af[m & 1], bf[n]);
             }
-#ifndef WN_NO_SGB
             // pin that order (the scheduler would put each LDS read right in front of its MFMAs)
             constexpr int RD = NS == 3 ? 2 : 1, MM = NT * NS;
             __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
@@ -261,18 +210,11 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
-#endif
         }
         stage_st(s + 1);
         __syncthreads();
     }
 
-#ifdef FW_DBG
-    __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && dbg_wg < 256) fw_clk[((size_t)a.n_d_dbg * 256 + dbg_wg) * 2 + 1] = __builtin_readcyclecounter();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     if (CND) {
         // conditioning bias as one more k-step: table fragments (hi + lo) times E[bucket][t] = (bucket(t) == bucket)
         typename T::vec8 e[NT];
@@ -328,11 +270,7 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
         for (int m = 0; m < MT2; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-#ifdef FW_T_NORES
-                res[m][i] = fvec{1.f, 2.f, 3.f, 4.f};      // TIMING build (wrong results): no residual re-read (the tap-1 operand would serve)
-#else
                 res[m][i] = VecN<NT>::ld(xin + (size_t)(16 * m + 4 * q + i) * a.pitch + tl);
-#endif
     }
 
     // gate: z tile m = tanh(f tile m) * sigmoid(g tile m)
@@ -345,11 +283,6 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
             for (int i = 0; i < 4; ++i)
                 z[m][n][i] = ENC ? acc[m][n][i] : wn_gate(acc[m][n][i], acc[ENC ? m : m + MT2][n][i]);
 
-#ifdef FW_DBG
-    __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     // z-crop store (rows 16m+4q+i; the lane's 4 N-tiles are 4 consecutive samples)
     {
         float* zo0 = a.z_out + (size_t)b * a.z_bstride;
@@ -370,17 +303,6 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
                 VecN<NT>::stm(zo + (size_t)(16 * m + 4 * q + i) * a.pitch + tl, v, tl, a.z_lo, a.t_hi);
             }
     }
-#ifdef FW_DBG
-    __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef FW_DBG
-    if (!a.write_x) {
-        if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
-        return;
-    }
-#endif
     if (!a.write_x) return;
 
     // dense: x' = Wd z + x   (B fragments straight from the z accumulators, chained k order)
@@ -419,11 +341,6 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
             for (int n = 0; n < NT; ++n) mma<T, NS>(acc2[m][n], af, bf[n]);
         }
     }
-#ifdef FW_DBG
-    __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     if (NT != 4) {                        // 128-VGPR budget: fetch the residual rows only now
 #pragma unroll
         for (int m = 0; m < MT2; ++m)
@@ -442,22 +359,11 @@ __global__ __launch_bounds__(64 * WV) void resblock_fwd_nt_k(WnResArgs a) {
             // streaming store here too, although the next launch reads these rows: a launch's stores all come in its last
             // third, and what they leave dirty in the L2s is written back at the kernel boundary with nothing running
             // (0.838 vs 0.88-0.90 ms for the stack; write-through `sc1` stores: 0.88)
-#ifndef FW_PLAIN_X
             if (NT == 4 && tl >= a.t_lo && tl + 3 < a.t_hi)
                 __builtin_nontemporal_store(v, reinterpret_cast<fvec*>(xo + (size_t)(16 * m + 4 * q + i) * a.pitch + tl));
             else
-#endif
             VecN<NT>::stm(xo + (size_t)(16 * m + 4 * q + i) * a.pitch + tl, v, tl, a.t_lo, a.t_hi);
         }
-#ifdef FW_DBG
-    __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef FW_DBG
-    __syncthreads();            // all waves have issued their stores
-    if (threadIdx.x == 0 && dbg_wg < 256) fw_dbg[((size_t)a.n_d_dbg * 256 + dbg_wg) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
-#endif
 }
 
 
@@ -466,10 +372,6 @@ static int launch_fwd_nt(const WnResArgs& a, int ch, int batch, hipStream_t st) 
     WnResArgs k = a;
     k.swz = wn_xcd_swizzle_enabled();
     k.t_base = wn_tile_origin(a.t_lo);
-#ifdef FW_DBG
-    k.n_d_dbg = fw_dbg_slot;
-    fw_dbg_slot = (fw_dbg_slot + 1) & 63;
-#endif
     const int ncol = a.t_hi - k.t_base;
     constexpr int COLS = NtCfg<NT>::WAVES * 16 * NT;
     dim3 g((ncol + COLS - 1) / COLS, batch), b(64 * NtCfg<NT>::WAVES);

@@ -36,13 +36,8 @@
 // L1 / L2 hit).  A chain is cut into segments for the 256 CUs; a segment that does not start at the top of its chain
 // first recomputes the item above it for its Q rows (HALO item: no stores, no weight gradients).  QIN = false: the block
 // above handed dx on whole (p_in alone).
-// PQ_T_* macros are timing-build switches (remove one ingredient; results are then wrong) used to see what a launch is
-// made of: -DPQ_T_NOREC / NOGATE / NOWG / NOPQ / NOSTORE / NOFILLDY / NOCONV via `make EXTRA=...` (tools/pq_phases.sh); for the
-// conditioned form -DPQ_T_NOCBIAS (no bias k-step), -DPQ_T_NOCSUM (no bucket sums), -DPQ_T_WD2 (rows two items ahead: spills)
-// with tools/ae_variant.sh.  Phase-order builds (correct results; tools/r4_abn.sh times them against the shipped order):
-// -DPQ_T_WORDER (W waves: weight gradients, dx product, conversion - rounds 2-4's order), -DPQ_T_RLATE / RMID / RFIRST (the R waves'
-// share of the dx product behind the gate / between recompute and gate / in front of the fills), -DPQ_T_FDLATE (dy fill behind that
-// share), -DPQ_T_NORMIX (pair form without the woven k-steps), -DPQ_T_WPRIO=n / -DPQ_T_RPRIO=n (static s_setprio of a role).
+// Timing / phase-clock / span builds of this kernel (one ingredient removed, phases reordered, stamps): tools/exp/dev_switches.patch,
+// applied to a scratch copy by tools/mkvar.sh - the shipped source builds correct code only.
 #include <stdlib.h>
 #include <string.h>
 #include "wn_common.h"
@@ -77,38 +72,6 @@ __device__ __forceinline__ void pq_split2(float a, float b, uint32_t& hi, uint32
 #define PQ_STAGE 24576
 #define PQ_W (2 * PQ_STAGE)
 #define PQ_LDS_HALFS (PQ_W + 32768)
-#ifdef PQ_SPAN
-// developer build (tools/pq_spans.py): realtime-clock (100 MHz) stamps of every workgroup of the last 64 launches:
-// [start, R first barrier, R loop end, W first barrier, W loop end, end (slab stores issued), n_items, -]
-__device__ unsigned long long pq_span[64 * 256 * 8];
-static int pq_span_slot = 0;
-extern "C" int wn_pq_span_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pq_span), sizeof(unsigned long long) * 64 * 256 * 8);
-}
-#define PQ_STAMP(i) do { if (lane == 0 && (wv == 0 || wv == 4) && blockIdx.x < 256) pq_span[((size_t)a.span_slot * 256 + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define PQ_STAMP(i)
-#endif
-#ifdef PQ_DBG
-// phase clock sums (developer build, tools/pq_clocks.py): [R: fill_x, recompute, gate+put, barrier | W: fill_dy, wgrad, pq, store, convert, barrier |
-// R's first phase apart: x fill + loads, dy fill + loads, its share of the dx product, dy row loads]
-__device__ unsigned long long pq_dbg[16];
-#define PQ_TICK(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
-#define PQ_ACC(slot, dt) dbg_acc[(slot)] += (unsigned long long)(dt)
-#define PQ_FLUSH(base, n) do { if (lane == 0) for (int z_ = 0; z_ < (n); ++z_) atomicAdd(&pq_dbg[(base) + z_], dbg_acc[(base) + z_]); } while (0)
-extern "C" int wn_pq_dbg_read(unsigned long long* out, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pq_dbg), sizeof(unsigned long long) * 16);
-    if (reset) {
-        unsigned long long z[16] = {};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(pq_dbg), z, sizeof(z));
-    }
-    return (int)e;
-}
-#else
-#define PQ_TICK(var)
-#define PQ_ACC(slot, dt)
-#define PQ_FLUSH(base, n)
-#endif
 
 // chunk swizzle of the result tiles: 16-byte chunk `ch` (8 positions) of row `r` sits at slot 16*ch + (r ^ K[ch])
 __device__ __forceinline__ int pq_k(int ch) { return ch == 0 ? 0 : ch == 1 ? 13 : ch == 2 ? 6 : 11; }
@@ -171,10 +134,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     const int g = wv & 3;
     const int c = lane & 15, q = lane >> 4;
     const int tile_rd = (16 * q + (c ^ pq_k(q))) * 8;            // halfs; chunk q of row c (a 16-byte row read)
-    if (wv == 0) PQ_STAMP(0);
-#ifdef PQ_DBG
-    unsigned long long dbg_acc[16] = {};
-#endif
     // items of this workgroup.  (P, Q) form: the workgroups of an XCD walk one contiguous item range interleaved (wn_resrw.hip).
     // CHAIN form: a run of `n_items` items in CHAIN ORDER (clip, residue r of the item index mod s, then downwards in time),
     // the first of them possibly a halo item; positions are stepped, a window of five (items it-1 .. it+3) lives in scalars.
@@ -204,9 +163,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         int n_real;
         CS c;
         pq_chain_start(chp, wgid, gridDim.x, c, n_real, has_halo);
-#ifdef PQ_T_NOHALO
-        if (has_halo) { has_halo = false; c = cs_next(c); }      // TIMING build (wrong results): what the halo items cost
-#endif
         n_items = n_real + (has_halo ? 1 : 0);
         win_b[0] = c.b; win_t[0] = cs_pos(c, -1);
 #pragma unroll
@@ -334,7 +290,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     auto pq_half_step = [&](int stage, int sel, int s, PqAcc& r) __attribute__((always_inline)) {
         const uint16_t* tt = lds + (size_t)stage * PQ_STAGE + PQ_T;
         const uint16_t* pw = lds + PQ_W;
-#ifndef PQ_T_NOPQ
         Frag<PQG> w;
         load_a<PQG, 3>(w, pw, (sel * 4 + g) * 4 + s, lane);
         const uint16_t* tb = tt + ((s >> 1) * 4 + 2 * (s & 1) + (q >> 1)) * 1024;
@@ -358,11 +313,9 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         ac[1] = PQG::mfma(ad[1].hi, w.lo, ac[1]);
         ac[0] = PQG::mfma(ad[0].hi, w.hi, ac[0]);
         ac[1] = PQG::mfma(ad[1].hi, w.hi, ac[1]);
-#endif
     };
     auto pq_half_tail = [&](int sel, Pos ps, const float* dy32, PqAcc& r) __attribute__((always_inline)) {
         f32x4 acc[2] = {r.a[0] + r.b[0], r.a[1] + r.b[1]};
-#ifndef PQ_T_NOSTORE
         if (ps.live) {
             float* out = (sel ? a.q_out : a.p_out) + (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q;
             const bool whole = ps.t0 >= a.t_lo && ps.t0 + PQ_COLS <= a.t_hi;
@@ -377,7 +330,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 else st4m(out + 16 * m, v, ps.t0 + 16 * m + 4 * q, a.t_lo, a.t_hi);
             }
         }
-#endif
     };
     auto pq_half = [&](int stage, int sel, Pos ps, const float* dy32) __attribute__((always_inline)) {
         PqAcc r;
@@ -441,9 +393,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 
     if (wv < 4) {
         // =========================== R waves: recompute, dz, gate ===========================
-#ifdef PQ_T_RPRIO
-        __builtin_amdgcn_s_setprio(PQ_T_RPRIO);
-#endif
         struct RawX { f32x2 x[8]; };
         // recompute operands ("time on lanes"; lane (c, q) of N-tile n holds sample t0 + 2c + n): wave g converts
         // k-step g = (tap g>>1, channel half g&1) of x, both N-tiles
@@ -452,32 +401,18 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             const float* xin = a.x_in + (size_t)ps.b * a.x_bstride;
             const float* p = ps.live ? xin + (size_t)(32 * (g & 1) + 8 * q) * a.pitch + ((g >> 1) == 0 ? tl - a.d : tl) : a.x_in;
             const size_t rp = ps.live ? (size_t)a.pitch : 0;
-#ifdef PQ_T_NOXR
-            return;
-#endif
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) r.x[jj] = pq_ld2u(p + jj * rp);
         };
         auto fill_x = [&](const RawX& r, int stage) {
-#ifdef PQ_T_NOXR
-            return;                                         // TIMING build (wrong results): x fragments arrive "by DMA" - the R waves neither load nor fill them
-#endif
             uint16_t* xf = lds + (size_t)stage * PQ_STAGE + PQ_XF;
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 Frag<F16> f;
-#ifdef PQ_T_NOCONVR
-                // TIMING build (wrong results): the loaded bits ARE the fragment (x stored MFMA-ready: same bytes, no vector work)
-                const u32x4 h_ = {__builtin_bit_cast(uint32_t, r.x[0][n]), __builtin_bit_cast(uint32_t, r.x[1][n]), __builtin_bit_cast(uint32_t, r.x[2][n]), __builtin_bit_cast(uint32_t, r.x[3][n])};
-                const u32x4 l_ = {__builtin_bit_cast(uint32_t, r.x[4][n]), __builtin_bit_cast(uint32_t, r.x[5][n]), __builtin_bit_cast(uint32_t, r.x[6][n]), __builtin_bit_cast(uint32_t, r.x[7][n])};
-                f.hi = __builtin_bit_cast(F16::vec8, h_ & 0x3BFF3BFFu);      // (kept finite: see wn_resblock2.hip)
-                f.lo = __builtin_bit_cast(F16::vec8, l_ & 0x13FF13FFu);
-#else
                 float v[8];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) v[jj] = r.x[jj][n];
                 split8<F16, 3>(f, v);
-#endif
                 pq_store_frag<F16>(xf, g * 2 + n, lane, f);
             }
         };
@@ -556,11 +491,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         // XD: items the raw x rows are requested ahead.  The chain form that is fed by a pair (the first chain block under a
         // (P, Q) block: 2 launches of 30) holds the dy rows twice more (dyrP, dyrQ) and keeps ONE set of x rows: no spills
         constexpr int XD = (CHAIN && QIN && HAS_DY) ? 1 : 2;
-#if defined(PQ_T_NORMIX) || defined(PQ_T_RLATE) || defined(PQ_T_RMID) || defined(PQ_T_RFIRST)
-        constexpr bool RMIX = false;
-#else
         constexpr bool RMIX = !CHAIN && !COND;
-#endif
         load_x(x0, pos_r(0, 0));
         load_dy(rd, pos_r(0, 0));
         if (XD == 2) load_x(x1, pos_r(0, 1));
@@ -569,7 +500,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         load_x(x0, pos_r(0, XD));
         load_dy(rd, pos_r(0, 1));
         __syncthreads();                                    // stage 0 operands of the first item, the weights, the zeros
-        if (wv == 0) PQ_STAMP(1);
         // conditioned form with the bucket bytes and <= 32 buckets: the conditioning bias T_b[row][bucket(t)] is one more
         // k-step of the recompute, T_b (this wave's f and g rows, k = bucket, f16 hi + lo) times the 0/1 matrix
         // E[bucket][t] = (bucket(t) == bucket) - four MFMAs per N-tile instead of 16 gathered loads per lane
@@ -591,7 +521,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             tc_b = b;
         };
         auto r_body = [&](const int it, f32x2* cr, RawX& rx) {
-#ifndef PQ_NO_VOIDSKIP
             if (it >= n_items) {
                 // the void item that pads an odd count: nothing of its own to do (its result tiles are never multiplied:
                 // the W waves skip a void item's products), only the Q rows of the last real item
@@ -600,8 +529,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 __syncthreads();
                 return;
             }
-#endif
-            PQ_TICK(k0);
             int cidx[2] = {0, 0};                            // buckets of this lane's two samples (used after the Q rows below)
             if (COND) {
                 const uint8_t* ip = a.cond_idx + (WN_PQ_IDX_PAD + pos_r(it, 0).t0 + 2 * c - a.t_lo);
@@ -610,10 +537,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             // (x operands written by the W waves instead - they hold the same rows for the weight gradients; f16 hi/lo [channel][time]
             // tiles read here with transposed reads, no x loads or conversions in the R waves - is correct and SLOWER, round 4: stack
             // 1.89-1.92 vs 1.85-1.87 ms same box; the R waves then wait 14-16 % at the barrier and the W waves set the pace)
-#ifdef PQ_T_RFIRST
-            pq_r((it + 1) & 1, pos_r(it, -1));                 // timing build: the R waves' share of the dx product in front of the fills
-            load_dyr(pos_r(it, 0));
-#endif
             // RMIX (pair form): the k-steps of the R waves' share of the dx product woven into the operand fills (1.81 vs 1.83 ms for
             // the stack, round 4; the chain form, at its register limit, gains nothing: 1.823 vs 1.829 with one set of x rows)
             PqAcc pa;
@@ -624,33 +547,18 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
             load_x(rx, pos_r(it, XD + 1));                  // (one item ahead instead of two: no change, 1.970 vs 1.976 ms)
             if (RMIX) pq_r_step((it + 1) & 1, 1, pa);
-            PQ_TICK(ka);
-#if !defined(PQ_T_NOFILLDY) && !defined(PQ_T_FDLATE)
             // (on the W waves instead - they wait 15 % of their time at the barrier in the chain form, the R waves 3.5 % - the stack
             // got SLOWER, 1.99-2.02 vs 1.93-1.97 ms same box, round 4: their loads of the same rows then queue behind each other)
             fill_dy(rd, pos_r(it, 1), (it + 1) & 1);
             load_dy(rd, pos_r(it, 2));
-#endif
             if (RMIX) {
                 pq_r_step((it + 1) & 1, 2, pa);
                 pq_r_step((it + 1) & 1, 3, pa);
                 pq_r_tail(pos_r(it, -1), pa);
                 load_dyr(pos_r(it, 0));
             }
-            PQ_TICK(kb);
-#if !defined(PQ_T_RLATE) && !defined(PQ_T_RMID) && !defined(PQ_T_RFIRST)
             if (!RMIX) pq_r((it + 1) & 1, pos_r(it, -1));                 // Q rows (CHAIN: the first half of dx) of the previous item
-#endif
-            PQ_TICK(kc);
-#if !defined(PQ_T_RLATE) && !defined(PQ_T_RMID) && !defined(PQ_T_RFIRST)
             if (!RMIX) load_dyr(pos_r(it, 0));
-#endif
-#ifdef PQ_T_FDLATE
-            fill_dy(rd, pos_r(it, 1), (it + 1) & 1);         // timing build: the dy fill behind the R waves' share of the dx product
-            load_dy(rd, pos_r(it, 2));
-#endif
-            PQ_TICK(k1);
-            PQ_ACC(10, ka - k0); PQ_ACC(11, kb - ka); PQ_ACC(12, kc - kb); PQ_ACC(13, k1 - kc);
             const Pos p_cur = pos_r(it, 0);
             const bool live = it < n_items;
             const int tl = p_cur.t0 + 2 * c;
@@ -665,7 +573,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 ag[n] = f32x4{0.f, 0.f, 0.f, 0.f};
                 dz[n] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-#ifndef PQ_T_NOREC
             {
                 // the three products of an x3 term and the f / g / N-tile accumulators are walked in rotation, the dz
                 // products woven in: no MFMA waits for the result of the one in front of it
@@ -695,8 +602,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                     }
                 }
             }
-#endif
-#ifndef PQ_T_NOCBIAS
             if (COND) {
                 if (p_cur.b != tc_b) load_tab(p_cur.b);
 #pragma unroll
@@ -714,12 +619,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                     ag[n] = F16::mfma(tcg.hi, e, ag[n]);
                 }
             }
-#endif
-#ifdef PQ_T_RMID
-            pq_r((it + 1) & 1, pos_r(it, -1));                 // timing build: the R waves' share of the dx product between recompute and gate
-            load_dyr(pos_r(it, 0));
-#endif
-            PQ_TICK(k2);
             uint16_t* tt = st + PQ_T;
             // (mask-free copies of this phase for items inside [t_lo, t_hi) and on one side of z_lo - a fifth of the R waves' vector
             // instructions are compares and selects - change nothing, round 4: 1.858 vs 1.858 ms chain form, 1.897 vs 1.910 pair form)
@@ -732,9 +631,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                     const bool ok = n ? ok1 : ok0;
                     float gz = dz[n][i];
                     if (tl + n >= a.z_lo && tl + n < a.t_hi) gz += cr[i][n];
-#ifdef PQ_T_NOGATE
-                    const float th = af[n][i], sg = ag[n][i];
-#else
                     // th = (1 - e1) / (1 + e1), sg = 1 / (1 + e2) with ONE reciprocal (e1 = exp(-2f), e2 = exp(-g)); the same
                     // values as wn_tanh / wn_sigmoid to ~1e-7 absolute
                     const float fc = fminf(fmaxf(af[n][i], -15.f), 15.f);
@@ -742,7 +638,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                     const float rr = __builtin_amdgcn_rcpf((1.0f + e1) * (1.0f + e2));
                     const float th = (1.0f - e1) * (1.0f + e2) * rr;
                     const float sg = (1.0f + e1) * rr;
-#endif
                     vz[n] = ok ? th * sg : 0.f;
                     vf[n] = ok ? gz * sg * (1.0f - th * th) : 0.f;
                     vg[n] = ok ? gz * th * sg * (1.0f - sg) : 0.f;
@@ -759,16 +654,9 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 put(1, vg);
                 if (HAS_DY) put(2, vz);
             }
-#ifdef PQ_T_RLATE
-            pq_r((it + 1) & 1, pos_r(it, -1));                 // timing build: the R waves' share of the dx product behind the gate
-            load_dyr(pos_r(it, 0));
-#endif
             load_cr(cr, pos_r(it, 2));
             win_advance();
-            PQ_TICK(k3);
             __syncthreads();
-            PQ_TICK(k4);
-            PQ_ACC(0, k1 - k0); PQ_ACC(1, k2 - k1); PQ_ACC(2, k3 - k2); PQ_ACC(3, k4 - k3);
         };
         for (int it = 0; it < n_items; it += 2) {
             r_body(it, crA, XD == 2 ? x1 : x0);
@@ -778,17 +666,11 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             const int n_even = (n_items + 1) & ~1;
             if (pos_r(n_even, -1).live) pq_r((n_even - 1) & 1, pos_r(n_even, -1));      // Q rows of the last item
         }
-        if (wv == 0) PQ_STAMP(2);
         __syncthreads();                                    // the W waves' extra round (products of the last item)
-        PQ_FLUSH(0, 4);
-        PQ_FLUSH(10, 4);
         return;
     }
 
     // =========================== W waves: weight gradients and the (P, Q) product ===========================
-#ifdef PQ_T_WPRIO
-    __builtin_amdgcn_s_setprio(PQ_T_WPRIO);               // timing build: static priority for the younger half of the workgroup
-#endif
     f32x4 cfg[8][2], cd[4];
 #pragma unroll
     for (int m = 0; m < 8; ++m) { cfg[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; cfg[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -834,21 +716,12 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     auto convert = [&](Ops& o, const RawRows& r, Pos ps) {
         float w[8];
         if (COND) { o.bk[0] = r.bk[0]; o.bk[1] = r.bk[1]; }
-#ifdef PQ_T_NOCONVW
-        // TIMING build (wrong results): the W waves' x rows as loaded are their MFMA operands (x stored split: same bytes)
-        {   // (kept finite: bf16 values below 2 / below 2^-8)
-            const u32x4 mh = {0x3FFF3FFFu, 0x3FFF3FFFu, 0x3FFF3FFFu, 0x3FFF3FFFu}, ml = {0x3BFF3BFFu, 0x3BFF3BFFu, 0x3BFF3BFFu, 0x3BFF3BFFu};
-            o.x0.hi = __builtin_bit_cast(pqg8, __builtin_bit_cast(u32x4, r.x0[0]) & mh); o.x0.lo = __builtin_bit_cast(pqg8, __builtin_bit_cast(u32x4, r.x0[1]) & ml);
-            o.x1.hi = __builtin_bit_cast(pqg8, __builtin_bit_cast(u32x4, r.x1[0]) & mh); o.x1.lo = __builtin_bit_cast(pqg8, __builtin_bit_cast(u32x4, r.x1[1]) & ml);
-        }
-#else
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) w[jj] = ps.live ? r.x0[jj >> 2][jj & 3] : 0.f;
         to_frag(o.x0, w);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) w[jj] = ps.live ? r.x1[jj >> 2][jj & 3] : 0.f;
         to_frag(o.x1, w);
-#endif
         if (HAS_DY) {
             if (interior(ps)) {
 #pragma unroll
@@ -905,13 +778,11 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         c_b = newb;
     };
     auto products = [&](int stage, const Ops& o, Pos ps) __attribute__((always_inline)) {
-        PQ_TICK(p0);
         const uint16_t* tt = lds + (size_t)stage * PQ_STAGE + PQ_T;
         const bool c_item = COND && do_c && ps.live;
         if (COND && c_item && ps.b != c_b) c_flush(ps.b);
         // ---- weight gradients: rows = all [df;dg] / z tiles, columns = this wave's x / dy rows (not for a halo item: the
         // workgroup above counts it)
-#ifndef PQ_T_NOWG
         if (!(CHAIN && ps.halo)) {
             // the three products of an x3 term are walked across FOUR accumulators (two tiles x two column blocks), so
             // no MFMA waits for the one in front of it; the next pair of tiles is read meanwhile
@@ -936,7 +807,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                         term(cfg[mm + 1][0], am[cur][1], o.x0, t);
                         term(cfg[mm + 1][1], am[cur][1], o.x1, t);
                     }
-#ifndef PQ_T_NOCSUM
                     if (COND && c_item && mm == 2 * g) {          // this wave's two row tiles of the bucket sums
 #pragma unroll
                         for (int n = 0; n < 2; ++n) {
@@ -956,7 +826,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                             cacc[1][n] = PQG::mfma(am[cur][1].hi, sel, cacc[1][n]);
                         }
                     }
-#endif
                 } else {
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
@@ -966,71 +835,45 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                 }
             }
         }
-#endif
-        PQ_TICK(p1);
-        PQ_ACC(5, p1 - p0);
     };
     // the W waves' share of the data gradient of item ps (result tiles in `stage`); dyk = the lane's fp32 dy rows of that item
     auto pq_w = [&](int stage, const float* dyk, Pos ps) __attribute__((always_inline)) {
-        PQ_TICK(p1);
         if (CHAIN) pq_mt(stage, 1, ps, HAS_DY ? dyk + 4 : nullptr, carry_w);
         else pq_half(stage, 0, ps, dyk);
-        PQ_TICK(p2);
-        PQ_ACC(6, p2 - p1);
     };
 
     {
         RawRows rr, rr2;                                    // raw rows of items it / it+1: requested two items ahead
         Ops ops;                                            // (one item ahead: 1.968 vs 1.941 ms for the stack; the conditioned
-#ifdef PQ_T_WD2
-        constexpr int WD = 2;
-#else
         constexpr int WD = COND ? 1 : 2;                    // form does that and spends the 32 registers on its bucket sums)
-#endif
         load_rows(rr, pos_r(0, 0));
         if (WD == 2) load_rows(rr2, pos_r(0, 1));
         convert(ops, rr, pos_r(0, -1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
         __syncthreads();
-        if (wv == 4) PQ_STAMP(3);
         // iteration it: products of item it-1 (result tiles of stage (it-1)&1, operands in `ops`); then the raw rows of
         // item it become `ops` and the rows of item it+2 are requested (loop unrolled by two: no register copies)
-#ifdef PQ_T_WORDER
-        constexpr bool WMID = false;                        // A/B build
-#else
         // (the conditioned form and the pair-fed chain form have no registers for it; forced on the conditioned form, 12 spilled registers
         // instead of 9: decoder stack backward 2.12 against 2.14 ms at config 4, inside the spread)
         constexpr bool WMID = !COND && !(CHAIN && QIN && HAS_DY);
-#endif
         auto w_body = [&](const int it, RawRows& rr) {
-            PQ_TICK(k0);
-            PQ_TICK(k1);
             products((it + 1) & 1, ops, pos_r(it, -1));
             if (!WMID) {
                 pq_w((it + 1) & 1, ops.dy32, pos_r(it, -1));      // rounds 2-4's order: weight gradients, dx product, conversion
-                PQ_TICK(k2);
                 convert(ops, rr, pos_r(it, 0));
                 load_rows(rr, pos_r(it, WD));
-                PQ_TICK(k3);
-                PQ_ACC(8, k3 - k2);
             } else {
                 // the row conversion BETWEEN the weight gradients and the dx product: vector work beside the R waves' recompute MFMAs,
                 // the product's MFMAs beside their gate phase (the other order pairs matrix with matrix and vector with vector)
                 float dyk[8];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) dyk[jj] = (jj >= (CHAIN ? 4 : 0)) ? ops.dy32[jj] : 0.f;
-                PQ_TICK(k2);
                 convert(ops, rr, pos_r(it, 0));
                 load_rows(rr, pos_r(it, WD));
-                PQ_TICK(k2b);
                 pq_w((it + 1) & 1, dyk, pos_r(it, -1));
-                PQ_ACC(8, k2b - k2);
             }
 
             win_advance();
-            PQ_TICK(k3b);
             __syncthreads();
-            PQ_TICK(k4);
-            PQ_ACC(4, k1 - k0); PQ_ACC(9, k4 - k3b);
         };
         const int n_even = (n_items + 1) & ~1;
         for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, WD == 1 ? rr : rr2); }
@@ -1039,8 +882,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             pq_w((n_even - 1) & 1, ops.dy32, pos_r(n_even, -1));
         }
         __syncthreads();
-        if (wv == 4) PQ_STAMP(4);
-        PQ_FLUSH(4, 6);
     }
     if (COND && do_c) c_flush(-1);                      // the last clip's sums
 
@@ -1060,10 +901,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             __builtin_nontemporal_store(cd[m], reinterpret_cast<f32x4*>(&sd[(size_t)(16 * g + c) * CH + 16 * m + 4 * q]));
     }
     if (wv == 4) {
-        PQ_STAMP(5);
-#ifdef PQ_SPAN
-        if (lane == 0 && blockIdx.x < 256) pq_span[((size_t)a.span_slot * 256 + blockIdx.x) * 8 + 6] = (unsigned long long)n_items;
-#endif
     }
 }
 
@@ -1249,10 +1086,6 @@ int wn_launch_resblock_bwd_pq(const WnResPqArgs& a, int batch, hipStream_t st) {
         if (a.t_lo - k.t_base > WN_PQ_IDX_PAD) return wn_set_error_msg(-4, "resblock_bwd_pq: item alignment beyond the cond_idx pad");
         k.cslab_slots = k.cslab ? wn_pq_cond_slots(a.t_lo, a.t_hi, batch) : 0;
     } else if (k.cslab) return wn_set_error_msg(-4, "resblock_bwd_pq: cslab without cond");
-#ifdef PQ_SPAN
-    k.span_slot = pq_span_slot;
-    pq_span_slot = (pq_span_slot + 1) & 63;
-#endif
     const size_t sh = (size_t)PQ_LDS_HALFS * sizeof(uint16_t);
     const bool has_dy = k.p_in != nullptr, qin = k.q_in != nullptr, cnd = k.cond != nullptr, chn = k.chain != 0;
     if (cnd) {

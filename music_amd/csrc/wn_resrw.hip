@@ -53,25 +53,6 @@ __device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint
 #define RW_T 24576
 #define RW_STAGE 36864
 
-#ifdef RW_DBG
-// phase clock sums (developer build): [role 0/1][phase 0..3]
-__device__ unsigned long long rw_dbg[8];
-#define RW_TICK(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
-#define RW_ACC(slot, dt) dbg_acc[(slot) & 3] += (unsigned long long)(dt)
-#define RW_FLUSH(base) do { if (lane == 0) for (int z_ = 0; z_ < 3; ++z_) atomicAdd(&rw_dbg[(base) + z_], dbg_acc[z_]); } while (0)
-extern "C" int wn_rw_dbg_read(unsigned long long* out, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(rw_dbg), sizeof(unsigned long long) * 8);
-    if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(rw_dbg), z, sizeof(z));
-    }
-    return (int)e;
-}
-#else
-#define RW_TICK(var)
-#define RW_ACC(slot, dt)
-#define RW_FLUSH(base)
-#endif
 
 template <class T>
 __device__ __forceinline__ void rw_store_frag(uint16_t* base, int idx, int lane, const Frag<T>& f) {
@@ -87,9 +68,6 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
 
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = wv & 3;
-#ifdef RW_DBG
-    unsigned long long dbg_acc[4] = {0, 0, 0, 0};
-#endif
     const int c = lane & 15, q = lane >> 4;
     // 16-byte chunk (row, q) of a [16 rows][32 samples] tile plane sits at slot 16q + (row ^ q): conflict free for
     // the ds_read_b128 lane groups and the 8-lane ds_write_b128 groups of lanes (row = c, q) AND for the 32-lane
@@ -153,25 +131,15 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         // and the loads stay unconditional
         const float* p = ps.live ? xin + (size_t)(32 * (g & 1) + 8 * q) * a.pitch + ((g >> 1) == 0 ? tl - a.d : tl) : a.x_in;
         const size_t rp = ps.live ? (size_t)a.pitch : 0;
-#ifdef RW_T_NOLOAD
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r.x[j] = f32x2{(float)(tl + j), (float)ps.b};
-#else
 #pragma unroll
         for (int j = 0; j < 8; ++j) r.x[j] = ld2u(p + j * rp);
-#endif
     };
     auto load_dy = [&](RawD& r, Pos ps) {
         const int tl = ps.t0 + 2 * c;
         const float* pd = ps.live ? dy_or_x + (size_t)ps.b * a.x_bstride + (size_t)(32 * (g >> 1) + 8 * q + 4 * (g & 1)) * a.pitch + tl : dy_or_x;
         const size_t rp = ps.live ? (size_t)a.pitch : 0;
-#ifdef RW_T_NOLOAD
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r.dy[j] = f32x2{(float)(tl - j), (float)ps.b};
-#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.dy[j] = ld2u(pd + j * rp);
-#endif
     };
     auto fill_x = [&](const RawX& r, int stage) {
         uint16_t* xf = lds + (size_t)stage * RW_STAGE + RW_XF;
@@ -232,13 +200,8 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         auto load_cr = [&](f32x2* cr, Pos ps) {
             const float* dzc = ps.live ? a.dz + (size_t)ps.b * a.dz_bstride + (size_t)(16 * g + 4 * q) * a.pitch + ps.t0 + 2 * c : a.dz;
             const size_t rp = ps.live ? (size_t)a.pitch : 0;
-#ifdef RW_T_NOCR
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cr[i] = f32x2{(float)ps.t0, 0.f};
-#else
 #pragma unroll
             for (int i = 0; i < 4; ++i) cr[i] = ld2u(dzc + i * rp);
-#endif
         };
 
         // The loop is unrolled by two so that every prefetch register set is re-armed TWO items ahead without
@@ -247,22 +210,15 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         f32x2 crA[4], crB[4];
         load_cr(crA, pos_k(0));
         load_cr(crB, pos_k(1));
-#ifndef RW_XF_W
         RawX x0, x1;                                        // x1 / x0 hold the raw rows of items it+1 / it+2
         load_x(x0, pos_k(0));
         load_x(x1, pos_k(1));
         fill_x(x0, 0);
         load_x(x0, pos_k(2));
-#else
-        RawX x0, x1;
-#endif
         __syncthreads();                                    // stage 0 operands of the first item are in LDS
         auto r_body = [&](const int it, f32x2* cr, RawX& rx) {
-            RW_TICK(k0);
-#if !defined(RW_XF_W) && !defined(RW_T_NOFILL)
             fill_x(rx, (it + 1) & 1);                        // recompute operands of the next item
             load_x(rx, pos_k(it + 3));
-#endif
             const Pos p_cur = pos_k(it);
             const bool live = it < n_items;
             const int b = p_cur.b, t0 = p_cur.t0;
@@ -278,7 +234,6 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
                 ag[n] = f32x4{bias_g[0], bias_g[1], bias_g[2], bias_g[3]};
                 dz[n] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-#ifndef RW_T_NOREC
             {
                 // One accumulator is touched by every 4th (5th) MFMA only: the three products of an x3 term and
                 // the f / g / N-tile accumulators are walked in rotation, with the dz products woven in, so no
@@ -309,8 +264,6 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
                     }
                 }
             }
-#endif
-            RW_TICK(k1);
             if (a.cond) {       // same conditioning bias as the forward (wavenet_autoencoder/model1.py:183)
                 const float* cb = a.cond + (size_t)b * a.cond_bstride;
                 int idx[2];
@@ -341,12 +294,8 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
                     const bool ok = n ? ok1 : ok0;
                     float gz = dz[n][i];
                     if (tl + n >= a.z_lo && tl + n < a.t_hi) gz += cr[i][n];
-#ifdef RW_T_NOGATE
-                    const float th = af[n][i], sg = ag[n][i];
-#else
                     const float th = wn_tanh(af[n][i]);
                     const float sg = wn_sigmoid(ag[n][i]);
-#endif
                     vz[n] = ok ? th * sg : 0.f;
                     vf[n] = ok ? gz * sg * (1.0f - th * th) : 0.f;
                     vg[n] = ok ? gz * th * sg * (1.0f - sg) : 0.f;
@@ -373,16 +322,12 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
                 if (HAS_DY) put(2, vz);
             }
             load_cr(cr, pos_k(it + 2));
-            RW_TICK(k2);
             __syncthreads();
-            RW_TICK(k3);
-            RW_ACC(0, k1 - k0); RW_ACC(1, k2 - k1); RW_ACC(2, k3 - k2);
         };
         for (int it = 0; it < n_items; it += 2) {
             r_body(it, crA, x1);
             r_body(it + 1, crB, x0);
         }
-        RW_FLUSH(0);
         return;
     }
 
@@ -402,13 +347,8 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         for (int kind = 0; kind < (HAS_DY ? 3 : 2); ++kind) {
             const float* base = (kind == 2 ? dy_or_x : a.x_in) + (size_t)ps.b * a.x_bstride;
             const float* p = ps.live ? base + (size_t)(16 * g + c) * a.pitch + ps.t0 + 8 * q + (kind == 0 ? -a.d : 0) : a.x_in;
-#ifdef RW_T_NOLOAD
-            r.v[kind][0] = f32x4{(float)ps.t0, (float)kind, 1.f, 2.f};
-            r.v[kind][1] = f32x4{(float)ps.b, (float)kind, 3.f, 4.f};
-#else
             r.v[kind][0] = ld4u(p);
             r.v[kind][1] = ld4u(p + 4);
-#endif
         }
     };
     auto fill_wo = [&](const RawWO& r, Pos ps, int stage) {
@@ -476,43 +416,21 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
         load_wo(rw1, pos_k(1));
         fill_dy(d0, pos_k(0), 0);
         load_dy(d0, pos_k(2));
-#ifdef RW_XF_W
         RawX x0, x1;
-        load_x(x0, pos_k(0));
-        load_x(x1, pos_k(1));
-        fill_x(x0, 0);
-        load_x(x0, pos_k(2));
-#else
-        RawX x0, x1;
-#endif
         __syncthreads();
         auto w_body = [&](const int it, RawD& rd, RawX& rx, RawWO& rw) {
-            RW_TICK(k0);
-#ifndef RW_T_NOFILL
-#ifdef RW_XF_W
-            fill_x(rx, (it + 1) & 1);
-            load_x(rx, pos_k(it + 3));
-#endif
             fill_dy(rd, pos_k(it + 1), (it + 1) & 1);        // recompute operands of the next item
             load_dy(rd, pos_k(it + 3));
             fill_wo(rw, pos_k(it), it & 1);                  // [row][time] operands of this item
             load_wo(rw, pos_k(it + 2));
-#endif
-            RW_TICK(k1);
-#ifndef RW_T_NOWG
             wgrad((it + 1) & 1);                             // products of the previous item
-#endif
-            RW_TICK(k2);
             __syncthreads();
-            RW_TICK(k3);
-            RW_ACC(4, k1 - k0); RW_ACC(5, k2 - k1); RW_ACC(6, k3 - k2);
         };
         for (int it = 0; it < n_items; it += 2) {
             w_body(it, d1, x1, rw0);
             w_body(it + 1, d0, x0, rw1);
         }
         wgrad(1);                                           // the last item of the (even) padded count
-        RW_FLUSH(4);
     }
 
     // ---- slab of this workgroup (every workgroup writes one, also an idle one: zeros)

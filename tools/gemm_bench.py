@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """GPU box: the six wide channel-mixing products of config 2's epilogue, each ALONE on the stream (no second stream, whole batch),
-HIP-event time per launch; with --ab the LDS-DMA form (wn_gemm_dma.hip) and chan_gemm_wide2_k alternate in ONE process.
+HIP-event time per launch; with --ab NAME an experimental form (tools/exp/wn_gemm_<name>.hip, built in by tools/mkvar.sh with
+-DWN_EXP_GEMM and selected by WN_GEMM_<NAME>=1) and chan_gemm_wide2_k alternate in ONE process.
 
-    python tools/gemm_bench.py [--reps 20] [--ab] [--rounds 3]
+    WAVENET_HIP_LIB=tools/_var_expg.so python tools/gemm_bench.py [--reps 20] [--ab w1|dma] [--rounds 3]
 """
 import argparse, json, os, statistics, sys
 import numpy as np
@@ -17,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--ab", action="store_true")
+    ap.add_argument("--ab", default="")
     args = ap.parse_args()
     from music_amd.model import wavenet
     from music_amd import _lib
@@ -63,11 +64,12 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / args.reps * 1e3
 
-    modes = [("dma", "1"), ("wide2", "0")] if args.ab else [("default", os.environ.get("WN_GEMM_DMA", "1"))]
+    key = "WN_GEMM_%s" % args.ab.upper()
+    modes = [(args.ab, "1"), ("wide2", "0")] if args.ab else [("wide2", "0")]
     res = {m: {k: [] for k in prods} for m, _ in modes}
     for _ in range(args.rounds):
         for m, v in modes:
-            os.environ["WN_GEMM_DMA"] = v
+            os.environ[key] = v
             for k, fn in prods.items():
                 res[m][k].append(timeit(fn))
     out = {m: {k: round(statistics.median(v), 1) for k, v in r.items()} for m, r in res.items()}
