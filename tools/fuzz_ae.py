@@ -19,6 +19,45 @@ from oracle import wavenet_oracle as wo  # noqa: E402
 from oracle import intops  # noqa: E402
 
 
+RELU_EPS = 2e-4          # tests/test_gpu_fullsize.py: the band around zero inside which a ReLU's subgradient follows the device
+
+
+def _device_relu(dev_pre):
+    """oracle `relu=` hook that follows the device's sign where the reference pre-activation is within RELU_EPS of zero (relative to
+    the tensor's max-abs) and insists on equal signs everywhere else (tests/test_gpu_fullsize.py:_device_relu)"""
+    stats = dict(near=0, flips=0)
+
+    def relu(name, t):
+        d = dev_pre[name]
+        assert d.shape == t.shape, (name, d.shape, t.shape)
+        eps = RELU_EPS * t.detach().abs().max().item()
+        near = t.detach().abs() < eps
+        ref_m, dev_m = t.detach() > 0, d > 0
+        assert not ((ref_m != dev_m) & ~near).any(), "ReLU mask of %s differs outside the tolerance band" % name
+        stats["near"] += int(near.sum())
+        stats["flips"] += int(((ref_m != dev_m) & near).sum())
+        return t * torch.where(near, dev_m, ref_m).to(t.dtype)
+    return relu, stats
+
+
+def _dev_pre(eng, B, T, n):
+    """every ReLU's pre-activation as the device holds it, in the oracle's names and shapes (fast engine and general plan)"""
+    from music_amd.engine import SLACK
+    ws = eng.workspace(B, T)
+    pitch, lo = ws["pitch"], eng.rf - 1
+    rp_x = getattr(eng, "ReP", None) or eng.CHe             # padded rows of the encoder's x / h tensors
+    rp_h = getattr(eng, "DeP", None) or eng.CHe
+    pre = {}
+    for i in range(n):
+        xe = ws["Xe"][SLACK + i * B * rp_x * pitch:SLACK + (i + 1) * B * rp_x * pitch].view(B, rp_x, pitch)
+        he = ws["He"][SLACK + i * B * rp_h * pitch:SLACK + (i + 1) * B * rp_h * pitch].view(B, rp_h, pitch)
+        pre["en_x%d" % i] = xe[:, :eng.Re, eng.off[i]:T].cpu()
+        pre["en_h%d" % i] = he[:, :eng.De, eng.off[i + 1]:T].cpu()
+    v = lambda buf: buf[SLACK:SLACK + B * eng.SP * pitch].view(B, eng.SP, pitch)[:, :eng.Sd, lo:T].cpu()
+    pre["de_skip"], pre["de_conn"] = v(ws["U"]), v(ws["R1"])
+    return pre
+
+
 def one_case(rng, k, general=False):
     from music_amd.model1 import wavenet_autoencoder
     n = int(rng.integers(2, 7))
@@ -78,63 +117,36 @@ def one_case(rng, k, general=False):
         if err > worst:
             worst, wname = err, name
     ok = e_p <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and worst <= 2e-3
-    if not ok and e_p <= 1e-3 and general:
-        # general plan: every ReLU's pre-activation (encoder x_i / h_i, skip sum, connection_1 output) as the device holds it
-        # against the oracle's: opposite signs within rounding of 0 make the gradients differ legitimately
-        from music_amd.engine import SLACK
-        eng = net._engine
-        T = idx.shape[1]
-        ws = eng.workspace(B, T)
-        pitch = ws["pitch"]
-        inter = {}
-        with torch.no_grad():
-            wo.autoencoder_forward(params, dil, x, cfg["en_pool_kernel_size"], cond, filter_width=fw, q=Q, intermediates=inter)
-        ties, near = 0, 0.0
-
-        def cmp(key, i, rows_p, rows, ref):
-            buf = ws[key][SLACK + i * B * rows_p * pitch:SLACK + (i + 1) * B * rows_p * pitch].view(B, rows_p, pitch)
-            gpu = buf[:, :rows, T - ref.size(2):T].cpu()
-            diff = (gpu > 0) != (ref > 0)
-            return int(diff.sum()), (float(ref[diff].abs().max() / ref.abs().max()) if diff.any() else 0.0)
-        for i in range(n):
-            for key, nm, rp, r in (("Xe", "en_x%d" % i, eng.ReP, eng.Re), ("He", "en_h%d" % i, eng.DeP, eng.De)):
-                t_, m_ = cmp(key, i, rp, r, inter[nm])
-                ties, near = ties + t_, max(near, m_)
-        for key, nm in (("U", "de_skip"), ("R1", "de_conn")):
-            t_, m_ = cmp(key, 0, eng.SP, eng.Sd, inter[nm])
-            ties, near = ties + t_, max(near, m_)
-        if ties and near < 1e-5:
-            print("tie  case %3d  %d ReLU pre-activation(s) within %.1e of 0 (relative) with opposite signs; grad %.1e (%s) not judged"
-                  % (k, ties, near, worst, wname), flush=True)
-            return True
-    if not ok and e_p <= 1e-3 and not general:
-        # ReLU ties in the encoder (its ReLUs sit on x_i and h_i): a pre-activation within rounding of 0 with opposite
-        # signs on the two sides makes the gradients differ legitimately
-        import torch.nn.functional as F
-        from music_amd.engine import SLACK
-        eng = net._engine
-        ws = eng.workspace(B, idx.shape[1])
-        pitch, T = ws["pitch"], idx.shape[1]
-        with torch.no_grad():
-            xr = F.conv1d(x, params["en_causal_layer.weight"], params.get("en_causal_layer.bias"))
-            ties, off = 0, 1
-            for i, d in enumerate(dil):
-                hr = F.conv1d(F.relu(xr), params["en_dilation_layer_stack.%d.weight" % i], params.get("en_dilation_layer_stack.%d.bias" % i), dilation=d)
-                for nm, ref, rows, o in (("Xe", xr, cfg["en_residual_channel"], off), ("He", hr, cfg["en_dilation_channel"], off + d)):
-                    buf = ws[nm][SLACK + i * B * eng.CHe * pitch:SLACK + (i + 1) * B * eng.CHe * pitch].view(B, eng.CHe, pitch)
-                    gpu = buf[:, :rows, o:T].cpu()
-                    ties += int(((gpu > 0) != (ref > 0)).sum())
-                xn = F.conv1d(F.relu(hr), params["en_dense_layer_stack.%d.weight" % i], params.get("en_dense_layer_stack.%d.bias" % i))
-                xr = xn + xr[:, :, -xn.size(2):]
-                off += d
-        if ties:
-            print("tie  case %3d  %d encoder ReLU pre-activation(s) within rounding of 0 with opposite signs; grad %.1e (%s) not judged"
-                  % (k, ties, worst, wname), flush=True)
-            return True
+    tie_note = ""
+    if not ok and e_p <= 1e-3:
+        # A ReLU pre-activation within rounding of 0 with opposite signs on the two sides makes the float32 gradients differ legitimately
+        # (tests/test_gpu_fullsize.py, module docstring).  Such a case is JUDGED, not skipped: the gradient is evaluated
+        # again in float64 with the DEVICE's sign wherever the reference pre-activation lies within RELU_EPS of zero (relative to the
+        # tensor's max-abs) - a mask that differs anywhere else fails the case - and held to the same bar.
+        dev_pre = _dev_pre(net._engine, B, idx.shape[1], n)
+        relu, stats = _device_relu(dev_pre)
+        leaf64 = {kk: v.double().requires_grad_(True) for kk, v in params.items()}
+        try:
+            p64, _ = wo.autoencoder_forward(leaf64, dil, x.double(), cfg["en_pool_kernel_size"], [(w.double(), b.double()) for w, b in cond],
+                                            filter_width=fw, q=Q, relu=relu)
+        except AssertionError as e:
+            print("FAIL case %3d  %s" % (k, e), flush=True)
+            return False
+        l64 = torch.nn.functional.cross_entropy(p64, target)
+        g64 = torch.autograd.grad(l64, list(leaf64.values()), allow_unused=True)
+        gs = [torch.zeros_like(leaf64[nm]) if g is None else g for (nm, _), g in zip(net.named_parameters(), g64)]
+        floor = 1e-3 * max(g.abs().max().item() for g in gs)
+        worst, wname = 0.0, ""
+        for (name, p), g in zip(net.named_parameters(), gs):
+            err = (p.grad.cpu().double() - g).abs().max().item() / max(g.abs().max().item(), floor)
+            if err > worst:
+                worst, wname = err, name
+        ok = abs(loss.item() - l64.item()) < 1e-4 and worst <= 2e-3
+        tie_note = " [float64 oracle with the device's sign at %d of %d near-zero ReLU pre-activations]" % (stats["flips"], stats["near"])
     print("%s case %3d fw=%d Q=%d dil=%s en=%d/%d bw=%d pool=%d de=%d/%d S=%d bias=%d B=%d W=%d  p %.1e grad %.1e %s"
           % ("ok  " if ok else "FAIL", k, fw, Q, dil, cfg["en_residual_channel"], cfg["en_dilation_channel"], cfg["en_bottleneck_width"],
              cfg["en_pool_kernel_size"], cfg["de_residual_channel"], cfg["de_dilation_channel"], cfg["de_skip_channel"],
-             cfg["use_bias"], B, W, e_p, worst, "" if ok else wname), flush=True)
+             cfg["use_bias"], B, W, e_p, worst, ("" if ok else wname) + tie_note), flush=True)
     return ok
 
 
