@@ -15,8 +15,8 @@ BENCH = "c2"
 def run(var, kreps, extra_env):
     env = dict(os.environ)
     env.update(extra_env)
-    if ":" in var:                                   # "name:ENV=VAL[,ENV=VAL]": the shipped library under these switches
-        env.update(dict(kv.split("=", 1) for kv in var.split(":", 1)[1].split(",")))
+    if ":" in var:                                   # "name:ENV=VAL[;ENV=VAL]": the shipped library under these switches
+        env.update(dict(kv.split("=", 1) for kv in var.split(":", 1)[1].split(";")))
     elif var != "shipped":
         env["WAVENET_HIP_LIB"] = os.path.join(ROOT, "tools", "_var_%s.so" % var)
     if BENCH == "ae":                                # config 4: tools/ae_phases.py prints "X ms/step; phase ms, ..."
