@@ -96,6 +96,30 @@ def enc_stack_bytes(dil, r, d, b, t):
     return fwd * b, bwd * b
 
 
+def c4_traffic(df, db_, ef, eb_):
+    """PMC bytes per launch of config 4's four stack kernels (profiles/pmc_kernels.json, "c4:" entries) beside the algorithmic
+    bytes per launch; None when there is no summary for these kernel sources."""
+    path = os.path.join(ROOT, "profiles", "pmc_kernels.json")
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        return None
+    if pmc.get("_csrc_sha16") not in (None, csrc_sha()):
+        return None
+    n = len(CFG["dilations"])
+
+    def pick(*must):
+        hit = [(v["hbm_bytes_per_launch"], v.get("launches", 0)) for k, v in pmc.items()
+               if k.startswith("c4:") and isinstance(v, dict) and all(m in k for m in must)]
+        tot = sum(c for _, c in hit)
+        return (sum(b * c for b, c in hit) / tot) if tot else None
+    out = {"decoder_fwd": {"kernel": "resblock_fwd_nt_k<.., CND>", "hbm_bytes": pick("resblock_fwd_nt_k", "false, 8, true"), "algorithmic_bytes": df / n},
+           "decoder_bwd": {"kernel": "resblock_bwd_pq_k<.., COND, ..>", "hbm_bytes": pick("resblock_bwd_pq_k", ", true, true, false>"), "algorithmic_bytes": db_ / n},
+           "encoder_fwd": {"kernel": "resblock_fwd_nt_k<.., ENC>", "hbm_bytes": pick("resblock_fwd_nt_k", "true, 8, false"), "algorithmic_bytes": ef / n},
+           "encoder_bwd": {"kernel": "enc_bwd_pq_k", "hbm_bytes": pick("enc_bwd_pq_k"), "algorithmic_bytes": eb_ / n}}
+    return out if any(v["hbm_bytes"] for v in out.values()) else None
+
+
 def host_cores():
     """(logical CPUs, physical cores) of this host, from /proc/cpuinfo where it says."""
     logical = os.cpu_count() or 1
@@ -240,6 +264,10 @@ def sub_benchmarks(net, x, target):
                                  "frac_encoder_fwd": frac(ef, ph.get("enc_stack_fwd", float("nan"))),
                                  "frac_encoder_bwd": frac(eb_, ph.get("enc_stack_bwd", float("nan"))),
                                  "frac": frac(df + db_ + ef + eb_, st_ms), "stacks_ms": st_ms,
+                                 # HBM bytes per launch of the four stack kernels from the config-4 PMC passes (tools/gpu_check.sh prof ->
+                                 # profiles/pmc_kernels.json, entries "c4:<kernel>"; FETCH doubled per MI355X_MICROARCH.md), next to the
+                                 # algorithmic bytes per launch; null when no committed summary belongs to these kernel sources
+                                 "traffic_per_launch": c4_traffic(df, db_, ef, eb_),
                                  "note": "decoder stack: SURVEY 8(d) A_f / A_b; encoder stack: the same accounting (enc_stack_bytes); the "
                                          "conditioning (packed tables, bucket bytes, per-workgroup bucket sums) is not counted"}}
     del ae, aeng

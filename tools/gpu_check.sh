@@ -27,8 +27,14 @@ if [ "$STAGE" = "all" ] || [ "$STAGE" = "prof" ]; then
   echo "pmc fetch exit $?" | tee -a gpurun_out/summary.txt
   (cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_write -- python3 $REPO/bench.py --steps 2 --warmup 1 --settle 0 --no-cpu-baseline --no-extras > $REPO/gpurun_out/pmc_write.log 2>&1)
   echo "pmc write exit $?" | tee -a gpurun_out/summary.txt
+  # config 4's stack kernels (conditioned decoder blocks, encoder blocks): the same two passes over its step
+  rm -rf gpurun_out/pmc_fetch_ae gpurun_out/pmc_write_ae
+  (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_fetch_ae -- python3 $REPO/tools/ae_phases.py > $REPO/gpurun_out/pmc_fetch_ae.log 2>&1)
+  echo "pmc fetch (config 4) exit $?" | tee -a gpurun_out/summary.txt
+  (cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_write_ae -- python3 $REPO/tools/ae_phases.py > $REPO/gpurun_out/pmc_write_ae.log 2>&1)
+  echo "pmc write (config 4) exit $?" | tee -a gpurun_out/summary.txt
   python3 tools/prof_summary.py gpurun_out > gpurun_out/prof_summary.md 2>&1
   # keep only the small files (the raw traces can be large)
-  find gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write -type f -size +3M -delete 2>/dev/null
+  find gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_fetch_ae gpurun_out/pmc_write_ae -type f -size +3M -delete 2>/dev/null
   cat gpurun_out/prof_summary.md | head -60
 fi

@@ -67,6 +67,33 @@ def main():
                 "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
                 "launches_per_step": round(launches.get(k, 0) / n_steps, 3)}
             for k, v in pmc.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    # config 4 (tools/ae_phases.py under the same two PMC passes): entries "c4:<kernel>" with a "source" (bench.py's config-2 figures skip
+    # them; its extra.c4_autoencoder.roofline_stacks.traffic_per_launch reads them)
+    c4 = {}
+    for tag, counter in (("pmc_fetch_ae", "FETCH_SIZE"), ("pmc_write_ae", "WRITE_SIZE")):
+        files = find(os.path.join(root, tag), "*counter_collection.csv")
+        if not files:
+            continue
+        acc = defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(files[0])):
+            if r.get("Counter_Name") != counter:
+                continue
+            k = short(r["Kernel_Name"])
+            acc[k][0] += 1
+            acc[k][1] += float(r["Counter_Value"])
+        print("## config 4: %s per launch (KiB)\n" % counter)
+        print("| kernel | launches | avg %s (KiB) |" % counter)
+        print("|---|---|---|")
+        for k, (n, v) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:14]:
+            print("| %s | %d | %.1f |" % (k, n, v / n))
+            c4.setdefault(k, {})[counter] = v / n
+            c4[k]["launches"] = n
+        print()
+    for k, v in c4.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            allk["c4:" + k] = {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"],
+                               "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024, "launches": v["launches"],
+                               "source": "config 4 step (tools/ae_phases.py), separate --pmc passes"}
     if allk:
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from bench import csrc_sha
