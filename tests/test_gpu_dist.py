@@ -116,6 +116,32 @@ def test_bench_two_ranks_on_this_box(tmp_path):
         assert ht["torch_intra_op"] <= _lib.thread_budget(q, 2)
 
 
+def test_bench_eight_ranks_on_this_box():
+    """BASELINE configs[2]'s launch shape - `python bench.py --gpus 8` - end to end on whatever the box has: eight ranks, config 2's batch
+    (8 x 16000) EACH, lock step, one all-reduce per step, ONE line for the job.  With fewer than eight GPUs the ranks share devices over gloo
+    (the line says so: `backend`, `rccl_ranks` 0); what is checked is everything the first real 8-GPU run depends on besides RCCL itself:
+    the self-launch, the per-rank host-thread budget (quota / 8), eight per-rank times, weak-scaling bookkeeping (global batch 64)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")}
+    n_gpu = torch.cuda.device_count()
+    if n_gpu < 8:
+        env["WN_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--settle", "2"], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = r.stdout.strip().split("\n")
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "dp8"
+    assert out["backend"] == ("gloo" if n_gpu < 8 else "nccl") and out["rccl_ranks"] == (8 if out["backend"] == "nccl" else 0)
+    assert len(out["ms_per_step_ranks"]["all"]) == 8 and "allreduce" in out["phase_ms_per_step"]
+    assert abs(out["value"] - 8 * 8 * 16000 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    from music_amd import _lib
+    q = _lib.cpu_quota()
+    ht = out["host_threads"]
+    assert ht["local_world_size"] == 8 and ht["torch_intra_op"] <= _lib.thread_budget(q, 8)
+    assert ht["OMP_NUM_THREADS"] == str(min(8, _lib.thread_budget(q, 8)))
+
+
 def test_bench_under_launcher_prints_one_json_line_with_rccl():
     """The driver's launch form: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (here N = 1, the
     collective really is RCCL).  RCCL prints a version banner to fd 1 when the process group comes up: stdout must
