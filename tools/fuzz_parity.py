@@ -7,9 +7,9 @@ Every case draws dilations, channel counts (ragged: not multiples of 16), skip w
 length and bias at random, runs forward + CE + backward through the HIP path twice (nn.Module autograd
 surface and the fused training-step entry) and checks pre-softmax logits / probabilities (1e-3), loss
 (1e-4) and every gradient (2e-3 of its tensor's max) against oracle/wavenet_oracle.py.  A case whose forward
-agrees but where a post-processing ReLU sits on a pre-activation within rounding of 0 with opposite signs on the
-two sides is reported as a 'tie' (its gradients differ legitimately: the derivative jumps there).  Test
-infrastructure (it imports oracle/); not part of the product path."""
+agrees but whose float32 gradients differ is judged again against the float64 oracle with the device's sign at the
+post-processing ReLUs' near-zero pre-activations (the derivative jumps there; tests/test_gpu_fullsize.py) - no case is
+skipped.  Test infrastructure (it imports oracle/); not part of the product path."""
 import argparse
 import os
 import sys
@@ -21,6 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import wavenet_oracle as wo  # noqa: E402
 from tests.helpers import scrambled_input  # noqa: E402
+
+RELU_EPS = 2e-4          # tests/test_gpu_fullsize.py: the band around zero inside which a ReLU's subgradient follows the device
 
 
 def one_case(rng, k, only=None):
@@ -75,35 +77,46 @@ def one_case(rng, k, only=None):
         if only is not None and e > 2e-3:
             print("   %-40s rel err %.2e" % (name, e))
         worst2 = max(worst2, e)
-    ties = 0
-    if True:
-        # ReLU ties: a pre-activation within rounding of 0 may get different signs on the two sides; the
-        # gradient is then legitimately different (the derivative jumps), so report them
+    ok = (e_pre <= 1e-3 and e_p <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and abs(loss2.item() - l_ref.item()) < 1e-4
+          and worst <= 2e-3 and worst2 <= 2e-3)
+    tie_note = ""
+    if not ok and e_pre <= 1e-3 and e_p <= 1e-3:
+        # A post-processing ReLU on a pre-activation within rounding of 0 with opposite signs on the two sides makes the float32 gradients
+        # differ legitimately (the derivative jumps).  Such a case is JUDGED, not skipped: the gradient is evaluated again
+        # in float64 with the DEVICE's sign wherever the reference pre-activation lies within RELU_EPS of zero (relative to the tensor's
+        # max-abs) - a mask that differs anywhere else fails the case - and both entry points are held to the same 2e-3 bar.
         from music_amd.engine import SLACK
         ws = eng.workspace(B, T)
         pitch, lo = ws["pitch"], eng.rf - 1
-        u_ref = inter["skip_sum"].reshape(B, S, W).double()
-        h_ref = torch.einsum("hs,bsw->bhw", params["post_process_1.weight"][:, :, 0].double(), torch.relu(u_ref))
-        if "post_process_1.bias" in params:
-            h_ref = h_ref + params["post_process_1.bias"].double()[None, :, None]
-        for nm, ref in (("U", u_ref), ("H", h_ref)):
-            gpu = ws[nm][SLACK:SLACK + B * eng.SP * pitch].view(B, eng.SP, pitch)[:, :S, lo:T].cpu().double()
-            flips = ((gpu > 0) != (ref > 0))
-            ties += int(flips.sum())
-            if only is not None:
-              print("   %s: max |gpu - ref| %.2e, smallest |ref| %.2e, ReLU sign flips %d %s" %
-                  (nm, (gpu - ref).abs().max().item(), ref.abs().min().item(), int(flips.sum()),
-                   [(float(ref[tuple(i)]), float(gpu[tuple(i)])) for i in flips.nonzero()[:4]]))
-    ok = (e_pre <= 1e-3 and e_p <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and abs(loss2.item() - l_ref.item()) < 1e-4
-          and worst <= 2e-3 and worst2 <= 2e-3)
-    if not ok and ties and e_pre <= 1e-3 and e_p <= 1e-3:
-        # forward parity holds and a post-processing ReLU sits on a pre-activation within rounding of 0 with opposite
-        # signs on the two sides: the gradients then differ legitimately (not counted as a failure)
-        print("tie  case %3d  %d ReLU pre-activation(s) within rounding of 0 with opposite signs; grad %.1e / %.1e not judged"
-              % (k, ties, worst, worst2), flush=True)
-        return True
+        v = lambda buf: buf[SLACK:SLACK + B * eng.SP * pitch].view(B, eng.SP, pitch)[:, :S, lo:T].cpu()
+        dev_pre = {"skip_sum": v(ws["U"]), "post_process_1": v(ws["H"])}
+        stats = dict(near=0, flips=0)
+
+        def relu(name, t):
+            d = dev_pre[name]
+            assert d.shape == t.shape, (name, d.shape, t.shape)
+            near = t.detach().abs() < RELU_EPS * t.detach().abs().max().item()
+            ref_m, dev_m = t.detach() > 0, d > 0
+            assert not ((ref_m != dev_m) & ~near).any(), "ReLU mask of %s differs outside the tolerance band" % name
+            stats["near"] += int(near.sum())
+            stats["flips"] += int(((ref_m != dev_m) & near).sum())
+            return t * torch.where(near, dev_m, ref_m).to(t.dtype)
+        try:
+            l64, _, g64 = wo.loss_and_grads({kk: vv.double() for kk, vv in params.items()}, dil, x.double(), target, relu=relu)
+        except AssertionError as e:
+            print("FAIL case %3d  %s" % (k, e), flush=True)
+            return False
+        floor = 1e-3 * max(g.abs().max().item() for g in g64.values() if g is not None)
+        worst = worst2 = 0.0
+        for name, p in net.named_parameters():
+            g = g64[name] if g64[name] is not None else torch.zeros_like(p, dtype=torch.float64, device="cpu")
+            den = max(g.abs().max().item(), floor)
+            worst = max(worst, (p.grad.cpu().double() - g).abs().max().item() / den)
+            worst2 = max(worst2, (eng.param_view(name, grad=True).cpu().double() - g).abs().max().item() / den)
+        ok = abs(loss.item() - l64.item()) < 1e-4 and abs(loss2.item() - l64.item()) < 1e-4 and worst <= 2e-3 and worst2 <= 2e-3
+        tie_note = "  [float64 oracle with the device's sign at %d of %d near-zero ReLU pre-activations]" % (stats["flips"], stats["near"])
     print("%s case %3d  dil=%s R=%d D=%d S=%d B=%d W=%d bias=%d  pre %.1e p %.1e grad %.1e / %.1e"
-          % ("ok  " if ok else "FAIL", k, dil, R, D, S, B, W, bias, e_pre, e_p, worst, worst2), flush=True)
+          % ("ok  " if ok else "FAIL", k, dil, R, D, S, B, W, bias, e_pre, e_p, worst, worst2) + tie_note, flush=True)
     return ok
 
 
