@@ -121,3 +121,31 @@ def test_fast_generate_end_to_end_writes_wav(tmp_path, monkeypatch):
     np.testing.assert_array_equal(audio, want)
     if tab is not None:
         np.testing.assert_array_equal(audio, tab[codes.cpu().numpy().reshape(-1)].astype(np.float32))
+
+
+def test_reference_smoke_script_runs_on_the_module():
+    """music_amd/test.py = the reference's wavenet/test.py (:11-70): the SHIPPED model on dense random features of 256 x 32000 with
+    27907 targets per item, batch 2, Adam 1e-3, three "consumption" lines per epoch."""
+    import math
+    from music_amd import test as T
+    ds = T.simple_dataset()
+    assert len(ds) == 100
+    s0 = ds[3]
+    assert tuple(s0["feature"].shape) == (256, 32000) and s0["feature"].dtype == torch.float32
+    assert tuple(s0["target"].shape) == (27907,) and s0["target"].dtype == torch.int64 and 0 <= int(s0["target"].min()) and int(s0["target"].max()) < 256
+    lines = []
+    fr = T.test(epochs=2, items=5, num_workers=0, out=lines.append)          # 5 items: the last batch of an epoch holds one
+    assert len(lines) == 6
+    for k, name in enumerate(["Forward", "Backward", "Optimize"] * 2):
+        assert lines[k].startswith(name + " consumption is "), lines
+        assert 0.0 < float(lines[k].split(" ")[-1]) < 1.0
+    assert abs(sum(fr) - 1.0) < 1e-9 and fr[1] > fr[0] > fr[2]
+    net = T.test.last_net
+    assert net.receptive_field == 4094 and len(net.dilations) == 40
+    # random targets on an untrained model: the loss sits at ln 256, and every parameter has moved and is finite
+    assert abs(float(T.test.last_loss) - math.log(256.0)) < 0.05
+    torch.manual_seed(0)
+    from music_amd.model import wavenet
+    fresh = wavenet(**json.load(open(T._PARAMS)))
+    for (n, a), (_, b) in zip(net.state_dict().items(), fresh.state_dict().items()):
+        assert torch.isfinite(a).all() and not torch.equal(a.cpu(), b), n
