@@ -147,5 +147,6 @@ def test_reference_smoke_script_runs_on_the_module():
     torch.manual_seed(0)
     from music_amd.model import wavenet
     fresh = wavenet(**json.load(open(T._PARAMS)))
+    dead = "dilation_layer_stack.%d.weight" % (4 * 39 + 2)     # the last block's dense conv feeds nothing (model.py:124-129): zero gradient
     for (n, a), (_, b) in zip(net.state_dict().items(), fresh.state_dict().items()):
-        assert torch.isfinite(a).all() and not torch.equal(a.cpu(), b), n
+        assert torch.isfinite(a).all() and torch.equal(a.cpu(), b) == (n == dead), n
