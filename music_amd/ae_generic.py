@@ -143,14 +143,14 @@ class GenericAutoencoderEngine:
             return w2
 
         # encoder (model1.py:137-156)
-        conv_k("en_causal_layer.weight", "en_causal", Re, ReP, Q, QP, with_T=False)
+        conv_k("en_causal_layer.weight", "en_causal", Re, ReP, Q, QP)       # (its transpose: input_grad)
         for i in range(N):
             conv_k("en_dilation_layer_stack.%d.weight" % i, "en_dil%d" % i, De, DeP, Re, ReP)
             conv_1("en_dense_layer_stack.%d.weight" % i, "en_dense%d" % i, Re, ReP, De, DeP)
         conv_1("bottleneck_layer.weight", "bottleneck", Bw, BwP, Re, ReP)
         # decoder (model1.py:158-225): filter_gate rows are [gate (Dd) | filter (Dd)] in the reference (:188-190); the pack puts
         # filter first, gate second - the [f | g] order of wn_gate_fwd / wn_gate_bwd
-        conv_k("de_causal_layer.weight", "de_causal", Rd, RdP, Q, QP, with_T=False)
+        conv_k("de_causal_layer.weight", "de_causal", Rd, RdP, Q, QP)
         self.fg_rows = np.concatenate([DdP + np.arange(Dd), np.arange(Dd)])          # reference row r -> pack row
         for i in range(N):
             conv_k("de_dilation_layer_stack.%d.weight" % (3 * i), "de_fg%d" % i, 2 * Dd, 2 * DdP, Rd, RdP, row_map=self.fg_rows)
@@ -409,6 +409,25 @@ class GenericAutoencoderEngine:
         bw["desc"] = torch.tensor(desc, dtype=torch.int64, device=dev)
         ws["bwd"] = bw
         return bw
+
+    def input_grad(self, ws):
+        """Gradient of the last backward w.r.t. the module's INPUT (the encoder's and the decoder's causal conv, model1.py:137,158):
+        din[q][s] = sum over both layers, taps j and rows r of  Wc_j[r][q] dx0[r][s + (k-1-j)],  dx0 living on [k-1, T)."""
+        bw = ws["bwd"]
+        if bw is None:
+            raise RuntimeError("music_amd: input_grad() needs the backward of this forward to have run")
+        B, T, pitch, QP, Q = ws["B"], ws["T"], ws["pitch"], self.QP, self.Q
+        din = None
+        for tag, rp, key in (("de_causalT", self.RdP, "dXd"), ("en_causalT", self.ReP, "dXe")):
+            dx0 = ptr(bw[key][0], SLACK)
+            for p, pair in enumerate(self.pairs):
+                s0, s1, two = self._taps(pair, 1)
+                out = torch.empty(B, Q, T, dtype=torch.float32, device=self.device)
+                self._gemm(_lib.stream(), B, self.mode_b, ptr(self.pk_b, self.pk_b_off["%s_%d" % (tag, p)]), dx0, dx0 if two else None,
+                           rp * pitch, pitch, self.k - 1, T, -s0, -s1, rp // 32, rp // 32 if two else 0, QP // 16, Q, ptr(out), Q * T, T, 0,
+                           None, (None, 0, 0, 0), (None, 0, 0), 0, T, 0)
+                din = out if din is None else din.add_(out)
+        return din
 
     def backward(self, ws, dprobs):
         """Fills self.flat_grad from d loss / d probabilities (B*W, Q); dprobs None = bw["dO"] already holds d loss / d logits."""

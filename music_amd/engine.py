@@ -262,6 +262,11 @@ class WaveNetEngine:
         w[:R, Q:] = wc[:, :, 1]
         fwd.append(("causal", pack_index(w)))
         gp.append(("causal", CH, 2 * Q))
+        # 1b. its transpose for the gradient w.r.t. the INPUT (input_grad): rows Q, K = [tap1^T over dx0[t] | tap0^T over dx0[t+1]]
+        w = full(Q, 2 * CH)
+        w[:, :R] = wc[:, :, 1].T
+        w[:, CH:CH + R] = wc[:, :, 0].T
+        bwd.append(("causalT", pack_index(w)))
         for i in range(N):
             wf = sp.conv("dilation_layer_stack.%d.weight" % (4 * i))       # [D,R,2]
             wg = sp.conv("dilation_layer_stack.%d.weight" % (4 * i + 1))
@@ -887,6 +892,20 @@ class WaveNetEngine:
         else:
             call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
         self.mark("slab_reduce")
+
+    def input_grad(self, ws):
+        """Gradient of the last backward w.r.t. the module's INPUT (what autograd gives the reference when the input requires grad:
+        the causal nn.Conv1d's data gradient, wavenet/model.py:104):  din[q][s] = sum_r W[r][q][1] dx0[r][s] + W[r][q][0] dx0[r][s + 1],
+        dx0 living on [1, T).  One channel product on the first block's data gradient, which the backward leaves in its workspace."""
+        bw = ws["bwd"]
+        if bw is None:
+            raise RuntimeError("music_amd: input_grad() needs the backward of this forward to have run")
+        B, T, pitch, CH, Q = ws["B"], ws["T"], ws["pitch"], self.CH, self.Q
+        din = torch.empty(B, Q, T, dtype=torch.float32, device=self.device)
+        dx0 = ptr(bw["dX"][0], SLACK)
+        call("wn_chan_gemm", dx0, dx0, CH * pitch, pitch, 1, T, 0, 1, CH // 32, CH // 32, ptr(self.pk_b, self.pk_b_off["causalT"]), Q // 16, Q,
+             ptr(din), Q * T, T, 0, None, None, 0, 0, 0, None, 0, 0, 0, T, 0, B, self.mode_bwd, _lib.stream())
+        return din
 
     def backward(self, ws, dprobs):
         """dprobs: (B*W, Q) gradient w.r.t. the probabilities returned by forward()."""

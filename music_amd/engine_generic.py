@@ -131,6 +131,10 @@ class GenericWaveNetEngine:
                 w[:R, tl * QP:tl * QP + Q] = wc[:, :, j]
                 gmap_c[:, :, j] = o0 + np.arange(R)[:, None] * (len(tp) * QP) + tl * QP + np.arange(Q)[None, :]
             fwd.append(("causal_%d" % p, pack_index(w)))
+            wt = full(QP, len(tp) * RP)                      # W_j^T per tap: the gradient w.r.t. the input (input_grad)
+            for tl, j in enumerate(tp):
+                wt[:Q, tl * RP:tl * RP + R] = wc[:, :, j].T
+            bwd.append(("causalT_%d" % p, pack_index(wt)))
         put("causal_layer.weight", gmap_c)
         for i in range(N):
             wf = sp.conv("dilation_layer_stack.%d.weight" % (4 * i))        # [D][R][k]
@@ -449,6 +453,24 @@ class GenericWaveNetEngine:
         call("wn_reduce_slabs", ptr(bw["desc"]), bw["nops"], bw["vec"], ptr(bw["slab"]), ptr(self.gpack), st)
         call("wn_gather_grads", ptr(self.gpack), ptr(self.gidx), ptr(self.flat_grad), self.spec.total, st)
         self.mark("slab_reduce")
+
+    def input_grad(self, ws):
+        """Gradient of the last backward w.r.t. the module's INPUT (the causal nn.Conv1d's data gradient, wavenet/model.py:104):
+        din[q][s] = sum_j sum_r Wc_j[r][q] dx0[r][s + (k-1-j)], dx0 living on [k-1, T).  One channel product per tap pair."""
+        bw = ws["bwd"]
+        if bw is None:
+            raise RuntimeError("music_amd: input_grad() needs the backward of this forward to have run")
+        B, T, pitch, RP, QP, Q = ws["B"], ws["T"], ws["pitch"], self.RP, self.QP, self.Q
+        dx0 = ptr(bw["dX"][0], SLACK)
+        din = None
+        for p, pair in enumerate(self.pairs):
+            s0, s1, two = self._taps(pair, 1)
+            out = torch.empty(B, Q, T, dtype=torch.float32, device=self.device)
+            self._gemm(_lib.stream(), B, self.mode_bwd, ptr(self.pk_b, self.pk_b_off["causalT_%d" % p]), dx0, dx0 if two else None, RP * pitch,
+                       pitch, self.k - 1, T, -s0, -s1, RP // 32, RP // 32 if two else 0, QP // 16, Q, ptr(out), Q * T, T, 0, None,
+                       (None, 0, 0, 0), (None, 0, 0), 0, T, 0)
+            din = out if din is None else din.add_(out)
+        return din
 
     def backward(self, ws, dprobs):
         """dprobs: (B*W, Q) gradient w.r.t. the probabilities returned by forward()."""

@@ -65,7 +65,9 @@ class _WaveNetFunction(torch.autograd.Function):
             for s in shp:
                 n *= s
             grads.append(g[o:o + n].view(shp))
-        return (None, None, None) + tuple(grads)
+        # the input's own gradient, when autograd asks for it (the reference's causal nn.Conv1d provides it, wavenet/model.py:104)
+        din = eng.input_grad(ws) if ctx.needs_input_grad[2] else None
+        return (None, None, din) + tuple(grads)
 
 
 class wavenet(nn.Module):
@@ -101,6 +103,14 @@ class wavenet(nn.Module):
         self.fuse_loss = True
         self._last_hook = None
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle / torch.save(module): the engine (HIP streams, workspaces, ctypes plans) stays behind and is rebuilt
+        # on the copy's first forward; the parameters travel as tensors
+        state = self.__dict__.copy()
+        state["_engine"] = None
+        state["_last_hook"] = None
+        return state
+
     def calc_receptive_field(self):
         return (self.filter_width - 1) * (sum(self.dilations) + 1) + 1
 
@@ -122,6 +132,10 @@ class wavenet(nn.Module):
                 return eng
         if any(p.device != device for _, p in named):
             raise RuntimeError("music_amd.wavenet: parameters and input are on different devices")
+        if any(p.dtype != torch.float32 for _, p in named):
+            # (.half() / .double() modules: the kernels keep float32 parameters and form fp32-grade products from 16-bit pieces,
+            # DESIGN.md section 5; re-typing the module's parameters behind the caller's back would be worse than saying so)
+            raise TypeError("music_amd.wavenet: parameters must be float32 (got %s)" % next(p.dtype for _, p in named if p.dtype != torch.float32))
         # the specialised kernels cover filter_width 2, 256 quantisation channels and up to 64 residual / dilation channels
         # (everything the reference ships and BASELINE.json names); any other constructor argument takes the general plan
         fast = (self.filter_width == 2 and self.quantization_channels == 256 and

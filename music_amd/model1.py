@@ -177,6 +177,9 @@ class _AutoencoderEngine:
             w = full(ch, 2 * Q)
             w[:r, :Q], w[:r, Q:] = wc[:, :, 0], wc[:, :, 1]
             add(name, w)
+            wT = full(Q, 2 * ch)                          # its transpose for the gradient w.r.t. the input (input_grad): K = [tap1^T | tap0^T]
+            wT[:, :r], wT[:, ch:ch + r] = wc[:, :, 1].T, wc[:, :, 0].T
+            bwd.append((name + "T", pack_index(wT)))
             # the same weight as [tap][q][ch] for the forward from codes (wn_causal_fwd_codes), a gather map
             wt = np.full((2, Q, ch), -1, dtype=np.int64)
             wt[:, :, :r] = wc.transpose(2, 1, 0)
@@ -594,6 +597,22 @@ class _AutoencoderEngine:
     def backward_from_dlogits(self, ws):
         self.backward(ws, None)
 
+    def input_grad(self, ws):
+        """Gradient of the last backward w.r.t. the module's INPUT (model1.py:137,158: the input feeds the encoder's and the decoder's causal
+        conv): din[q][s] = sum over both layers of  W[r][q][1] dx0[r][s] + W[r][q][0] dx0[r][s + 1],  dx0 living on [1, T)."""
+        bw = ws["bwd"]
+        if bw is None:
+            raise RuntimeError("music_amd: input_grad() needs the backward of this forward to have run")
+        B, T, pitch, Q = ws["B"], ws["T"], ws["pitch"], self.Q
+        parts = []
+        for name, ch, key in (("de_causalT", self.CHd, "dXd"), ("en_causalT", self.CHe, "dXe")):
+            out = torch.empty(B, Q, T, dtype=torch.float32, device=self.device)
+            dx0 = ptr(bw[key][0], SLACK)
+            call("wn_chan_gemm", dx0, dx0, ch * pitch, pitch, 1, T, 0, 1, ch // 32, ch // 32, ptr(self.pkb, self.pkb_off[name]), Q // 16, Q,
+                 ptr(out), Q * T, T, 0, None, None, 0, 0, 0, None, 0, 0, 0, T, 0, B, self.mode_b, _lib.stream())
+            parts.append(out)
+        return parts[0].add_(parts[1])
+
     def backward(self, ws, dprobs):
         """Fills self.flat_grad from d loss / d probabilities (B*W, Q); dprobs None = bw["dO"] already holds
         d loss / d logits (loss_and_grad)."""
@@ -882,7 +901,8 @@ class _AutoencoderFunction(torch.autograd.Function):
         for name in eng.param_names:
             o, shp = eng.spec.off[name], eng.spec.shape[name]
             grads.append(g[o:o + int(np.prod(shp))].view(shp))
-        return (None, None, None, None) + tuple(grads)
+        din = eng.input_grad(ws) if ctx.needs_input_grad[2] else None       # (the reference's two causal nn.Conv1d give it, model1.py:137,158)
+        return (None, None, din, None) + tuple(grads)
 
 
 class wavenet_autoencoder(nn.Module):
@@ -929,6 +949,14 @@ class wavenet_autoencoder(nn.Module):
         self.fuse_loss = True
         self._last_hook = None
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle / torch.save(module): the engine (HIP streams, workspaces, ctypes plans) stays behind and is rebuilt
+        # on the copy's first forward; the parameters travel as tensors
+        state = self.__dict__.copy()
+        state["_engine"] = None
+        state["_last_hook"] = None
+        return state
+
     def _calc_receptive_field(self):
         return (self.filter_width - 1) * (sum(self.dilations) + 1) + 1
 
@@ -960,6 +988,9 @@ class wavenet_autoencoder(nn.Module):
         if eng is None or eng.device != device or p0.data_ptr() != eng.flat.data_ptr():
             if any(p.device != device for p in self.parameters()):
                 raise RuntimeError("music_amd.wavenet_autoencoder: parameters and input are on different devices")
+            if any(p.dtype != torch.float32 for p in self.parameters()):
+                raise TypeError("music_amd.wavenet_autoencoder: parameters must be float32 (got %s)"
+                                % next(p.dtype for p in self.parameters() if p.dtype != torch.float32))
             # the specialised kernels cover filter_width 2, 256 quantisation channels and up to 64 residual / dilation channels on
             # both sides (what the reference ships and BASELINE.json names); any other constructor argument takes the general plan
             fast = (self.filter_width == 2 and self.quantization_channel == 256 and

@@ -170,8 +170,8 @@ def test_optimizer_state_survives_a_restart(tmp_path, monkeypatch):
 
 def test_generic_engine_index_maps_cover_every_parameter_once():
     """music_amd/engine_generic.py (any filter_width / channel counts): every weight appears exactly once in the forward
-    packs and (except the causal layer, which has no data gradient) once in the backward packs, at the (row, k) its
-    product expects; the gradient gather map is a bijection into the gradient matrices."""
+    packs and once in the backward packs (the causal layer's transpose is there for the gradient w.r.t. the input), at the
+    (row, k) its product expects; the gradient gather map is a bijection into the gradient matrices."""
     import numpy as np
     import torch
     from music_amd.engine import pack_positions
@@ -184,8 +184,17 @@ def test_generic_engine_index_maps_cover_every_parameter_once():
     assert len(seen) == n_w and len(np.unique(seen)) == n_w
     bidx = eng.pk_b_idx.numpy()
     seen_b = bidx[bidx >= 0]
-    n_causal = int(np.prod(eng.spec.shape["causal_layer.weight"]))
-    assert len(seen_b) == n_w - n_causal and len(np.unique(seen_b)) == n_w - n_causal
+    assert len(seen_b) == n_w and len(np.unique(seen_b)) == n_w
+    # the causal layer's transposed pack, element by element: rows = input channel q, K = [tap 0 rows r | tap 1 rows r] of pair 0
+    o = eng.pk_b_off["causalT_0"] // 2
+    mt, ks = eng.QP // 16, 2 * eng.RP // 32
+    row, k = pack_positions(mt, ks, False)
+    idx = bidx[o:o + mt * ks * 512]
+    wc = eng.spec.conv("causal_layer.weight")            # [R][Q][k] of flat offsets
+    for r, kk, v in zip(row[::53], k[::53], idx[::53]):
+        tap, ch = divmod(int(kk), eng.RP)
+        want = wc[ch, int(r), tap] if (int(r) < eng.Q and ch < eng.R) else -1
+        assert v == want, (r, kk, v, want)
     g = eng.gidx.numpy()
     assert len(np.unique(g)) == eng.spec.total and g.min() >= 0 and g.max() < eng.gpack.numel()
     # one pack checked element by element: fg of layer 1, tap pair 0 = taps (0, 1): rows [f | g] x K = [tap 0 ch | tap 1 ch]
