@@ -170,3 +170,78 @@ def test_input_gradient_of_the_autoencoder_vs_oracle(plan):
     err = (xi.grad.cpu() - g_ref).abs().max().item() / g_ref.abs().max().item()
     print("autoencoder input gradient (%s): relative error %.2e" % (plan, err))
     assert err <= GRAD_RTOL
+
+
+def test_autograd_and_module_usage_patterns():
+    """Accumulating backward passes, retain_graph, torch.autograd.grad, scaled losses, parameter / forward hooks, an optimizer that was
+    built before the module moved to the device, re-initialisation and load_state_dict after the engine exists, a side stream, frozen
+    models - each against the module's own plain gradient (tools/surface_probe2.py prints the same as a table)."""
+    from music_amd.model import wavenet
+    cfg = dict(WN, use_bias=True)
+    net = _wavenet(cfg)
+    opt_before = torch.optim.SGD(net.parameters(), lr=0.1)
+    net = net.cuda()
+    T = net.receptive_field + 300
+    x = _dense(2, T, 1).cuda()
+    W = T - net.receptive_field + 1
+    tgt = torch.randint(0, 256, (2 * W,), generator=torch.Generator().manual_seed(2)).cuda()
+    ce = nn.CrossEntropyLoss()
+
+    def grads():
+        return torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+    net.zero_grad()
+    ce(net(x), tgt).backward()
+    g1 = grads()
+    net.zero_grad()
+    ce(net(x), tgt).backward()
+    ce(net(x), tgt).backward()
+    assert torch.equal(grads(), 2 * g1)
+    net.zero_grad()
+    loss = ce(net(x), tgt)
+    loss.backward(retain_graph=True)
+    loss.backward()
+    assert torch.equal(grads(), 2 * g1)
+    gs = torch.autograd.grad(ce(net(x), tgt), list(net.parameters()))
+    assert torch.equal(torch.cat([a.reshape(-1) for a in gs]), g1)
+    net.zero_grad()
+    (ce(net(x), tgt) * 0.5).backward()
+    assert torch.equal(grads(), 0.5 * g1)
+    seen = []
+    h = net.causal_layer.weight.register_hook(lambda gr: seen.append(gr.clone()) or gr * 2)
+    net.zero_grad()
+    ce(net(x), tgt).backward()
+    h.remove()
+    assert torch.equal(net.causal_layer.weight.grad, 2 * seen[0])
+    shapes = []
+    h = net.register_forward_hook(lambda m, i, o: shapes.append(tuple(o.shape)))
+    ref = net(x).detach().clone()
+    h.remove()
+    assert shapes == [(2 * W, 256)]
+    # the optimizer holds the Parameter objects; the engine re-points their storage, not the objects
+    net.zero_grad()
+    ce(net(x), tgt).backward()
+    w0 = net.post_process_2.weight.detach().clone()
+    opt_before.step()
+    assert not torch.equal(net.post_process_2.weight.detach(), w0) and not torch.equal(net(x).detach(), ref)
+    # in-place re-initialisation and load_state_dict land in the flat buffer the kernels read
+    with torch.no_grad():
+        net.apply(lambda m: nn.init.normal_(m.weight, std=0.05) if isinstance(m, nn.Conv1d) else None)
+    n2 = wavenet(**cfg)
+    n2.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+    assert torch.equal(n2.cuda()(x).detach(), net(x).detach())
+    sd = {k: torch.randn_like(v) * 0.05 for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    n2 = wavenet(**cfg)
+    n2.load_state_dict(sd)
+    ref = net(x).detach().clone()
+    assert torch.equal(n2.cuda()(x).detach(), ref)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        o = net(x)
+        ce(o, tgt).backward()
+    torch.cuda.current_stream().wait_stream(s)
+    assert torch.equal(o.detach(), ref)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    assert not net(x).requires_grad
