@@ -10,6 +10,9 @@
  *   - plain C types only: device pointers, sizes, a stream handle (hipStream_t passed as void*);
  *   - returns 0 on success, a negative code on error (wn_last_error() gives the text); no C++
  *     exceptions cross the boundary;
+ *   - a call that has work to do checks its REQUIRED pointers first: a NULL one returns -4 and wn_last_error() names the
+ *     function and the argument, nothing is launched (pointers documented as optional may be NULL; a call with no work -
+ *     zero clips / rows / columns / elements - returns 0 whatever its pointers are);
  *   - no allocation, no synchronisation, no retained pointers: all workspace is the caller's,
  *     every call only enqueues work on `stream` (safe under hipGraph stream capture);
  *   - re-entrant across devices/streams and threads: no global mutable state; the last-error text is

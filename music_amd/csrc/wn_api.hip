@@ -22,6 +22,25 @@ int wn_set_error_msg(int code, const char* msg) {
     return code;
 }
 
+// Required pointers of a call that has work to do: a NULL one is reported (-4, the argument's name in wn_last_error) before anything is
+// launched - the alternative is a memory fault on the device, which takes the caller's process with it.
+static int wn_null_error(const char* fn, const char* names, int which) {
+    const char* b = names;
+    for (int i = 0; i < which && *b; ++b)
+        if (*b == ',') ++i;
+    while (*b == ' ') ++b;
+    int len = 0;
+    while (b[len] && b[len] != ',') ++len;
+    snprintf(g_err, sizeof(g_err), "%s: argument '%.*s' must not be NULL", fn, len, b);
+    return -4;
+}
+#define WN_REQUIRE(fn, ...)                                                          \
+    do {                                                                             \
+        const void* wn_req_[] = {__VA_ARGS__};                                       \
+        for (int wn_i_ = 0; wn_i_ < (int)(sizeof(wn_req_) / sizeof(wn_req_[0])); ++wn_i_) \
+            if (!wn_req_[wn_i_]) return wn_null_error(fn, #__VA_ARGS__, wn_i_);      \
+    } while (0)
+
 static_assert(WN_F16X3 == WN_MODE_F16X3 && WN_F16X1 == WN_MODE_F16X1 && WN_BF16X3 == WN_MODE_BF16X3 &&
               WN_BF16X1 == WN_MODE_BF16X1, "mode enums out of sync");
 static_assert(WN_CE_NUM_PARTIALS == WN_CE_PARTIALS, "partials out of sync");
@@ -33,6 +52,7 @@ const char* wn_last_error(void) { return g_err; }
 
 int wn_pack_weights(const float* flat, const int32_t* idx, uint16_t* out, int n, int mode, wn_stream_t stream) {
     if (n % 512 != 0) return wn_set_error_msg(-4, "wn_pack_weights: n must be a multiple of 512");
+    if (n > 0) WN_REQUIRE("wn_pack_weights", flat, idx, out);
     return wn_launch_pack(flat, idx, out, n, wn_mode_is_bf16(mode), wn_mode_ns(mode), (hipStream_t)stream);
 }
 
@@ -43,6 +63,7 @@ int wn_chan_gemm(const float* in0, const float* in1, int64_t in_bstride, int in_
                  const float* mask, int64_t mask_bstride, int mask_pitch,
                  int t_lo, int t_hi, int relu_in, int batch, int mode, wn_stream_t stream) {
     if (ks0 <= 0 || (ks1 > 0 && !in1) || mt <= 0) return wn_set_error_msg(-4, "wn_chan_gemm: bad shape");
+    if (batch > 0 && t_hi > t_lo) WN_REQUIRE("wn_chan_gemm", in0, wpack, out);
     WnGemmArgs a;
     memset(&a, 0, sizeof(a));
     a.in0 = in0; a.in1 = ks1 > 0 ? in1 : nullptr; a.in_bstride = in_bstride; a.in_pitch = in_pitch; a.in_lo = in_lo; a.in_hi = in_hi;
@@ -59,6 +80,7 @@ int wn_enc_resblock_fwd(const float* x_in, float* x_out, float* h_out, int64_t x
                         int n_d, int ch, int d, int t_lo, int t_hi, int batch, int mode, wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_enc_resblock_fwd: pitch must be a multiple of 4");
     if (t_lo < d + 1) return wn_set_error_msg(-4, "wn_enc_resblock_fwd: t_lo must be >= d + 1");
+    if (batch > 0 && t_hi > t_lo) WN_REQUIRE("wn_enc_resblock_fwd", x_in, x_out, h_out, wdil, wd);
     WnResArgs a;
     memset(&a, 0, sizeof(a));
     a.x_in = x_in; a.x_out = x_out; a.z_out = h_out; a.x_bstride = x_bstride; a.z_bstride = h_bstride; a.pitch = pitch;
@@ -78,6 +100,10 @@ int wn_resblock_fwd(const float* x_in, float* x_out, float* z_out, int64_t x_bst
     if (cond && (cond_le <= 0 || (cond_mode == 1 && cond_q <= 0) || (cond_mode != 1 && cond_mode != 2)))
         return wn_set_error_msg(-4, "wn_resblock_fwd: bad conditioning arguments");
     if (t_lo < d + 1) return wn_set_error_msg(-4, "wn_resblock_fwd: t_lo must be >= d + 1");
+    if (batch > 0 && t_hi > t_lo) {
+        WN_REQUIRE("wn_resblock_fwd", x_in, wfg, wd, z_out);
+        if (write_x) WN_REQUIRE("wn_resblock_fwd", x_out);
+    }
     WnResArgs a;
     memset(&a, 0, sizeof(a));
     a.x_in = x_in; a.x_out = x_out; a.z_out = z_out; a.x_bstride = x_bstride; a.z_bstride = z_bstride; a.pitch = pitch;
@@ -98,6 +124,10 @@ int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* 
                     const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode, int cond_le, int cond_q,
                     int batch, int mode_fwd, int mode_bwd, wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_resblock_bwd: pitch must be a multiple of 4");
+    if (batch > 0 && t_hi > t_lo) {
+        WN_REQUIRE("wn_resblock_bwd", x_in, dz, dfg, wfg);
+        if (dy) WN_REQUIRE("wn_resblock_bwd", wdT);
+    }
     WnResBwdArgs a;
     memset(&a, 0, sizeof(a));
     a.x_in = x_in; a.dy = dy; a.dz = dz; a.dfg = dfg; a.z = z;
@@ -114,6 +144,7 @@ int wn_wgrad(const float* a_, int64_t a_bstride, int a_pitch, int a_shift, int a
              int b_shift1, int b_cols, int nt_per_tap, int mt, int relu_b, float* c, int ldc,
              int64_t c_slab_stride, int t_lo, int t_hi, int chunk, int batch, int mode, wn_stream_t stream) {
     if (c_slab_stride < (int64_t)mt * 16 * ldc) return wn_set_error_msg(-4, "wn_wgrad: slab stride smaller than C");
+    if (batch > 0 && t_hi > t_lo) WN_REQUIRE("wn_wgrad", a_, b0, c);
     WnWgradArgs a;
     memset(&a, 0, sizeof(a));
     a.a = a_; a.a_bstride = a_bstride; a.a_pitch = a_pitch; a.a_shift = a_shift; a.a_cols = a_cols;
@@ -126,36 +157,44 @@ int wn_wgrad(const float* a_, int64_t a_bstride, int a_pitch, int a_shift, int a
 int wn_wgrad_slabs(int t_lo, int t_hi, int chunk, int batch) { return wn_wgrad_num_slabs(t_lo, t_hi, chunk, batch); }
 
 int wn_reduce_slabs(const int64_t* desc, int n_ops, int64_t total_vec, const float* slab, float* out, wn_stream_t stream) {
+    if (n_ops > 0 && total_vec > 0) WN_REQUIRE("wn_reduce_slabs", desc, slab, out);
     return wn_launch_reduce_slabs(reinterpret_cast<const long*>(desc), n_ops, total_vec, slab, out, (hipStream_t)stream);
 }
 
 int wn_bias_grad(const float* a, int64_t a_bstride, int a_pitch, int a_shift, int rows, int t_lo,
                  int t_hi, int batch, float* out, wn_stream_t stream) {
+    if (batch > 0 && t_hi > t_lo && rows > 0) WN_REQUIRE("wn_bias_grad", a, out);
     return wn_launch_bias_grad(a, a_bstride, a_pitch, a_shift, rows, t_lo, t_hi, batch, out, (hipStream_t)stream);
 }
 
 int wn_chunk_softmax256_fwd(const float* x, float* y, int64_t nrows, wn_stream_t stream) {
+    if (nrows > 0) WN_REQUIRE("wn_chunk_softmax256_fwd", x, y);
     return wn_launch_softmax_fwd(x, y, nrows, (hipStream_t)stream);
 }
 int wn_chunk_softmax256_bwd(const float* y, const float* dy, float* dx, int64_t nrows, wn_stream_t stream) {
+    if (nrows > 0) WN_REQUIRE("wn_chunk_softmax256_bwd", y, dy, dx);
     return wn_launch_softmax_bwd(y, dy, dx, nrows, (hipStream_t)stream);
 }
 int wn_chunk_softmax256_ce(const float* x, const int64_t* target, float* probs, float* dx,
                            float* loss_part, int64_t nrows, float inv_n, wn_stream_t stream) {
+    if (nrows > 0) WN_REQUIRE("wn_chunk_softmax256_ce", x, target);
     return wn_launch_softmax_ce(x, target, probs, dx, loss_part, nrows, inv_n, (hipStream_t)stream);
 }
 int wn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, float bias_corr1, float bias_corr2, float gscale, wn_stream_t stream) {
+    if (n > 0) WN_REQUIRE("wn_adam_flat", p, g, m, v);
     return wn_launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, bias_corr1, bias_corr2, gscale, (hipStream_t)stream);
 }
 int wn_sgd_flat(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum, float gscale, int first_step,
                 wn_stream_t stream) {
     if (momentum != 0.f && !momentum_buf) return wn_set_error_msg(-4, "wn_sgd_flat: momentum needs its buffer");
+    if (n > 0) WN_REQUIRE("wn_sgd_flat", p, g);
     return wn_launch_sgd(p, g, momentum_buf, n, lr, momentum, gscale, first_step, (hipStream_t)stream);
 }
 int wn_rmsprop_flat(float* p, const float* g, float* square_avg, float* momentum_buf, int64_t n, float lr, float alpha, float eps,
                     float momentum, float gscale, wn_stream_t stream) {
     if (!square_avg || (momentum > 0.f && !momentum_buf)) return wn_set_error_msg(-4, "wn_rmsprop_flat: missing state buffer");
+    if (n > 0) WN_REQUIRE("wn_rmsprop_flat", p, g);
     return wn_launch_rmsprop(p, g, square_avg, momentum_buf, n, lr, alpha, eps, momentum, gscale, (hipStream_t)stream);
 }
 int wn_coll_available(void) { return wn_coll_loaded(); }
@@ -166,6 +205,7 @@ int wn_allreduce_flat(void* comm, float* buf, int64_t n, wn_stream_t stream) {
     return wn_coll_allreduce_flat(comm, buf, n, (hipStream_t)stream);
 }
 int wn_gather_grads(const float* packed, const int32_t* idx, float* flat_grad, int n, wn_stream_t stream) {
+    if (n > 0) WN_REQUIRE("wn_gather_grads", packed, idx, flat_grad);
     return wn_launch_gather_grads(packed, idx, flat_grad, n, (hipStream_t)stream);
 }
 int wn_gather_grads2(const float* packed, const int32_t* idx, const int32_t* idx2, float* flat_grad, int n, wn_stream_t stream) {
@@ -173,12 +213,15 @@ int wn_gather_grads2(const float* packed, const int32_t* idx, const int32_t* idx
     return wn_launch_gather_grads2(packed, idx, idx2, flat_grad, n, (hipStream_t)stream);
 }
 int wn_onehot(const int32_t* codes, float* out, int batch, int q, int t, int scrambled, wn_stream_t stream) {
+    if (batch > 0 && q > 0 && t > 0) WN_REQUIRE("wn_onehot", codes, out);
     return wn_launch_onehot(codes, out, batch, q, t, scrambled, (hipStream_t)stream);
 }
 int wn_mulaw_encode_tbl(const float* audio, const float* thresholds, uint8_t* codes, int64_t n, wn_stream_t stream) {
+    if (n > 0) WN_REQUIRE("wn_mulaw_encode_tbl", audio, thresholds, codes);
     return wn_launch_mulaw_encode(audio, thresholds, codes, n, (hipStream_t)stream);
 }
 int wn_mulaw_decode_lut(const uint8_t* codes, const float* table, float* audio, int64_t n, wn_stream_t stream) {
+    if (n > 0) WN_REQUIRE("wn_mulaw_decode_lut", codes, table, audio);
     return wn_launch_mulaw_decode(codes, table, audio, n, (hipStream_t)stream);
 }
 int wn_mulaw_encode_q(const float* audio, const float* thresholds, int q, int32_t* codes, int64_t n, wn_stream_t stream) {
@@ -200,6 +243,10 @@ int wn_resblock_bwd_ms(const float* x_in, const float* dy, const float* dz, floa
     if (cond && (cond_le <= 0 || (cond_mode == 1 && cond_q <= 0) || (cond_mode != 1 && cond_mode != 2)))
         return wn_set_error_msg(-4, "wn_resblock_bwd_ms: bad conditioning arguments");
     if (!slab_fg) return wn_set_error_msg(-4, "wn_resblock_bwd_ms: slab_fg is required");
+    if (batch > 0 && t_hi > t_lo) {
+        WN_REQUIRE("wn_resblock_bwd_ms", x_in, dz, dfg, wfg);
+        if (dy) WN_REQUIRE("wn_resblock_bwd_ms", wdT, slab_d);
+    }
     WnResMsArgs a;
     memset(&a, 0, sizeof(a));
     a.x_in = x_in; a.dy = dy; a.dz = dz; a.dfg = dfg; a.x_bstride = x_bstride; a.dz_bstride = dz_bstride;
@@ -307,6 +354,7 @@ int wn_split16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, int is_bf1
 }
 int wn_shift_add(const float* p, const float* q, float* out, int64_t bstride, int pitch, int rows, int dn, int p_lo,
                  int t_lo, int t_hi, int batch, wn_stream_t stream) {
+    if (batch > 0 && rows > 0 && t_hi > t_lo) WN_REQUIRE("wn_shift_add", p, q, out);
     return wn_launch_shift_add(p, q, out, bstride, pitch, rows, dn, p_lo, t_lo, t_hi, batch, (hipStream_t)stream);
 }
 
@@ -326,6 +374,7 @@ int wn_causal_fwd_codes(const int32_t* codes, int scrambled, const float* wt, co
 
 int wn_cond_grad(const float* in, int64_t in_bstride, int in_pitch, int rows, int t_lo, int t_hi, int mode, int le,
                  int q, float* out, int64_t out_bstride, int out_pitch, int batch, wn_stream_t stream) {
+    if (batch > 0 && rows > 0 && t_hi > t_lo) WN_REQUIRE("wn_cond_grad", in, out);
     return wn_launch_cond_grad(in, in_bstride, in_pitch, rows, t_lo, t_hi, mode, le, q, out, out_bstride, out_pitch, batch,
                                (hipStream_t)stream);
 }
@@ -338,12 +387,14 @@ int wn_cond_expand(const float* tab, int64_t tab_bstride, int tab_pitch, int row
 }
 int wn_avgpool_bwd(const float* denc, int64_t denc_bstride, int denc_pitch, int t0, int pool, int n_out, int rows,
                    float* out, int64_t out_bstride, int out_pitch, int t_hi, int batch, wn_stream_t stream) {
+    if (batch > 0 && rows > 0) WN_REQUIRE("wn_avgpool_bwd", denc, out);
     return wn_launch_avgpool_bwd(denc, denc_bstride, denc_pitch, t0, pool, n_out, rows, out, out_bstride, out_pitch, t_hi,
                                  batch, (hipStream_t)stream);
 }
 
 int wn_avgpool(const float* in, int64_t in_bstride, int in_pitch, int t0, int pool, int n_out, int rows,
                float* out, int64_t out_bstride, int out_pitch, int batch, wn_stream_t stream) {
+    if (batch > 0 && rows > 0 && n_out > 0) WN_REQUIRE("wn_avgpool", in, out);
     return wn_launch_avgpool(in, in_bstride, in_pitch, t0, pool, n_out, rows, out, out_bstride, out_pitch, batch,
                              (hipStream_t)stream);
 }
@@ -429,6 +480,8 @@ static int decode_impl(int n_layers, int R, int D, int S, int Q, const int32_t* 
                        int64_t pk_skip, int64_t pk_p1, int64_t pk_p2, wn_stream_t stream) {
     if (n_utt <= 0) return 0;
     if (n_layers > WN_DEC_MAX_LAYERS || n_layers <= 0) return wn_set_error_msg(-4, "wn_decode: 1..64 layers supported");
+    WN_REQUIRE("wn_decode", dilations_host, q_off_host);              // (host arrays, read right here)
+    if (n_steps > 0) WN_REQUIRE("wn_decode", queues, w_causal, w_layers, w_p1, w_p2, sync);
     WnDecodeArgs a;
     memset(&a, 0, sizeof(a));
     a.n_layers = n_layers; a.R = R; a.D = D; a.S = S; a.Q = Q;

@@ -148,3 +148,60 @@ def test_collective_entry_points_check_their_arguments_without_a_device():
     assert lib.wn_comm_create(2, 2, b"\0" * 128, ctypes.byref(comm)) == -4
     assert lib.wn_comm_destroy(None) == 0
 
+
+
+def test_null_required_pointers_are_reported_not_dereferenced():
+    """Every compute entry point checks its REQUIRED pointers before anything is launched (a NULL that reaches a kernel is a memory
+    fault on the device and takes the caller's process with it): status -4, wn_last_error names the function and the argument.  A call
+    with no work (zero rows / columns / clips) may carry NULLs and returns 0.  Runs without a device: the checks come first."""
+    import ctypes
+    from music_amd import _lib
+    lib = _lib.load()
+    P = 1 << 20            # "some non-NULL address": never dereferenced, every case below fails (or is empty) before a launch
+
+    def bad(name, arg, *args):
+        rc = getattr(lib, name)(*args)
+        msg = lib.wn_last_error().decode()
+        assert rc == -4 and name.replace("_batch_pk", "").replace("_batch", "") in msg and ("'%s'" % arg) in msg, (name, rc, msg)
+
+    bad("wn_pack_weights", "idx", P, None, P, 512, 0, None)
+    assert lib.wn_pack_weights(None, None, None, 0, 0, None) == 0
+    #            in0 in1 bs pitch lo hi s0 s1 ks0 ks1 wpack mt mv out obs op osh bias resid rbs rp rlo mask mbs mp t_lo t_hi relu batch mode
+    gemm = [P, None, 64, 64, 0, 64, 0, 0, 1, 0, P, 1, 16, P, 64, 64, 0, None, None, 0, 0, 0, None, 0, 0, 0, 64, 0, 1, 0, None]
+    for i, arg in ((0, "in0"), (10, "wpack"), (13, "out")):
+        a = list(gemm)
+        a[i] = None
+        bad("wn_chan_gemm", arg, *a)
+    a = list(gemm)
+    a[0], a[28] = None, 0                                    # batch 0: nothing to do
+    assert lib.wn_chan_gemm(*a) == 0
+    #      x_in x_out z_out xbs zbs pitch wfg wd bf bg bd n_f n_d ch d t_lo t_hi z_lo write_x cond cbs cp cm cle cq cpk cpbs cidx zhalf batch mode
+    fwd = [P, P, P, 64, 64, 64, P, P, None, None, None, 32, 32, 32, 1, 2, 66, 2, 1, None, 0, 0, 0, 0, 0, None, 0, None, 0, 1, 0, None]
+    for i, arg in ((0, "x_in"), (1, "x_out"), (2, "z_out"), (6, "wfg"), (7, "wd")):
+        a = list(fwd)
+        a[i] = None
+        bad("wn_resblock_fwd", arg, *a)
+    bad("wn_wgrad", "c", P, 64, 64, 0, 64, P, None, 64, 64, 0, 0, 64, 2, 2, 0, None, 32, 1 << 20, 0, 64, 64, 1, 2, None)
+    bad("wn_reduce_slabs", "slab", P, 1, 4, None, P, None)
+    assert lib.wn_reduce_slabs(None, 0, 0, None, None, None) == 0
+    bad("wn_bias_grad", "out", P, 64, 64, 0, 4, 0, 64, 1, None, None)
+    bad("wn_chunk_softmax256_fwd", "y", P, None, 4, None)
+    bad("wn_chunk_softmax256_bwd", "dy", P, None, P, 4, None)
+    bad("wn_chunk_softmax256_ce", "target", P, None, None, None, None, 4, 0.25, None)
+    assert lib.wn_chunk_softmax256_ce(None, None, None, None, None, 0, 1.0, None) == 0
+    bad("wn_adam_flat", "v", P, P, P, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.1, 0.001, 1.0, None)
+    bad("wn_sgd_flat", "g", P, None, None, 8, 0.1, 0.0, 1.0, 1, None)
+    bad("wn_rmsprop_flat", "p", None, P, P, None, 8, 0.1, 0.99, 1e-8, 0.0, 1.0, None)
+    bad("wn_gather_grads", "flat_grad", P, P, None, 8, None)
+    bad("wn_onehot", "codes", None, P, 1, 256, 8, 0, None)
+    bad("wn_mulaw_encode_tbl", "thresholds", P, None, P, 8, None)
+    bad("wn_mulaw_decode_lut", "audio", P, P, None, 8, None)
+    bad("wn_shift_add", "q", P, None, P, 64, 64, 4, 1, 2, 1, 64, 1, None)
+    dil = (ctypes.c_int32 * 2)(1, 2)
+    qoff = (ctypes.c_int64 * 2)(0, 64)
+    dec = [2, 32, 32, 64, 256, ctypes.cast(dil, ctypes.c_void_p), ctypes.cast(qoff, ctypes.c_void_p), P, P, None, P, 0, None, P, None, P, None,
+           None, None, None, None, None, P, None, 0, 4, 1, P, None]
+    for i, arg in ((5, "dilations_host"), (7, "queues"), (10, "w_layers"), (27, "sync")):
+        a = list(dec)
+        a[i] = None
+        bad("wn_decode", arg, *a)
