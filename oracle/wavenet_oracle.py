@@ -93,12 +93,17 @@ def ce_on_probs(probs, target):
     return F.cross_entropy(probs, target.view(-1))
 
 
-def loss_and_grads(params, dilations, wave_sample, target, **kw):
+def loss_and_grads(params, dilations, wave_sample, target, input_grad=False, **kw):
     """One forward + CE + backward (wavenet/train.py:178-181) on detached copies of ``params``.
-    Returns (loss float tensor, probs, OrderedDict name -> grad)."""
+    Returns (loss float tensor, probs, OrderedDict name -> grad); with ``input_grad`` the dict also holds the gradient with
+    respect to ``wave_sample`` (what autograd gives through the causal nn.Conv1d, model.py:104) under the key "(input)"."""
     leaf = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
+    if input_grad:
+        wave_sample = wave_sample.detach().clone().requires_grad_(True)
     probs = wavenet_forward(leaf, dilations, wave_sample, **kw)
     loss = ce_on_probs(probs, target)
+    if input_grad:
+        leaf["(input)"] = wave_sample
     grads = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
     # the last block's dense conv never reaches the output (its x_N is unused): the reference
     # leaves that .grad None; reported here as exact zeros

@@ -2,7 +2,7 @@
 """Randomised parity fuzz of the autoencoder (GPU): random widths (decoder / encoder at 64 padded channels half of the time
 each, so that the one-launch backward blocks run - the decoder's WITH the conditioning on the matrix cores), dilations,
 pooling (stretch and tile conditioning, more than 32 pooled frames included), batch (a quarter of the cases: 20-60 short
-clips), clip length and bias; loss and every gradient against autograd on oracle/wavenet_oracle.py with the same per-forward
+clips), clip length and bias; loss and every gradient - the input's included - against autograd on oracle/wavenet_oracle.py with the same per-forward
 projections.  Test infrastructure (imports oracle/); not part of the product path.
 
     python tools/fuzz_ae.py [--cases N] [--seed S]"""
@@ -99,15 +99,18 @@ def one_case(rng, k, general=False):
     target = torch.from_numpy(rng.integers(0, Q, size=(B * W,)).astype(np.int64))
     torch.manual_seed(900 + k)
     net.zero_grad()
-    probs = net(x.cuda())
+    xi = x.cuda().requires_grad_(True)          # the input's own gradient is checked too (the two causal nn.Conv1d give it, model1.py:137,158)
+    probs = net(xi)
     loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
     loss.backward()
     torch.manual_seed(900 + k)
     cond = wo.draw_conditioning(n, cfg["en_bottleneck_width"], cfg["de_dilation_channel"], cfg["de_skip_channel"])
     leaf = {kk: v.clone().requires_grad_(True) for kk, v in params.items()}
-    p_ref, _ = wo.autoencoder_forward(leaf, dil, x, cfg["en_pool_kernel_size"], cond, filter_width=fw, q=Q)
+    xr = x.clone().requires_grad_(True)
+    p_ref, _ = wo.autoencoder_forward(leaf, dil, xr, cfg["en_pool_kernel_size"], cond, filter_width=fw, q=Q)
     l_ref = torch.nn.functional.cross_entropy(p_ref, target)
-    g_ref = torch.autograd.grad(l_ref, list(leaf.values()), allow_unused=True)
+    g_ref = torch.autograd.grad(l_ref, list(leaf.values()) + [xr], allow_unused=True)
+    g_in, g_ref = g_ref[-1], g_ref[:-1]
     e_p = (probs.detach().cpu() - p_ref.detach()).abs().max().item()
     gs = [torch.zeros_like(leaf[nm]) if g is None else g for (nm, _), g in zip(net.named_parameters(), g_ref)]
     floor = 1e-3 * max(g.abs().max().item() for g in gs)
@@ -116,6 +119,9 @@ def one_case(rng, k, general=False):
         err = (p.grad.cpu() - g).abs().max().item() / max(g.abs().max().item(), floor)
         if err > worst:
             worst, wname = err, name
+    err = (xi.grad.cpu() - g_in).abs().max().item() / max(g_in.abs().max().item(), 1e-30)
+    if err > worst:
+        worst, wname = err, "(the input)"
     ok = e_p <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and worst <= 2e-3
     tie_note = ""
     if not ok and e_p <= 1e-3:
@@ -127,13 +133,15 @@ def one_case(rng, k, general=False):
         relu, stats = _device_relu(dev_pre)
         leaf64 = {kk: v.double().requires_grad_(True) for kk, v in params.items()}
         try:
-            p64, _ = wo.autoencoder_forward(leaf64, dil, x.double(), cfg["en_pool_kernel_size"], [(w.double(), b.double()) for w, b in cond],
+            x64 = x.double().requires_grad_(True)
+            p64, _ = wo.autoencoder_forward(leaf64, dil, x64, cfg["en_pool_kernel_size"], [(w.double(), b.double()) for w, b in cond],
                                             filter_width=fw, q=Q, relu=relu)
         except AssertionError as e:
             print("FAIL case %3d  %s" % (k, e), flush=True)
             return False
         l64 = torch.nn.functional.cross_entropy(p64, target)
-        g64 = torch.autograd.grad(l64, list(leaf64.values()), allow_unused=True)
+        g64 = torch.autograd.grad(l64, list(leaf64.values()) + [x64], allow_unused=True)
+        g_in64, g64 = g64[-1], g64[:-1]
         gs = [torch.zeros_like(leaf64[nm]) if g is None else g for (nm, _), g in zip(net.named_parameters(), g64)]
         floor = 1e-3 * max(g.abs().max().item() for g in gs)
         worst, wname = 0.0, ""
@@ -141,6 +149,9 @@ def one_case(rng, k, general=False):
             err = (p.grad.cpu().double() - g).abs().max().item() / max(g.abs().max().item(), floor)
             if err > worst:
                 worst, wname = err, name
+        err = (xi.grad.cpu().double() - g_in64).abs().max().item() / max(g_in64.abs().max().item(), 1e-30)
+        if err > worst:
+            worst, wname = err, "(the input)"
         ok = abs(loss.item() - l64.item()) < 1e-4 and worst <= 2e-3
         tie_note = " [float64 oracle with the device's sign at %d of %d near-zero ReLU pre-activations]" % (stats["flips"], stats["near"])
     print("%s case %3d fw=%d Q=%d dil=%s en=%d/%d bw=%d pool=%d de=%d/%d S=%d bias=%d B=%d W=%d  p %.1e grad %.1e %s"

@@ -2,7 +2,7 @@
 # GPU box: every randomised parity fuzzer on fresh seeds; log under gpurun_out/ (copied into profiles/rNN_fuzz.md by hand).
 #   bash tools/fuzz_all.sh SEED0 [SCALE]      SCALE multiplies the case counts (default 1)
 S=${1:-100}; K=${2:-1}; L=gpurun_out/fuzz_all_$S.log; mkdir -p gpurun_out; : > $L
-run() { echo "== $*" >> $L; timeout 3000 "$@" 2>&1 | grep -v "^ok   case.*e-0[0-9] *$\|^ok   case.*rows equal$\|amdgpu.ids\|torch intra-op" | tail -12 >> $L; }
+run() { echo "== $*" >> $L; timeout 3000 "$@" 2>&1 | grep -v "^ok   case.*e-[0-9][0-9] *$\|^ok   case.*rows equal$\|amdgpu.ids\|torch intra-op" | tail -12 >> $L; }
 run python tools/fuzz_parity.py --cases $((120 * K)) --seed $S
 WN_PQ_CHAIN=0 run python tools/fuzz_parity.py --cases $((60 * K)) --seed $((S + 1))
 run python tools/fuzz_ae.py --cases $((80 * K)) --seed $((S + 2))

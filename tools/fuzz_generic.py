@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU parity fuzz of the GENERAL plan (music_amd/engine_generic.py): random filter width 1..5, quantisation
 width 8..600, channel counts 4..200 / skip 8..300, depth 1..7 with random dilations, bias on / off, batch 1..3, 1..600 output
-columns; pre-softmax, probabilities, loss and every gradient against the oracle (ReLU signs near zero taken from the device,
+columns; pre-softmax, probabilities, loss and every gradient (the input's included) against the oracle (ReLU signs near zero taken from the device,
 tests/test_gpu_fullsize.py).  Test infrastructure (imports oracle/); not part of the product path.
 
     python tools/fuzz_generic.py [--cases N] [--seed S]"""
@@ -44,7 +44,8 @@ def one_case(rng, k):
     T = rf + win - 1
     x = torch.from_numpy(rng.standard_normal((B, Q, T)).astype(np.float32) * 0.5)
     target = torch.from_numpy(rng.integers(0, Q, size=(B * win,)).astype(np.int64))
-    probs = net(x.cuda())
+    xi = x.cuda().requires_grad_(True)          # the input's own gradient is checked with the parameters'
+    probs = net(xi)
     eng = net._engine
     assert isinstance(eng, GenericWaveNetEngine)
     loss = torch.nn.functional.cross_entropy(probs, target.cuda())
@@ -55,18 +56,21 @@ def one_case(rng, k):
     relu, _ = _device_relu({"skip_sum": v(ws["U"]), "post_process_1": v(ws["H"])})
     inter = {}
     l_ref, p_ref, g_ref = wo.loss_and_grads(params, dil, x, target, filter_width=fw, quantization_channels=Q, intermediates=inter,
-                                            relu=relu)
+                                            relu=relu, input_grad=True)
     e_p = (probs.detach().cpu() - p_ref).abs().max().item()
     e_o = (ws["O"][:B * Q * win].view(B, Q, win).cpu() - inter["pre_softmax"].detach()).abs().max().item()
     gmax = max(g.abs().max().item() for g in g_ref.values())
     worst = 0.0
+    gmax = max(g.abs().max().item() for nme, g in g_ref.items() if nme != "(input)")
     for nme, p in net.named_parameters():
         want = g_ref[nme]
         got = torch.zeros_like(want) if p.grad is None else p.grad.cpu()
         worst = max(worst, (got - want).abs().max().item() / max(want.abs().max().item(), 1e-3 * gmax))
-    ok = e_p <= 1e-3 and e_o <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and worst <= 2e-3
-    print("%s case %3d  fw=%d dil=%s R=%d D=%d S=%d Q=%d bias=%d B=%d W=%d  pre %.1e p %.1e grad %.1e" % (
-        "ok  " if ok else "FAIL", k, fw, dil, R, D, S, Q, bias, B, win, e_o, e_p, worst))
+    g_in = g_ref["(input)"]
+    e_in = (xi.grad.cpu() - g_in).abs().max().item() / max(g_in.abs().max().item(), 1e-30)
+    ok = e_p <= 1e-3 and e_o <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and worst <= 2e-3 and e_in <= 2e-3
+    print("%s case %3d  fw=%d dil=%s R=%d D=%d S=%d Q=%d bias=%d B=%d W=%d  pre %.1e p %.1e grad %.1e d input %.1e" % (
+        "ok  " if ok else "FAIL", k, fw, dil, R, D, S, Q, bias, B, win, e_o, e_p, worst, e_in))
     return ok
 
 

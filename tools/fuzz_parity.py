@@ -6,7 +6,7 @@
 Every case draws dilations, channel counts (ragged: not multiples of 16), skip width, batch, clip
 length and bias at random, runs forward + CE + backward through the HIP path twice (nn.Module autograd
 surface and the fused training-step entry) and checks pre-softmax logits / probabilities (1e-3), loss
-(1e-4) and every gradient (2e-3 of its tensor's max) against oracle/wavenet_oracle.py.  A case whose forward
+(1e-4), every gradient (2e-3 of its tensor's max) and the gradient w.r.t. a dense input against oracle/wavenet_oracle.py.  A case whose forward
 agrees but whose float32 gradients differ is judged again against the float64 oracle with the device's sign at the
 post-processing ReLUs' near-zero pre-activations (the derivative jumps there; tests/test_gpu_fullsize.py) - no case is
 skipped.  Test infrastructure (it imports oracle/); not part of the product path."""
@@ -115,8 +115,19 @@ def one_case(rng, k, only=None):
             worst2 = max(worst2, (eng.param_view(name, grad=True).cpu().double() - g).abs().max().item() / den)
         ok = abs(loss.item() - l64.item()) < 1e-4 and abs(loss2.item() - l64.item()) < 1e-4 and worst <= 2e-3 and worst2 <= 2e-3
         tie_note = "  [float64 oracle with the device's sign at %d of %d near-zero ReLU pre-activations]" % (stats["flips"], stats["near"])
-    print("%s case %3d  dil=%s R=%d D=%d S=%d B=%d W=%d bias=%d  pre %.1e p %.1e grad %.1e / %.1e"
-          % ("ok  " if ok else "FAIL", k, dil, R, D, S, B, W, bias, e_pre, e_p, worst, worst2) + tie_note, flush=True)
+    # the gradient w.r.t. the INPUT (a dense float tensor that requires grad: the causal nn.Conv1d's data gradient, model.py:104), when the
+    # float32 comparison stands on its own (no ReLU tie in this case)
+    e_in = float("nan")
+    if ok and not tie_note:
+        xi = x.cuda().clone().requires_grad_(True)
+        net.zero_grad()
+        torch.nn.CrossEntropyLoss()(net(xi), target.cuda()).backward()
+        xr = x.clone().requires_grad_(True)
+        (g_in,) = torch.autograd.grad(torch.nn.functional.cross_entropy(wo.wavenet_forward(params, dil, xr), target), [xr])
+        e_in = (xi.grad.cpu() - g_in).abs().max().item() / max(g_in.abs().max().item(), 1e-30)
+        ok = ok and e_in <= 2e-3
+    print("%s case %3d  dil=%s R=%d D=%d S=%d B=%d W=%d bias=%d  pre %.1e p %.1e grad %.1e / %.1e  d input %.1e"
+          % ("ok  " if ok else "FAIL", k, dil, R, D, S, B, W, bias, e_pre, e_p, worst, worst2, e_in) + tie_note, flush=True)
     return ok
 
 
