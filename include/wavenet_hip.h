@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* wn_stream_t;                 /* hipStream_t */
 enum { WN_F16X3 = 0, WN_F16X1 = 1, WN_BF16X3 = 2, WN_BF16X1 = 3 };
-#define WN_ABI_VERSION 3
+#define WN_ABI_VERSION 4
 #define WN_CE_NUM_PARTIALS 1024
 
 int wn_version(void);
@@ -130,11 +130,16 @@ int wn_enc_resblock_bwd_slabs(int t_lo, int t_hi, int batch);
  * out: p_out[t] = dy[t] + [x(t) > 0] W1^T dh[t],  q_out[t] = [x(t-d) > 0] W0^T dh[t]  on [t_lo, t_hi), so that
  * dx[s] = p_out[s] + q_out[s + d] (wn_shift_add makes it whole); dh never reaches HBM.  x / P / Q share x_bstride and pitch,
  * q buffers must read as zero beyond t_hi.  wpq: packed [W1^T; W0^T] ([2ch rows][K = ch dh channels], bf16x3); slabs as
- * wn_enc_resblock_bwd.  Autograd of wavenet_autoencoder/model1.py:143-152 for one layer. */
+ * wn_enc_resblock_bwd.  Autograd of wavenet_autoencoder/model1.py:143-152 for one layer.
+ * chain != 0 (d a multiple of 32, wn_resblock_bwd_pq_chain_ok; slabs = wn_resblock_bwd_pq_slabs(.., chain)): the CHAIN form of
+ * wn_resblock_bwd_pq - a workgroup walks the items of one residue class downwards in time and carries the Q rows in registers, dx
+ * leaves the launch WHOLE in p_out (valid on [t_lo - d, t_hi)), q_out is not touched (may be NULL); the block below takes it as a
+ * plain tensor (q_in = NULL, p_lo = this launch's t_lo - d).  4 activation tensors per block instead of 6: the launch is bound by
+ * its bytes (profiles/r05_ab_enc_noq.json). */
 int wn_enc_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, int dn, int p_lo, const float* h,
                            float* p_out, float* q_out, int64_t x_bstride, int64_t h_bstride, int pitch, const uint16_t* wdT,
-                           const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, float* slab_dil, float* slab_d, int batch,
-                           int mode_bwd, wn_stream_t stream);
+                           const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, float* slab_dil, float* slab_d, int chain,
+                           int batch, int mode_bwd, wn_stream_t stream);
 
 /* Backward of one residual block with BOTH weight gradients in the launch (channel-split form,
  * 64 padded channels, modes (f16x3, bf16x3)): what wn_resblock_bwd + the two per-layer wn_wgrad calls

@@ -271,16 +271,16 @@ int wn_enc_resblock_bwd(const float* x_in, const float* dy, const float* h, floa
 int wn_enc_resblock_bwd_slabs(int t_lo, int t_hi, int batch) { return wn_enc_bwd_slabs(t_lo, t_hi, batch); }
 int wn_enc_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, int dn, int p_lo, const float* h,
                            float* p_out, float* q_out, int64_t x_bstride, int64_t h_bstride, int pitch, const uint16_t* wdT,
-                           const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, float* slab_dil, float* slab_d, int batch,
+                           const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, float* slab_dil, float* slab_d, int chain, int batch,
                            int mode_bwd, wn_stream_t stream) {
     if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_enc_resblock_bwd_pq: pitch must be a multiple of 4");
-    if (!x_in || !p_in || !h || !p_out || !q_out || !wdT || !wpq || !slab_dil || !slab_d)
+    if (!x_in || !p_in || !h || !p_out || (!q_out && !chain) || !wdT || !wpq || !slab_dil || !slab_d)
         return wn_set_error_msg(-4, "wn_enc_resblock_bwd_pq: null argument");
     WnEncPqArgs a;
     memset(&a, 0, sizeof(a));
     a.x_in = x_in; a.p_in = p_in; a.q_in = q_in; a.dn = q_in ? dn : 0; a.p_lo = p_lo; a.h = h; a.h_bstride = h_bstride;
     a.p_out = p_out; a.q_out = q_out; a.x_bstride = x_bstride; a.pitch = pitch; a.wdT = wdT; a.wpq = wpq;
-    a.slab_dil = slab_dil; a.slab_d = slab_d; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi;
+    a.slab_dil = slab_dil; a.slab_d = slab_d; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.chain = chain ? 1 : 0;
     return wn_launch_enc_bwd_pq(a, ch, batch, mode_bwd, (hipStream_t)stream);
 }
 int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch) { return wn_resms_slabs(t_lo, t_hi, batch); }

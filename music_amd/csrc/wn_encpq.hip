@@ -24,6 +24,7 @@
 #include <string.h>
 #include "wn_common.h"
 #include "wn_kernels.h"
+#include "wn_pqchain.h"
 
 #define EP_THREADS 512
 #define EP_CH 64
@@ -33,7 +34,10 @@
 #define EP_T 4096
 #define EP_STAGE 12288
 #define EP_W (2 * EP_STAGE)
-#define EP_LDS_HALFS (EP_W + 16384)
+// CHAIN form: what the W waves hand the R waves per item (two parities): their fp32 dy rows of samples 0..15 and the ReLU signs of x(t) / x(t-d)
+#define EP_HD (EP_W + 16384)                               // [parity][wave g][lane] f32x4
+#define EP_HK (EP_HD + 4096)                               // [parity][wave g][lane] uint32: keep | keepb << 4
+#define EP_LDS_HALFS (EP_HK + 1024)
 
 typedef float ep_f32x2 __attribute__((ext_vector_type(2)));
 typedef short ep_s16x4 __attribute__((ext_vector_type(4)));
@@ -48,7 +52,7 @@ __device__ __forceinline__ void ep_split2(float a, float b, uint32_t& hi, uint32
 // chunk swizzle of the result tiles (wn_respq.hip): 16-byte chunk `ch` (8 positions) of row `r` sits at slot 16*ch + (r ^ K[ch])
 __device__ __forceinline__ int ep_k(int ch) { return ch == 0 ? 0 : ch == 1 ? 13 : ch == 2 ? 6 : 11; }
 
-template <bool HAS_Q>
+template <bool HAS_Q, bool CHAIN>
 __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
     constexpr int CH = EP_CH;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -57,26 +61,61 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
     const int c = lane & 15, q = lane >> 4;
     const int tile_rd = (16 * q + (c ^ ep_k(q))) * 8;            // halfs; chunk q of row c (a 16-byte row read)
 
-    // items of this workgroup: the workgroups of an XCD walk one contiguous item range interleaved (wn_resrw.hip)
-    int first, cnt, j;
-    if (a.swz) {
-        const int nwg = gridDim.x, id = blockIdx.x;
-        const int qn = nwg >> 3, rn = nwg & 7, xcd = id & 7;
-        first = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
-        cnt = xcd < rn ? qn + 1 : qn;
-        j = id >> 3;
+    // items of this workgroup.  (P, Q) form: the workgroups of an XCD walk one contiguous item range interleaved (wn_resrw.hip).
+    // CHAIN form (wn_respq.hip, wn_pqchain.h): a run of `n_items` items in CHAIN ORDER (clip, residue of the item index mod d / 32, then
+    // downwards in time), the first of them possibly a halo item; a window of five positions (items it-1 .. it+3) lives in scalars.
+    struct Pos { int b, t0; bool live, halo, top, bot; };
+    int first = 0, cnt = 1, j = 0, wgid, total = 0, i_lo = 0, n_items;
+    const PqChain chp = {a.ch_s, a.ch_qn, a.ch_rm, a.ch_g, a.ch_nchain, a.steps_per_clip};
+    PqCS cs_front = {0, 0, 0, 1};
+    int k_front = 0;
+    bool has_halo = false;
+    int win_b[5], win_t[5];                                 // clip | t0 (a multiple of 32) + live, halo, top, bot bits
+    auto cs_pos = [&](PqCS cc, int k) __attribute__((always_inline)) {
+        const int t0 = a.t_base + EP_COLS * (cc.r + (cc.m - 1 - cc.pos) * a.ch_s);
+        return t0 | ((k >= 0 && k < n_items) ? 1 : 0) | ((has_halo && k == 0) ? 2 : 0) | (cc.pos == 0 ? 4 : 0) | (cc.pos == cc.m - 1 ? 8 : 0);
+    };
+    if (CHAIN) {
+        wgid = blockIdx.x;
+        int n_real;
+        PqCS cc;
+        pq_chain_start(chp, wgid, gridDim.x, cc, n_real, has_halo);
+        n_items = n_real + (has_halo ? 1 : 0);
+        win_b[0] = cc.b; win_t[0] = cs_pos(cc, -1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            win_b[k + 1] = cc.b; win_t[k + 1] = cs_pos(cc, k);
+            if (k < 3) cc = pq_cs_next(cc, chp);
+        }
+        cs_front = cc;
+        k_front = 3;
     } else {
-        first = 0; cnt = gridDim.x; j = blockIdx.x;
+        if (a.swz) {
+            const int nwg = gridDim.x, id = blockIdx.x;
+            const int qn = nwg >> 3, rn = nwg & 7, xcd = id & 7;
+            first = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+            cnt = xcd < rn ? qn + 1 : qn;
+            j = id >> 3;
+        } else {
+            first = 0; cnt = gridDim.x; j = blockIdx.x;
+        }
+        wgid = first + j;
+        total = a.steps_per_clip * a.batch;
+        i_lo = first * a.items_per_wg + j;
+        int i_hi = (first + cnt) * a.items_per_wg;
+        if (i_hi > total) i_hi = total;
+        n_items = i_lo < i_hi ? (i_hi - i_lo + cnt - 1) / cnt : 0;
     }
-    const int wgid = first + j;
-    const int total = a.steps_per_clip * a.batch;
-    const int i_lo = first * a.items_per_wg + j;
-    int i_hi = (first + cnt) * a.items_per_wg;
-    if (i_hi > total) i_hi = total;
-    const int n_items = i_lo < i_hi ? (i_hi - i_lo + cnt - 1) / cnt : 0;
-
-    struct Pos { int b, t0; bool live; };
-    auto pos_k = [&](int k) {                                  // position of this workgroup's k-th item, clamped
+    auto win_advance = [&]() __attribute__((always_inline)) {
+        if (CHAIN) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { win_b[k] = win_b[k + 1]; win_t[k] = win_t[k + 1]; }
+            cs_front = pq_cs_next(cs_front, chp);
+            k_front += 1;
+            win_b[4] = cs_front.b; win_t[4] = cs_pos(cs_front, k_front);
+        }
+    };
+    auto pos_k = [&](int k) {                                  // (P, Q) form: position of this workgroup's k-th item, clamped
         const bool live = k >= 0 && k < n_items;
         k = k < n_items ? k : n_items - 1;
         int it = i_lo + (k < 0 ? 0 : k) * cnt;
@@ -85,6 +124,17 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         p.b = it / a.steps_per_clip;
         p.t0 = a.t_base + EP_COLS * (it - p.b * a.steps_per_clip);
         p.live = live;
+        p.halo = p.top = p.bot = false;
+        return p;
+    };
+    // position of item `it + rel`, `it` being the iteration the window stands at (rel = -1 .. 3, a constant at every call site)
+    auto pos_r = [&](int it, int rel) __attribute__((always_inline)) {
+        if (!CHAIN) return pos_k(it + rel);
+        Pos p;
+        const int v = win_t[rel + 1];
+        p.b = win_b[rel + 1];
+        p.t0 = v & ~31;
+        p.live = v & 1; p.halo = v & 2; p.top = v & 4; p.bot = v & 8;
         return p;
     };
 
@@ -198,8 +248,61 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         }
     };
 
+    // ---- CHAIN form: the 16-sample half `mt` of the item's 32 columns, BOTH weight halves: dx rows = dy + [x > 0] (P rows + the Q
+    // rows carried from the item above), then this item's Q rows become the carry; the last item of a chain leaves its carry d columns
+    // further down (dx on [t_lo - d, t_base): nothing but the masked Q).  A halo item only makes the carry.  keep4 / keepb4: the ReLU
+    // masks of the lane's four samples at x(t) / x(t - d).
+    auto pq_mt = [&](int stage, int mt, Pos ps, const float* dy4, uint32_t keep4, uint32_t keepb4, f32x4& carry) __attribute__((always_inline)) {
+        if (!ps.live) return;
+        const uint16_t* tt = lds + (size_t)stage * EP_STAGE + EP_T;
+        const uint16_t* pw = lds + EP_W;
+        f32x4 aP[2], aQ[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            aP[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            aQ[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            Frag<BF16> w1, w0;
+            load_a<BF16, 3>(w1, pw, g * 2 + s, lane);
+            load_a<BF16, 3>(w0, pw, (4 + g) * 2 + s, lane);
+            const uint16_t* tb = tt + (2 * s + (q >> 1)) * 1024;
+            typedef __attribute__((address_space(3))) ep_s16x4 lds_s16x4;
+            ep_s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[0] + 4 * mt));
+            ep_s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[1] + 4 * mt));
+            ep_s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[0] + 4 * mt));
+            ep_s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[1] + 4 * mt));
+            ep_s16x8 hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            ep_s16x8 ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            Frag<BF16> ad;
+            ad.hi = __builtin_bit_cast(bf16x8, hh);
+            ad.lo = __builtin_bit_cast(bf16x8, ll);
+            aP[s] = BF16::mfma(ad.lo, w1.hi, aP[s]);
+            aQ[s] = BF16::mfma(ad.lo, w0.hi, aQ[s]);
+            aP[s] = BF16::mfma(ad.hi, w1.lo, aP[s]);
+            aQ[s] = BF16::mfma(ad.hi, w0.lo, aQ[s]);
+            aP[s] = BF16::mfma(ad.hi, w1.hi, aP[s]);
+            aQ[s] = BF16::mfma(ad.hi, w0.hi, aQ[s]);
+        }
+        if (ps.top) carry = f32x4{0.f, 0.f, 0.f, 0.f};
+        float* out = a.p_out + (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 16 * mt + 4 * q;
+        const int tq = ps.t0 + 16 * mt + 4 * q;
+        if (!ps.halo) {
+            f32x4 v = (aP[0] + aP[1]) + carry;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (((keep4 >> i) & 1u) ? v[i] : 0.f) + dy4[i];
+            if (ps.t0 + EP_COLS <= a.t_hi) *reinterpret_cast<f32x4*>(out) = v;      // (t0 >= t_base > t_lo - d always)
+            else st4m(out, v, tq, a.t_lo - a.d, a.t_hi);
+        }
+        carry = aQ[0] + aQ[1];
+        if (ps.bot) {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ((keepb4 >> i) & 1u) ? carry[i] : 0.f;
+            st4m(out - a.d, v, tq - a.d, a.t_lo - a.d, a.t_lo);
+        }
+    };
+
     if (wv < 4) {
-        // =========================== R waves: dr = Wd^T dy, mask, tiles; Q half ===========================
+        // =========================== R waves: dr = Wd^T dy, mask, tiles; Q half (CHAIN: samples 0..15 of dx) ===========================
         Frag<BF16> wd[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) load_a<BF16, 3>(wd[s], a.wdT, g * 2 + s, lane);
@@ -227,27 +330,45 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
             return keep;
         };
 
+        // CHAIN: what the wave's half of dx needs besides the product - the fp32 dy rows (the residual term) and the ReLU signs of x(t) /
+        // x(t - d) at row 16g + c, samples t0 + 4q .. + 3 - is what W wave g holds for the same lane: it leaves them in LDS when it converts
+        // the item's rows (loaded here in the output layout instead - three 16-byte loads per lane that touch 16 cache lines each - the chain
+        // form's launches took 4.8 us longer: encoder stack backward 1.523 against 1.451 ms in a timing build without them)
+        f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+        auto mt_r = [&](int stage, Pos ps) __attribute__((always_inline)) {      // CHAIN: samples 0..15 of dx of item ps
+            if (!ps.live) return;
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds + EP_HD) + ((stage * 4 + g) * 64 + lane) * 16);
+            const uint32_t kk = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds + EP_HK) + ((stage * 4 + g) * 64 + lane) * 4);
+            float d4[4] = {dv[0], dv[1], dv[2], dv[3]};
+            pq_mt(stage, 0, ps, d4, kk & 15u, (kk >> 4) & 15u, carry);
+        };
         ep_f32x2 hA[4], hB[4];
-        load_h(hA, pos_k(0));
-        load_h(hB, pos_k(1));
+        load_h(hA, pos_r(0, 0));
+        load_h(hB, pos_r(0, 1));
         RawD rd;                                            // dy rows (as the pair) of item it+1
-        load_dy(rd, pos_k(0));
-        fill_dy(rd, pos_k(0), 0);
-        load_dy(rd, pos_k(1));
+        load_dy(rd, pos_r(0, 0));
+        fill_dy(rd, pos_r(0, 0), 0);
+        load_dy(rd, pos_r(0, 1));
         uint32_t keep_q = 0;                                // Q mask of the previous item
         __syncthreads();                                    // stage 0 operands of the first item, the weights, the zeros
         auto r_body = [&](const int it, ep_f32x2* hr) {
             if (it >= n_items) {
-                // the void item that pads an odd count: only the Q rows of the last real item
-                pq_half((it + 1) & 1, 1, pos_k(it - 1), nullptr, keep_q);
+                // the void item that pads an odd count: only the Q rows (CHAIN: the first half of dx) of the last real item
+                if (CHAIN) mt_r((it + 1) & 1, pos_r(it, -1));
+                else pq_half((it + 1) & 1, 1, pos_r(it, -1), nullptr, keep_q);
+                win_advance();
                 __syncthreads();
                 return;
             }
-            fill_dy(rd, pos_k(it + 1), (it + 1) & 1);        // dy fragments of the next item
-            load_dy(rd, pos_k(it + 2));
-            pq_half((it + 1) & 1, 1, pos_k(it - 1), nullptr, keep_q);       // Q rows of the previous item
-            const Pos p_cur = pos_k(it);
-            keep_q = load_xm(p_cur);                         // (waited for at the next item's store)
+            fill_dy(rd, pos_r(it, 1), (it + 1) & 1);         // dy fragments of the next item
+            load_dy(rd, pos_r(it, 2));
+            const Pos p_cur = pos_r(it, 0);
+            if (CHAIN) {
+                mt_r((it + 1) & 1, pos_r(it, -1));           // the first half of dx of the previous item
+            } else {
+                pq_half((it + 1) & 1, 1, pos_r(it, -1), nullptr, keep_q);   // Q rows of the previous item
+                keep_q = load_xm(p_cur);                     // (waited for at the next item's store)
+            }
             const int tl = p_cur.t0 + 2 * c;
             uint16_t* st = lds + (size_t)(it & 1) * EP_STAGE;
             const uint16_t* dyf = st + EP_DYF;
@@ -286,7 +407,8 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
                 put(0, vh);
                 put(1, vr);
             }
-            load_h(hr, pos_k(it + 2));
+            load_h(hr, pos_r(it, 2));
+            win_advance();
             __syncthreads();
         };
         for (int it = 0; it < n_items; it += 2) {
@@ -295,7 +417,11 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         }
         {
             const int n_even = (n_items + 1) & ~1;
-            if (pos_k(n_even - 1).live) pq_half((n_even - 1) & 1, 1, pos_k(n_even - 1), nullptr, keep_q);      // Q rows of the last item
+            const Pos pl = pos_r(n_even, -1);
+            if (pl.live) {                                      // Q rows (CHAIN: the first half of dx) of the last item
+                if (CHAIN) mt_r((n_even - 1) & 1, pl);
+                else pq_half((n_even - 1) & 1, 1, pl, nullptr, keep_q);
+            }
         }
         __syncthreads();                                    // the W waves' extra round (products of the last item)
         return;
@@ -320,7 +446,7 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
     };
     // this wave's B operands of the weight-gradient products (k = the 8 positions of the lane's chunk), its dy rows in fp32
     // (the residual term of P) and the ReLU mask of its x(t) rows
-    struct Ops { Frag<BF16> x0, x1, dy; float dy32[8]; uint32_t keep; };
+    struct Ops { Frag<BF16> x0, x1, dy; float dy32[8]; uint32_t keep, keepb; };      // keepb (CHAIN): the signs of the x(t - d) rows
     auto to_frag = [&](Frag<BF16>& f, const float* w) {
         u32x4 fh, fl;
 #pragma unroll
@@ -333,11 +459,17 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         f.hi = __builtin_bit_cast(bf16x8, fh);
         f.lo = __builtin_bit_cast(bf16x8, fl);
     };
-    auto convert = [&](Ops& o, const RawRows& r, Pos ps) {
+    auto convert = [&](Ops& o, const RawRows& r, Pos ps, int par) {
         float w[8];
+        uint32_t keepb = 0;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) w[jj] = ps.live ? fmaxf(r.x0[jj >> 2][jj & 3], 0.f) : 0.f;
+        for (int jj = 0; jj < 8; ++jj) {
+            const float v = r.x0[jj >> 2][jj & 3];
+            w[jj] = ps.live ? fmaxf(v, 0.f) : 0.f;
+            if (CHAIN) keepb |= v > 0.f ? 1u << jj : 0u;
+        }
         to_frag(o.x0, w);
+        o.keepb = keepb;
         uint32_t keep = 0;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
@@ -358,15 +490,21 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
             }
         }
         to_frag(o.dy, o.dy32);
+        if (CHAIN) {                                            // the R waves' residual term and masks (samples 0..15), parity of the item
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds + EP_HD) + ((par * 4 + g) * 64 + lane) * 16) =
+                f32x4{o.dy32[0], o.dy32[1], o.dy32[2], o.dy32[3]};
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds + EP_HK) + ((par * 4 + g) * 64 + lane) * 4) = (o.keep & 15u) | ((o.keepb & 15u) << 4);
+        }
     };
     auto load_tile = [&](Frag<BF16>& f, const uint16_t* base, int tile) {
         const u32x4* p = reinterpret_cast<const u32x4*>(base + tile * 1024 + tile_rd);
         f.hi = __builtin_bit_cast(bf16x8, p[0]);
         f.lo = __builtin_bit_cast(bf16x8, p[64]);
     };
+    f32x4 carry_w = {0.f, 0.f, 0.f, 0.f};                  // CHAIN: Q rows of samples 16..31 of the item above
     auto products = [&](int stage, const Ops& o, Pos ps) __attribute__((always_inline)) {
         const uint16_t* tt = lds + (size_t)stage * EP_STAGE + EP_T;
-        {
+        if (!(CHAIN && ps.halo)) {                              // (a halo item's weight gradients belong to the workgroup above)
             // weight gradients: rows = all dh / relu(h) tiles, columns = this wave's x / dy rows; the three products of an x3
             // term are walked across the accumulators of a tile pair, the next pair is read meanwhile
             auto term = [](f32x4& acc, const Frag<BF16>& wa, const Frag<BF16>& xb, int t) {
@@ -399,29 +537,31 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
                 }
             }
         }
-        pq_half(stage, 0, ps, o.dy32, o.keep);
+        if (CHAIN) pq_mt(stage, 1, ps, o.dy32 + 4, o.keep >> 4, o.keepb >> 4, carry_w);      // samples 16..31 of dx
+        else pq_half(stage, 0, ps, o.dy32, o.keep);
     };
 
     {
         RawRows rr, rr2;                                    // raw rows of items it / it+1: requested two items ahead
         Ops ops;
-        load_rows(rr, pos_k(0));
-        load_rows(rr2, pos_k(1));
-        convert(ops, rr, pos_k(-1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
+        load_rows(rr, pos_r(0, 0));
+        load_rows(rr2, pos_r(0, 1));
+        convert(ops, rr, pos_r(0, -1), 1);                  // "item -1": zeros (its products meet the zeroed tiles of stage 1)
         __syncthreads();
         // iteration it: products of item it-1 (result tiles of stage (it-1)&1, operands in `ops`); then the raw rows of
         // item it become `ops` and the rows of item it+2 are requested (loop unrolled by two: no register copies)
         // (the row conversion between the weight gradients and the dx product - what pays in wn_respq.hip, whose R waves have a long
         // vector phase - is SLOWER here, round 4: encoder stack backward 1.64 against 1.57 ms at config 4, three alternations)
         auto w_body = [&](const int it, RawRows& r) {
-            products((it + 1) & 1, ops, pos_k(it - 1));
-            convert(ops, r, pos_k(it));
-            load_rows(r, pos_k(it + 2));
+            products((it + 1) & 1, ops, pos_r(it, -1));
+            convert(ops, r, pos_r(it, 0), it & 1);
+            load_rows(r, pos_r(it, 2));
+            win_advance();
             __syncthreads();
         };
         const int n_even = (n_items + 1) & ~1;
         for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, rr2); }
-        if (pos_k(n_even - 1).live) products((n_even - 1) & 1, ops, pos_k(n_even - 1));    // the last item, unless it is the void one
+        if (pos_r(n_even, -1).live) products((n_even - 1) & 1, ops, pos_r(n_even, -1));    // the last item, unless it is the void one
         __syncthreads();
     }
 
@@ -448,7 +588,13 @@ int wn_launch_enc_bwd_pq(const WnEncPqArgs& a, int ch, int batch, int mode_bwd, 
     if (mode_bwd != WN_MODE_BF16X3) return wn_set_error_msg(-2, "enc_resblock_bwd_pq: bf16x3 only");
     WnEncPqArgs k = a;
     int nwg;
-    wn_resrw_plan(a.t_lo, a.t_hi, batch, k.t_base, k.steps_per_clip, k.items_per_wg, nwg);      // same items and slabs as enc_bwd_rw_k
+    if (k.chain) {
+        if (!wn_pq_chain_ok(a.t_lo, a.t_hi, batch, a.d)) return wn_set_error_msg(-4, "enc_resblock_bwd_pq: chain form needs d % 32 == 0 and an item per chain");
+        wn_pq_chain_plan(a.t_lo, a.t_hi, batch, a.d, k.t_base, k.steps_per_clip, k.ch_s, k.ch_qn, k.ch_rm, k.ch_g, k.ch_nchain, nwg);
+        k.items_per_wg = 0;
+    } else {
+        wn_resrw_plan(a.t_lo, a.t_hi, batch, k.t_base, k.steps_per_clip, k.items_per_wg, nwg);      // same items and slabs as enc_bwd_rw_k
+    }
     k.batch = batch;
     k.swz = wn_xcd_swizzle_enabled();
     const size_t sh = (size_t)EP_LDS_HALFS * sizeof(uint16_t);
@@ -456,12 +602,19 @@ int wn_launch_enc_bwd_pq(const WnEncPqArgs& a, int ch, int batch, int mode_bwd, 
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (done.need(dev)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         done.done(dev);
     }
-    if (k.q_in) hipLaunchKernelGGL(enc_bwd_pq_k<true>, dim3(nwg), dim3(EP_THREADS), sh, st, k);
-    else hipLaunchKernelGGL(enc_bwd_pq_k<false>, dim3(nwg), dim3(EP_THREADS), sh, st, k);
+    if (k.chain) {
+        if (k.q_in) hipLaunchKernelGGL((enc_bwd_pq_k<true, true>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
+        else hipLaunchKernelGGL((enc_bwd_pq_k<false, true>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
+    } else {
+        if (k.q_in) hipLaunchKernelGGL((enc_bwd_pq_k<true, false>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
+        else hipLaunchKernelGGL((enc_bwd_pq_k<false, false>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
+    }
     WN_CHECK_LAUNCH();
     return 0;
 }

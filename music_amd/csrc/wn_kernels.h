@@ -144,6 +144,9 @@ struct WnEncPqArgs {
     float* slab_dil; float* slab_d;                        // one slab per workgroup: [CH][2CH] and [CH][CH] (enc_bwd_rw_k's)
     int d, t_lo, t_hi, t_base;
     int steps_per_clip, items_per_wg, batch, swz;          // set by the launcher
+    // CHAIN form (WnResPqArgs: d a multiple of 32, every chain non-empty): dx leaves the launch WHOLE in p_out (valid on [t_lo - d, t_hi)),
+    // q_out is not touched; the plan fields are set by the launcher (wn_pq_chain_plan)
+    int chain, ch_s, ch_qn, ch_rm, ch_g, ch_nchain;
 };
 int wn_launch_enc_bwd_pq(const WnEncPqArgs& a, int ch, int batch, int mode_bwd, hipStream_t st);
 

@@ -532,8 +532,12 @@ class _AutoencoderEngine:
             bw["PQe"] = (bw["PQ"] if bw["pq"] and self.CHe == self.CHd else     # the decoder's pairs are free again by then
                          [(buf(self.CHe), buf(self.CHe)), (buf(self.CHe), buf(self.CHe))])
         sfx = "2_" if pair else ""                            # pair mode: the block-diagonal gradient matrices, B / 2 "clips"
+        # one-launch encoder blocks whose dilation is a multiple of 32 hand dx on WHOLE (chain form of wn_enc_resblock_bwd_pq, as
+        # wn_resblock_bwd_pq's in music_amd/engine.py): 4 activation tensors per block instead of 6 - the launch is bound by its bytes
+        want_chain = bw["enc_pq"] and os.environ.get("WN_PQ_CHAIN", "1") == "1"
+        bw["enc_chain"] = [want_chain and _lib.pq_chain_ok(self.off[i + 1], T, B // 2 if pair else B, self.dil[i]) for i in range(N)]
         for i in range(N):
-            ench = -2 if enc_fused else 512
+            ench = (-3 - i if bw["enc_chain"][i] else -2) if enc_fused else 512      # -3 - i: layer i in chain form (its own slab count)
             ops += [("de_fg%s%d" % (sfx, i), self.off[i + 1], T, -1 if ms else 512), ("en_dil%s%d" % (sfx, i), self.off[i + 1], T, ench),
                     ("en_dense%s%d" % (sfx, i), self.off[i + 1], T, ench)]
             if i < N - 1:
@@ -545,7 +549,8 @@ class _AutoencoderEngine:
             n = r * c
             Bs = B // 2 if pair and chunk < 0 else B
             ns = (_lib.wgrad_slabs(t_lo, t_hi, chunk, B) if chunk > 0 else
-                  _lib.ms_slabs(t_lo, t_hi, Bs) if chunk == -1 else _lib.enc_slabs(t_lo, t_hi, Bs))
+                  _lib.ms_slabs(t_lo, t_hi, Bs) if chunk == -1 else _lib.enc_slabs(t_lo, t_hi, Bs) if chunk == -2 else
+                  _lib.pq_slabs(t_lo, t_hi, Bs, self.dil[-3 - chunk], True))
             plan[name] = (so, n, chunk)
             row_of[name] = len(desc)
             desc.append([vs, so, ns, n, go, n])
@@ -815,20 +820,25 @@ class _AutoencoderEngine:
             if bw["enc_pq"]:
                 # the whole backward of the block in one launch; dx travels as the unshifted pair (P, Q)
                 p_out, q_out = (ptr(t, SLACK) for t in bw["PQe"][i % 2])
+                chain = 1 if bw["enc_chain"][i] else 0
+                if i == 0 and chain:
+                    p_out = dxe[0]                                # a first block in chain form hands dx_0 on whole: straight to the causal layer's buffer
                 if i < N - 1:
                     p_in, q_in = (ptr(t, SLACK) for t in bw["PQe"][(i + 1) % 2])
                     dn, p_lo = self.dil[i + 1], self.off[i + 2]
+                    if bw["enc_chain"][i + 1]:                    # the block above handed dx on whole (valid from ITS t_lo - d = this t_lo)
+                        q_in, dn, p_lo = None, 0, t_lo
                 else:
                     p_in, q_in, dn, p_lo = dy, None, 0, y_lo
                 if pair:
                     call("wn_enc_resblock_bwd_pq", xe(i), p_in, q_in, dn, p_lo, he(i), p_out, q_out, 2 * eb, 2 * eb, pitch,
                          br("en_denseT2_%d" % i), br("en_pq2_%d" % i), 64, d, t_lo, T, ptr(bw["slab"], plan["en_dil2_%d" % i][0]),
-                         ptr(bw["slab"], plan["en_dense2_%d" % i][0]), Bp, mb, st)
+                         ptr(bw["slab"], plan["en_dense2_%d" % i][0]), chain, Bp, mb, st)
                 else:
                     call("wn_enc_resblock_bwd_pq", xe(i), p_in, q_in, dn, p_lo, he(i), p_out, q_out, eb, eb, pitch,
                          br("en_denseT%d" % i), br("en_pq%d" % i), CHe, d, t_lo, T, ptr(bw["slab"], plan["en_dil%d" % i][0]),
-                         ptr(bw["slab"], plan["en_dense%d" % i][0]), B, mb, st)
-                if i == 0:
+                         ptr(bw["slab"], plan["en_dense%d" % i][0]), chain, B, mb, st)
+                if i == 0 and not chain:
                     call("wn_shift_add", p_out, q_out, dxe[0], eb, pitch, CHe, d, t_lo, self.off[0], T, B, st)
                 continue
             if bw["enc_fused"]:

@@ -61,7 +61,7 @@ def _dev_pre(eng, B, T, n):
 def one_case(rng, k, general=False):
     from music_amd.model1 import wavenet_autoencoder
     n = int(rng.integers(2, 7))
-    dil = [int(rng.choice([1, 2, 3, 4, 8, 16, 5])) for _ in range(n)]
+    dil = [int(rng.choice([1, 2, 3, 4, 8, 16, 5, 32, 64, 32])) for _ in range(n)]
     wide = rng.random() < 0.5
     ewide = rng.random() < 0.5                  # 64 padded encoder channels: the one-launch encoder backward block
     cfg = dict(filter_width=2, quantization_channel=256, dilations=dil,
