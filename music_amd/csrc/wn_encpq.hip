@@ -320,16 +320,6 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) hr[i] = ep_ld2u(hp + i * rp);
         };
-        // x(t - d) in the layout of the Q rows this wave stores: row 16g + c, samples t0 + 4q .. + 3 and t0 + 16 + 4q .. + 3
-        auto load_xm = [&](Pos ps) {
-            const float* p = ps.live ? a.x_in + (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q - a.d : a.x_in;
-            const f32x4 v0 = ld4u(p), v1 = ld4u(p + (ps.live ? 16 : 0));
-            uint32_t keep = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) keep |= (v0[i] > 0.f ? 1u << i : 0u) | (v1[i] > 0.f ? 1u << (4 + i) : 0u);
-            return keep;
-        };
-
         // CHAIN: what the wave's half of dx needs besides the product - the fp32 dy rows (the residual term) and the ReLU signs of x(t) /
         // x(t - d) at row 16g + c, samples t0 + 4q .. + 3 - is what W wave g holds for the same lane: it leaves them in LDS when it converts
         // the item's rows (loaded here in the output layout instead - three 16-byte loads per lane that touch 16 cache lines each - the chain
@@ -340,7 +330,7 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
             const f32x4 dv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds + EP_HD) + ((stage * 4 + g) * 64 + lane) * 16);
             const uint32_t kk = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds + EP_HK) + ((stage * 4 + g) * 64 + lane) * 4);
             float d4[4] = {dv[0], dv[1], dv[2], dv[3]};
-            pq_mt(stage, 0, ps, d4, kk & 15u, (kk >> 4) & 15u, carry);
+            pq_mt(stage, 0, ps, d4, kk & 15u, (kk >> 8) & 15u, carry);
         };
         ep_f32x2 hA[4], hB[4];
         load_h(hA, pos_r(0, 0));
@@ -349,13 +339,17 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         load_dy(rd, pos_r(0, 0));
         fill_dy(rd, pos_r(0, 0), 0);
         load_dy(rd, pos_r(0, 1));
-        uint32_t keep_q = 0;                                // Q mask of the previous item
+        // the Q mask of an item = the signs of x(t - d) at this lane's row and samples: W wave g holds those rows for the weight gradients and
+        // leaves the bits in LDS (a load of the rows in the output layout here costs the launch 3 us)
+        auto q_keep = [&](int par) __attribute__((always_inline)) {
+            return (*reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds + EP_HK) + ((par * 4 + g) * 64 + lane) * 4) >> 8) & 255u;
+        };
         __syncthreads();                                    // stage 0 operands of the first item, the weights, the zeros
         auto r_body = [&](const int it, ep_f32x2* hr) {
             if (it >= n_items) {
                 // the void item that pads an odd count: only the Q rows (CHAIN: the first half of dx) of the last real item
                 if (CHAIN) mt_r((it + 1) & 1, pos_r(it, -1));
-                else pq_half((it + 1) & 1, 1, pos_r(it, -1), nullptr, keep_q);
+                else pq_half((it + 1) & 1, 1, pos_r(it, -1), nullptr, q_keep((it + 1) & 1));
                 win_advance();
                 __syncthreads();
                 return;
@@ -366,8 +360,7 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
             if (CHAIN) {
                 mt_r((it + 1) & 1, pos_r(it, -1));           // the first half of dx of the previous item
             } else {
-                pq_half((it + 1) & 1, 1, pos_r(it, -1), nullptr, keep_q);   // Q rows of the previous item
-                keep_q = load_xm(p_cur);                     // (waited for at the next item's store)
+                pq_half((it + 1) & 1, 1, pos_r(it, -1), nullptr, q_keep((it + 1) & 1));   // Q rows of the previous item
             }
             const int tl = p_cur.t0 + 2 * c;
             uint16_t* st = lds + (size_t)(it & 1) * EP_STAGE;
@@ -420,7 +413,7 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
             const Pos pl = pos_r(n_even, -1);
             if (pl.live) {                                      // Q rows (CHAIN: the first half of dx) of the last item
                 if (CHAIN) mt_r((n_even - 1) & 1, pl);
-                else pq_half((n_even - 1) & 1, 1, pl, nullptr, keep_q);
+                else pq_half((n_even - 1) & 1, 1, pl, nullptr, q_keep((n_even - 1) & 1));
             }
         }
         __syncthreads();                                    // the W waves' extra round (products of the last item)
@@ -466,7 +459,7 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         for (int jj = 0; jj < 8; ++jj) {
             const float v = r.x0[jj >> 2][jj & 3];
             w[jj] = ps.live ? fmaxf(v, 0.f) : 0.f;
-            if (CHAIN) keepb |= v > 0.f ? 1u << jj : 0u;
+            keepb |= v > 0.f ? 1u << jj : 0u;
         }
         to_frag(o.x0, w);
         o.keepb = keepb;
@@ -490,11 +483,12 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
             }
         }
         to_frag(o.dy, o.dy32);
-        if (CHAIN) {                                            // the R waves' residual term and masks (samples 0..15), parity of the item
+        // what R wave g needs of these rows for the same lane, parity of the item: the ReLU signs of x(t) / x(t - d) (its Q mask; CHAIN:
+        // the masks of samples 0..15 of dx) and, CHAIN, the fp32 dy rows of samples 0..15 (the residual term)
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds + EP_HK) + ((par * 4 + g) * 64 + lane) * 4) = o.keep | (o.keepb << 8);
+        if (CHAIN)
             *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds + EP_HD) + ((par * 4 + g) * 64 + lane) * 16) =
                 f32x4{o.dy32[0], o.dy32[1], o.dy32[2], o.dy32[3]};
-            *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds + EP_HK) + ((par * 4 + g) * 64 + lane) * 4) = (o.keep & 15u) | ((o.keepb & 15u) << 4);
-        }
     };
     auto load_tile = [&](Frag<BF16>& f, const uint16_t* base, int tile) {
         const u32x4* p = reinterpret_cast<const u32x4*>(base + tile * 1024 + tile_rd);
@@ -537,7 +531,7 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
                 }
             }
         }
-        if (CHAIN) pq_mt(stage, 1, ps, o.dy32 + 4, o.keep >> 4, o.keepb >> 4, carry_w);      // samples 16..31 of dx
+        if (CHAIN) pq_mt(stage, 1, ps, o.dy32 + 4, (o.keep >> 4) & 15u, (o.keepb >> 4) & 15u, carry_w);      // samples 16..31 of dx
         else pq_half(stage, 0, ps, o.dy32, o.keep);
     };
 
