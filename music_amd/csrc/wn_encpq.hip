@@ -427,12 +427,14 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
 
     // raw rows of this wave's row tile: lane (row c, q) holds samples t0 + 4q .. + 3 and t0 + 16 + 4q .. + 3
     struct RawRows { f32x4 x0[2], x1[2], p[2], qq[2]; };
-    auto load_rows = [&](RawRows& r, Pos ps) {
+    // CHAIN: the x(t) rows of an item that continues its chain ARE the x(t - d) rows of the item before it (the chain steps d columns down):
+    // only a chain's first item and the workgroup's first item request them (`fresh`); the others take the previous item's x0 rows
+    auto load_rows = [&](RawRows& r, Pos ps, bool fresh) {
         const size_t ro = ps.live ? (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q : 0;
         const int dd = ps.live ? a.d : 0, dn = ps.live ? a.dn : 0, h = ps.live ? 16 : 0;
         const float* xr = a.x_in + ro;
         r.x0[0] = ld4u(xr - dd); r.x0[1] = ld4u(xr - dd + h);
-        r.x1[0] = ld4u(xr); r.x1[1] = ld4u(xr + h);
+        if (!CHAIN || fresh) { r.x1[0] = ld4u(xr); r.x1[1] = ld4u(xr + h); }
         r.p[0] = ld4u(a.p_in + ro); r.p[1] = ld4u(a.p_in + ro + h);
         if (HAS_Q) { r.qq[0] = ld4u(q_or_p + ro + dn); r.qq[1] = ld4u(q_or_p + ro + dn + h); }
         else { r.qq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; r.qq[1] = r.qq[0]; }
@@ -452,7 +454,8 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         f.hi = __builtin_bit_cast(bf16x8, fh);
         f.lo = __builtin_bit_cast(bf16x8, fl);
     };
-    auto convert = [&](Ops& o, const RawRows& r, Pos ps, int par) {
+    f32x4 prev_x0[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto convert = [&](Ops& o, const RawRows& r, Pos ps, int par, bool fresh) {
         float w[8];
         uint32_t keepb = 0;
 #pragma unroll
@@ -466,11 +469,12 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         uint32_t keep = 0;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-            const float v = r.x1[jj >> 2][jj & 3];
+            const float v = (!CHAIN || fresh) ? r.x1[jj >> 2][jj & 3] : prev_x0[jj >> 2][jj & 3];
             w[jj] = ps.live ? fmaxf(v, 0.f) : 0.f;
             keep |= v > 0.f ? 1u << jj : 0u;
         }
         to_frag(o.x1, w);
+        if (CHAIN) { prev_x0[0] = r.x0[0]; prev_x0[1] = r.x0[1]; }
         o.keep = keep;
         if (interior(ps)) {
 #pragma unroll
@@ -538,9 +542,9 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
     {
         RawRows rr, rr2;                                    // raw rows of items it / it+1: requested two items ahead
         Ops ops;
-        load_rows(rr, pos_r(0, 0));
-        load_rows(rr2, pos_r(0, 1));
-        convert(ops, rr, pos_r(0, -1), 1);                  // "item -1": zeros (its products meet the zeroed tiles of stage 1)
+        load_rows(rr, pos_r(0, 0), true);
+        load_rows(rr2, pos_r(0, 1), pos_r(0, 1).top);
+        convert(ops, rr, pos_r(0, -1), 1, true);            // "item -1": zeros (its products meet the zeroed tiles of stage 1)
         __syncthreads();
         // iteration it: products of item it-1 (result tiles of stage (it-1)&1, operands in `ops`); then the raw rows of
         // item it become `ops` and the rows of item it+2 are requested (loop unrolled by two: no register copies)
@@ -548,8 +552,8 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         // vector phase - is SLOWER here, round 4: encoder stack backward 1.64 against 1.57 ms at config 4, three alternations)
         auto w_body = [&](const int it, RawRows& r) {
             products((it + 1) & 1, ops, pos_r(it, -1));
-            convert(ops, r, pos_r(it, 0), it & 1);
-            load_rows(r, pos_r(it, 2));
+            convert(ops, r, pos_r(it, 0), it & 1, it == 0 || pos_r(it, 0).top);
+            load_rows(r, pos_r(it, 2), pos_r(it, 2).top);
             win_advance();
             __syncthreads();
         };
