@@ -644,12 +644,15 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
     struct PqU32U { uint32_t v; } __attribute__((packed, aligned(1)));
     struct RawRows { f32x4 x0[2], x1[2], p[2], qq[2]; uint32_t bk[2]; };
     const bool do_c = COND && a.cslab != nullptr;
-    auto load_rows = [&](RawRows& r, Pos ps) {
+    // CHAIN: the x(t) rows of an item that continues its chain ARE the x(t - d) rows of the item before it (the chain steps d columns down): only
+    // a chain's first item and the workgroup's first item request them (`fresh`); for the others w_body copies the previous item's x0 rows
+    // (16-byte loads in this layout touch 16 cache lines per wave: wn_encpq.hip)
+    auto load_rows = [&](RawRows& r, Pos ps, bool fresh) {
         const size_t ro = ps.live ? (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 4 * q : 0;
         const int dd = ps.live ? a.d : 0, dn = ps.live ? a.dn : 0, h = ps.live ? 16 : 0;
         const float* xr = a.x_in + ro;
         r.x0[0] = ld4u(xr - dd); r.x0[1] = ld4u(xr - dd + h);
-        r.x1[0] = ld4u(xr); r.x1[1] = ld4u(xr + h);
+        if (!CHAIN || fresh) { r.x1[0] = ld4u(xr); r.x1[1] = ld4u(xr + h); }
         if (HAS_DY) {
             r.p[0] = PQ_LD4(p_or_x, ro); r.p[1] = PQ_LD4(p_or_x, ro + h);
             if (QIN) { r.qq[0] = PQ_LD4(q_or_x, ro + dn); r.qq[1] = PQ_LD4(q_or_x, ro + dn + h); }
@@ -809,8 +812,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         RawRows rr, rr2;                                    // raw rows of items it / it+1: requested two items ahead
         Ops ops;                                            // (one item ahead: 1.968 vs 1.941 ms for the stack; the conditioned
         constexpr int WD = COND ? 1 : 2;                    // form does that and spends the 32 registers on its bucket sums)
-        load_rows(rr, pos_r(0, 0));
-        if (WD == 2) load_rows(rr2, pos_r(0, 1));
+        load_rows(rr, pos_r(0, 0), true);
+        if (WD == 2) load_rows(rr2, pos_r(0, 1), pos_r(0, 1).top);
         convert(ops, rr, pos_r(0, -1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
         __syncthreads();
         // iteration it: products of item it-1 (result tiles of stage (it-1)&1, operands in `ops`); then the raw rows of
@@ -818,12 +821,17 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         // (the conditioned form and the pair-fed chain form have no registers for it; forced on the conditioned form, 12 spilled registers
         // instead of 9: decoder stack backward 2.12 against 2.14 ms at config 4, inside the spread)
         constexpr bool WMID = !COND && !(CHAIN && QIN && HAS_DY);
-        auto w_body = [&](const int it, RawRows& rr) {
+        auto w_body = [&](const int it, RawRows& rr, RawRows& rn) {
+            // (rn: the rows of item it + 1; when that item continues the chain its x(t) rows are this item's x(t - d) rows)
+            auto hand_x = [&]() __attribute__((always_inline)) {
+                if (CHAIN && WD == 2 && !pos_r(it, 1).top) { rn.x1[0] = rr.x0[0]; rn.x1[1] = rr.x0[1]; }
+            };
             products((it + 1) & 1, ops, pos_r(it, -1));
             if (!WMID) {
                 pq_w((it + 1) & 1, ops.dy32, pos_r(it, -1));      // rounds 2-4's order: weight gradients, dx product, conversion
                 convert(ops, rr, pos_r(it, 0));
-                load_rows(rr, pos_r(it, WD));
+                hand_x();
+                load_rows(rr, pos_r(it, WD), WD == 1 || pos_r(it, WD).top);
             } else {
                 // the row conversion BETWEEN the weight gradients and the dx product: vector work beside the R waves' recompute MFMAs,
                 // the product's MFMAs beside their gate phase (the other order pairs matrix with matrix and vector with vector)
@@ -831,7 +839,8 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) dyk[jj] = (jj >= (CHAIN ? 4 : 0)) ? ops.dy32[jj] : 0.f;
                 convert(ops, rr, pos_r(it, 0));
-                load_rows(rr, pos_r(it, WD));
+                hand_x();
+                load_rows(rr, pos_r(it, WD), WD == 1 || pos_r(it, WD).top);
                 pq_w((it + 1) & 1, dyk, pos_r(it, -1));
             }
 
@@ -839,7 +848,7 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
             __syncthreads();
         };
         const int n_even = (n_items + 1) & ~1;
-        for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, WD == 1 ? rr : rr2); }
+        for (int it = 0; it < n_even; it += 2) { w_body(it, rr, WD == 1 ? rr : rr2); w_body(it + 1, WD == 1 ? rr : rr2, rr); }
         if (pos_r(n_even, -1).live) {                        // the last item, unless it is the void one
             products((n_even - 1) & 1, ops, pos_r(n_even, -1));
             pq_w((n_even - 1) & 1, ops.dy32, pos_r(n_even, -1));
