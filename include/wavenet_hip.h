@@ -135,7 +135,10 @@ int wn_enc_resblock_bwd_slabs(int t_lo, int t_hi, int batch);
  * wn_resblock_bwd_pq - a workgroup walks the items of one residue class downwards in time and carries the Q rows in registers, dx
  * leaves the launch WHOLE in p_out (valid on [t_lo - d, t_hi)), q_out is not touched (may be NULL); the block below takes it as a
  * plain tensor (q_in = NULL, p_lo = this launch's t_lo - d).  4 activation tensors per block instead of 6: the launch is bound by
- * its bytes (profiles/r05_ab_enc_noq.json). */
+ * its bytes (profiles/r05_ab_enc_noq.json).
+ * chain == 2 (1 <= d < 32; slabs = wn_resblock_bwd_pq_slabs(t_lo, t_hi, batch, 32, 1)): the same hand-over for the small dilations - the
+ * workgroups walk ADJACENT items downwards (the chain plan of d = 32) and an item's Q rows reach the dx rows of the same and of the next
+ * item through LDS; dx whole in p_out on [t_lo - d, t_hi) as above. */
 int wn_enc_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_in, int dn, int p_lo, const float* h,
                            float* p_out, float* q_out, int64_t x_bstride, int64_t h_bstride, int pitch, const uint16_t* wdT,
                            const uint16_t* wpq, int ch, int d, int t_lo, int t_hi, float* slab_dil, float* slab_d, int chain,

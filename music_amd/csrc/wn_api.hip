@@ -280,7 +280,7 @@ int wn_enc_resblock_bwd_pq(const float* x_in, const float* p_in, const float* q_
     memset(&a, 0, sizeof(a));
     a.x_in = x_in; a.p_in = p_in; a.q_in = q_in; a.dn = q_in ? dn : 0; a.p_lo = p_lo; a.h = h; a.h_bstride = h_bstride;
     a.p_out = p_out; a.q_out = q_out; a.x_bstride = x_bstride; a.pitch = pitch; a.wdT = wdT; a.wpq = wpq;
-    a.slab_dil = slab_dil; a.slab_d = slab_d; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.chain = chain ? 1 : 0;
+    a.slab_dil = slab_dil; a.slab_d = slab_d; a.d = d; a.t_lo = t_lo; a.t_hi = t_hi; a.chain = chain == 2 ? 2 : chain ? 1 : 0;
     return wn_launch_enc_bwd_pq(a, ch, batch, mode_bwd, (hipStream_t)stream);
 }
 int wn_resblock_bwd_ms_slabs(int t_lo, int t_hi, int batch) { return wn_resms_slabs(t_lo, t_hi, batch); }

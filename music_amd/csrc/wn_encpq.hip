@@ -37,7 +37,11 @@
 // CHAIN form: what the W waves hand the R waves per item (two parities): their fp32 dy rows of samples 0..15 and the ReLU signs of x(t) / x(t-d)
 #define EP_HD (EP_W + 16384)                               // [parity][wave g][lane] f32x4
 #define EP_HK (EP_HD + 4096)                               // [parity][wave g][lane] uint32: keep | keepb << 4
-#define EP_LDS_HALFS (EP_HK + 1024)
+// LCH form: the unmasked Q rows of the last three items, fp32 [slot][channel][32 samples + 4] (9 KB each)
+#define EP_QB (EP_HK + 1024)
+#define EP_QROW 36
+#define EP_LDS_HALFS_CHAIN (EP_HK + 1024)
+#define EP_LDS_HALFS (EP_QB + 3 * EP_CH * EP_QROW * 2)
 
 typedef float ep_f32x2 __attribute__((ext_vector_type(2)));
 typedef short ep_s16x4 __attribute__((ext_vector_type(4)));
@@ -52,8 +56,11 @@ __device__ __forceinline__ void ep_split2(float a, float b, uint32_t& hi, uint32
 // chunk swizzle of the result tiles (wn_respq.hip): 16-byte chunk `ch` (8 positions) of row `r` sits at slot 16*ch + (r ^ K[ch])
 __device__ __forceinline__ int ep_k(int ch) { return ch == 0 ? 0 : ch == 1 ? 13 : ch == 2 ? 6 : 11; }
 
-template <bool HAS_Q, bool CHAIN>
+// FORM 0: the (P, Q) pair; 1: CHAIN (d a multiple of 32, Q rows carried in registers); 2: LCH (d < 32: a workgroup walks ADJACENT items
+// downwards - the chain plan of d = 32 - and the Q rows of an item reach the dx rows of the same and the next item through LDS)
+template <bool HAS_Q, int FORM>
 __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
+    constexpr bool CHAIN = FORM != 0, LCH = FORM == 2;
     constexpr int CH = EP_CH;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -252,6 +259,98 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
     // rows carried from the item above), then this item's Q rows become the carry; the last item of a chain leaves its carry d columns
     // further down (dx on [t_lo - d, t_base): nothing but the masked Q).  A halo item only makes the carry.  keep4 / keepb4: the ReLU
     // masks of the lane's four samples at x(t) / x(t - d).
+    // the P and Q sums of the 16-sample tile `mt` (both weight halves), nothing added, nothing masked
+    auto pq_mt_acc = [&](int stage, int mt, f32x4& sP, f32x4& sQ) __attribute__((always_inline)) {
+        const uint16_t* tt = lds + (size_t)stage * EP_STAGE + EP_T;
+        const uint16_t* pw = lds + EP_W;
+        f32x4 aP[2], aQ[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            aP[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            aQ[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            Frag<BF16> w1, w0;
+            load_a<BF16, 3>(w1, pw, g * 2 + s, lane);
+            load_a<BF16, 3>(w0, pw, (4 + g) * 2 + s, lane);
+            const uint16_t* tb = tt + (2 * s + (q >> 1)) * 1024;
+            typedef __attribute__((address_space(3))) ep_s16x4 lds_s16x4;
+            ep_s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[0] + 4 * mt));
+            ep_s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + tr_off[1] + 4 * mt));
+            ep_s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[0] + 4 * mt));
+            ep_s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + 512 + tr_off[1] + 4 * mt));
+            ep_s16x8 hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            ep_s16x8 ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            Frag<BF16> ad;
+            ad.hi = __builtin_bit_cast(bf16x8, hh);
+            ad.lo = __builtin_bit_cast(bf16x8, ll);
+            aP[s] = BF16::mfma(ad.lo, w1.hi, aP[s]);
+            aQ[s] = BF16::mfma(ad.lo, w0.hi, aQ[s]);
+            aP[s] = BF16::mfma(ad.hi, w1.lo, aP[s]);
+            aQ[s] = BF16::mfma(ad.hi, w0.lo, aQ[s]);
+            aP[s] = BF16::mfma(ad.hi, w1.hi, aP[s]);
+            aQ[s] = BF16::mfma(ad.hi, w0.hi, aQ[s]);
+        }
+        sP = aP[0] + aP[1];
+        sQ = aQ[0] + aQ[1];
+    };
+    // ---- LCH (d < 32, adjacent items walked downwards): each role takes ONE 16-sample tile of an item (R waves tile 0, W waves tile 1) -
+    // its P and Q sums, the Q sums to LDS (slot = item index mod 3), and an iteration later, when both tiles' Q rows of that item and
+    // of the item above are there, its tile of dx[s] = dy[s] + [x(s) > 0] (P[s] + Q[s + d]).  A chain's last item also owns the columns
+    // below it: dx[s] = [x(s) > 0] Q[s + d] on [t_lo - d, t_base).
+    struct LchHold { f32x4 p; float dy4[4]; uint32_t keep4; Pos ps; };
+    auto lch_put = [&](int k, int mt, const f32x4& sQ) __attribute__((always_inline)) {
+        float* qb = reinterpret_cast<float*>(lds + EP_QB) + ((size_t)(((k % 3) + 3) % 3) * CH + 16 * g + c) * EP_QROW + 16 * mt + 4 * q;
+        *reinterpret_cast<f32x4*>(qb) = sQ;
+    };
+    auto lch_dx = [&](int k, int mt, const LchHold& h) __attribute__((always_inline)) {      // tile mt of dx of item k (held in h)
+        const Pos ps = h.ps;
+        if (!ps.live || ps.halo) return;
+        const float* qbase = reinterpret_cast<const float*>(lds + EP_QB);
+        const float* q_own = qbase + ((size_t)(((k % 3) + 3) % 3) * CH + 16 * g + c) * EP_QROW;
+        const float* q_abv = qbase + ((size_t)((((k - 1) % 3) + 3) % 3) * CH + 16 * g + c) * EP_QROW;
+        float* out = a.p_out + (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + ps.t0 + 16 * mt + 4 * q;
+        const int tq = ps.t0 + 16 * mt + 4 * q;
+        // Q[s + d] of the lane's four samples: position jd0 .. jd0 + 3 counted from this item's first column, out of the item's own slot or,
+        // beyond 32, the slot of the item above (a chain's first item has none).  One 16-byte read when d is a multiple of 4 (the four sit
+        // on one side of the boundary), two 8-byte reads for an even d, four 4-byte reads otherwise (those hit 8 banks: 8-way conflicts)
+        const int jd0 = 16 * mt + 4 * q + a.d;
+        f32x4 qv4;
+        if ((a.d & 3) == 0) {
+            const float* src = jd0 < EP_COLS ? q_own + jd0 : q_abv + (jd0 - EP_COLS);
+            qv4 = *reinterpret_cast<const f32x4*>(src);
+            if (jd0 >= EP_COLS && ps.top) qv4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if ((a.d & 1) == 0) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int jd = jd0 + 2 * hh;
+                const float* src = jd < EP_COLS ? q_own + jd : q_abv + (jd - EP_COLS);
+                ep_f32x2 t2 = *reinterpret_cast<const ep_f32x2*>(src);
+                if (jd >= EP_COLS && ps.top) t2 = ep_f32x2{0.f, 0.f};
+                qv4[2 * hh] = t2[0];
+                qv4[2 * hh + 1] = t2[1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int jd = jd0 + i;
+                qv4[i] = jd < EP_COLS ? q_own[jd] : (ps.top ? 0.f : q_abv[jd - EP_COLS]);
+            }
+        }
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (((h.keep4 >> i) & 1u) ? h.p[i] + qv4[i] : 0.f) + h.dy4[i];
+        if (ps.t0 + EP_COLS <= a.t_hi && ps.t0 >= a.t_lo - a.d) *reinterpret_cast<f32x4*>(out) = v;
+        else st4m(out, v, tq, a.t_lo - a.d, a.t_hi);
+        if (ps.bot) {                                           // the columns below the chain: nothing but the masked Q of this item
+            const f32x4 xv = ld4u(a.x_in + (size_t)ps.b * a.x_bstride + (size_t)(16 * g + c) * a.pitch + tq - EP_COLS);
+            f32x4 vb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int jd = 16 * mt + 4 * q + i + a.d - EP_COLS;     // Q[s + d] for s = t0 - 32 + (16 mt + 4q + i)
+                vb[i] = (jd >= 0 && xv[i] > 0.f) ? q_own[jd] : 0.f;
+            }
+            st4m(out - EP_COLS, vb, tq - EP_COLS, a.t_lo - a.d, a.t_lo);
+        }
+    };
     auto pq_mt = [&](int stage, int mt, Pos ps, const float* dy4, uint32_t keep4, uint32_t keepb4, f32x4& carry) __attribute__((always_inline)) {
         if (!ps.live) return;
         const uint16_t* tt = lds + (size_t)stage * EP_STAGE + EP_T;
@@ -332,6 +431,28 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
             float d4[4] = {dv[0], dv[1], dv[2], dv[3]};
             pq_mt(stage, 0, ps, d4, kk & 15u, (kk >> 8) & 15u, carry);
         };
+        // LCH: tile 0 of an item - products, Q to LDS, and the item before it gets its dx tile; the residual rows and masks of that tile
+        // come from W wave g (EP_HD / EP_HK of the item's parity), read one iteration before they are used (the parity is rewritten then)
+        LchHold hold_r;
+        hold_r.p = f32x4{0.f, 0.f, 0.f, 0.f};
+        hold_r.keep4 = 0;
+        hold_r.ps = pos_r(0, -1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hold_r.dy4[i] = 0.f;
+        auto lch_r = [&](int stage, Pos ps, int k) __attribute__((always_inline)) {      // k = index of the item in `stage`
+            f32x4 sP = {0.f, 0.f, 0.f, 0.f}, sQ;
+            if (ps.live) {
+                pq_mt_acc(stage, 0, sP, sQ);
+                lch_put(k, 0, sQ);
+            }
+            lch_dx(k - 1, 0, hold_r);
+            hold_r.p = sP;
+            hold_r.ps = ps;
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds + EP_HD) + ((stage * 4 + g) * 64 + lane) * 16);
+            hold_r.keep4 = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds + EP_HK) + ((stage * 4 + g) * 64 + lane) * 4) & 15u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hold_r.dy4[i] = dv[i];
+        };
         ep_f32x2 hA[4], hB[4];
         load_h(hA, pos_r(0, 0));
         load_h(hB, pos_r(0, 1));
@@ -348,7 +469,8 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         auto r_body = [&](const int it, ep_f32x2* hr) {
             if (it >= n_items) {
                 // the void item that pads an odd count: only the Q rows (CHAIN: the first half of dx) of the last real item
-                if (CHAIN) mt_r((it + 1) & 1, pos_r(it, -1));
+                if (LCH) lch_r((it + 1) & 1, pos_r(it, -1), it - 1);
+                else if (CHAIN) mt_r((it + 1) & 1, pos_r(it, -1));
                 else pq_half((it + 1) & 1, 1, pos_r(it, -1), nullptr, q_keep((it + 1) & 1));
                 win_advance();
                 __syncthreads();
@@ -357,7 +479,9 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
             fill_dy(rd, pos_r(it, 1), (it + 1) & 1);         // dy fragments of the next item
             load_dy(rd, pos_r(it, 2));
             const Pos p_cur = pos_r(it, 0);
-            if (CHAIN) {
+            if (LCH) {
+                lch_r((it + 1) & 1, pos_r(it, -1), it - 1);  // tile 0 of the previous item; dx tile 0 of the one before it
+            } else if (CHAIN) {
                 mt_r((it + 1) & 1, pos_r(it, -1));           // the first half of dx of the previous item
             } else {
                 pq_half((it + 1) & 1, 1, pos_r(it, -1), nullptr, q_keep((it + 1) & 1));   // Q rows of the previous item
@@ -411,12 +535,15 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         {
             const int n_even = (n_items + 1) & ~1;
             const Pos pl = pos_r(n_even, -1);
-            if (pl.live) {                                      // Q rows (CHAIN: the first half of dx) of the last item
+            if (LCH) {
+                lch_r((n_even - 1) & 1, pl, n_even - 1);        // (a void last item: only the dx tile of the item before it)
+            } else if (pl.live) {                               // Q rows (CHAIN: the first half of dx) of the last item
                 if (CHAIN) mt_r((n_even - 1) & 1, pl);
                 else pq_half((n_even - 1) & 1, 1, pl, nullptr, q_keep((n_even - 1) & 1));
             }
         }
         __syncthreads();                                    // the W waves' extra round (products of the last item)
+        if (LCH) lch_dx(((n_items + 1) & ~1) - 1, 0, hold_r);     // ... whose dx tile needs the W waves' Q rows of it
         return;
     }
 
@@ -434,7 +561,7 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         const int dd = ps.live ? a.d : 0, dn = ps.live ? a.dn : 0, h = ps.live ? 16 : 0;
         const float* xr = a.x_in + ro;
         r.x0[0] = ld4u(xr - dd); r.x0[1] = ld4u(xr - dd + h);
-        if (!CHAIN || fresh) { r.x1[0] = ld4u(xr); r.x1[1] = ld4u(xr + h); }
+        if (!CHAIN || LCH || fresh) { r.x1[0] = ld4u(xr); r.x1[1] = ld4u(xr + h); }
         r.p[0] = ld4u(a.p_in + ro); r.p[1] = ld4u(a.p_in + ro + h);
         if (HAS_Q) { r.qq[0] = ld4u(q_or_p + ro + dn); r.qq[1] = ld4u(q_or_p + ro + dn + h); }
         else { r.qq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; r.qq[1] = r.qq[0]; }
@@ -469,12 +596,12 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         uint32_t keep = 0;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-            const float v = (!CHAIN || fresh) ? r.x1[jj >> 2][jj & 3] : prev_x0[jj >> 2][jj & 3];
+            const float v = (!CHAIN || LCH || fresh) ? r.x1[jj >> 2][jj & 3] : prev_x0[jj >> 2][jj & 3];
             w[jj] = ps.live ? fmaxf(v, 0.f) : 0.f;
             keep |= v > 0.f ? 1u << jj : 0u;
         }
         to_frag(o.x1, w);
-        if (CHAIN) { prev_x0[0] = r.x0[0]; prev_x0[1] = r.x0[1]; }
+        if (CHAIN && !LCH) { prev_x0[0] = r.x0[0]; prev_x0[1] = r.x0[1]; }
         o.keep = keep;
         if (interior(ps)) {
 #pragma unroll
@@ -500,7 +627,8 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         f.lo = __builtin_bit_cast(bf16x8, p[64]);
     };
     f32x4 carry_w = {0.f, 0.f, 0.f, 0.f};                  // CHAIN: Q rows of samples 16..31 of the item above
-    auto products = [&](int stage, const Ops& o, Pos ps) __attribute__((always_inline)) {
+    f32x4 p_new = {0.f, 0.f, 0.f, 0.f};                     // LCH: the P sums (tile 1) of the item `products` just saw
+    auto products = [&](int stage, const Ops& o, Pos ps, int k_item) __attribute__((always_inline)) {
         const uint16_t* tt = lds + (size_t)stage * EP_STAGE + EP_T;
         if (!(CHAIN && ps.halo)) {                              // (a halo item's weight gradients belong to the workgroup above)
             // weight gradients: rows = all dh / relu(h) tiles, columns = this wave's x / dy rows; the three products of an x3
@@ -535,8 +663,28 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
                 }
             }
         }
-        if (CHAIN) pq_mt(stage, 1, ps, o.dy32 + 4, (o.keep >> 4) & 15u, (o.keepb >> 4) & 15u, carry_w);      // samples 16..31 of dx
+        if (LCH) {                                              // tile 1: products, Q to LDS; its dx tile an iteration later (w_body)
+            p_new = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ps.live) {
+                f32x4 sQ;
+                pq_mt_acc(stage, 1, p_new, sQ);
+                lch_put(k_item, 1, sQ);
+            }
+        } else if (CHAIN) pq_mt(stage, 1, ps, o.dy32 + 4, (o.keep >> 4) & 15u, (o.keepb >> 4) & 15u, carry_w);      // samples 16..31 of dx
         else pq_half(stage, 0, ps, o.dy32, o.keep);
+    };
+    LchHold hold_w;
+    hold_w.p = f32x4{0.f, 0.f, 0.f, 0.f};
+    hold_w.keep4 = 0;
+    hold_w.ps = pos_r(0, -1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hold_w.dy4[i] = 0.f;
+    auto lch_w_shift = [&](const Ops& o, Pos ps) __attribute__((always_inline)) {      // the item `products` just saw becomes the held one
+        hold_w.p = p_new;
+        hold_w.keep4 = (o.keep >> 4) & 15u;
+        hold_w.ps = ps;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hold_w.dy4[i] = o.dy32[4 + i];
     };
 
     {
@@ -551,7 +699,11 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         // (the row conversion between the weight gradients and the dx product - what pays in wn_respq.hip, whose R waves have a long
         // vector phase - is SLOWER here, round 4: encoder stack backward 1.64 against 1.57 ms at config 4, three alternations)
         auto w_body = [&](const int it, RawRows& r) {
-            products((it + 1) & 1, ops, pos_r(it, -1));
+            products((it + 1) & 1, ops, pos_r(it, -1), it - 1);
+            if (LCH) {
+                lch_dx(it - 2, 1, hold_w);                      // the item before the one `products` just saw
+                lch_w_shift(ops, pos_r(it, -1));
+            }
             convert(ops, r, pos_r(it, 0), it & 1, it == 0 || pos_r(it, 0).top);
             load_rows(r, pos_r(it, 2), pos_r(it, 2).top);
             win_advance();
@@ -559,8 +711,14 @@ __global__ __launch_bounds__(EP_THREADS) void enc_bwd_pq_k(WnEncPqArgs a) {
         };
         const int n_even = (n_items + 1) & ~1;
         for (int it = 0; it < n_even; it += 2) { w_body(it, rr); w_body(it + 1, rr2); }
-        if (pos_r(n_even, -1).live) products((n_even - 1) & 1, ops, pos_r(n_even, -1));    // the last item, unless it is the void one
+        const Pos p_last = pos_r(n_even, -1);
+        if (p_last.live) products((n_even - 1) & 1, ops, p_last, n_even - 1);    // the last item, unless it is the void one
+        if (LCH) lch_dx(n_even - 2, 1, hold_w);
         __syncthreads();
+        if (LCH && p_last.live) {                               // ... and its dx tile, once the R waves have left their Q rows of it
+            lch_w_shift(ops, p_last);
+            lch_dx(n_even - 1, 1, hold_w);
+        }
     }
 
     // ---- slabs of this workgroup (every workgroup writes them, also an idle one: zeros); layouts of enc_bwd_rw_k
@@ -586,7 +744,12 @@ int wn_launch_enc_bwd_pq(const WnEncPqArgs& a, int ch, int batch, int mode_bwd, 
     if (mode_bwd != WN_MODE_BF16X3) return wn_set_error_msg(-2, "enc_resblock_bwd_pq: bf16x3 only");
     WnEncPqArgs k = a;
     int nwg;
-    if (k.chain) {
+    if (k.chain == 2) {
+        // LCH: d < 32; the workgroups walk adjacent items downwards = the chain plan of d = 32 (one chain per clip)
+        if (a.d >= EP_COLS || a.d < 1) return wn_set_error_msg(-4, "enc_resblock_bwd_pq: chain form 2 is for 1 <= d < 32");
+        wn_pq_chain_plan(a.t_lo, a.t_hi, batch, EP_COLS, k.t_base, k.steps_per_clip, k.ch_s, k.ch_qn, k.ch_rm, k.ch_g, k.ch_nchain, nwg);
+        k.items_per_wg = 0;
+    } else if (k.chain) {
         if (!wn_pq_chain_ok(a.t_lo, a.t_hi, batch, a.d)) return wn_set_error_msg(-4, "enc_resblock_bwd_pq: chain form needs d % 32 == 0 and an item per chain");
         wn_pq_chain_plan(a.t_lo, a.t_hi, batch, a.d, k.t_base, k.steps_per_clip, k.ch_s, k.ch_qn, k.ch_rm, k.ch_g, k.ch_nchain, nwg);
         k.items_per_wg = 0;
@@ -600,18 +763,23 @@ int wn_launch_enc_bwd_pq(const WnEncPqArgs& a, int ch, int batch, int mode_bwd, 
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (done.need(dev)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_bwd_pq_k<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         done.done(dev);
     }
-    if (k.chain) {
-        if (k.q_in) hipLaunchKernelGGL((enc_bwd_pq_k<true, true>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
-        else hipLaunchKernelGGL((enc_bwd_pq_k<false, true>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
+    if (k.chain == 2) {
+        if (k.q_in) hipLaunchKernelGGL((enc_bwd_pq_k<true, 2>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
+        else hipLaunchKernelGGL((enc_bwd_pq_k<false, 2>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
+    } else if (k.chain) {
+        if (k.q_in) hipLaunchKernelGGL((enc_bwd_pq_k<true, 1>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
+        else hipLaunchKernelGGL((enc_bwd_pq_k<false, 1>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
     } else {
-        if (k.q_in) hipLaunchKernelGGL((enc_bwd_pq_k<true, false>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
-        else hipLaunchKernelGGL((enc_bwd_pq_k<false, false>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
+        if (k.q_in) hipLaunchKernelGGL((enc_bwd_pq_k<true, 0>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
+        else hipLaunchKernelGGL((enc_bwd_pq_k<false, 0>), dim3(nwg), dim3(EP_THREADS), sh, st, k);
     }
     WN_CHECK_LAUNCH();
     return 0;

@@ -534,8 +534,11 @@ class _AutoencoderEngine:
         sfx = "2_" if pair else ""                            # pair mode: the block-diagonal gradient matrices, B / 2 "clips"
         # one-launch encoder blocks whose dilation is a multiple of 32 hand dx on WHOLE (chain form of wn_enc_resblock_bwd_pq, as
         # wn_resblock_bwd_pq's in music_amd/engine.py): 4 activation tensors per block instead of 6 - the launch is bound by its bytes
+        # ... and those with d < 32 too (form 2: adjacent items walked downwards, the Q rows cross from item to item through LDS)
         want_chain = bw["enc_pq"] and os.environ.get("WN_PQ_CHAIN", "1") == "1"
-        bw["enc_chain"] = [want_chain and _lib.pq_chain_ok(self.off[i + 1], T, B // 2 if pair else B, self.dil[i]) for i in range(N)]
+        want_lch = want_chain and os.environ.get("WN_ENC_LCH", "1") == "1"
+        bw["enc_chain"] = [(1 if want_chain and _lib.pq_chain_ok(self.off[i + 1], T, B // 2 if pair else B, self.dil[i]) else
+                            2 if want_lch and self.dil[i] < 32 else 0) for i in range(N)]
         for i in range(N):
             ench = (-3 - i if bw["enc_chain"][i] else -2) if enc_fused else 512      # -3 - i: layer i in chain form (its own slab count)
             ops += [("de_fg%s%d" % (sfx, i), self.off[i + 1], T, -1 if ms else 512), ("en_dil%s%d" % (sfx, i), self.off[i + 1], T, ench),
@@ -550,7 +553,7 @@ class _AutoencoderEngine:
             Bs = B // 2 if pair and chunk < 0 else B
             ns = (_lib.wgrad_slabs(t_lo, t_hi, chunk, B) if chunk > 0 else
                   _lib.ms_slabs(t_lo, t_hi, Bs) if chunk == -1 else _lib.enc_slabs(t_lo, t_hi, Bs) if chunk == -2 else
-                  _lib.pq_slabs(t_lo, t_hi, Bs, self.dil[-3 - chunk], True))
+                  _lib.pq_slabs(t_lo, t_hi, Bs, self.dil[-3 - chunk] if bw["enc_chain"][-3 - chunk] == 1 else 32, True))
             plan[name] = (so, n, chunk)
             row_of[name] = len(desc)
             desc.append([vs, so, ns, n, go, n])
@@ -820,7 +823,7 @@ class _AutoencoderEngine:
             if bw["enc_pq"]:
                 # the whole backward of the block in one launch; dx travels as the unshifted pair (P, Q)
                 p_out, q_out = (ptr(t, SLACK) for t in bw["PQe"][i % 2])
-                chain = 1 if bw["enc_chain"][i] else 0
+                chain = bw["enc_chain"][i]
                 if i == 0 and chain:
                     p_out = dxe[0]                                # a first block in chain form hands dx_0 on whole: straight to the causal layer's buffer
                 if i < N - 1:
