@@ -220,3 +220,55 @@ def test_chain_form_equals_pair_form(monkeypatch):
         assert worst < 2e-5, worst
     monkeypatch.delenv("WN_PQ_CHAIN")
     eng._ws.clear()
+
+
+def test_encoder_block_forms_agree(monkeypatch):
+    """The autoencoder's encoder block hands dx on as the (P, Q) pair (form 0), whole by the chain walk (form 1: d % 32 == 0, Q rows in
+    registers) or whole by the walk over adjacent items (form 2: d < 32, Q rows through LDS).  WN_PQ_CHAIN=0 forces form 0 everywhere,
+    WN_ENC_LCH=0 form 0 for d < 32 only.  Same products per item, other summation orders: loss bit-identical, every gradient (the input's
+    included) within 2e-5 of its max-abs; each form reproduces its bits.  Shapes: ragged lengths with short chains and halo segments,
+    a batch of many short clips (workgroups spanning clips), every small dilation incl. d = 3 and 5 (unaligned LDS reads)."""
+    import numpy as np
+    import torch
+    from music_amd.model1 import wavenet_autoencoder
+    for dil, B, extra, seed in (([1, 2, 4, 8, 16, 32, 64, 128], 2, 1500, 3), ([3, 5, 32, 1, 64, 2], 3, 777, 4), ([16, 8, 4, 2, 1, 32], 24, 90, 5)):
+        cfg = dict(filter_width=2, quantization_channel=256, dilations=dil, en_residual_channel=64, en_dilation_channel=48,
+                   en_bottleneck_width=8, en_pool_kernel_size=25, de_residual_channel=32, de_dilation_channel=32, de_skip_channel=64,
+                   use_bias=False)
+        torch.manual_seed(seed)
+        net = wavenet_autoencoder(**cfg)
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(2.0)
+        net = net.cuda()
+        g = torch.Generator().manual_seed(seed)
+        T = net.receptive_field + extra
+        x = (torch.randn(B, 256, T, generator=g) * 0.5).cuda()
+        W = T - net.receptive_field + 1
+        target = torch.randint(0, 256, (B * W,), generator=g).cuda()
+        got = {}
+        for tag, env in (("all", {}), ("nolch", {"WN_ENC_LCH": "0"}), ("pair", {"WN_PQ_CHAIN": "0"}), ("all_b", {})):
+            for k in ("WN_ENC_LCH", "WN_PQ_CHAIN"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            if net._engine is not None:
+                net._engine._ws.clear()
+            net.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            torch.manual_seed(100 + seed)
+            loss = torch.nn.CrossEntropyLoss()(net(xi), target)
+            loss.backward()
+            torch.cuda.synchronize()
+            forms = net._engine.workspace(B, T)["bwd"]["enc_chain"]
+            want = {"all": [1 if d % 32 == 0 else 2 for d in dil], "nolch": [1 if d % 32 == 0 else 0 for d in dil], "pair": [0] * len(dil)}
+            assert [int(f) for f in forms] == want[tag.split("_")[0]], (tag, forms)
+            got[tag] = (loss.detach().clone(), [p.grad.clone() for p in net.parameters()] + [xi.grad.clone()])
+        assert torch.equal(got["all"][0], got["pair"][0]) and torch.equal(got["all"][0], got["nolch"][0])
+        assert all(torch.equal(a, b) for a, b in zip(got["all"][1], got["all_b"][1]))
+        for other in ("nolch", "pair"):
+            worst = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() for a, b in zip(got["all"][1], got[other][1]))
+            print("encoder block, shipped forms vs %s: worst gradient difference %.2e of max-abs (dilations %s, batch %d)" % (other, worst, dil, B))
+            assert worst < 2e-5, (other, worst)
+    for k in ("WN_ENC_LCH", "WN_PQ_CHAIN"):
+        monkeypatch.delenv(k, raising=False)
