@@ -649,9 +649,11 @@ def main():
     # one event per step end (enable_timing): median / min / max of the per-step GPU time
     t0 = time.perf_counter()
     step_ev[0].record()
+    host_t = [0.0] * args.steps                              # when the host had a step enqueued (ms after t0): one float store per step
     for i_ in range(args.steps):
         loss = step()
         step_ev[i_ + 1].record()
+        host_t[i_] = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -806,7 +808,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
         "ms_per_step": dt / args.steps * 1e3,
         "ms_per_step_stats": {"median": per_step[len(per_step) // 2], "min": per_step[0], "max": per_step[-1],
-                              "p90": per_step[min(len(per_step) - 1, (len(per_step) * 9) // 10)], "first_10_in_order": per_step_order[:10], **({"all_in_order": per_step_order} if args.dump_steps else {}),
+                              "p90": per_step[min(len(per_step) - 1, (len(per_step) * 9) // 10)], "first_10_in_order": per_step_order[:10], **({"all_in_order": per_step_order, "host_enqueued_at_ms": [round((t - t0) * 1e3, 2) for t in host_t]} if args.dump_steps else {}),
                               "note": "GPU time between the end-of-step HIP events of consecutive timed steps (rank 0); the interpreter's garbage collector runs before the timed region, not inside it"} if per_step else None,
         "ms_per_step_ranks": {"min": min(dt_ranks) / args.steps * 1e3, "max": max(dt_ranks) / args.steps * 1e3,
                               "all": [round(v / args.steps * 1e3, 4) for v in dt_ranks],
