@@ -445,7 +445,7 @@ int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st) {
     WnGemmArgs k = a;
     k.t_base = wn_tile_origin(a.t_lo);
     k.swz = wn_xcd_swizzle_enabled();
-    if (wn_launch_gemm_rw(k, batch, mode, st)) {
+    if (wn_launch_gemm_rw(k, batch, mode, st) || wn_launch_gemm_bst(k, batch, mode, st)) {
         WN_CHECK_LAUNCH();
         return 0;
     }

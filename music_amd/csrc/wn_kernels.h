@@ -27,6 +27,8 @@ struct WnGemmArgs {
 int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 // two-role persistent form of the narrow product (wn_gemm_rw.hip); 1 = launched, 0 = arguments not covered
 int wn_launch_gemm_rw(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
+// B-stationary persistent form of the wide product for K = 256 and >= 512 rows (wn_gemm_bst.hip); 1 = launched, 0 = not covered
+int wn_launch_gemm_bst(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 struct WnResArgs;
 int wn_launch_enc_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);   // wn_resblock2.hip (ENC)
 int wn_launch_pack(const float* flat, const int32_t* idx, uint16_t* out, int n, int is_bf16, int ns,

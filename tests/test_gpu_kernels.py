@@ -65,6 +65,69 @@ def test_chan_gemm_single_tap(mode):
     assert got[:, M - 3:].abs().sum().item() == 0
 
 
+@pytest.mark.parametrize("mode", [_lib.BF16X3, _lib.F16X3])
+@pytest.mark.parametrize("B,T,t_lo,M,m_valid,epi", [
+    (2, 1500, 37, 576, 576, "plain"),         # 24 tiles < 256 workgroups: every tile is dealt out by passes
+    (3, 12700, 3069, 576, 570, "plain"),      # 300+ tiles: whole tiles round-robin + a leftover round split by passes; partial last row tile
+    (2, 2000, 130, 768, 768, "mask+bias+relu+compact"),
+])
+def test_chan_gemm_b_stationary(mode, B, T, t_lo, M, m_valid, epi, monkeypatch):
+    """K = 256, >= 512 rows in groups of 3 row tiles: chan_gemm_bst_k (wn_gemm_bst.hip; the dZ = Ws^T dU product of
+    wavenet/model.py:127-134's backward).  Against float64, and BIT for bit against chan_gemm_wide2_k (same order of terms)."""
+    rng = np.random.default_rng(7)
+    K = 256
+    pitch = ((T + 255) // 256) * 256 + 512
+    w = rng.standard_normal((M, K)).astype(np.float32) * 0.1
+    pk = _packed(w, mode)
+    xin = _buf(B, K, pitch, 1.0, 11)
+    fancy = epi != "plain"
+    t_hi = T
+    in_lo, in_hi = (t_lo + 3, T - 5) if fancy else (t_lo, T)
+    W_out = t_hi - t_lo
+    bias = torch.from_numpy(rng.standard_normal(M).astype(np.float32)).to(DEV) if fancy else None
+    msk = _buf(B, M, pitch, 1.0, 5) if fancy else None
+
+    def run():
+        if fancy:       # compact output (column t - t_lo), mask, bias, ReLU on the input
+            out = torch.zeros(B * M * W_out + 512, device=DEV)
+            call("wn_chan_gemm", ptr(xin, SLACK), None, K * pitch, pitch, in_lo, in_hi, 0, 0, K // 32, 0, ptr(pk), M // 16, m_valid,
+                 ptr(out), M * W_out, W_out, -t_lo, ptr(bias), None, 0, 0, 0, ptr(msk, SLACK), M * pitch, pitch,
+                 t_lo, t_hi, 1, B, mode, _lib.stream())
+            torch.cuda.synchronize()
+            return out[:B * M * W_out].view(B, M, W_out).clone()
+        out = _buf(B, M, pitch)
+        call("wn_chan_gemm", ptr(xin, SLACK), None, K * pitch, pitch, in_lo, in_hi, 0, 0, K // 32, 0, ptr(pk), M // 16, m_valid,
+             ptr(out, SLACK), M * pitch, pitch, 0, None, None, 0, 0, 0, None, 0, 0, t_lo, t_hi, 0, B, mode, _lib.stream())
+        torch.cuda.synchronize()
+        return _view(out, B, M, pitch).clone()
+
+    monkeypatch.setenv("WN_GEMM_BST", "1")
+    got = run()
+    monkeypatch.setenv("WN_GEMM_BST", "0")
+    wide = run()
+    assert torch.equal(got, wide), "B-stationary and 256 x 256-tile forms differ: %g" % (got - wide).abs().max().item()
+    x = _view(xin, B, K, pitch).cpu().double()
+    if fancy:
+        x = x.clamp(min=0)
+    win = torch.zeros_like(x)
+    win[:, :, in_lo:in_hi] = x[:, :, in_lo:in_hi]
+    ref = torch.einsum("mk,bkt->bmt", torch.from_numpy(w).double(), win[:, :, t_lo:t_hi])
+    g = got.cpu().double()
+    if fancy:
+        ref = ref + bias.cpu().double()[None, :, None]
+        ref = torch.where(_view(msk, B, M, pitch).cpu().double()[:, :, t_lo:t_hi] > 0, ref, torch.zeros_like(ref))
+        gv = g
+    else:
+        gv = g[:, :, t_lo:t_hi]
+        assert g[:, :, :t_lo].abs().max().item() == 0 and g[:, :, t_hi:].abs().max().item() == 0
+    err = (gv[:, :m_valid] - ref[:, :m_valid]).abs().max().item()
+    scale = ref.abs().max().item()
+    print("mode", mode, epi, "err", err, "scale", scale)
+    assert err <= TOL[mode] * scale
+    if m_valid < M:
+        assert gv[:, m_valid:].abs().sum().item() == 0
+
+
 def test_chan_gemm_two_taps_epilogues():
     mode = _lib.F16X3
     rng = np.random.default_rng(2)

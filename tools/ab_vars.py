@@ -15,8 +15,11 @@ BENCH = "c2"
 def run(var, kreps, extra_env):
     env = dict(os.environ)
     env.update(extra_env)
-    if ":" in var:                                   # "name:ENV=VAL[;ENV=VAL]": the shipped library under these switches
+    if ":" in var:                                   # "name:ENV=VAL[;ENV=VAL]": the shipped library (or the variant `name`, if built) under these switches
         env.update(dict(kv.split("=", 1) for kv in var.split(":", 1)[1].split(";")))
+        lib = os.path.join(ROOT, "tools", "_var_%s.so" % var.split(":", 1)[0])
+        if os.path.exists(lib):
+            env["WAVENET_HIP_LIB"] = lib
     elif var != "shipped":
         env["WAVENET_HIP_LIB"] = os.path.join(ROOT, "tools", "_var_%s.so" % var)
     if BENCH == "ae":                                # config 4: tools/ae_phases.py prints "X ms/step; phase ms, ..."
