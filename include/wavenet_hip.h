@@ -42,7 +42,7 @@ extern "C" {
 
 typedef void* wn_stream_t;                 /* hipStream_t */
 enum { WN_F16X3 = 0, WN_F16X1 = 1, WN_BF16X3 = 2, WN_BF16X1 = 3 };
-#define WN_ABI_VERSION 4
+#define WN_ABI_VERSION 5
 #define WN_CE_NUM_PARTIALS 1024
 
 int wn_version(void);
@@ -104,6 +104,20 @@ int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* 
                     const float* bias_g, int n_f, int ch, int d, int t_lo, int t_hi, int z_lo,
                     const float* cond, int64_t cond_bstride, int cond_pitch, int cond_mode, int cond_le, int cond_q,
                     int batch, int mode_fwd, int mode_bwd, wn_stream_t stream);
+
+/* The forward epilogue in ONE launch (ABI v5; replaces the skip 1x1 convs + Python sum, F.relu, post_process_1, F.relu,
+ * post_process_2 of wavenet/model.py:127-138 - three wn_chan_gemm launches):  per tile of 128 columns
+ *   u = bias_skip + Ws z ;  h = bias_p1 + P1 relu(u) ;  o = bias_p2 + P2 relu(h)        on [t_lo, t_hi)
+ * z: the z-crops of all blocks stacked on the channel axis, [B][32 ks_skip][pitch] (ks_skip even), valid on [t_lo, t_hi) (columns
+ * outside read as 0 and are never dereferenced).  u, h: [B][256][pitch] (s_bstride floats per clip; rows >= s_valid are not written) -
+ * the backward masks with them.  o: compact [B][256][o_pitch], column t - t_lo (the reference's pre-softmax memory order).
+ * w_skip: packed [16][ks_skip], natural k.  w_p1c / w_p2c: packed [16][8] in the CHAINED k order (the u / h tile is handed from
+ * product to product out of the accumulators, like wn_resblock_fwd's dense weights).  At most 256 skip and 256 quantisation
+ * channels; x3 modes.  Biases may be NULL. */
+int wn_skip_epilogue_fwd(const float* z, int64_t z_bstride, int pitch, int ks_skip, const uint16_t* w_skip, const float* bias_skip,
+                         float* u, float* h, int64_t s_bstride, const uint16_t* w_p1c, const float* bias_p1,
+                         const uint16_t* w_p2c, const float* bias_p2, float* o, int64_t o_bstride, int o_pitch,
+                         int s_valid, int q_valid, int t_lo, int t_hi, int batch, int mode, wn_stream_t stream);
 
 /* Encoder block of the autoencoder, forward (wavenet_autoencoder/model1.py:137-152 for one dilation d), one launch:
  *   h = Wdil [relu x(t-d); relu x(t)] (+ bias_dil) ; x_out = Wd relu(h) (+ bias_d) + x(t)   on [t_lo, t_hi);

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("WAVENET_HIP_LIB") or os.path.join(_HERE, "libwavenet_
 F16X3, F16X1, BF16X3, BF16X1 = 0, 1, 2, 3
 MODE_NAMES = {"f16x3": F16X3, "f16x1": F16X1, "bf16x3": BF16X3, "bf16x1": BF16X1}
 CE_NUM_PARTIALS = 1024
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -28,6 +28,7 @@ SIGNATURES = {
                      _p, _l, _i, _i,
                      _p, _l, _i,
                      _i, _i, _i, _i, _i, _p],
+    "wn_skip_epilogue_fwd": [_p, _l, _i, _i, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i,
                         _i, _i, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l, _i, _i, _p],
     "wn_enc_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],

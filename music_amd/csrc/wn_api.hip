@@ -75,6 +75,22 @@ int wn_chan_gemm(const float* in0, const float* in1, int64_t in_bstride, int in_
     return wn_launch_gemm(a, batch, mode, (hipStream_t)stream);
 }
 
+int wn_skip_epilogue_fwd(const float* z, int64_t z_bstride, int pitch, int ks_skip, const uint16_t* w_skip, const float* bias_skip,
+                         float* u, float* h, int64_t s_bstride, const uint16_t* w_p1c, const float* bias_p1,
+                         const uint16_t* w_p2c, const float* bias_p2, float* o, int64_t o_bstride, int o_pitch,
+                         int s_valid, int q_valid, int t_lo, int t_hi, int batch, int mode, wn_stream_t stream) {
+    if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_skip_epilogue_fwd: pitch must be a multiple of 4");
+    if (s_valid <= 0 || s_valid > 256 || q_valid <= 0 || q_valid > 256)
+        return wn_set_error_msg(-4, "wn_skip_epilogue_fwd: at most 256 skip and 256 quantisation channels (wn_chan_gemm covers the rest)");
+    if (batch > 0 && t_hi > t_lo) WN_REQUIRE("wn_skip_epilogue_fwd", z, w_skip, u, h, w_p1c, w_p2c, o);
+    WnEpiFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.z = z; a.z_bstride = z_bstride; a.pitch = pitch; a.ks_skip = ks_skip; a.w_skip = w_skip; a.bias_s = bias_skip;
+    a.u = u; a.h = h; a.s_bstride = s_bstride; a.w_p1c = w_p1c; a.bias_1 = bias_p1; a.w_p2c = w_p2c; a.bias_2 = bias_p2;
+    a.o = o; a.o_bstride = o_bstride; a.o_pitch = o_pitch; a.s_valid = s_valid; a.q_valid = q_valid; a.t_lo = t_lo; a.t_hi = t_hi;
+    return wn_launch_skip_epilogue_fwd(a, batch, mode, (hipStream_t)stream);
+}
+
 int wn_enc_resblock_fwd(const float* x_in, float* x_out, float* h_out, int64_t x_bstride, int64_t h_bstride, int pitch,
                         const uint16_t* wdil, const uint16_t* wd, const float* bias_dil, const float* bias_d, int n_h,
                         int n_d, int ch, int d, int t_lo, int t_hi, int batch, int mode, wn_stream_t stream) {

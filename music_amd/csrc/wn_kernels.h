@@ -29,6 +29,19 @@ int wn_launch_gemm(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 int wn_launch_gemm_rw(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
 // B-stationary persistent form of the wide product for K = 256 and >= 512 rows (wn_gemm_bst.hip); 1 = launched, 0 = not covered
 int wn_launch_gemm_bst(const WnGemmArgs& a, int batch, int mode, hipStream_t st);
+// fused forward epilogue: skip product over the stacked z-crops -> post_process_1 -> post_process_2 per 128-column tile (wn_epilogue.hip)
+struct WnEpiFwdArgs {
+    const float* z; long z_bstride; int pitch;             // [B][32 ks_skip rows][pitch] stacked z-crops; u / h share the pitch
+    int ks_skip;                                           // 32-row k-steps of the skip product (even)
+    const uint16_t* w_skip; const float* bias_s;           // packed [16][ks_skip] (natural k), summed skip bias or null
+    float* u; float* h; long s_bstride;                    // out: pre-ReLU skip sum and post_process_1 output, [B][256][pitch]
+    const uint16_t* w_p1c; const float* bias_1;            // packed [16][8] in the CHAINED k order
+    const uint16_t* w_p2c; const float* bias_2;
+    float* o; long o_bstride; int o_pitch;                 // out: compact pre-softmax [B][256][o_pitch], column t - t_lo
+    int s_valid, q_valid;                                  // real skip / quantisation rows (<= 256)
+    int t_lo, t_hi, t_base, ntx;                           // valid columns; t_base / tiles per clip set by the launcher
+};
+int wn_launch_skip_epilogue_fwd(const WnEpiFwdArgs& a, int batch, int mode, hipStream_t st);
 struct WnResArgs;
 int wn_launch_enc_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);   // wn_resblock2.hip (ENC)
 int wn_launch_pack(const float* flat, const int32_t* idx, uint16_t* out, int n, int is_bf16, int ns,

@@ -188,6 +188,9 @@ class WaveNetEngine:
         # the forward epilogue's three products as this many per-clip-group chains, every second one on the side stream (1 = one
         # chain on the main stream; bit-identical results: tests/test_gpu_switches.py)
         self.epi_chains = 2
+        # ... or all three in ONE launch per 128-column tile (wn_skip_epilogue_fwd, round 6; 256 skip / 256 quantisation channels, x3
+        # modes; WN_EPI_FUSED=0 = the three launches above)
+        self.epi_fused = os.environ.get("WN_EPI_FUSED", "1") == "1"
         # Channel-split backward block with both weight gradients in the launch (wn_resblock_bwd_ms):
         # 64 padded channels, (f16x3, bf16x3) only; None = whenever it applies (WN_MS_BWD=0 turns it off)
         self.ms_bwd = None
@@ -336,11 +339,13 @@ class WaveNetEngine:
         w = full(SP, SP)
         w[:S, :S] = p1
         fwd.append(("p1", pack_index(w)))
+        fwd.append(("p1c", pack_index(w, chained=True)))     # chained k order: the fused forward epilogue takes relu(U) out of the accumulators
         gp.append(("p1", SP, SP))
         bwd.append(("p1T", pack_index(np.ascontiguousarray(w.T))))
         w = full(Q, SP)
         w[:, :S] = p2
         fwd.append(("p2", pack_index(w)))
+        fwd.append(("p2c", pack_index(w, chained=True)))
         gp.append(("p2", Q, SP))
         bwd.append(("p2T", pack_index(np.ascontiguousarray(w.T))))        # rows SP, K = Q
 
@@ -642,7 +647,12 @@ class WaveNetEngine:
                  ptr(ws["O"], b0 * Q * W), Q * W, W, -lo, self._bias_ptr("post_process_2.bias"),
                  None, 0, 0, 0, None, 0, 0, lo, T, 1, nb, mf, s_)
         nsplit = min(int(self.epi_chains), B)
-        if nsplit >= 2:
+        if self.epi_fused and SP == 256 and Q == 256 and (N * CH // 32) % 2 == 0 and mf in (_lib.F16X3, _lib.BF16X3):
+            # the three products in ONE launch per 128-column tile, U and H handed on chip (wn_skip_epilogue_fwd, ABI v5)
+            call("wn_skip_epilogue_fwd", ptr(ws["Z"], SLACK), zb, pitch, N * CH // 32, fr("skip"), bias_s,
+                 ptr(ws["U"], SLACK), ptr(ws["H"], SLACK), SP * pitch, fr("p1c"), self._bias_ptr("post_process_1.bias"),
+                 fr("p2c"), self._bias_ptr("post_process_2.bias"), ptr(ws["O"]), Q * W, W, self.S, Q, lo, T, B, mf, st)
+        elif nsplit >= 2:
             # the three products of each part of the clips as a chain of its own, every second chain on the side stream: a
             # product's half-empty last round of workgroups (408 tiles of 256 columns on 256 CUs) then packs into the other
             # chain's launches (0.435-0.445 vs 0.466-0.469 ms with two chains)

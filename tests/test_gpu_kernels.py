@@ -128,6 +128,68 @@ def test_chan_gemm_b_stationary(mode, B, T, t_lo, M, m_valid, epi, monkeypatch):
         assert gv[:, m_valid:].abs().sum().item() == 0
 
 
+@pytest.mark.parametrize("mode", [_lib.F16X3, _lib.BF16X3])
+@pytest.mark.parametrize("B,T,t_lo,KZ,S,Qv,bias", [(2, 1500, 37, 128, 256, 256, False), (3, 2300, 1023, 192, 250, 256, True)])
+def test_skip_epilogue_fwd_fused(mode, B, T, t_lo, KZ, S, Qv, bias):
+    """wn_skip_epilogue_fwd (wavenet/model.py:127-138 in one launch): u, h and the compact pre-softmax against float64 and against
+    the three wn_chan_gemm launches it replaces (chained vs natural k order inside an MFMA: same terms, other order)."""
+    rng = np.random.default_rng(11)
+    pitch = ((T + 255) // 256) * 256 + 512
+    ws_ = np.zeros((256, KZ), np.float32); ws_[:S] = rng.standard_normal((S, KZ)).astype(np.float32) * 0.08
+    p1 = np.zeros((256, 256), np.float32); p1[:S, :S] = rng.standard_normal((S, S)).astype(np.float32) * 0.08
+    p2 = np.zeros((256, 256), np.float32); p2[:Qv, :S] = rng.standard_normal((Qv, S)).astype(np.float32) * 0.08
+    pk_s, pk_1, pk_2 = _packed(ws_, mode), _packed(p1, mode), _packed(p2, mode)
+    pk_1c, pk_2c = _packed(p1, mode, chained=True), _packed(p2, mode, chained=True)
+    z = _buf(B, KZ, pitch, 1.0, 3)
+    bs = [torch.from_numpy(rng.standard_normal(256).astype(np.float32)).to(DEV) if bias else None for _ in range(3)]
+    W = T - t_lo
+    st = _lib.stream()
+
+    def fused():
+        u, h = _buf(B, 256, pitch), _buf(B, 256, pitch)
+        o = torch.zeros(B * 256 * W + 512, device=DEV)
+        call("wn_skip_epilogue_fwd", ptr(z, SLACK), KZ * pitch, pitch, KZ // 32, ptr(pk_s), ptr(bs[0]) if bias else None,
+             ptr(u, SLACK), ptr(h, SLACK), 256 * pitch, ptr(pk_1c), ptr(bs[1]) if bias else None, ptr(pk_2c),
+             ptr(bs[2]) if bias else None, ptr(o), 256 * W, W, S, Qv, t_lo, T, B, mode, st)
+        torch.cuda.synchronize()
+        return _view(u, B, 256, pitch).clone(), _view(h, B, 256, pitch).clone(), o[:B * 256 * W].view(B, 256, W).clone()
+
+    def three():
+        u, h = _buf(B, 256, pitch), _buf(B, 256, pitch)
+        o = torch.zeros(B * 256 * W + 512, device=DEV)
+        call("wn_chan_gemm", ptr(z, SLACK), None, KZ * pitch, pitch, t_lo, T, 0, 0, KZ // 32, 0, ptr(pk_s), 16, S, ptr(u, SLACK), 256 * pitch,
+             pitch, 0, ptr(bs[0]) if bias else None, None, 0, 0, 0, None, 0, 0, t_lo, T, 0, B, mode, st)
+        call("wn_chan_gemm", ptr(u, SLACK), None, 256 * pitch, pitch, t_lo, T, 0, 0, 8, 0, ptr(pk_1), 16, S, ptr(h, SLACK), 256 * pitch,
+             pitch, 0, ptr(bs[1]) if bias else None, None, 0, 0, 0, None, 0, 0, t_lo, T, 1, B, mode, st)
+        call("wn_chan_gemm", ptr(h, SLACK), None, 256 * pitch, pitch, t_lo, T, 0, 0, 8, 0, ptr(pk_2), 16, Qv, ptr(o), 256 * W, W, -t_lo,
+             ptr(bs[2]) if bias else None, None, 0, 0, 0, None, 0, 0, t_lo, T, 1, B, mode, st)
+        torch.cuda.synchronize()
+        return _view(u, B, 256, pitch).clone(), _view(h, B, 256, pitch).clone(), o[:B * 256 * W].view(B, 256, W).clone()
+
+    fu, fh, fo = fused()
+    tu, th, to = three()
+    zz = _view(z, B, KZ, pitch).cpu().double()[:, :, t_lo:T]
+    bb = [b_.cpu().double()[None, :, None] if bias else 0.0 for b_ in bs]
+    ru = torch.einsum("mk,bkt->bmt", torch.from_numpy(ws_).double(), zz) + bb[0]
+    rh = torch.einsum("mk,bkt->bmt", torch.from_numpy(p1).double(), ru.clamp(min=0)) + bb[1]
+    ro = torch.einsum("mk,bkt->bmt", torch.from_numpy(p2).double(), rh.clamp(min=0)) + bb[2]
+    tol = TOL[mode] * 3
+    for name, got, other, ref, rows in (("u", fu, tu, ru, S), ("h", fh, th, rh, S)):
+        g = got.cpu().double()
+        assert g[:, :, :t_lo].abs().max().item() == 0 and g[:, :, T:].abs().max().item() == 0, name
+        assert g[:, rows:].abs().sum().item() == 0, name
+        err = (g[:, :rows, t_lo:T] - ref[:, :rows]).abs().max().item()
+        dev = (g - other.cpu().double()).abs().max().item()
+        print(name, "err", err, "vs three launches", dev, "scale", ref.abs().max().item())
+        assert err <= tol * ref.abs().max().item() and dev <= tol * ref.abs().max().item()
+    g = fo.cpu().double()
+    err = (g[:, :Qv] - ro[:, :Qv]).abs().max().item()
+    dev = (g - to.cpu().double()).abs().max().item()
+    print("o err", err, "vs three launches", dev, "scale", ro.abs().max().item())
+    assert err <= tol * ro.abs().max().item() and dev <= tol * ro.abs().max().item()
+    assert g[:, Qv:].abs().sum().item() == 0
+
+
 def test_chan_gemm_two_taps_epilogues():
     mode = _lib.F16X3
     rng = np.random.default_rng(2)
