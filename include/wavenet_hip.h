@@ -119,6 +119,18 @@ int wn_skip_epilogue_fwd(const float* z, int64_t z_bstride, int pitch, int ks_sk
                          const uint16_t* w_p2c, const float* bias_p2, float* o, int64_t o_bstride, int o_pitch,
                          int s_valid, int q_valid, int t_lo, int t_hi, int batch, int mode, wn_stream_t stream);
 
+/* The backward of that epilogue, data gradients, in ONE launch (ABI v5; autograd of wavenet/model.py:127-138 - three
+ * wn_chan_gemm launches):  per tile of 128 columns
+ *   dh = (P2^T d_o) * [h > 0] ;  du = (P1^T dh) * [u > 0] ;  dz = Ws^T du        on [t_lo, t_hi)
+ * d_o: compact [B][256][o_pitch], column t - t_lo (d loss / d pre-softmax).  h, u: the forward's tensors (masks); dh, du: same
+ * layout, stored for the weight gradients (wn_wgrad).  dz: [B][16 mt_z][pitch], all blocks' z-crop gradients stacked on the channel
+ * axis, mt_z a multiple of 3.  w_p2T: packed P2^T [16][8], natural k; w_p1Tc, w_skipTc: P1^T [16][8] and Ws^T [mt_z][8] in the
+ * CHAINED k order.  The mask rows are read unguarded over the tile's 128 columns (workspace rows of the activation layout). */
+int wn_skip_epilogue_bwd(const float* d_o, int64_t o_bstride, int o_pitch, const float* h, const float* u, int64_t s_bstride, int pitch,
+                         float* d_h, float* d_u, float* d_z, int64_t z_bstride, const uint16_t* w_p2T, const uint16_t* w_p1Tc,
+                         const uint16_t* w_skipTc, int mt_z, int z_valid, int s_valid, int t_lo, int t_hi, int batch, int mode,
+                         wn_stream_t stream);
+
 /* Encoder block of the autoencoder, forward (wavenet_autoencoder/model1.py:137-152 for one dilation d), one launch:
  *   h = Wdil [relu x(t-d); relu x(t)] (+ bias_dil) ; x_out = Wd relu(h) (+ bias_d) + x(t)   on [t_lo, t_hi);
  *   h (the pre-activation the backward masks with) is stored on the same range.  wdil: packed [ch/16][2ch/32] (natural

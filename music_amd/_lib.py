@@ -29,6 +29,7 @@ SIGNATURES = {
                      _p, _l, _i,
                      _i, _i, _i, _i, _i, _p],
     "wn_skip_epilogue_fwd": [_p, _l, _i, _i, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
+    "wn_skip_epilogue_bwd": [_p, _l, _i, _p, _p, _l, _i, _p, _p, _p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "wn_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i,
                         _i, _i, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l, _i, _i, _p],
     "wn_enc_resblock_fwd": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],

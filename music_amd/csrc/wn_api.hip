@@ -91,6 +91,21 @@ int wn_skip_epilogue_fwd(const float* z, int64_t z_bstride, int pitch, int ks_sk
     return wn_launch_skip_epilogue_fwd(a, batch, mode, (hipStream_t)stream);
 }
 
+int wn_skip_epilogue_bwd(const float* d_o, int64_t o_bstride, int o_pitch, const float* h, const float* u, int64_t s_bstride, int pitch,
+                         float* d_h, float* d_u, float* d_z, int64_t z_bstride, const uint16_t* w_p2T, const uint16_t* w_p1Tc,
+                         const uint16_t* w_skipTc, int mt_z, int z_valid, int s_valid, int t_lo, int t_hi, int batch, int mode,
+                         wn_stream_t stream) {
+    if (pitch % 4 != 0) return wn_set_error_msg(-4, "wn_skip_epilogue_bwd: pitch must be a multiple of 4");
+    if (s_valid <= 0 || s_valid > 256) return wn_set_error_msg(-4, "wn_skip_epilogue_bwd: at most 256 skip channels");
+    if (batch > 0 && t_hi > t_lo) WN_REQUIRE("wn_skip_epilogue_bwd", d_o, h, u, d_h, d_u, d_z, w_p2T, w_p1Tc, w_skipTc);
+    WnEpiBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.d_o = d_o; a.o_bstride = o_bstride; a.o_pitch = o_pitch; a.h = h; a.u = u; a.s_bstride = s_bstride; a.pitch = pitch;
+    a.d_h = d_h; a.d_u = d_u; a.d_z = d_z; a.z_bstride = z_bstride; a.w_p2T = w_p2T; a.w_p1Tc = w_p1Tc; a.w_skipTc = w_skipTc;
+    a.mt_z = mt_z; a.z_valid = z_valid; a.s_valid = s_valid; a.t_lo = t_lo; a.t_hi = t_hi;
+    return wn_launch_skip_epilogue_bwd(a, batch, mode, (hipStream_t)stream);
+}
+
 int wn_enc_resblock_fwd(const float* x_in, float* x_out, float* h_out, int64_t x_bstride, int64_t h_bstride, int pitch,
                         const uint16_t* wdil, const uint16_t* wd, const float* bias_dil, const float* bias_d, int n_h,
                         int n_d, int ch, int d, int t_lo, int t_hi, int batch, int mode, wn_stream_t stream) {

@@ -18,6 +18,7 @@
 // the place of the stages; the P1 / P2 products then read it like the B-stationary product does (wn_gemm_bst.hip): no
 // barrier, no LDS write inside them.
 #include <stdlib.h>
+#include <type_traits>
 #include "wn_common.h"
 #include "wn_kernels.h"
 
@@ -32,6 +33,16 @@ __global__ __launch_bounds__(512) void skip_epilogue_fwd_k(WnEpiFwdArgs a) {
     const int c = lane & 15, q = lane >> 4;
     const int b = blockIdx.x / a.ntx, tile0 = a.t_base + (blockIdx.x % a.ntx) * EPI_COLS;
     const int KS = a.ks_skip, NI = KS >> 1;
+    // Workgroups of one round run in step: every CU streams z (reads only) for the same 70 us, then every CU stores its U, H and O
+    // tiles in the same 20 us - a burst of pure writes that HBM takes at its write rate while nothing else moves.  The first round is
+    // therefore STAGGERED: workgroup g of the first `stagger_n` waits g / stagger_n of `stagger_cycles` (most of a tile's time) before it
+    // starts, later rounds inherit the offsets, and one CU's stores land beside another's reads.  Costs nothing at a fill like 3.19
+    // rounds: the CUs that start first take the fourth-round tiles
+    if (blockIdx.x < (unsigned)a.stagger_n && a.stagger_cycles > 0) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        const unsigned long long wait = (unsigned long long)a.stagger_cycles * blockIdx.x / a.stagger_n;
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
     const int m0 = 2 * wave;                                  // this wave's two row tiles (of 16)
 
     // loader role: k-step sp of an iteration's pair, column group lg, row half lh
@@ -242,6 +253,249 @@ __global__ __launch_bounds__(512) void skip_epilogue_fwd_k(WnEpiFwdArgs a) {
     store_rows(acc, 0, 16, a.o, a.o_bstride, a.o_pitch, -a.t_lo, a.q_valid);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of the same epilogue, data gradients (autograd of wavenet/model.py:127-138), one launch per 128-column tile:
+//
+//   dH = (P2^T dO) * [H > 0] ;  dU = (P1^T dH) * [U > 0] ;  dZ = Ws^T dU          (dH, dU stored: the weight gradients read them)
+//
+// The compact dO tile (256 rows x 128 columns) is split ONCE into the 128 KB B operand; dH and dU are handed from product to
+// product out of the accumulators like U and H in the forward (chained packs of P1^T and Ws^T); the dZ product - 30 x 64 rows
+// against K = 256, 795 MB of output - walks its row tiles over the resident dU like chan_gemm_bst_k: a wave owns 3 row tiles x 8
+// column tiles per pass, weights straight from L2 one k-step ahead, streaming stores.  Replaces three wn_chan_gemm launches that
+// each paid a cold start and a half-empty last round; dH / dU are never read back here.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
+    constexpr int NS = 3, FR = 1024;
+    extern __shared__ __attribute__((aligned(16))) uint16_t l_s[];      // [8 k-steps][8 column tiles] B fragments
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x / a.ntx, tile0 = a.t_base + (blockIdx.x % a.ntx) * EPI_COLS;
+    const int m0 = 2 * wave;
+    const bool tile_in = tile0 >= a.t_lo && tile0 + EPI_COLS <= a.t_hi;
+
+    // ---- fill: dO rows (k-steps sp, sp + 2, ..), column group lg, row half lh; compact layout: column t - t_lo, 4-byte aligned rows
+    {
+        const int lg = wave & 1, lh = (wave >> 1) & 1, sp = wave >> 2;
+        const float* in = a.d_o + (size_t)b * a.o_bstride;
+        const int tg0 = tile0 + lg * 64;
+        const bool inner = tg0 >= a.t_lo && tg0 + 64 <= a.t_hi;
+        const int col = tg0 + 4 * c;
+        f32x4 raw[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* p = in + (size_t)((sp + 2 * i) * 32 + 8 * q + 4 * lh) * a.o_pitch + (col - a.t_lo);
+            if (inner) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) raw[i][j] = ld4u(p + (size_t)j * a.o_pitch);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) raw[i][j] = ld4g(p + (size_t)j * a.o_pitch, col, a.t_lo, a.t_hi);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint16_t* bb = l_s + (size_t)((sp + 2 * i) * 8 + lg * 4) * FR + lane * 8 + lh * 4;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                uint2 hv, lv;
+                split2<T>(raw[i][0][n], raw[i][1][n], hv.x, lv.x);
+                split2<T>(raw[i][2][n], raw[i][3][n], hv.y, lv.y);
+                *reinterpret_cast<uint2*>(bb + (size_t)n * FR) = hv;
+                *reinterpret_cast<uint2*>(bb + (size_t)n * FR + 512) = lv;
+            }
+        }
+    }
+
+    auto mma_step = [&](auto& acc, const uint16_t* frags, Frag<T>* af, auto mt) {      // one k-step: 8 column tiles x MT row tiles
+        constexpr int MT = decltype(mt)::value;
+        Frag<T> bf[3];
+        load_a<T, NS>(bf[0], frags, 0, lane);
+        load_a<T, NS>(bf[1], frags, 1, lane);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            if (n + 2 < 8) load_a<T, NS>(bf[(n + 2) % 3], frags, n + 2, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) mma<T, NS>(acc[i][n], af[i], bf[n % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // masks of this lane's 2 x 8 accumulator tiles: mask[row][col] > 0 for e = 8 i + 2 r + g (row tile i, register r, group g)
+    auto load_mask = [&](f32x4* mk, const float* base, int valid) {
+        const float* mp = base + (size_t)b * a.s_bstride + (size_t)(m0 * 16 + 4 * q) * a.pitch + tile0 + 4 * c;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = e >> 3, r = (e >> 1) & 3, g = e & 1;
+            // (unguarded: the mask rows are workspace rows with the activation layout's slack; values outside the tile's valid
+            // columns only gate results that are never stored)
+            mk[e] = ((m0 + i) * 16 + 4 * q + r < 256) ? ld4u(mp + (size_t)(16 * i + r) * a.pitch + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto apply_mask = [&](f32x4 (*acc)[8], const f32x4* mk) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = e >> 3, r = (e >> 1) & 3, g = e & 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[i][4 * g + k][r] = mk[e][k] > 0.f ? acc[i][4 * g + k][r] : 0.f;
+        }
+    };
+    auto store_rows = [&](f32x4 (*acc)[8], float* base, int valid) {
+        float* out = base + (size_t)b * a.s_bstride + (size_t)(m0 * 16 + 4 * q) * a.pitch + tile0 + 4 * c;
+        if (tile_in && (m0 + 2) * 16 <= valid) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = e >> 3, r = (e >> 1) & 3, g = e & 1;
+                F4U u = {{acc[i][4 * g][r], acc[i][4 * g + 1][r], acc[i][4 * g + 2][r], acc[i][4 * g + 3][r]}};
+                *reinterpret_cast<F4U*>(out + (size_t)(16 * i + r) * a.pitch + 64 * g) = u;
+            }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = e >> 3, r = (e >> 1) & 3, g = e & 1;
+            if ((m0 + i) * 16 + 4 * q + r >= valid) continue;
+            const int tl = tile0 + 64 * g + 4 * c;
+            float* op = out + (size_t)(16 * i + r) * a.pitch + 64 * g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (tl + k >= a.t_lo && tl + k < a.t_hi) op[k] = acc[i][4 * g + k][r];
+        }
+    };
+    auto hand_over = [&](f32x4 (*acc)[8]) {                   // acc as the B fragments of k-step `wave`, chained k order
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = acc[j >> 2][n][j & 3];
+            Frag<T> f;
+            split8<T, NS>(f, v);
+            u32x4* p = reinterpret_cast<u32x4*>(l_s) + (size_t)(wave * 8 + n) * 128 + lane;
+            p[0] = __builtin_bit_cast(u32x4, f.hi);
+            p[64] = __builtin_bit_cast(u32x4, f.lo);
+        }
+    };
+    // acc = W x (the operand in LDS), 16 row tiles in all (this wave: 2), weights three k-steps ahead through a 3-slot ring
+    auto product16 = [&](f32x4 (*acc)[8], const uint16_t* pack) {
+        Frag<T> wf[3][2];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) load_a<T, NS>(wf[s][i], pack, (m0 + i) * 8 + s, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            mma_step(acc, l_s + (size_t)s * 8 * FR, wf[s % 3], std::integral_constant<int, 2>());
+            if (s + 3 < 8) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) load_a<T, NS>(wf[s % 3][i], pack, (m0 + i) * 8 + s + 3, lane);
+            }
+        }
+    };
+
+    f32x4 acc[2][8], mk[16];
+    load_mask(mk, a.h, a.s_valid);                            // (requested in front of the product: they land while it runs)
+    __syncthreads();                                          // the dO fragments are in place
+    product16(acc, a.w_p2T);
+    apply_mask(acc, mk);
+    load_mask(mk, a.u, a.s_valid);
+    store_rows(acc, a.d_h, a.s_valid);
+    __syncthreads();                                          // every wave has read dO
+    hand_over(acc);
+    __syncthreads();
+    product16(acc, a.w_p1Tc);
+    apply_mask(acc, mk);
+    store_rows(acc, a.d_u, a.s_valid);
+    __syncthreads();                                          // every wave has read dH
+    hand_over(acc);
+    __syncthreads();
+
+    // ---- dZ = Ws^T dU: passes of 3 row tiles per wave over the resident operand (wn_gemm_bst.hip), streaming stores
+    {
+        constexpr int MT = 3;
+        float* out = a.d_z + (size_t)b * a.z_bstride;
+        const int npass = (a.mt_z / MT + 7) / 8;
+        Frag<T> af[2][MT];
+        int mz = wave * MT;
+        auto load_w = [&](Frag<T>* f, int m, int s) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) load_a<T, NS>(f[i], a.w_skipTc, (m + i) * 8 + s, lane);
+        };
+        if (mz < a.mt_z) load_w(af[0], mz, 0);
+        for (int p = 0; p < npass; ++p, mz += 8 * MT) {
+            if (mz >= a.mt_z) break;
+            f32x4 az[MT][8];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int n = 0; n < 8; ++n) az[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s + 1 < 8) load_w(af[(s + 1) & 1], mz, s + 1);
+                mma_step(az, l_s + (size_t)s * 8 * FR, af[s & 1], std::integral_constant<int, MT>());
+            }
+            const int mn = mz + 8 * MT;
+            load_w(af[0], mn < a.mt_z ? mn : mz, 0);          // the next pass's first weights in front of this pass's stores
+            if (tile_in && (mz + MT) * 16 <= a.z_valid) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* op = out + (size_t)((mz + i) * 16 + 4 * q + r) * a.pitch + tile0 + 4 * c;
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const f32x4 v = {az[i][4 * g][r], az[i][4 * g + 1][r], az[i][4 * g + 2][r], az[i][4 * g + 3][r]};
+                            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(op + 64 * g));
+                        }
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (mz + i) * 16 + 4 * q + r;
+                    if (row >= a.z_valid) continue;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int tl = tile0 + 64 * g + 4 * c;
+                        float* op = out + (size_t)row * a.pitch + tl;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (tl + k >= a.t_lo && tl + k < a.t_hi) op[k] = az[i][4 * g + k][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+int wn_launch_skip_epilogue_bwd(const WnEpiBwdArgs& a0, int batch, int mode, hipStream_t st) {
+    if (a0.t_hi <= a0.t_lo || batch <= 0) return 0;
+    if (mode != WN_MODE_F16X3 && mode != WN_MODE_BF16X3) return wn_set_error_msg(-2, "wn_skip_epilogue_bwd: x3 modes only");
+    if (a0.mt_z <= 0 || a0.mt_z % 3 != 0) return wn_set_error_msg(-4, "wn_skip_epilogue_bwd: the z rows in groups of 48");
+    WnEpiBwdArgs a = a0;
+    a.t_base = wn_tile_origin(a.t_lo);
+    a.ntx = (a.t_hi - a.t_base + EPI_COLS - 1) / EPI_COLS;
+    const size_t sh = (size_t)64 * 1024 * sizeof(uint16_t);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static WnDevOnce done;
+    if (done.need(dev)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skip_epilogue_bwd_k<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skip_epilogue_bwd_k<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        done.done(dev);
+    }
+    const dim3 g(a.ntx * batch), bl(512);
+    if (mode == WN_MODE_F16X3) hipLaunchKernelGGL(skip_epilogue_bwd_k<F16>, g, bl, sh, st, a);
+    else hipLaunchKernelGGL(skip_epilogue_bwd_k<BF16>, g, bl, sh, st, a);
+    WN_CHECK_LAUNCH();
+    return 0;
+}
+
 int wn_launch_skip_epilogue_fwd(const WnEpiFwdArgs& a0, int batch, int mode, hipStream_t st) {
     if (a0.t_hi <= a0.t_lo || batch <= 0) return 0;
     if (mode != WN_MODE_F16X3 && mode != WN_MODE_BF16X3)
@@ -259,6 +513,17 @@ int wn_launch_skip_epilogue_fwd(const WnEpiFwdArgs& a0, int batch, int mode, hip
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skip_epilogue_fwd_k<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         done.done(dev);
     }
+    // stagger of the first round (kernel comment): on when the launch has more than one round; WN_EPI_STAGGER = cycles per k-step pair
+    // (0 = off; default 3600, i.e. about 0.75 of a tile's loop time)
+    int cus = 256;
+    {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    }
+    const char* es = getenv("WN_EPI_STAGGER");
+    const int per_it = es ? atoi(es) : 3600;
+    a.stagger_n = a.ntx * batch > cus ? cus : 0;
+    a.stagger_cycles = per_it * (a.ks_skip / 2);
     const dim3 g(a.ntx * batch), bl(512);
     if (mode == WN_MODE_F16X3) hipLaunchKernelGGL(skip_epilogue_fwd_k<F16>, g, bl, sh, st, a);
     else hipLaunchKernelGGL(skip_epilogue_fwd_k<BF16>, g, bl, sh, st, a);

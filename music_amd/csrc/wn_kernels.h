@@ -40,8 +40,20 @@ struct WnEpiFwdArgs {
     float* o; long o_bstride; int o_pitch;                 // out: compact pre-softmax [B][256][o_pitch], column t - t_lo
     int s_valid, q_valid;                                  // real skip / quantisation rows (<= 256)
     int t_lo, t_hi, t_base, ntx;                           // valid columns; t_base / tiles per clip set by the launcher
+    int stagger_n, stagger_cycles;                         // first-round stagger (set by the launcher)
 };
 int wn_launch_skip_epilogue_fwd(const WnEpiFwdArgs& a, int batch, int mode, hipStream_t st);
+// ... and its backward, data gradients: dH = (P2^T dO) [H > 0], dU = (P1^T dH) [U > 0], dZ = Ws^T dU per 128-column tile
+struct WnEpiBwdArgs {
+    const float* d_o; long o_bstride; int o_pitch;         // compact d loss / d pre-softmax [B][256][o_pitch], column t - t_lo
+    const float* h; const float* u; long s_bstride; int pitch;   // the forward's H and U (masks), [B][256][pitch]
+    float* d_h; float* d_u;                                // out, same layout (the weight gradients read them)
+    float* d_z; long z_bstride;                            // out: [B][16 mt_z][pitch]
+    const uint16_t* w_p2T; const uint16_t* w_p1Tc; const uint16_t* w_skipTc;   // packed [16][8] natural, [16][8] chained, [mt_z][8] chained
+    int mt_z, z_valid, s_valid;                            // 16-row tiles of dZ (a multiple of 3), real z rows, real skip rows
+    int t_lo, t_hi, t_base, ntx;
+};
+int wn_launch_skip_epilogue_bwd(const WnEpiBwdArgs& a, int batch, int mode, hipStream_t st);
 struct WnResArgs;
 int wn_launch_enc_resblock_fwd(const WnResArgs& a, int ch, int batch, int mode, hipStream_t st);   // wn_resblock2.hip (ENC)
 int wn_launch_pack(const float* flat, const int32_t* idx, uint16_t* out, int n, int is_bf16, int ns,

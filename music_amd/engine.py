@@ -191,6 +191,7 @@ class WaveNetEngine:
         # ... or all three in ONE launch per 128-column tile (wn_skip_epilogue_fwd, round 6; 256 skip / 256 quantisation channels, x3
         # modes; WN_EPI_FUSED=0 = the three launches above)
         self.epi_fused = os.environ.get("WN_EPI_FUSED", "1") == "1"
+        self.epi_fused_bwd = os.environ.get("WN_EPI_FUSED_BWD", "1") == "1"
         # Channel-split backward block with both weight gradients in the launch (wn_resblock_bwd_ms):
         # 64 padded channels, (f16x3, bf16x3) only; None = whenever it applies (WN_MS_BWD=0 turns it off)
         self.ms_bwd = None
@@ -333,6 +334,7 @@ class WaveNetEngine:
         fwd.append(("skip", pack_index(w)))
         gp.append(("skip", SP, N * CH))
         bwd.append(("skipT", pack_index(np.ascontiguousarray(w.T))))      # rows N*CH, K = SP
+        bwd.append(("skipTc", pack_index(np.ascontiguousarray(w.T), chained=True)))     # chained k order: the fused backward epilogue
         # 5/6. post-process
         p1 = sp.conv("post_process_1.weight")[:, :, 0]
         p2 = sp.conv("post_process_2.weight")[:, :, 0]
@@ -342,6 +344,7 @@ class WaveNetEngine:
         fwd.append(("p1c", pack_index(w, chained=True)))     # chained k order: the fused forward epilogue takes relu(U) out of the accumulators
         gp.append(("p1", SP, SP))
         bwd.append(("p1T", pack_index(np.ascontiguousarray(w.T))))
+        bwd.append(("p1Tc", pack_index(np.ascontiguousarray(w.T), chained=True)))
         w = full(Q, SP)
         w[:, :S] = p2
         fwd.append(("p2", pack_index(w)))
@@ -735,6 +738,25 @@ class WaveNetEngine:
         # weight gradients of the epilogue run on the side stream as soon as their operands exist
         wgrad_s("p2", dO, Q * W, W, -lo, W, H, None, sb, pitch, 0, 0, pitch, SP // 16, Q // 16, 1, SP, lo, T)
         self.fmark("b_wgrad_p2")
+        if (self.epi_fused_bwd and SP == 256 and Q == 256 and (N * CH // 16) % 3 == 0 and mb in (_lib.F16X3, _lib.BF16X3)
+                and not self.use_bias):
+            # dH, dU and dZ in ONE launch per 128-column tile (wn_skip_epilogue_bwd, ABI v5); the two weight gradients that read
+            # dH / dU follow on the side stream
+            call("wn_skip_epilogue_bwd", dO, Q * W, W, H, U, sb, pitch, dH, dU, dZ, zb, br("p2T"), br("p1Tc"), br("skipTc"),
+                 N * CH // 16, N * CH, self.S, lo, T, B, mb, st)
+            self.fmark("b_fused")
+            wgrad_s("p1", dH, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
+            order = os.environ.get("WN_EPI_BWD_ORDER", "0")
+            if order == "1":        # the skip weight gradient on the MAIN stream, beside post_process_1's on the side stream
+                wgrad("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CH // 16, SP // 16, 0, N * CH, lo, T)
+            else:
+                wgrad_s("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CH // 16, SP // 16, 0, N * CH, lo, T)
+            if order in ("1", "2") and overlap:      # the stack starts when the epilogue's weight gradients are done
+                ev = torch.cuda.Event()
+                ev.record(side)
+                main.wait_event(ev)
+            self.mark("epilogue_bwd")
+            return self._backward_stack(ws, bw, st, main, side, overlap, plan, wgrad)
         # dH = (P2^T dO) * [H > 0]
         call("wn_chan_gemm", dO, None, Q * W, W, 0, W, -lo, 0, Q // 32, 0, br("p2T"), SP // 16, self.S,
              dH, sb, pitch, 0, None, None, 0, 0, 0, H, sb, pitch, lo, T, 0, B, mb, st)
@@ -758,6 +780,16 @@ class WaveNetEngine:
                 call("wn_bias_grad", dU, sb, pitch, 0, self.S, lo, T, B,
                      ptr(self.gpack, bo["dilation_layer_stack.%d.bias" % (4 * i + 3)]), st)
         self.mark("epilogue_bwd")
+        return self._backward_stack(ws, bw, st, main, side, overlap, plan, wgrad)
+
+    def _backward_stack(self, ws, bw, st, main, side, overlap, plan, wgrad):
+        """The residual stack's backward, the causal layer's weight gradient and the slab reduction (second half of backward_from_dlogits)."""
+        B, T, W, pitch = ws["B"], ws["T"], ws["W"], ws["pitch"]
+        CH, N, SP, Q, mb, mf = self.CH, self.N, self.SP, self.Q, self.mode_bwd, self.mode_fwd
+        br = lambda name: ptr(self.pk_b, self.pk_b_off[name])
+        fr = lambda name: ptr(self.pk_f, self.pk_f_off[name])
+        lo = self.rf - 1
+        xb, zb, sb = CH * pitch, N * CH * pitch, SP * pitch
         # The per-layer weight-gradient products only feed the slab reduction at the very end, so
         # they run on a second HIP stream next to the data-gradient chain
         # (resblock_bwd -> dx product -> next block); dfg / z scratch is double-buffered for that.

@@ -190,6 +190,61 @@ def test_skip_epilogue_fwd_fused(mode, B, T, t_lo, KZ, S, Qv, bias):
     assert g[:, Qv:].abs().sum().item() == 0
 
 
+@pytest.mark.parametrize("mode", [_lib.BF16X3, _lib.F16X3])
+@pytest.mark.parametrize("B,T,t_lo,MZ,S", [(2, 1500, 37, 192, 256), (3, 2300, 1023, 480, 250)])
+def test_skip_epilogue_bwd_fused(mode, B, T, t_lo, MZ, S):
+    """wn_skip_epilogue_bwd (autograd of wavenet/model.py:127-138, data gradients, in one launch): dh, du, dz against float64 and
+    against the three wn_chan_gemm launches it replaces."""
+    rng = np.random.default_rng(13)
+    pitch = ((T + 255) // 256) * 256 + 512
+    W = T - t_lo
+    p2 = np.zeros((256, 256), np.float32); p2[:, :S] = rng.standard_normal((256, S)).astype(np.float32) * 0.08       # [Q][S]
+    p1 = np.zeros((256, 256), np.float32); p1[:S, :S] = rng.standard_normal((S, S)).astype(np.float32) * 0.08       # [S][S]
+    ws_ = np.zeros((256, MZ), np.float32); ws_[:S] = rng.standard_normal((S, MZ)).astype(np.float32) * 0.08         # [S][N*CH]
+    pk_p2T, pk_p1T, pk_sT = _packed(p2.T.copy(), mode), _packed(p1.T.copy(), mode), _packed(ws_.T.copy(), mode)
+    pk_p1Tc, pk_sTc = _packed(p1.T.copy(), mode, chained=True), _packed(ws_.T.copy(), mode, chained=True)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    dO = (torch.randn(B, 256, W, generator=g) * 1e-3).to(DEV).contiguous()
+    h, u = _buf(B, 256, pitch, 1.0, 6), _buf(B, 256, pitch, 1.0, 7)
+    st = _lib.stream()
+
+    def fused():
+        dh, du, dz = _buf(B, 256, pitch), _buf(B, 256, pitch), _buf(B, MZ, pitch)
+        call("wn_skip_epilogue_bwd", ptr(dO), 256 * W, W, ptr(h, SLACK), ptr(u, SLACK), 256 * pitch, pitch, ptr(dh, SLACK), ptr(du, SLACK),
+             ptr(dz, SLACK), MZ * pitch, ptr(pk_p2T), ptr(pk_p1Tc), ptr(pk_sTc), MZ // 16, MZ, S, t_lo, T, B, mode, st)
+        torch.cuda.synchronize()
+        return _view(dh, B, 256, pitch).clone(), _view(du, B, 256, pitch).clone(), _view(dz, B, MZ, pitch).clone()
+
+    def three():
+        dh, du, dz = _buf(B, 256, pitch), _buf(B, 256, pitch), _buf(B, MZ, pitch)
+        call("wn_chan_gemm", ptr(dO), None, 256 * W, W, 0, W, -t_lo, 0, 8, 0, ptr(pk_p2T), 16, S, ptr(dh, SLACK), 256 * pitch, pitch, 0, None,
+             None, 0, 0, 0, ptr(h, SLACK), 256 * pitch, pitch, t_lo, T, 0, B, mode, st)
+        call("wn_chan_gemm", ptr(dh, SLACK), None, 256 * pitch, pitch, t_lo, T, 0, 0, 8, 0, ptr(pk_p1T), 16, S, ptr(du, SLACK), 256 * pitch,
+             pitch, 0, None, None, 0, 0, 0, ptr(u, SLACK), 256 * pitch, pitch, t_lo, T, 0, B, mode, st)
+        call("wn_chan_gemm", ptr(du, SLACK), None, 256 * pitch, pitch, t_lo, T, 0, 0, 8, 0, ptr(pk_sT), MZ // 16, MZ, ptr(dz, SLACK), MZ * pitch,
+             pitch, 0, None, None, 0, 0, 0, None, 0, 0, t_lo, T, 0, B, mode, st)
+        torch.cuda.synchronize()
+        return _view(dh, B, 256, pitch).clone(), _view(du, B, 256, pitch).clone(), _view(dz, B, MZ, pitch).clone()
+
+    fh, fu, fz = fused()
+    th, tu, tz = three()
+    dod = dO.cpu().double()
+    hm = (_view(h, B, 256, pitch).cpu().double()[:, :, t_lo:T] > 0)
+    um = (_view(u, B, 256, pitch).cpu().double()[:, :, t_lo:T] > 0)
+    rh = torch.einsum("qs,bqt->bst", torch.from_numpy(p2).double(), dod) * hm
+    ru = torch.einsum("rs,brt->bst", torch.from_numpy(p1).double(), rh) * um
+    rz = torch.einsum("sm,bst->bmt", torch.from_numpy(ws_).double(), ru)
+    tol = TOL[mode] * 3
+    for name, got, other, ref, rows in (("dh", fh, th, rh, S), ("du", fu, tu, ru, S), ("dz", fz, tz, rz, MZ)):
+        gd = got.cpu().double()
+        assert gd[:, :, :t_lo].abs().max().item() == 0 and gd[:, :, T:].abs().max().item() == 0, name
+        assert gd[:, rows:].abs().sum().item() == 0, name
+        err = (gd[:, :rows, t_lo:T] - ref[:, :rows]).abs().max().item()
+        dev = (gd - other.cpu().double()).abs().max().item()
+        print(name, "err", err, "vs three launches", dev, "scale", ref.abs().max().item())
+        assert err <= tol * ref.abs().max().item() and dev <= tol * ref.abs().max().item()
+
+
 def test_chan_gemm_two_taps_epilogues():
     mode = _lib.F16X3
     rng = np.random.default_rng(2)

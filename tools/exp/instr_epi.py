@@ -31,35 +31,38 @@ rep("            for (int i = 0; i < 2; ++i) mma<T, NS>(acc[i][n], af[i], bf[n %
                 else mma<T, NS>(acc[i][n], af[i], bf[n % 3]);
             }
 """)
-rep('''        load_w2(afn, a.w_skip, KS, it + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(acc, st, afc[0]);
+rep("""        const int itw = it + 2 < NI ? it + 2 : NI - 1, itr = it + 3 < NI ? it + 3 : NI - 1;
+""","""        const int itw = it + 2 < NI ? it + 2 : NI - 1, itr = it + 3 < NI ? it + 3 : NI - 1;
+#ifdef EPI_DBG
+        EPI_TICK(c0);
+        const unsigned long long c1 = c0;
+#endif
+""")
+rep("""            if (n & 1) afn[kk][i].lo = __builtin_bit_cast(typename T::vec8, *p);
+            else afn[kk][i].hi = __builtin_bit_cast(typename T::vec8, *p);
+        });
         __builtin_amdgcn_sched_barrier(0);
         store_raw(rnext, (it + 1) & 1);                       // (the last iteration fills a stage nobody reads)
-        load_raw(rnext, it + 3);
         __builtin_amdgcn_sched_barrier(0);
-        mma_half(acc, st + 8 * FR, afc[1]);
-        __syncthreads();''','''#ifdef EPI_DBG
-        EPI_TICK(c0);
-#endif
-        if (EPI_T != 2) load_w2(afn, a.w_skip, KS, it + 2);
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef EPI_DBG
-        EPI_TICK(c1);
-#endif
-        mma_half(acc, st, afc[0]);
+""","""            if (EPI_T == 2) return;
+            if (n & 1) afn[kk][i].lo = __builtin_bit_cast(typename T::vec8, *p);
+            else afn[kk][i].hi = __builtin_bit_cast(typename T::vec8, *p);
+        });
         __builtin_amdgcn_sched_barrier(0);
 #ifdef EPI_DBG
         EPI_TICK(c2);
 #endif
         if (EPI_T != 8) store_raw(rnext, (it + 1) & 1);                       // (the last iteration fills a stage nobody reads)
         else asm volatile("" :: "v"(rnext[0]), "v"(rnext[1]), "v"(rnext[2]), "v"(rnext[3]));
-        if (EPI_T != 3) load_raw(rnext, it + 3);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef EPI_DBG
         EPI_TICK(c3);
 #endif
-        mma_half(acc, st + 8 * FR, afc[1]);
+""")
+rep("""            if (n < 4) rnext[n] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zrow + (size_t)itr * 64 * a.pitch + (size_t)n * a.pitch));
+        });
+        __syncthreads();""","""            if (EPI_T != 3 && n < 4) rnext[n] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zrow + (size_t)itr * 64 * a.pitch + (size_t)n * a.pitch));
+        });
 #ifdef EPI_DBG
         EPI_TICK(c4);
 #endif
@@ -67,7 +70,7 @@ rep('''        load_w2(afn, a.w_skip, KS, it + 2);
 #ifdef EPI_DBG
         EPI_TICK(c5);
         dbg_acc[0] += c1 - c0; dbg_acc[1] += c2 - c1; dbg_acc[2] += c3 - c2; dbg_acc[3] += c4 - c3; dbg_acc[4] += c5 - c4;
-#endif''')
+#endif""")
 rep("        load_w2(af1, a.w_skip, KS, it0 + 1);\n","        load_w2(af1, a.w_skip, KS, it0 + 1);\n        if (EPI_T == 2) load_w2(af2, a.w_skip, KS, it0 + 2);\n")
 rep("    init_acc(acc, a.bias_s, a.s_valid);\n","#ifdef EPI_DBG\n    unsigned long long dbg_acc[5] = {};\n    const unsigned long long k0_ = __builtin_readcyclecounter();\n#endif\n    init_acc(acc, a.bias_s, a.s_valid);\n")
 rep("    if (it0 < NI) {\n","#ifdef EPI_DBG\n    const unsigned long long l0_ = __builtin_readcyclecounter();\n#endif\n    if (it0 < NI) {\n")

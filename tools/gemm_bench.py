@@ -53,6 +53,14 @@ def main():
         "b_skipT (1920 x 256)": lambda: call("wn_chan_gemm", dU, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, br("skipT"), N * CH // 16, N * CH, dZ, zb, pitch, 0, None, None, 0, 0, 0, None, 0, 0, lo, T, 0, B, mb, st),
     }
 
+    if hasattr(_lib.load(), "wn_skip_epilogue_fwd"):
+        prods["fused forward epilogue (skip -> p1 -> p2, one launch)"] = lambda: call(
+            "wn_skip_epilogue_fwd", Z, zb, pitch, N * CH // 32, fr("skip"), None, U, H, sb, fr("p1c"), None, fr("p2c"), None, O, Q * W, W,
+            eng.S, Q, lo, T, B, mf, st)
+        prods["fused backward epilogue (dH, dU, dZ, one launch)"] = lambda: call(
+            "wn_skip_epilogue_bwd", dO, Q * W, W, H, U, sb, pitch, dH, dU, dZ, zb, br("p2T"), br("p1Tc"), br("skipTc"), N * CH // 16, N * CH,
+            eng.S, lo, T, B, mb, st)
+
     def timeit(fn):
         fn()
         torch.cuda.synchronize()
