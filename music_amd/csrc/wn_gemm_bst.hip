@@ -11,6 +11,7 @@
 // to LDS and there is no barrier: a wave owns MT row tiles x all 8 column tiles (MT x 8 accumulator tiles), takes its packed
 // weight fragments straight from L2 (they are read by one wave only: no sharing to organise; the 2 MB pack of Ws^T stays
 // L2-resident) one k-step ahead, reads the B fragments with ds_read_b128 (22 % of the LDS read rate), and stores a pass's rows
+// (streaming stores where the rows are 16-byte aligned: 333 -> 293 us alone)
 // while the next pass's first weights are already on their way (vector memory completes in order: the requests are issued in
 // front of the stores).  The eight waves run free of each other; the two on a SIMD fill each other's stalls.
 //
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(512) void chan_gemm_bst_k(WnGemmArgs a, int ntx, in
 
     // loader role of this wave in a fill: column group lg, row half lh, k-steps sp, sp + 2, ...
     const int lg = wave & 1, lh = (wave >> 1) & 1, sp = wave >> 2;
+    const bool nt_ok = ((a.out_shift | a.out_pitch | (int)(a.out_bstride & 3) | (int)((size_t)a.out & 15)) & 3) == 0 && ((size_t)a.out & 15) == 0;
 
     auto fill = [&](int b, int tile0) {
         const float* in = a.in0 + (size_t)b * a.in_bstride;
@@ -143,8 +145,13 @@ __global__ __launch_bounds__(512) void chan_gemm_bst_k(WnGemmArgs a, int ntx, in
                         float* op = out + (size_t)((m0 + i) * 16 + 4 * q + r) * a.out_pitch + tile0 + 4 * c + a.out_shift;
 #pragma unroll
                         for (int g = 0; g < 2; ++g) {
-                            F4U u = {{acc[i][4 * g][r], acc[i][4 * g + 1][r], acc[i][4 * g + 2][r], acc[i][4 * g + 3][r]}};
-                            *reinterpret_cast<F4U*>(op + 64 * g) = u;
+                            if (nt_ok) {        // 16-byte aligned rows (dZ): streaming stores, the output is read by a later launch
+                                const f32x4 v = {acc[i][4 * g][r], acc[i][4 * g + 1][r], acc[i][4 * g + 2][r], acc[i][4 * g + 3][r]};
+                                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(op + 64 * g));
+                            } else {
+                                F4U u = {{acc[i][4 * g][r], acc[i][4 * g + 1][r], acc[i][4 * g + 2][r], acc[i][4 * g + 3][r]}};
+                                *reinterpret_cast<F4U*>(op + 64 * g) = u;
+                            }
                         }
                     }
                 }
@@ -234,13 +241,16 @@ int wn_launch_gemm_bst(const WnGemmArgs& k, int batch, int mode, hipStream_t st)
     if (k.ks1 != 0 || k.in1 != nullptr || k.resid != nullptr) return 0;
     if (k.ks0 != 8 || k.mt < 32 || k.mt % 3 != 0) return 0;            // K = 256, >= 512 rows in whole groups of 3 row tiles
     if (k.t_base & 63) return 0;
-    const char* e = getenv("WN_GEMM_BST");             // 0: chan_gemm_wide2_k; 2: one workgroup per tile instead of one per CU
+    // WN_GEMM_BST: 0 = chan_gemm_wide2_k; 1 = one workgroup per CU (the balanced persistent walk: fastest ALONE, 293 against 321 us);
+    // default = one workgroup per tile: this product runs beside the epilogue's weight gradients on the side stream, and a grid that
+    // holds every CU for its whole duration pushes them out to run beside the backward stack (same-box bench: 4.48 against 4.51 ms)
+    const char* e = getenv("WN_GEMM_BST");
     if (e && e[0] == '0') return 0;
     const int ntx = (k.t_hi - k.t_base + BST_COLS - 1) / BST_COLS;
     const int ntiles = ntx * batch;
     const int npass = (k.mt / 3 + 7) / 8;
     int grid = bst_cus();
-    if (grid > ntiles || (e && e[0] == '2')) grid = ntiles;
+    if (grid > ntiles || !(e && e[0] == '1')) grid = ntiles;
     if (mode == WN_MODE_BF16X3) bst_launch<BF16, 3, 3, 8>(k, ntx, ntiles, npass, grid, st);
     else bst_launch<F16, 3, 3, 8>(k, ntx, ntiles, npass, grid, st);
     return 1;

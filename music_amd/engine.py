@@ -746,12 +746,16 @@ class WaveNetEngine:
                  N * CH // 16, N * CH, self.S, lo, T, B, mb, st)
             self.fmark("b_fused")
             wgrad_s("p1", dH, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
-            order = os.environ.get("WN_EPI_BWD_ORDER", "0")
-            if order == "1":        # the skip weight gradient on the MAIN stream, beside post_process_1's on the side stream
+            # the skip weight gradient on the MAIN stream, beside post_process_1's on the side stream, and the stack starts when both are
+            # done: left to run beside the stack (WN_EPI_BWD_ORDER=0) they stretch every backward-block launch - a block launch wants all
+            # 256 CUs at once - for the same total (bench A/B on one box: 0.95 + 2.0 against 0.52 + 2.6 ms), and the stack's own time
+            # (what `roofline` is computed from) would read 40 % high
+            order = os.environ.get("WN_EPI_BWD_ORDER", "1")
+            if order == "1":
                 wgrad("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CH // 16, SP // 16, 0, N * CH, lo, T)
             else:
                 wgrad_s("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CH // 16, SP // 16, 0, N * CH, lo, T)
-            if order in ("1", "2") and overlap:      # the stack starts when the epilogue's weight gradients are done
+            if order == "1" and overlap:
                 ev = torch.cuda.Event()
                 ev.record(side)
                 main.wait_event(ev)
