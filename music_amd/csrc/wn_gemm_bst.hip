@@ -40,7 +40,7 @@ __global__ __launch_bounds__(512) void chan_gemm_bst_k(WnGemmArgs a, int ntx, in
 
     // loader role of this wave in a fill: column group lg, row half lh, k-steps sp, sp + 2, ...
     const int lg = wave & 1, lh = (wave >> 1) & 1, sp = wave >> 2;
-    const bool nt_ok = ((a.out_shift | a.out_pitch | (int)(a.out_bstride & 3) | (int)((size_t)a.out & 15)) & 3) == 0 && ((size_t)a.out & 15) == 0;
+    const bool nt_ok = ((a.out_shift | a.out_pitch) & 3) == 0 && (a.out_bstride & 3) == 0 && ((size_t)a.out & 15) == 0;
 
     auto fill = [&](int b, int tile0) {
         const float* in = a.in0 + (size_t)b * a.in_bstride;
