@@ -1,7 +1,7 @@
 """GPU parity of the GENERAL plan (music_amd/engine_generic.py): constructor arguments the specialised kernels do not
 cover - filter_width 1, 3, 4, quantization_channels 64 / 100 / 512, up to 160 residual / dilation channels, with and
 without biases - against the CPU oracle on gain-scaled weights.  Probabilities and pre-softmax within 1e-3, loss 1e-4,
-every gradient within 2e-3 of its tensor's max-abs, through the nn.Module surface (autograd) and the fused step.
+every gradient within 3e-4 of its tensor's max-abs, through the nn.Module surface (autograd) and the fused step.
 Run with -m gpu."""
 import numpy as np
 import pytest
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 from oracle import wavenet_oracle as wo
 
 LOGIT_TOL = 1e-3
-GRAD_RTOL = 2e-3
+GRAD_RTOL = 3e-4
 
 CASES = [
     # (name, filter_width, dilations, D, R, S, Q, bias, B, extra window)

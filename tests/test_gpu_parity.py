@@ -3,7 +3,7 @@ C ABI) vs the golden vectors from the real reference and vs the CPU oracle.  Run
 
 Tolerances (BASELINE.json north_star): integers bit-exact; float logits / probabilities within
 1e-3 absolute — checked here on GAIN-SCALED weights (at default init a constant 1/256
-passes).  Gradients: 2e-3 of the tensor's max-abs."""
+passes).  Gradients: 3e-4 of the tensor's max-abs."""
 from collections import OrderedDict
 
 import os
@@ -19,7 +19,7 @@ from tests.helpers import g1_input, g1_meta, grads_from, load_npz, nonvacuous, p
 from tests.tools_cfg import TINY
 
 LOGIT_TOL = 1e-3
-GRAD_RTOL = 2e-3
+GRAD_RTOL = 3e-4
 
 
 def build(cfg, params, precision=None):

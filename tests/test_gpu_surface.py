@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 from oracle import wavenet_oracle as wo
 from tests.helpers import nonvacuous
 
-GRAD_RTOL = 2e-3
+GRAD_RTOL = 3e-4
 WN = dict(filter_width=2, dilations=[1, 2, 4, 8, 32], dilation_channels=32, residual_channels=32, skip_channels=64,
           quantization_channels=256, use_bias=False)
 AE = dict(filter_width=2, quantization_channel=256, dilations=[1, 2, 4, 8], en_residual_channel=32, en_dilation_channel=32,

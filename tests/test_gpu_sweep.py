@@ -2,7 +2,7 @@
 every packed matrix), odd clip lengths (column tiles that end mid-float4, unaligned (B,Q,W) rows),
 dilations that are not multiples of 4 (unaligned shifted taps), batch 1..3, bias on and off, one
 output column (W = 1) up to several 512-column tiles.  Every case: pre-softmax logits and
-probabilities within 1e-3 of the CPU oracle, loss within 1e-4, every gradient within 2e-3 of the
+probabilities within 1e-3 of the CPU oracle, loss within 1e-4, every gradient within 3e-4 of the
 tensor's max-abs, through both the nn.Module surface and the fused training step.  Run with -m gpu."""
 import numpy as np
 import pytest
@@ -14,7 +14,7 @@ from oracle import wavenet_oracle as wo
 from tests.helpers import nonvacuous, scrambled_input
 
 LOGIT_TOL = 1e-3
-GRAD_RTOL = 2e-3
+GRAD_RTOL = 3e-4
 # a gradient that is analytically zero (post_process_2.bias: the chunk softmax removes any per-row
 # constant) is rounding noise of order 1e-12 in the oracle and on the GPU alike
 GRAD_FLOOR_REL = 1e-3        # ... so a tensor's scale is at least this fraction of the largest gradient of the model

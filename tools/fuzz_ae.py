@@ -122,7 +122,7 @@ def one_case(rng, k, general=False):
     err = (xi.grad.cpu() - g_in).abs().max().item() / max(g_in.abs().max().item(), 1e-30)
     if err > worst:
         worst, wname = err, "(the input)"
-    ok = e_p <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and worst <= 2e-3
+    ok = e_p <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and worst <= 3e-4
     tie_note = ""
     if not ok and e_p <= 1e-3:
         # A ReLU pre-activation within rounding of 0 with opposite signs on the two sides makes the float32 gradients differ legitimately
@@ -152,7 +152,7 @@ def one_case(rng, k, general=False):
         err = (xi.grad.cpu().double() - g_in64).abs().max().item() / max(g_in64.abs().max().item(), 1e-30)
         if err > worst:
             worst, wname = err, "(the input)"
-        ok = abs(loss.item() - l64.item()) < 1e-4 and worst <= 2e-3
+        ok = abs(loss.item() - l64.item()) < 1e-4 and worst <= 3e-4
         tie_note = " [float64 oracle with the device's sign at %d of %d near-zero ReLU pre-activations]" % (stats["flips"], stats["near"])
     print("%s case %3d fw=%d Q=%d dil=%s en=%d/%d bw=%d pool=%d de=%d/%d S=%d bias=%d B=%d W=%d  p %.1e grad %.1e %s"
           % ("ok  " if ok else "FAIL", k, fw, Q, dil, cfg["en_residual_channel"], cfg["en_dilation_channel"], cfg["en_bottleneck_width"],

@@ -68,7 +68,7 @@ def one_case(rng, k):
         worst = max(worst, (got - want).abs().max().item() / max(want.abs().max().item(), 1e-3 * gmax))
     g_in = g_ref["(input)"]
     e_in = (xi.grad.cpu() - g_in).abs().max().item() / max(g_in.abs().max().item(), 1e-30)
-    ok = e_p <= 1e-3 and e_o <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and worst <= 2e-3 and e_in <= 2e-3
+    ok = e_p <= 1e-3 and e_o <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and worst <= 3e-4 and e_in <= 3e-4
     print("%s case %3d  fw=%d dil=%s R=%d D=%d S=%d Q=%d bias=%d B=%d W=%d  pre %.1e p %.1e grad %.1e d input %.1e" % (
         "ok  " if ok else "FAIL", k, fw, dil, R, D, S, Q, bias, B, win, e_o, e_p, worst, e_in))
     return ok

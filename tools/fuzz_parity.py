@@ -6,7 +6,7 @@
 Every case draws dilations, channel counts (ragged: not multiples of 16), skip width, batch, clip
 length and bias at random, runs forward + CE + backward through the HIP path twice (nn.Module autograd
 surface and the fused training-step entry) and checks pre-softmax logits / probabilities (1e-3), loss
-(1e-4), every gradient (2e-3 of its tensor's max) and the gradient w.r.t. a dense input against oracle/wavenet_oracle.py.  A case whose forward
+(1e-4), every gradient (3e-4 of its tensor's max) and the gradient w.r.t. a dense input against oracle/wavenet_oracle.py.  A case whose forward
 agrees but whose float32 gradients differ is judged again against the float64 oracle with the device's sign at the
 post-processing ReLUs' near-zero pre-activations (the derivative jumps there; tests/test_gpu_fullsize.py) - no case is
 skipped.  Test infrastructure (it imports oracle/); not part of the product path."""
@@ -74,17 +74,17 @@ def one_case(rng, k, only=None):
     for name in eng.param_names:
         g = g_ref[name]
         e = (eng.param_view(name, grad=True).cpu() - g).abs().max().item() / max(g.abs().max().item(), floor)
-        if only is not None and e > 2e-3:
+        if only is not None and e > 3e-4:
             print("   %-40s rel err %.2e" % (name, e))
         worst2 = max(worst2, e)
     ok = (e_pre <= 1e-3 and e_p <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and abs(loss2.item() - l_ref.item()) < 1e-4
-          and worst <= 2e-3 and worst2 <= 2e-3)
+          and worst <= 3e-4 and worst2 <= 3e-4)
     tie_note = ""
     if not ok and e_pre <= 1e-3 and e_p <= 1e-3:
         # A post-processing ReLU on a pre-activation within rounding of 0 with opposite signs on the two sides makes the float32 gradients
         # differ legitimately (the derivative jumps).  Such a case is JUDGED, not skipped: the gradient is evaluated again
         # in float64 with the DEVICE's sign wherever the reference pre-activation lies within RELU_EPS of zero (relative to the tensor's
-        # max-abs) - a mask that differs anywhere else fails the case - and both entry points are held to the same 2e-3 bar.
+        # max-abs) - a mask that differs anywhere else fails the case - and both entry points are held to the same 3e-4 bar.
         from music_amd.engine import SLACK
         ws = eng.workspace(B, T)
         pitch, lo = ws["pitch"], eng.rf - 1
@@ -113,7 +113,7 @@ def one_case(rng, k, only=None):
             den = max(g.abs().max().item(), floor)
             worst = max(worst, (p.grad.cpu().double() - g).abs().max().item() / den)
             worst2 = max(worst2, (eng.param_view(name, grad=True).cpu().double() - g).abs().max().item() / den)
-        ok = abs(loss.item() - l64.item()) < 1e-4 and abs(loss2.item() - l64.item()) < 1e-4 and worst <= 2e-3 and worst2 <= 2e-3
+        ok = abs(loss.item() - l64.item()) < 1e-4 and abs(loss2.item() - l64.item()) < 1e-4 and worst <= 3e-4 and worst2 <= 3e-4
         tie_note = "  [float64 oracle with the device's sign at %d of %d near-zero ReLU pre-activations]" % (stats["flips"], stats["near"])
     # the gradient w.r.t. the INPUT (a dense float tensor that requires grad: the causal nn.Conv1d's data gradient, model.py:104), when the
     # float32 comparison stands on its own (no ReLU tie in this case)
@@ -125,7 +125,7 @@ def one_case(rng, k, only=None):
         xr = x.clone().requires_grad_(True)
         (g_in,) = torch.autograd.grad(torch.nn.functional.cross_entropy(wo.wavenet_forward(params, dil, xr), target), [xr])
         e_in = (xi.grad.cpu() - g_in).abs().max().item() / max(g_in.abs().max().item(), 1e-30)
-        ok = ok and e_in <= 2e-3
+        ok = ok and e_in <= 3e-4
     print("%s case %3d  dil=%s R=%d D=%d S=%d B=%d W=%d bias=%d  pre %.1e p %.1e grad %.1e / %.1e  d input %.1e"
           % ("ok  " if ok else "FAIL", k, dil, R, D, S, B, W, bias, e_pre, e_p, worst, worst2, e_in) + tie_note, flush=True)
     return ok
