@@ -15,6 +15,18 @@ int wn_set_error(hipError_t e, const char* file, int line) {
 }
 int wn_tile_origin(int t_lo) { return t_lo & ~63; }       // 64 samples = two 128-byte lines of a row (29.7 -> 27.3 us per forward block)
 
+// compute units of the current device (all devices of a node are the same part: asked once)
+int wn_num_cus() {
+    static std::atomic<int> cus{0};
+    int v = cus.load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) return 256;
+    cus.store(pr.multiProcessorCount, std::memory_order_relaxed);
+    return pr.multiProcessorCount;
+}
+
 int wn_xcd_swizzle_enabled() { return 1; }                 // the XCD-aware block remap is always on (speed only: wn_common.h)
 
 int wn_set_error_msg(int code, const char* msg) {

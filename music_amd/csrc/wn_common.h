@@ -209,6 +209,7 @@ __device__ __forceinline__ WnBlock wn_block(int swz) {
     return o;
 }
 int wn_xcd_swizzle_enabled();      // host: 1 (a switch until round 4)
+int wn_num_cus();                  // host: compute units of the device (cached)
 // host: first column of a launch's tiling.  A multiple of 64 samples of absolute time, so that
 // the 256-byte row segment of a 64-column wave tile is exactly two 128-byte lines (pitch and bases are
 // multiples of 128 B); columns in front of t_lo are masked.  Must stay a multiple of 4 (float4 lanes).

@@ -270,7 +270,19 @@ __global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t l_s[];      // [8 k-steps][8 column tiles] B fragments
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.x / a.ntx, tile0 = a.t_base + (blockIdx.x % a.ntx) * EPI_COLS;
+    // whole tiles first; the tiles of a last, partly filled round are dealt out by dZ PASSES (one workgroup per pass re-forms dH and dU -
+    // a quarter of a tile's work - and walks one pass of row tiles; only pass 0 stores dH / dU): 816 tiles on 256 CUs are then 3 rounds
+    // + 240 short workgroups instead of 4 rounds
+    const int npass = (a.mt_z / 3 + 7) / 8;
+    int tile = blockIdx.x, p0 = 0, p1 = npass;
+    if ((int)blockIdx.x >= a.n_whole) {
+        const int u = blockIdx.x - a.n_whole;
+        tile = a.n_whole + u / npass;
+        p0 = u % npass;
+        p1 = p0 + 1;
+    }
+    const bool store_sd = p0 == 0;
+    const int b = tile / a.ntx, tile0 = a.t_base + (tile % a.ntx) * EPI_COLS;
     const int m0 = 2 * wave;
     const bool tile_in = tile0 >= a.t_lo && tile0 + EPI_COLS <= a.t_hi;
 
@@ -401,13 +413,13 @@ __global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
     product16(acc, a.w_p2T);
     apply_mask(acc, mk);
     load_mask(mk, a.u, a.s_valid);
-    store_rows(acc, a.d_h, a.s_valid);
+    if (store_sd) store_rows(acc, a.d_h, a.s_valid);
     __syncthreads();                                          // every wave has read dO
     hand_over(acc);
     __syncthreads();
     product16(acc, a.w_p1Tc);
     apply_mask(acc, mk);
-    store_rows(acc, a.d_u, a.s_valid);
+    if (store_sd) store_rows(acc, a.d_u, a.s_valid);
     __syncthreads();                                          // every wave has read dH
     hand_over(acc);
     __syncthreads();
@@ -416,15 +428,14 @@ __global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
     {
         constexpr int MT = 3;
         float* out = a.d_z + (size_t)b * a.z_bstride;
-        const int npass = (a.mt_z / MT + 7) / 8;
         Frag<T> af[2][MT];
-        int mz = wave * MT;
+        int mz = (p0 * 8 + wave) * MT;
         auto load_w = [&](Frag<T>* f, int m, int s) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) load_a<T, NS>(f[i], a.w_skipTc, (m + i) * 8 + s, lane);
         };
         if (mz < a.mt_z) load_w(af[0], mz, 0);
-        for (int p = 0; p < npass; ++p, mz += 8 * MT) {
+        for (int p = p0; p < p1; ++p, mz += 8 * MT) {
             if (mz >= a.mt_z) break;
             f32x4 az[MT][8];
 #pragma unroll
@@ -489,7 +500,12 @@ int wn_launch_skip_epilogue_bwd(const WnEpiBwdArgs& a0, int batch, int mode, hip
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skip_epilogue_bwd_k<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         done.done(dev);
     }
-    const dim3 g(a.ntx * batch), bl(512);
+    const int cus = wn_num_cus();
+    const int ntiles = a.ntx * batch, npass = (a.mt_z / 3 + 7) / 8, rest = ntiles % cus;
+    const char* es = getenv("WN_EPI_BWD_SPLIT");              // 0: every tile whole
+    const bool split = ntiles > cus && rest > 0 && rest * npass <= cus && !(es && es[0] == '0');
+    a.n_whole = split ? ntiles - rest : ntiles;
+    const dim3 g(a.n_whole + (split ? rest * npass : 0)), bl(512);
     if (mode == WN_MODE_F16X3) hipLaunchKernelGGL(skip_epilogue_bwd_k<F16>, g, bl, sh, st, a);
     else hipLaunchKernelGGL(skip_epilogue_bwd_k<BF16>, g, bl, sh, st, a);
     WN_CHECK_LAUNCH();
@@ -515,11 +531,7 @@ int wn_launch_skip_epilogue_fwd(const WnEpiFwdArgs& a0, int batch, int mode, hip
     }
     // stagger of the first round (kernel comment): on when the launch has more than one round; WN_EPI_STAGGER = cycles per k-step pair
     // (0 = off; default 3600, i.e. about 0.75 of a tile's loop time)
-    int cus = 256;
-    {
-        hipDeviceProp_t pr;
-        if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-    }
+    const int cus = wn_num_cus();
     const char* es = getenv("WN_EPI_STAGGER");
     const int per_it = es ? atoi(es) : 3600;
     a.stagger_n = a.ntx * batch > cus ? cus : 0;

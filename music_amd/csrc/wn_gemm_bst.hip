@@ -224,17 +224,6 @@ static void bst_launch(const WnGemmArgs& k, int ntx, int ntiles, int npass, int 
     hipLaunchKernelGGL((chan_gemm_bst_k<T, NS, MT, KS>), dim3(grid), dim3(512), sh, st, k, ntx, ntiles, npass);
 }
 
-static int bst_cus() {
-    static std::atomic<int> cus{0};
-    int v = cus.load(std::memory_order_relaxed);
-    if (v > 0) return v;
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) return 256;
-    cus.store(pr.multiProcessorCount, std::memory_order_relaxed);
-    return pr.multiProcessorCount;
-}
-
 // returns 1 if the launch was taken, 0 if the arguments are outside this kernel's preconditions
 int wn_launch_gemm_bst(const WnGemmArgs& k, int batch, int mode, hipStream_t st) {
     if (mode != WN_MODE_BF16X3 && mode != WN_MODE_F16X3) return 0;
@@ -249,7 +238,7 @@ int wn_launch_gemm_bst(const WnGemmArgs& k, int batch, int mode, hipStream_t st)
     const int ntx = (k.t_hi - k.t_base + BST_COLS - 1) / BST_COLS;
     const int ntiles = ntx * batch;
     const int npass = (k.mt / 3 + 7) / 8;
-    int grid = bst_cus();
+    int grid = wn_num_cus();
     if (grid > ntiles || !(e && e[0] == '1')) grid = ntiles;
     if (mode == WN_MODE_BF16X3) bst_launch<BF16, 3, 3, 8>(k, ntx, ntiles, npass, grid, st);
     else bst_launch<F16, 3, 3, 8>(k, ntx, ntiles, npass, grid, st);

@@ -497,7 +497,11 @@ class WaveNetEngine:
             bw["PQ"] = [(buf(self.CH), buf(self.CH)), (buf(self.CH), buf(self.CH))]
         # (time chunk per workgroup of the epilogue's weight gradients; 512 / 256 / 2048-4096 measured on one box in round 5: step 4.36 /
         # 4.46 / 4.35 against 4.34 ms - shorter chunks pay in slabs to reduce, longer ones in the blocks that run beside them)
-        ops = [("p2", lo, T, 1024), ("p1", lo, T, 1024), ("skip", lo, T, 2048)]
+        # round 6 (the fused epilogue: the weight gradients of post_process_1 and of the skip convs now run on their own, beside each
+        # other, behind the fused launch): 2048 for all three - step 4.141 against 4.19 - 4.23 at (1024, 1024, 2048), 4.22 at (512, 512, 1024),
+        # 4.25 at 3264, 4.38 at 4096 (profiles/r06_ab_wgrad_chunks.json)
+        ck = [int(v) for v in os.environ.get("WN_EPI_WGRAD_CHUNKS", "2048,2048,2048").split(",")]
+        ops = [("p2", lo, T, ck[0]), ("p1", lo, T, ck[1]), ("skip", lo, T, ck[2])]
         # one-launch blocks whose dilation is a multiple of 32 hand dx on WHOLE (chain form of wn_resblock_bwd_pq: the Q rows
         # of an item are the carry of the next item of its chain); decided here, once per workspace, with the slab counts
         Bp = B // 2 if pair else B
