@@ -291,29 +291,53 @@ __global__ __launch_bounds__(512) void wgrad_big_k(WnWgradArgs a) {
                 }
             }
         };
+        // one request of the 8 per k-step (tile k, first / second 16 bytes of the lane's 8 samples)
+        auto issue_piece = [&](int tb, int k, int half) {
+            const int t = tb + 8 * q;
+            if (decltype(guarded)::value) {
+                if (half == 0) raw[k] = wg_load(lrow[k], t + lshift[k], lcols[k]);
+            } else {
+                const float* p = lrow[k] + t + lshift[k];
+                if (half == 0) raw[k].u0 = ld4u(p);
+                else raw[k].u1 = ld4u(p + 4);
+            }
+        };
+        const int tb_last = tc0 + ((tc1 - 1 - tc0) & ~31);
         if (tc0 < tc1) {
             issue(tc0);
             park(0, tc0);
+            issue(tc0 + 32 < tc1 ? tc0 + 32 : tb_last);
         }
         __syncthreads();
         int it = 0;
-        const int tb_last = tc0 + ((tc1 - 1 - tc0) & ~31);
+        // k-step it: MFMAs out of stage it & 1.  Between its row tiles 3 and 4 the rows of k-step it + 1 (requested during the second
+        // half of k-step it - 1) are split into the other stage, and behind that their registers are re-armed for k-step it + 2 one
+        // tile (two requests) per row tile: eight waves that request 8 KB each right behind the barrier queue for the CU's one address path while
+        // the matrix pipe waits (round 6, profiles/r06_gemm_tiles.md).  A fragments one row tile ahead of their MFMAs (two register
+        // sets, fenced: hipcc folds them back into read - wait - 12 MFMAs otherwise).
         for (int tb = tc0; tb < tc1; tb += 32, ++it) {
-            const bool more = tb + 32 < tc1;
-            issue(more ? tb + 32 : tb_last);        // unconditional: see wgrad_k
-            __builtin_amdgcn_sched_barrier(0);      // keep the loads AHEAD of the MFMAs
+            const int tb1 = tb + 32 < tc1 ? tb + 32 : tb_last, tb2 = tb + 64 < tc1 ? tb + 64 : tb_last;
             const uint16_t* base = l_f + (size_t)(it & 1) * 32 * FR;
-            Frag<T> bf[4];
+            Frag<T> bf[4], af[2];
 #pragma unroll
             for (int n = 0; n < 4; ++n) load_a<T, NS>(bf[n], base, 16 + wn * 4 + n, lane);
+            load_a<T, NS>(af[0], base, wm * 8, lane);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                Frag<T> af;
-                load_a<T, NS>(af, base, wm * 8 + m, lane);
+                if (m + 1 < 8) load_a<T, NS>(af[(m + 1) & 1], base, wm * 8 + m + 1, lane);
+                if (m == 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    park((it + 1) & 1, tb1);                   // (the last fill is never read)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (m >= 4) {
+                    issue_piece(tb2, m - 4, 0);                // tile m - 4: both halves of the lane's 8 samples
+                    issue_piece(tb2, m - 4, 1);
+                }
 #pragma unroll
-                for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af, bf[n]);
+                for (int n = 0; n < 4; ++n) mma<T, NS>(acc[m][n], af[m & 1], bf[n]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            park((it + 1) & 1, more ? tb + 32 : tb_last);      // (the last fill is never read)
             __syncthreads();
         }
     };
