@@ -52,7 +52,7 @@ CFG = dict(filter_width=2, dilations=[2 ** i for i in range(10)] * 3, dilation_c
            residual_channels=64, skip_channels=256, quantization_channels=256, use_bias=False)
 B_LOCAL, T = 8, 16000
 MARK_EVERY = 4             # timed region: HIP events of the stack kernels on every 4th step (an event costs a marker packet)
-HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec); 6.29e12 measured copy
+HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec); the line reports the box's own copy rate beside it (5.0 - 5.3e12: roofline.measured_copy_GBs)
 MFMA_PEAK = 2.5e15         # FLOP/s, dense bf16 / f16 MFMA (same guide)
 BWD_KERNELS = "resblock_bwd_pq_k"
 BWD_PMC = "resblock_bwd_pq_k<"                       # every form of the backward block (pair / chain, with / without dy)
@@ -825,7 +825,12 @@ def main():
         "config": {"workload": "BASELINE configs[1]: 30-layer (3x dilations 1..512) WaveNet, 64 res/dil, 256 skip, "
                                "batch 8x16000 per GPU, full train step (H2D of codes and targets, prefetched one step ahead on a copy stream, + fwd on the loader-layout one-hot of the codes (never materialised) + CE + bwd + all-reduce + Adam)",
                    "global_batch": world * B_LOCAL, "seq_len": T, "parallelism": "dp%d" % world,
-                   "precision": args.precision, "final_loss": float(loss.item())},
+                   "precision": args.precision, "final_loss": float(loss.item()),
+                   # (the driver's record keeps `config`: the median of the K timed steps beside the mean in ms_per_step - the device has
+                   # bursts of 6 ms steps on some boxes, profiles/r06_gemm_tiles.md section 3)
+                   "ms_per_step_median": per_step[len(per_step) // 2] if per_step else None,
+                   "ms_per_step_p90": per_step[min(len(per_step) - 1, (len(per_step) * 9) // 10)] if per_step else None,
+                   "slow_steps_over_1p15_median": sum(1 for v in per_step if v > 1.15 * per_step[len(per_step) // 2]) if per_step else None},
         # the time-dominant kernels: one residual block's backward (SURVEY 8d A_b per block; duration = the HIP-event
         # time of the backward stack inside the timed region / its 30 blocks)
         "roofline": roof(bwd_b / n_layers, bwd_launch_ms,
