@@ -458,7 +458,8 @@ __global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
 #pragma unroll
                         for (int g = 0; g < 2; ++g) {
                             const f32x4 v = {az[i][4 * g][r], az[i][4 * g + 1][r], az[i][4 * g + 2][r], az[i][4 * g + 3][r]};
-                            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(op + 64 * g));
+                            if (a.nt_dz) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(op + 64 * g));
+                            else *reinterpret_cast<f32x4*>(op + 64 * g) = v;
                         }
                     }
                 }
@@ -502,6 +503,9 @@ int wn_launch_skip_epilogue_bwd(const WnEpiBwdArgs& a0, int batch, int mode, hip
     }
     const int cus = wn_num_cus();
     const int ntiles = a.ntx * batch, npass = (a.mt_z / 3 + 7) / 8, rest = ntiles % cus;
+    // dZ by plain stores: streaming stores are 12 % faster for this product ALONE (wn_gemm_bst.hip) but inside the step nothing
+    // (4.176 against 4.192 ms; the stack's first blocks read the rows written last out of the caches); WN_EPI_BWD_NT=1 = streaming
+    { const char* en = getenv("WN_EPI_BWD_NT"); a.nt_dz = en ? atoi(en) : 0; }
     const char* es = getenv("WN_EPI_BWD_SPLIT");              // 0: every tile whole
     const bool split = ntiles > cus && rest > 0 && rest * npass <= cus && !(es && es[0] == '0');
     a.n_whole = split ? ntiles - rest : ntiles;

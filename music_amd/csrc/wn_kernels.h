@@ -52,6 +52,7 @@ struct WnEpiBwdArgs {
     const uint16_t* w_p2T; const uint16_t* w_p1Tc; const uint16_t* w_skipTc;   // packed [16][8] natural, [16][8] chained, [mt_z][8] chained
     int mt_z, z_valid, s_valid;                            // 16-row tiles of dZ (a multiple of 3), real z rows, real skip rows
     int t_lo, t_hi, t_base, ntx;
+    int nt_dz;                                             // dZ by streaming (non-temporal) stores
     int n_whole;                                           // tiles done whole; the rest are dealt out by dZ passes (set by the launcher)
 };
 int wn_launch_skip_epilogue_bwd(const WnEpiBwdArgs& a, int batch, int mode, hipStream_t st);

@@ -245,10 +245,12 @@ class _AutoencoderEngine:
             w[:Sd, i * CHd:i * CHd + Dd] = sp.conv("de_dilation_layer_stack.%d.weight" % (3 * i + 2))[:, :, 0]
         add("skip", w)
         bwd.append(("skipT", pack_index(np.ascontiguousarray(w.T))))
+        bwd.append(("skipTc", pack_index(np.ascontiguousarray(w.T), chained=True)))     # chained k order: wn_skip_epilogue_bwd
         w = full(SP, SP)
         w[:Sd, :Sd] = sp.conv("connection_1.weight")[:, :, 0]
         add("c1", w)
         bwd.append(("c1T", pack_index(np.ascontiguousarray(w.T))))
+        bwd.append(("c1Tc", pack_index(np.ascontiguousarray(w.T), chained=True)))
         w = full(Q, SP)
         w[:, :Sd] = sp.conv("connection_2.weight")[:, :, 0]
         add("c2", w)
@@ -690,21 +692,37 @@ class _AutoencoderEngine:
         sb, db, zb, eb = SP * pitch, CHd * pitch, N * CHd * pitch, CHe * pitch
         # ---- decoder epilogue: o = c2(relu(r)), r = c1(relu(u)) + cond_f, u = skip(z)
         wgrad_s("c2", dO, Q * W, W, -lo, W, R1, None, sb, pitch, 0, 0, pitch, SP // 16, Q // 16, 1, SP, lo, T)
-        gemm("c2T", dO, None, Q * W, W, 0, W, -lo, 0, Q // 32, 0, SP // 16, Sd, dR1, sb, pitch, 0, None, NONE3,
-             (R1, sb, pitch), lo, T, 0)
         cmode, cq = ws["cf_mode"]
         d_enf = torch.zeros(B, Sd, Le, dtype=torch.float32, device=self.device)
-        call("wn_cond_grad", dR1, sb, pitch, Sd, lo, T, cmode, Le, max(cq, 1), ptr(d_enf), Sd * Le, Le, B, st)
-        wgrad_s("c1", dR1, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
-        gemm("c1T", dR1, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, SP // 16, Sd, dU, sb, pitch, 0, None, NONE3,
-             (U, sb, pitch), lo, T, 0)
+        fused = (os.environ.get("WN_EPI_FUSED_BWD", "1") == "1" and SP == 256 and Q == 256 and (N * CHd // 16) % 3 == 0
+                 and mb in (_lib.F16X3, _lib.BF16X3))
+        if fused:
+            # dR1, dU and dZ in ONE launch per 128-column tile (wn_skip_epilogue_bwd, music_amd/engine.py); the weight gradients that read
+            # dR1 / dU follow - connection_1's on the side stream, the skip convs' on the main stream - and the stack starts behind both
+            call("wn_skip_epilogue_bwd", dO, Q * W, W, R1, U, sb, pitch, dR1, dU, dZ, zb, br("c2T"), br("c1Tc"), br("skipTc"),
+                 N * CHd // 16, N * CHd, Sd, lo, T, B, mb, st)
+            call("wn_cond_grad", dR1, sb, pitch, Sd, lo, T, cmode, Le, max(cq, 1), ptr(d_enf), Sd * Le, Le, B, st)
+            wgrad_s("c1", dR1, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
+            wgrad("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CHd // 16, SP // 16, 0, N * CHd, lo, T)
+            if overlap:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                main.wait_event(ev)
+        else:
+            gemm("c2T", dO, None, Q * W, W, 0, W, -lo, 0, Q // 32, 0, SP // 16, Sd, dR1, sb, pitch, 0, None, NONE3,
+                 (R1, sb, pitch), lo, T, 0)
+            call("wn_cond_grad", dR1, sb, pitch, Sd, lo, T, cmode, Le, max(cq, 1), ptr(d_enf), Sd * Le, Le, B, st)
+            wgrad_s("c1", dR1, sb, pitch, 0, pitch, U, None, sb, pitch, 0, 0, pitch, SP // 16, SP // 16, 1, SP, lo, T)
+            gemm("c1T", dR1, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, SP // 16, Sd, dU, sb, pitch, 0, None, NONE3,
+                 (U, sb, pitch), lo, T, 0)
         bias_grad("connection_2", dO, Q * W, W, -lo, Q, lo, T)
         bias_grad("connection_1", dR1, sb, pitch, 0, Sd, lo, T)
         for i in range(N if self.use_bias else 0):
             bias_grad("de_dilation_layer_stack.%d" % (3 * i + 2), dU, sb, pitch, 0, Sd, lo, T)
-        wgrad_s("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CHd // 16, SP // 16, 0, N * CHd, lo, T)
-        gemm("skipT", dU, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, N * CHd // 16, N * CHd, dZ, zb, pitch, 0, None, NONE3,
-             NONE3, lo, T, 0)
+        if not fused:
+            wgrad_s("skip", dU, sb, pitch, 0, pitch, Z, None, zb, pitch, 0, 0, pitch, N * CHd // 16, SP // 16, 0, N * CHd, lo, T)
+            gemm("skipT", dU, None, sb, pitch, lo, T, 0, 0, SP // 32, 0, N * CHd // 16, N * CHd, dZ, zb, pitch, 0, None, NONE3,
+                 NONE3, lo, T, 0)
         self.mark("ce_epilogue_bwd")
         # ---- decoder stack
         xd = lambda i: self._lay(ws["Xd"], i, CHd, ws)
