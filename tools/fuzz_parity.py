@@ -25,6 +25,9 @@ from tests.helpers import scrambled_input  # noqa: E402
 RELU_EPS = 2e-4          # tests/test_gpu_fullsize.py: the band around zero inside which a ReLU's subgradient follows the device
 
 
+EPI = False              # --epi: every case has 256 skip channels (the fused epilogue launches), most of them no biases and 3 or 6 blocks
+
+
 def one_case(rng, k, only=None):
     from music_amd.model import wavenet
     n = int(rng.integers(1, 7))
@@ -36,6 +39,11 @@ def one_case(rng, k, only=None):
     B = int(rng.integers(1, 4))
     extra = int(rng.choice([0, 1, 3, 17, 63, 64, 65, 255, 511, 513, 1025]))
     bias = bool(rng.random() < 0.4)
+    if EPI:
+        S = 256
+        if rng.random() < 0.7:              # the fused BACKWARD launch wants the stacked z rows in groups of 48 and no biases
+            bias = False
+            dil = (dil * 6)[:3 if rng.random() < 0.5 else 6]
     cfg = dict(filter_width=2, dilations=dil, dilation_channels=D, residual_channels=R, skip_channels=S,
                quantization_channels=256, use_bias=bias)
     torch.manual_seed(1000 + k)
@@ -125,6 +133,33 @@ def one_case(rng, k, only=None):
         xr = x.clone().requires_grad_(True)
         (g_in,) = torch.autograd.grad(torch.nn.functional.cross_entropy(wo.wavenet_forward(params, dil, xr), target), [xr])
         e_in = (xi.grad.cpu() - g_in).abs().max().item() / max(g_in.abs().max().item(), 1e-30)
+        if e_in > 3e-4:
+            # the same ReLU-tie rule for the input gradient (round 6, the 3e-4 bar): one flipped post-processing ReLU that the weight
+            # gradients (sums over all rows) absorb under the bar can still move a column of d loss / d input by more - judged against
+            # the float64 oracle with the device's sign inside the band, like the weight gradients above
+            from music_amd.engine import SLACK
+            ws = eng.workspace(B, T)
+            pitch, lo = ws["pitch"], eng.rf - 1
+            v = lambda buf: buf[SLACK:SLACK + B * eng.SP * pitch].view(B, eng.SP, pitch)[:, :S, lo:T].cpu()
+            dev_pre = {"skip_sum": v(ws["U"]), "post_process_1": v(ws["H"])}
+            stats = dict(near=0, flips=0)
+
+            def relu_in(name, t):
+                d = dev_pre[name]
+                near = t.detach().abs() < RELU_EPS * t.detach().abs().max().item()
+                ref_m, dev_m = t.detach() > 0, d > 0
+                assert not ((ref_m != dev_m) & ~near).any(), "ReLU mask of %s differs outside the tolerance band" % name
+                stats["near"] += int(near.sum())
+                stats["flips"] += int(((ref_m != dev_m) & near).sum())
+                return t * torch.where(near, dev_m, ref_m).to(t.dtype)
+            try:
+                _, _, g64 = wo.loss_and_grads({kk: vv.double() for kk, vv in params.items()}, dil, x.double(), target, input_grad=True, relu=relu_in)
+                g_in64 = g64["(input)"]
+                e_in = (xi.grad.cpu().double() - g_in64).abs().max().item() / max(g_in64.abs().max().item(), 1e-30)
+                tie_note = "  [input gradient: float64 oracle with the device's sign at %d of %d near-zero ReLU pre-activations]" % (stats["flips"], stats["near"])
+            except AssertionError as e:
+                print("FAIL case %3d  %s" % (k, e), flush=True)
+                return False
         ok = ok and e_in <= 3e-4
     print("%s case %3d  dil=%s R=%d D=%d S=%d B=%d W=%d bias=%d  pre %.1e p %.1e grad %.1e / %.1e  d input %.1e"
           % ("ok  " if ok else "FAIL", k, dil, R, D, S, B, W, bias, e_pre, e_p, worst, worst2, e_in) + tie_note, flush=True)
@@ -135,8 +170,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=30)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--epi", action="store_true", help="256 skip channels in every case: wn_skip_epilogue_fwd / _bwd on random shapes")
     ap.add_argument("--only", type=int, default=None, help="run just this case of the stream (prints the failing tensors)")
     args = ap.parse_args()
+    global EPI
+    EPI = args.epi
     rng = np.random.default_rng(args.seed)
     bad = sum(0 if one_case(rng, k, args.only) else 1 for k in range(args.cases))
     print("%d / %d cases failed" % (bad, args.cases))
