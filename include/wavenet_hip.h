@@ -108,8 +108,9 @@ int wn_resblock_bwd(const float* x_in, const float* dy, const float* dz, float* 
 /* The forward epilogue in ONE launch (ABI v5; replaces the skip 1x1 convs + Python sum, F.relu, post_process_1, F.relu,
  * post_process_2 of wavenet/model.py:127-138 - three wn_chan_gemm launches):  per tile of 128 columns
  *   u = bias_skip + Ws z ;  h = bias_p1 + P1 relu(u) ;  o = bias_p2 + P2 relu(h)        on [t_lo, t_hi)
- * z: the z-crops of all blocks stacked on the channel axis, [B][32 ks_skip][pitch] (ks_skip even), valid on [t_lo, t_hi) (columns
- * outside read as 0 and are never dereferenced).  u, h: [B][256][pitch] (s_bstride floats per clip; rows >= s_valid are not written) -
+ * z: the z-crops of all blocks stacked on the channel axis, [B][32 ks_skip][pitch] (ks_skip even), valid on [t_lo, t_hi).  The launch
+ * tiles the columns from t_lo & ~63 in steps of 128 and READS every row over whole tiles (values outside [t_lo, t_hi) are ignored, NaN
+ * included): the tiles must lie inside the row pitch (-4 otherwise), i.e. the rows need the activation layout's slack.  u, h: [B][256][pitch] (s_bstride floats per clip; rows >= s_valid are not written) -
  * the backward masks with them.  o: compact [B][256][o_pitch], column t - t_lo (the reference's pre-softmax memory order).
  * w_skip: packed [16][ks_skip], natural k.  w_p1c / w_p2c: packed [16][8] in the CHAINED k order (the u / h tile is handed from
  * product to product out of the accumulators, like wn_resblock_fwd's dense weights).  At most 256 skip and 256 quantisation

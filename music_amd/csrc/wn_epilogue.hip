@@ -492,6 +492,8 @@ int wn_launch_skip_epilogue_bwd(const WnEpiBwdArgs& a0, int batch, int mode, hip
     WnEpiBwdArgs a = a0;
     a.t_base = wn_tile_origin(a.t_lo);
     a.ntx = (a.t_hi - a.t_base + EPI_COLS - 1) / EPI_COLS;
+    if (a.t_base + a.ntx * EPI_COLS > a.pitch)
+        return wn_set_error_msg(-4, "wn_skip_epilogue_bwd: the 128-column tiles over [t_lo & ~63, t_hi) must lie inside the row pitch (mask rows are read over whole tiles)");
     const size_t sh = (size_t)64 * 1024 * sizeof(uint16_t);
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -524,6 +526,8 @@ int wn_launch_skip_epilogue_fwd(const WnEpiFwdArgs& a0, int batch, int mode, hip
     WnEpiFwdArgs a = a0;
     a.t_base = wn_tile_origin(a.t_lo);
     a.ntx = (a.t_hi - a.t_base + EPI_COLS - 1) / EPI_COLS;
+    if (a.t_base + a.ntx * EPI_COLS > a.pitch)
+        return wn_set_error_msg(-4, "wn_skip_epilogue_fwd: the 128-column tiles over [t_lo & ~63, t_hi) must lie inside the row pitch (rows are read over whole tiles)");
     const size_t sh = (size_t)64 * 1024 * sizeof(uint16_t);  // 128 KB: the hand-over operand (the two 32 KB stages lie inside it)
     int dev = 0;
     (void)hipGetDevice(&dev);

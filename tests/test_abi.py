@@ -181,6 +181,33 @@ def test_null_required_pointers_are_reported_not_dereferenced():
         a = list(fwd)
         a[i] = None
         bad("wn_resblock_fwd", arg, *a)
+    #         z zbs pitch ks w_skip bias u h sbs w_p1c b1 w_p2c b2 o obs op s_valid q_valid t_lo t_hi batch mode
+    epf = [P, 1 << 20, 512, 4, P, None, P, P, 1 << 20, P, None, P, None, P, 1 << 20, 200, 256, 256, 100, 300, 1, 0, None]
+    for i, arg in ((0, "z"), (4, "w_skip"), (6, "u"), (7, "h"), (9, "w_p1c"), (11, "w_p2c"), (13, "o")):
+        a = list(epf)
+        a[i] = None
+        bad("wn_skip_epilogue_fwd", arg, *a)
+    a = list(epf)
+    a[2] = 256                                               # the 128-column tiles over [64, 300) do not fit a pitch of 256: refused, not read
+    assert lib.wn_skip_epilogue_fwd(*a) == -4 and "pitch" in lib.wn_last_error().decode()
+    a = list(epf)
+    a[3] = 3                                                 # an odd number of k-steps
+    assert lib.wn_skip_epilogue_fwd(*a) == -4
+    a = list(epf)
+    a[0], a[20] = None, 0                                    # batch 0: nothing to do
+    assert lib.wn_skip_epilogue_fwd(*a) == 0
+    #         d_o obs op h u sbs pitch d_h d_u d_z zbs w_p2T w_p1Tc w_skipTc mt_z z_valid s_valid t_lo t_hi batch mode
+    epb = [P, 1 << 20, 200, P, P, 1 << 20, 512, P, P, P, 1 << 20, P, P, P, 6, 96, 256, 100, 300, 1, 2, None]
+    for i, arg in ((0, "d_o"), (3, "h"), (4, "u"), (7, "d_h"), (8, "d_u"), (9, "d_z"), (11, "w_p2T"), (12, "w_p1Tc"), (13, "w_skipTc")):
+        a = list(epb)
+        a[i] = None
+        bad("wn_skip_epilogue_bwd", arg, *a)
+    a = list(epb)
+    a[14] = 7                                                # z row tiles not in groups of 3
+    assert lib.wn_skip_epilogue_bwd(*a) == -4
+    a = list(epb)
+    a[6] = 256
+    assert lib.wn_skip_epilogue_bwd(*a) == -4 and "pitch" in lib.wn_last_error().decode()
     bad("wn_wgrad", "c", P, 64, 64, 0, 64, P, None, 64, 64, 0, 0, 64, 2, 2, 0, None, 32, 1 << 20, 0, 64, 64, 1, 2, None)
     bad("wn_reduce_slabs", "slab", P, 1, 4, None, P, None)
     assert lib.wn_reduce_slabs(None, 0, 0, None, None, None) == 0
