@@ -175,6 +175,61 @@ def test_forward_epilogue_chains_give_the_same_bits(bias, monkeypatch):
             assert torch.equal(a, b), split
 
 
+def test_fused_epilogue_equals_the_three_launches(monkeypatch):
+    """256 skip / 256 quantisation channels: the skip product, the post-processing and their data gradients run as ONE launch per
+    direction (wn_skip_epilogue_fwd / _bwd, engine.epi_fused / epi_fused_bwd; round 6); WN_EPI_FUSED=0 / WN_EPI_FUSED_BWD=0 are the three
+    wn_chan_gemm launches each (dZ then on the B-stationary product, and with WN_GEMM_BST=0 on chan_gemm_wide2_k).  Same products, the
+    intermediate tiles in the chained k order: probabilities within 2e-6, loss within 1e-6, every gradient within 2e-5 of its max-abs;
+    a second run of the fused form reproduces its bits.  Ragged batch of 3 (a partly filled last round: tiles dealt out by dZ passes
+    is exercised at the bench geometry by tests/test_gpu_fullsize.py)."""
+    import numpy as np
+    import torch
+    from music_amd.model import wavenet
+    from tests.helpers import scrambled_input
+    cfg = dict(filter_width=2, dilations=[1, 2, 4, 8, 16, 32], dilation_channels=64, residual_channels=64,
+               skip_channels=256, quantization_channels=256, use_bias=False)
+    rng = np.random.default_rng(31)
+    got = {}
+    for tag, env in (("fused", {}), ("fused2", {}), ("three", {"WN_EPI_FUSED": "0", "WN_EPI_FUSED_BWD": "0"}),
+                     ("three_wide2", {"WN_EPI_FUSED": "0", "WN_EPI_FUSED_BWD": "0", "WN_GEMM_BST": "0"})):
+        for k in ("WN_EPI_FUSED", "WN_EPI_FUSED_BWD", "WN_GEMM_BST"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(33)
+        net = wavenet(**cfg)
+        with torch.no_grad():
+            for p_ in net.parameters():
+                p_.mul_(2.5)
+        net = net.cuda()
+        if tag == "fused":
+            T = net.receptive_field + 900
+            x = scrambled_input(rng.integers(0, 256, size=(3, T))).cuda()
+            target = torch.from_numpy(rng.integers(0, 256, size=(3 * 901,)).astype(np.int64)).cuda()
+        probs = net(x).detach().clone()
+        eng = net._engine
+        assert eng.epi_fused == (tag.startswith("fused")) and eng.epi_fused_bwd == (tag.startswith("fused"))
+        loss = eng.loss_and_grad(x, target)
+        torch.cuda.synchronize()
+        got[tag] = (probs, loss.clone(), eng.flat_grad.clone())
+    for a, b in zip(got["fused"], got["fused2"]):
+        assert torch.equal(a, b)
+    assert torch.equal(got["three"][2], got["three_wide2"][2])          # the B-stationary product is bit-identical to wide2
+    for other in ("three",):
+        assert (got["fused"][0] - got[other][0]).abs().max().item() <= 2e-6
+        assert abs(got["fused"][1].item() - got[other][1].item()) <= 1e-6
+        g0, g1 = got["fused"][2], got[other][2]
+        eng = net._engine
+        worst = 0.0
+        for name in eng.param_names:
+            o, n = eng.spec.off[name], int(np.prod(eng.spec.shape[name]))
+            scale = g1[o:o + n].abs().max().item()
+            if scale > 0:
+                worst = max(worst, (g0[o:o + n] - g1[o:o + n]).abs().max().item() / scale)
+        print("fused vs three launches: probs %.2e, worst gradient %.2e of its max-abs" % ((got["fused"][0] - got[other][0]).abs().max().item(), worst))
+        assert worst <= 2e-5
+
+
 def test_chain_form_equals_pair_form(monkeypatch):
     """Blocks with d % 32 == 0 hand dx on whole (chain walk, Q rows carried in registers); WN_PQ_CHAIN=0 makes every block hand
     the (P, Q) pair on.  Same products per item, another summation order of the weight-gradient slabs and of P + Q + dy:
