@@ -674,11 +674,16 @@ def main():
         dt = tt.item()
 
     # per-phase GPU time from the HIP events recorded on the launch stream inside the timed region
-    phase = {}
+    phase, phase_all = {}, {}
     for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
         if n1 != "step_begin":
-            phase[n1] = phase.get(n1, 0.0) + e0.elapsed_time(e1)
+            dt_ = e0.elapsed_time(e1)
+            phase[n1] = phase.get(n1, 0.0) + dt_
+            phase_all.setdefault(n1, []).append(dt_)
     phase = {k: v / n_sampled for k, v in phase.items()}       # ms per step (mean of the sampled steps)
+    # ... and the MEDIAN over the sampled steps beside it: the device inserts steps of 6 ms, and one of them among
+    # the 13 sampled steps of a 50-step run moves a phase's mean by 5 - 10 %
+    phase_median = {k: sorted(v)[len(v) // 2] for k, v in phase_all.items()}
     # with the coarse marks: "causal_fwd" = everything from the step's begin to the causal layer's end, "epilogue_bwd" =
     # epilogue forward + softmax/CE + epilogue backward; stack_fwd / stack_bwd are exact
     timed = {"stack_fwd": phase.get("stack_fwd"), "stack_bwd": phase.get("stack_bwd"),
@@ -843,6 +848,10 @@ def main():
                                          "MI355X_MICROARCH.md; not measured in this run; mean over the step's %d launches" % n_layers),
                          algorithmic_bytes_per_launch=bwd_b / n_layers,
                          avg_launch_ms=bwd_launch_ms, measured_copy_GBs=copy_gbs,
+                         median_step={"avg_launch_ms": phase_median.get("stack_bwd", nan) / n_layers,
+                                      "frac": (gbs(bwd_b / n_layers, phase_median.get("stack_bwd", nan) / n_layers) or nan) * 1e9 / HBM_PEAK,
+                                      "note": "the same figure from the MEDIAN of the sampled steps' backward-stack times (a burst step among "
+                                              "the sampled ones moves the mean, which `frac` is computed from as the contract asks)"},
                          frac_of_measured_copy=(gbs(bwd_b / n_layers, bwd_launch_ms) / copy_gbs) if copy_gbs and bwd_ms == bwd_ms else None),
         # the dilated-conv stack of the north star, forward / backward / both (SURVEY 8d A_f, A_b)
         "roofline_stack_fwd": roof(fwd_b, fwd_ms, kernel="resblock_fwd_nt_k x %d" % n_layers, traffic=traffic_of("resblock_fwd_nt_k"),
