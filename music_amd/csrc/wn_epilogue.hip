@@ -218,26 +218,26 @@ __global__ __launch_bounds__(512) void skip_epilogue_fwd_k(WnEpiFwdArgs a) {
             p[64] = __builtin_bit_cast(u32x4, f.lo);
         }
     };
-    // H = bias_1 + P1 relu(U), O = bias_2 + P2 relu(H): 8 k-steps each over the 128 KB operand.  ONE ring of three weight slots runs
-    // through both products (chained packs [16][8]): a slot is re-armed three k-steps ahead once its MFMAs are issued.  U stays in its
+    // H = bias_1 + P1 relu(U), O = bias_2 + P2 relu(H): 8 k-steps each over the 128 KB operand.  ONE ring of two weight slots runs
+    // through both products (chained packs [16][8]): a slot is re-armed two k-steps ahead once its MFMAs are issued (three slots: 9 registers spilled).  U stays in its
     // accumulators while H is formed in the second set (and H while O is formed in the first), and a tile's 16 row-stores per lane
     // go out two per k-step BEHIND that k-step's weight request: vector memory completes in order, so a request waits for every
-    // store in front of it - spread like this a store has three k-steps to drain before anything waits for it
-    Frag<T> wf[3][2];
+    // store in front of it - spread like this a store has two k-steps to drain before anything waits for it
+    Frag<T> wf[2][2];
     auto request = [&](Frag<T>* slot, const uint16_t* pack, int s) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) load_a<T, NS>(slot[i], pack, (m0 + i) * 8 + s, lane);
     };
 #pragma unroll
-    for (int s = 0; s < 3; ++s) request(wf[s], a.w_p1c, s);
+    for (int s = 0; s < 2; ++s) request(wf[s], a.w_p1c, s);
     hand_over(acc);                                           // (the loop's last barrier: every wave is done with the stages)
     __syncthreads();
     init_acc(acc2, a.bias_1, a.s_valid);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        mma_half(acc2, l_s + (size_t)s * 8 * FR, wf[s % 3], nothing);
-        if (s + 3 < 8) request(wf[s % 3], a.w_p1c, s + 3);
-        else request(wf[s % 3], a.w_p2c, s + 3 - 8);
+        mma_half(acc2, l_s + (size_t)s * 8 * FR, wf[s & 1], nothing);
+        if (s + 2 < 8) request(wf[s & 1], a.w_p1c, s + 2);
+        else request(wf[s & 1], a.w_p2c, s + 2 - 8);
         store_rows(acc, 2 * s, 2 * s + 2, a.u, a.s_bstride, a.pitch, 0, a.s_valid);
     }
     __syncthreads();                                          // every wave has read relu(U)
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(512) void skip_epilogue_fwd_k(WnEpiFwdArgs a) {
     init_acc(acc, a.bias_2, a.q_valid);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        mma_half(acc, l_s + (size_t)s * 8 * FR, wf[(s + 8) % 3], nothing);
-        if (s + 3 < 8) request(wf[(s + 8) % 3], a.w_p2c, s + 3);
+        mma_half(acc, l_s + (size_t)s * 8 * FR, wf[s & 1], nothing);
+        if (s + 2 < 8) request(wf[s & 1], a.w_p2c, s + 2);
         store_rows(acc2, 2 * s, 2 * s + 2, a.h, a.s_bstride, a.pitch, 0, a.s_valid);
     }
     store_rows(acc, 0, 16, a.o, a.o_bstride, a.o_pitch, -a.t_lo, a.q_valid);
@@ -285,6 +285,7 @@ __global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
     const int b = tile / a.ntx, tile0 = a.t_base + (tile % a.ntx) * EPI_COLS;
     const int m0 = 2 * wave;
     const bool tile_in = tile0 >= a.t_lo && tile0 + EPI_COLS <= a.t_hi;
+    const unsigned lane_off = (unsigned)(4 * q) * (unsigned)a.pitch + 4u * c;      // this lane inside a 16-row x 64-column piece
 
     // ---- fill: dO rows (k-steps sp, sp + 2, ..), column group lg, row half lh; compact layout: column t - t_lo, 4-byte aligned rows
     {
@@ -332,15 +333,19 @@ __global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // masks of this lane's 2 x 8 accumulator tiles: mask[row][col] > 0 for e = 8 i + 2 r + g (row tile i, register r, group g)
-    auto load_mask = [&](f32x4* mk, const float* base, int valid) {
-        const float* mp = base + (size_t)b * a.s_bstride + (size_t)(m0 * 16 + 4 * q) * a.pitch + tile0 + 4 * c;
+    // masks of this lane's 2 x 8 accumulator tiles: mask[row][col] > 0 for e = 8 i + 2 r + g (row tile i, register r, group g).  They are
+    // requested BEHIND k-step 5 of the product they gate - the weight ring is draining by then, so their 64 registers are free - and land
+    // during its last two k-steps (requested in front of the product they lay beside two accumulator sets' worth of live values: 22
+    // registers spilled; packed into sign bits as they landed: 31)
+    auto load_mask = [&](f32x4* mk, const float* base) {
+        // (addresses as a wave-uniform row pointer + ONE 32-bit lane offset)
+        const float* mp = base + (size_t)b * a.s_bstride + (size_t)(m0 * 16) * a.pitch + tile0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int i = e >> 3, r = (e >> 1) & 3, g = e & 1;
             // (unguarded: the mask rows are workspace rows with the activation layout's slack; values outside the tile's valid
             // columns only gate results that are never stored)
-            mk[e] = ((m0 + i) * 16 + 4 * q + r < 256) ? ld4u(mp + (size_t)(16 * i + r) * a.pitch + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            mk[e] = ld4u(mp + (size_t)(16 * i + r) * a.pitch + 64 * g + lane_off);
         }
     };
     auto apply_mask = [&](f32x4 (*acc)[8], const f32x4* mk) {
@@ -352,13 +357,13 @@ __global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
         }
     };
     auto store_rows = [&](f32x4 (*acc)[8], float* base, int valid) {
-        float* out = base + (size_t)b * a.s_bstride + (size_t)(m0 * 16 + 4 * q) * a.pitch + tile0 + 4 * c;
+        float* out = base + (size_t)b * a.s_bstride + (size_t)(m0 * 16) * a.pitch + tile0;
         if (tile_in && (m0 + 2) * 16 <= valid) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int i = e >> 3, r = (e >> 1) & 3, g = e & 1;
                 F4U u = {{acc[i][4 * g][r], acc[i][4 * g + 1][r], acc[i][4 * g + 2][r], acc[i][4 * g + 3][r]}};
-                *reinterpret_cast<F4U*>(out + (size_t)(16 * i + r) * a.pitch + 64 * g) = u;
+                *reinterpret_cast<F4U*>(out + (size_t)(16 * i + r) * a.pitch + 64 * g + lane_off) = u;
             }
             return;
         }
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
             const int i = e >> 3, r = (e >> 1) & 3, g = e & 1;
             if ((m0 + i) * 16 + 4 * q + r >= valid) continue;
             const int tl = tile0 + 64 * g + 4 * c;
-            float* op = out + (size_t)(16 * i + r) * a.pitch + 64 * g;
+            float* op = out + (size_t)(16 * i + r) * a.pitch + 64 * g + lane_off;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (tl + k >= a.t_lo && tl + k < a.t_hi) op[k] = acc[i][4 * g + k][r];
@@ -386,8 +391,9 @@ __global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
             p[64] = __builtin_bit_cast(u32x4, f.lo);
         }
     };
-    // acc = W x (the operand in LDS), 16 row tiles in all (this wave: 2), weights three k-steps ahead through a 3-slot ring
-    auto product16 = [&](f32x4 (*acc)[8], const uint16_t* pack) {
+    // acc = W x (the operand in LDS), 16 row tiles in all (this wave: 2), weights three k-steps ahead through a 3-slot ring; `late` runs
+    // behind k-step 5 (the masks are requested there)
+    auto product16 = [&](f32x4 (*acc)[8], const uint16_t* pack, auto late) {
         Frag<T> wf[3][2];
 #pragma unroll
         for (int s = 0; s < 3; ++s)
@@ -404,20 +410,19 @@ __global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) load_a<T, NS>(wf[s % 3][i], pack, (m0 + i) * 8 + s + 3, lane);
             }
+            if (s == 5) late();
         }
     };
 
     f32x4 acc[2][8], mk[16];
-    load_mask(mk, a.h, a.s_valid);                            // (requested in front of the product: they land while it runs)
     __syncthreads();                                          // the dO fragments are in place
-    product16(acc, a.w_p2T);
+    product16(acc, a.w_p2T, [&]() { load_mask(mk, a.h); });
     apply_mask(acc, mk);
-    load_mask(mk, a.u, a.s_valid);
     if (store_sd) store_rows(acc, a.d_h, a.s_valid);
     __syncthreads();                                          // every wave has read dO
     hand_over(acc);
     __syncthreads();
-    product16(acc, a.w_p1Tc);
+    product16(acc, a.w_p1Tc, [&]() { load_mask(mk, a.u); });
     apply_mask(acc, mk);
     if (store_sd) store_rows(acc, a.d_u, a.s_valid);
     __syncthreads();                                          // every wave has read dH
@@ -454,12 +459,12 @@ __global__ __launch_bounds__(512) void skip_epilogue_bwd_k(WnEpiBwdArgs a) {
                 for (int i = 0; i < MT; ++i) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float* op = out + (size_t)((mz + i) * 16 + 4 * q + r) * a.pitch + tile0 + 4 * c;
+                        float* op = out + (size_t)((mz + i) * 16 + r) * a.pitch + tile0;
 #pragma unroll
                         for (int g = 0; g < 2; ++g) {
                             const f32x4 v = {az[i][4 * g][r], az[i][4 * g + 1][r], az[i][4 * g + 2][r], az[i][4 * g + 3][r]};
-                            if (a.nt_dz) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(op + 64 * g));
-                            else *reinterpret_cast<f32x4*>(op + 64 * g) = v;
+                            if (a.nt_dz) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(op + 64 * g + lane_off));
+                            else *reinterpret_cast<f32x4*>(op + 64 * g + lane_off) = v;
                         }
                     }
                 }
