@@ -12,5 +12,6 @@ run python tools/fuzz_ae.py --general --cases $((40 * K)) --seed $((S + 3))
 run python tools/fuzz_decode.py --shapes --cases $((40 * K)) --seed $((S + 4))
 run python tools/fuzz_decode.py --cases $((40 * K)) --seed $((S + 5))
 run python tools/fuzz_generic.py --cases $((40 * K)) --seed $((S + 6))
+run python tools/fuzz_epilogue.py --cases $((150 * K)) --seed $((S + 9))       # the fused epilogue launches at kernel level (NaN outside the window, canaries)
 echo "ties judged by the float64 oracle: $(grep -c 'float64 oracle' $L)" >> $L
 cat $L
