@@ -691,10 +691,13 @@ def main():
     # how long the HOST takes to enqueue a step (device idle at the start, nothing waited for inside): the margin by which the
     # interpreter runs ahead of the device.  Timed steps that take longer than the median are host stalls when this is close to it
     barrier()
+    depth, eng._throttle.depth = eng._throttle.depth, 0      # (the engine keeps at most WN_MAX_STEPS_IN_FLIGHT steps in flight - _lib.StepThrottle -; this measures the enqueue alone)
     t_h = time.perf_counter()
     for _ in range(8):
         step()
     host_enqueue_ms = (time.perf_counter() - t_h) / 8 * 1e3
+    eng._throttle.depth = depth
+    del eng._throttle._ev[:]
     barrier()
     # full phase table: 3 untimed steps with every mark
     eng.marks = []

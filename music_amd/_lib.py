@@ -116,6 +116,29 @@ def cpu_quota():
         return None
 
 
+class StepThrottle:
+    """At most `depth` fused training steps of one engine in flight.  The host enqueues a step in 0.7 ms and the device takes 4: a loop that
+    never reads a result back (the reference reads loss.data[0] every step, wavenet/train.py:182; a benchmark loop does not) is 40 steps
+    ahead ten steps after a synchronisation, the HIP runtime's command and kernel-argument pools run full there, and while they do the
+    device is handed its work in fits: 8 - 11 of the next 25 steps take 6 ms instead of 4 (round 6).  enter() waits
+    for the END of the step issued `depth` steps ago, leave() marks the end of this one; WN_MAX_STEPS_IN_FLIGHT (default 4; 0 = no limit)."""
+
+    def __init__(self):
+        self.depth = int(os.environ.get("WN_MAX_STEPS_IN_FLIGHT", "4"))
+        self._ev = []
+
+    def enter(self):
+        if self.depth > 0 and len(self._ev) >= self.depth:
+            self._ev.pop(0).synchronize()
+
+    def leave(self):
+        if self.depth > 0:
+            import torch
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ev.append(ev)
+
+
 def local_world_size(env=None):
     """Ranks the launcher started on THIS host (torchrun exports LOCAL_WORLD_SIZE; 1 without a launcher)."""
     env = os.environ if env is None else env

@@ -191,6 +191,7 @@ class WaveNetEngine:
         # ... or all three in ONE launch per 128-column tile (wn_skip_epilogue_fwd, round 6; 256 skip / 256 quantisation channels, x3
         # modes; WN_EPI_FUSED=0 = the three launches above)
         self.epi_fused = os.environ.get("WN_EPI_FUSED", "1") == "1"
+        self._throttle = _lib.StepThrottle()
         self.epi_fused_bwd = os.environ.get("WN_EPI_FUSED_BWD", "1") == "1"
         # Channel-split backward block with both weight gradients in the launch (wn_resblock_bwd_ms):
         # 64 padded channels, (f16x3, bf16x3) only; None = whenever it applies (WN_MS_BWD=0 turns it off)
@@ -975,6 +976,7 @@ class WaveNetEngine:
     def loss_and_grad(self, x, target, want_probs=False, codes=None):
         """forward + CrossEntropyLoss(probs, target) + backward (wavenet/train.py:178-181).
         Returns the loss as a 0-d device tensor; gradients land in self.flat_grad."""
+        self._throttle.enter()                 # at most WN_MAX_STEPS_IN_FLIGHT fused steps in flight (_lib.StepThrottle)
         self.mark("begin")
         self.pack_weights()
         self.mark("pack")
@@ -994,7 +996,9 @@ class WaveNetEngine:
              n, 1.0 / n, _lib.stream())
         self.mark("softmax_ce")
         self.backward_from_dlogits(ws)
-        return ws["loss_part"].sum()
+        loss = ws["loss_part"].sum()
+        self._throttle.leave()
+        return loss
 
     def adam_init(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
         self.adam_state = dict(m=torch.zeros_like(self.flat), v=torch.zeros_like(self.flat), t=0,

@@ -485,6 +485,9 @@ class GenericWaveNetEngine:
 
     # ------------------------------------------------------------------ fused training step (wavenet/train.py:178-181)
     def loss_and_grad(self, x, target, want_probs=False):
+        if getattr(self, "_throttle", None) is None:
+            self._throttle = _lib.StepThrottle()   # at most WN_MAX_STEPS_IN_FLIGHT fused steps in flight (music_amd/_lib.py)
+        self._throttle.enter()
         self.mark("begin")
         self.pack_weights()
         ws = self.forward_logits(x)
@@ -505,7 +508,9 @@ class GenericWaveNetEngine:
             call("wn_chunk_softmax_ce", ptr(ws["O"]), ptr(target), ptr(probs), ptr(bw["dO"]), ptr(ws["loss_part"]), n, self.Q,
                  1.0 / n, _lib.stream())
         self.backward_from_dlogits(ws)
-        return ws["loss_part"].sum()
+        loss = ws["loss_part"].sum()
+        self._throttle.leave()
+        return loss
 
     def loss_and_grad_codes(self, codes, target, scrambled=True, want_probs=False):
         """the fast engine's entry point on integer codes; here the one-hot is built (wn_onehot) and the dense path runs"""

@@ -581,6 +581,9 @@ class _AutoencoderEngine:
         """Fused training step body (the autoencoder counterpart of engine.loss_and_grad): forward to the logits, ONE
         kernel for chunk softmax + CrossEntropyLoss on the probabilities (wavenet_autoencoder/train.py:146-160) + both
         backward steps, then the backward.  Returns the loss (0-d device tensor); gradients land in self.flat_grad."""
+        if getattr(self, "_throttle", None) is None:
+            self._throttle = _lib.StepThrottle()   # at most WN_MAX_STEPS_IN_FLIGHT fused steps in flight (music_amd/_lib.py)
+        self._throttle.enter()
         _, enc, ws = self.forward(x, cond, want_probs=False)
         bw = self._bwd_workspace(ws)
         n = ws["B"] * ws["W"]
@@ -591,7 +594,9 @@ class _AutoencoderEngine:
         call("wn_chunk_softmax256_ce", ptr(ws["O"]), ptr(target), None, ptr(bw["dO"]), ptr(ws["loss_part"]), n, 1.0 / n,
              _lib.stream())
         self.backward(ws, None)
-        return ws["loss_part"].sum()
+        loss = ws["loss_part"].sum()
+        self._throttle.leave()
+        return loss
 
     def adam_init(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
         self.adam_state = dict(m=torch.zeros_like(self.flat), v=torch.zeros_like(self.flat), t=0,
