@@ -77,7 +77,7 @@ rep("    if (it0 < NI) {\n","#ifdef EPI_DBG\n    const unsigned long long l0_ = 
 rep("    const bool tile_in = tile0 >= a.t_lo && tile0 + EPI_COLS <= a.t_hi;\n","#ifdef EPI_DBG\n    const unsigned long long l1_ = __builtin_readcyclecounter();\n#endif\n    const bool tile_in = tile0 >= a.t_lo && tile0 + EPI_COLS <= a.t_hi;\n")
 old="        float* out = base + (size_t)b * bstride + (size_t)(m0 * 16 + 4 * q) * pitch + tile0 + 4 * c + shift;\n"
 rep(old,old+"        if (EPI_T == 6) {\n#pragma unroll\n            for (int i = 0; i < 2; ++i)\n#pragma unroll\n                for (int n = 0; n < 8; ++n) asm volatile(\"\" :: \"v\"(acc[i][n]));\n            return;\n        }\n")
-old="#pragma unroll\n    for (int s = 0; s < 3; ++s) request(wf[s], a.w_p1c, s);\n"
+old="#pragma unroll\n    for (int s = 0; s < 2; ++s) request(wf[s], a.w_p1c, s);\n"
 rep(old,"    if (EPI_T == 7) { store_rows(acc, 0, 16, a.u, a.s_bstride, a.pitch, 0, a.s_valid); return; }\n"+old)
 old="    store_rows(acc, 0, 16, a.o, a.o_bstride, a.o_pitch, -a.t_lo, a.q_valid);\n}"
 rep(old,old[:-1]+'''#ifdef EPI_DBG
