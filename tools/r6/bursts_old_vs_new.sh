@@ -1,7 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out/r6c16
+mkdir -p gpurun_out/r6
 export PYTHONUNBUFFERED=1
-O=gpurun_out/r6c16
+O=gpurun_out/r6
 timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_switches.py -m gpu -q -p no:cacheprovider -k "skip_epilogue or fused_epilogue or b_stationary" > $O/kernels.log 2>&1; echo "kernels exit $?"; tail -2 $O/kernels.log
 timeout 300 python tools/gemm_bench.py --rounds 3 2>/dev/null | grep fused
 for r in 1 2 3; do

@@ -1,8 +1,8 @@
 #!/bin/bash
 # burst frequency under HIP / HSA runtime switches (300 timed steps each, same box)
-mkdir -p gpurun_out/r6c18
+mkdir -p gpurun_out/r6
 export PYTHONUNBUFFERED=1
-O=gpurun_out/r6c18
+O=gpurun_out/r6
 env | grep -E "^(HIP|HSA|GPU|AMD|ROC)" | head -20
 for r in 1 2; do
 for v in "base:" "noint:HSA_ENABLE_INTERRUPT=0" "q2:GPU_MAX_HW_QUEUES=2" "q8:GPU_MAX_HW_QUEUES=8" "nodd:AMD_DIRECT_DISPATCH=0" "nosdma:HSA_ENABLE_SDMA=0"; do

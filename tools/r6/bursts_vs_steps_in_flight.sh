@@ -1,7 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out/r6c21
+mkdir -p gpurun_out/r6
 export PYTHONUNBUFFERED=1
-O=gpurun_out/r6c21
+O=gpurun_out/r6
 run() { n=$1; e=$2; shift 2
   env $e python bench.py --gpus 1 "$@" --no-cpu-baseline --no-extras --dump-steps > $O/$n.json 2> $O/$n.err
   python - <<PY
