@@ -502,6 +502,15 @@ class WaveNetEngine:
         # other, behind the fused launch): 2048 for all three - step 4.141 against 4.19 - 4.23 at (1024, 1024, 2048), 4.22 at (512, 512, 1024),
         # 4.25 at 3264, 4.38 at 4096 (profiles/r06_ab_wgrad_chunks.json)
         ck = [int(v) for v in os.environ.get("WN_EPI_WGRAD_CHUNKS", "2048,2048,2048").split(",")]
+        if "WN_EPI_WGRAD_CHUNKS" not in os.environ:
+            # ... cut into EQUAL chunks of at most that: 12960 columns are 6 x 2048 + 672, and the launch takes as long as its full chunks
+            # (7 x 1856: epilogue backward 0.861 -> 0.845 ms)
+            span = T - (lo & ~31)
+
+            def even(c):
+                n = -(-span // c)                      # chunks per clip
+                return -(-(-(-span // n)) // 32) * 32    # their common length, a multiple of the 32-sample k-step
+            ck = [even(c) for c in ck]
         ops = [("p2", lo, T, ck[0]), ("p1", lo, T, ck[1]), ("skip", lo, T, ck[2])]
         # one-launch blocks whose dilation is a multiple of 32 hand dx on WHOLE (chain form of wn_resblock_bwd_pq: the Q rows
         # of an item are the carry of the next item of its chain); decided here, once per workspace, with the slab counts
