@@ -38,7 +38,8 @@ def _view(t, b, rows, pitch):
     return t[SLACK:SLACK + b * rows * pitch].view(b, rows, pitch)
 
 
-TOL = {_lib.F16X3: 2e-5, _lib.BF16X3: 3e-4, _lib.F16X1: 2e-2, _lib.BF16X1: 1e-1}
+# relative to the reference tensor's max-abs; observed 2.6e-7 / 5.7e-6 / 3.6e-4 / 2.6e-3 (round 6: halved - thirded, they were 40 - 80 x loose)
+TOL = {_lib.F16X3: 1e-5, _lib.BF16X3: 1e-4, _lib.F16X1: 1e-2, _lib.BF16X1: 5e-2}
 
 
 @pytest.mark.parametrize("mode", [_lib.F16X3, _lib.BF16X3, _lib.F16X1, _lib.BF16X1])
@@ -427,7 +428,7 @@ def test_resblock_fwd(CH, R, D, d, mode):
     ey = (goty[:, :R, t_lo:T] - y).abs().max().item()
     ez = (gotz[:, :D, z_lo:T] - z[:, :, z_lo - t_lo:]).abs().max().item()
     print("CH", CH, "d", d, "mode", mode, "err y", ey, "err z", ez, "scale", y.abs().max().item())
-    tol = 3e-5 if mode == _lib.F16X3 else 5e-4
+    tol = 1e-5 if mode == _lib.F16X3 else 2e-4               # observed 1.8e-6 / 8.3e-5
     assert ey <= tol * max(1.0, y.abs().max().item()) and ez <= tol
     assert goty[:, :, :t_lo].abs().max().item() == 0 and gotz[:, :, :z_lo].abs().max().item() == 0
     assert goty[:, R:].abs().sum().item() == 0 and gotz[:, D:].abs().sum().item() == 0
@@ -501,7 +502,7 @@ def test_resblock_bwd_and_dx(CH, R, D, d):
     e5 = (got_wg - ref_wg).abs().max().item() / ref_wg.abs().max().item()
     e6 = (gD.cpu().double()[:R, :D] - gwd1[:, :, 0]).abs().max().item() / gwd1.abs().max().item()
     print("df", e1, "dg", e2, "z", ez, "dx", e3, "dWf", e4, "dWg", e5, "dWd", e6)
-    assert max(e1, e2, e3, e4, e5, e6) < 2e-3 and ez < 3e-5
+    assert max(e1, e2, e3, e4, e5, e6) < 1e-4 and ez < 1e-5      # observed 8.1e-6 / 2.1e-6
 
 
 def test_wgrad_compact_relu():
@@ -519,7 +520,7 @@ def test_wgrad_compact_relu():
     ref = torch.einsum("bmt,bnt->mn", a.cpu().double(), bb)
     err = (c.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     print("wgrad rel err", err)
-    assert err < 1e-3
+    assert err < 5e-5                                            # observed 3.4e-6
 
 
 def test_chunk_softmax_fwd_bwd_ce():
@@ -658,7 +659,7 @@ def test_wgrad_big_lds_path():
     ref = torch.cat([ref0, ref1], 1)
     err = (c.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     print("wgrad big rel err", err)
-    assert err < 1e-4
+    assert err < 5e-5                                            # observed 4.6e-6
 
 
 @pytest.mark.parametrize("mode,le,q", [(1, 7, 41), (1, 31, 16), (2, 31, 0), (2, 5, 0), (2, 64, 0), (2, 100, 0)])
@@ -686,7 +687,7 @@ def test_cond_grad_bucket_sums(mode, le, q):
         ref[:, :, j] = x[:, :, t_lo:t_hi][:, :, ix == j].sum(-1)
     err = np.abs(out.cpu().numpy() - ref).max()
     print("cond_grad mode %d le %d: max err %.2e" % (mode, le, err))
-    assert err < 2e-4
+    assert err < 5e-5                                            # observed <= 5.9e-6
 
 
 def test_conditioned_block_entry_points_refuse_bad_arguments():
