@@ -180,6 +180,32 @@ __device__ __forceinline__ float wn_tanh(float f) {
     return (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// The gate and its two derivatives for the backward kernels (round 6): z = tanh(f) sigmoid(g), dz/df = sigmoid(g) (1 - tanh^2 f),
+// dz/dg = tanh(f) sigmoid(g) (1 - sigmoid(g)), from e1 = exp(-2|f|), e2 = exp(-|g|) - both <= 1 - and ONE reciprocal:
+//   1 / (1 + e1) = u, 1 / (1 + e2) = w;  |tanh f| = (1 - e1) u;  1 - tanh^2 f = 4 e1 u^2;  sigmoid(g) = w (g >= 0) or e2 w;
+//   sigmoid (1 - sigmoid) = e2 w^2.
+// Nothing overflows (every intermediate lies in [0, 4]: no clamps), and neither `1 - th * th` nor `1 - sg` is formed by subtraction: where the
+// gate saturates the derivatives go to 0 as fast as they do in exact arithmetic.  The forms they replace - exp(-2f) up to e^30 with th = (1 - e1) /
+// (1 + e1) one ulp off -1, then 1 - th^2 = +-1.2e-7 in place of 4e-13, and a product (1 + e1)(1 + e2) that overflowed to inf for f <= -15, g <= -59
+// (th = -inf * 0 = NaN) - cost a model whose filter / gate convs are 40 x / 150 x the usual size 1.6e-3 of its gradients (the float32 CPU path:
+// 2e-6) or all of them (tests/test_gpu_parity.py: test_saturated_gates_give_finite_gradients_vs_oracle; found by tools/soak_determinism.py).
+struct WnGateD { float z, dzdf, dzdg; };
+__device__ __forceinline__ WnGateD wn_gate_d(float f, float g) {
+    const float e1 = __builtin_amdgcn_exp2f(__builtin_fabsf(f) * -2.88539008177792681472f);
+    const float e2 = __builtin_amdgcn_exp2f(__builtin_fabsf(g) * -1.44269504088896340736f);
+    const float a1 = 1.0f + e1, b1 = 1.0f + e2;
+    const float rr = __builtin_amdgcn_rcpf(a1 * b1);
+    const float u = b1 * rr, w = a1 * rr;
+    const float th = __builtin_copysignf((1.0f - e1) * u, f);
+    const float sm = e2 * w;                              // sigmoid(-|g|) = 1 - sigmoid(|g|)
+    const float sg = g >= 0.f ? w : sm;
+    WnGateD r;
+    r.z = th * sg;
+    r.dzdf = sg * (4.0f * e1) * (u * u);
+    r.dzdg = th * (sm * w);
+    return r;
+}
+
 // XCD-aware work mapping.  Workgroups are observed to be dealt round-robin over the 8 XCDs in
 // dispatch order (x fastest), so blocks with equal (linear id % 8) share one 4 MB L2.  The remap gives
 // each XCD one CONTIGUOUS run of the (x, y, z) work items: neighbouring time tiles of one clip then sit

@@ -38,11 +38,11 @@ __global__ __launch_bounds__(256) void gate_bwd_k(const float* __restrict__ fg, 
     if (t >= t_hi) return;
     const int r = blockIdx.y, b = blockIdx.z;
     const float* p = fg + (size_t)b * fg_bstride + (size_t)r * pitch + t;
-    const float th = wn_tanh(p[0]), sg = wn_sigmoid(p[(size_t)dp * pitch]);
+    const WnGateD gd = wn_gate_d(p[0], p[(size_t)dp * pitch]);
     const float g = dz[(size_t)b * dz_bstride + (size_t)r * pitch + t];
     float* o = dfg + (size_t)b * dfg_bstride + (size_t)r * pitch + t;
-    o[0] = g * sg * (1.0f - th * th);
-    o[(size_t)dp * pitch] = g * th * sg * (1.0f - sg);
+    o[0] = g * gd.dzdf;
+    o[(size_t)dp * pitch] = g * gd.dzdg;
 }
 int wn_launch_gate_fwd(const float* fg, long fg_bstride, int dp, int rows, float* z, long z_bstride, int pitch, int t_lo, int t_hi,
                        int batch, hipStream_t st) {

@@ -179,11 +179,10 @@ __global__ __launch_bounds__(WN_RES_THREADS) void resblock_bwd_k(WnResBwdArgs a)
             f32x4 df, dg, zz;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                float th = wn_tanh(acc[m][n][i]);
-                float sg = wn_sigmoid(acc[m + MT2][n][i]);
-                zz[n] = th * sg;
-                df[n] = g[n] * sg * (1.0f - th * th);
-                dg[n] = g[n] * th * sg * (1.0f - sg);
+                const WnGateD gd = wn_gate_d(acc[m][n][i], acc[m + MT2][n][i]);
+                zz[n] = gd.z;
+                df[n] = g[n] * gd.dzdf;
+                dg[n] = g[n] * gd.dzdg;
             }
             st4m(dfg + (size_t)row * a.pitch + tl, df, tl, a.t_lo, a.t_hi);
             st4m(dfg + (size_t)(CH + row) * a.pitch + tl, dg, tl, a.t_lo, a.t_hi);

@@ -594,16 +594,10 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
                     const bool ok = n ? ok1 : ok0;
                     float gz = dz[n][i];
                     if (tl + n >= a.z_lo && tl + n < a.t_hi) gz += cr[i][n];
-                    // th = (1 - e1) / (1 + e1), sg = 1 / (1 + e2) with ONE reciprocal (e1 = exp(-2f), e2 = exp(-g)); the same
-                    // values as wn_tanh / wn_sigmoid to ~1e-7 absolute
-                    const float fc = fminf(fmaxf(af[n][i], -15.f), 15.f);
-                    const float e1 = __expf(-2.0f * fc), e2 = fminf(__expf(-ag[n][i]), 1e30f);
-                    const float rr = __builtin_amdgcn_rcpf((1.0f + e1) * (1.0f + e2));
-                    const float th = (1.0f - e1) * (1.0f + e2) * rr;
-                    const float sg = (1.0f + e1) * rr;
-                    vz[n] = ok ? th * sg : 0.f;
-                    vf[n] = ok ? gz * sg * (1.0f - th * th) : 0.f;
-                    vg[n] = ok ? gz * th * sg * (1.0f - sg) : 0.f;
+                    const WnGateD gd = wn_gate_d(af[n][i], ag[n][i]);          // (wn_common.h: one reciprocal, no cancellation, no overflow)
+                    vz[n] = ok ? gd.z : 0.f;
+                    vf[n] = ok ? gz * gd.dzdf : 0.f;
+                    vg[n] = ok ? gz * gd.dzdg : 0.f;
                 }
                 // 16-bit hi/lo pairs of (sample 2c, sample 2c+1) -> one dword each in the [channel][time] tiles
                 auto put = [&](int kind, const float* v) {

@@ -294,11 +294,10 @@ __global__ __launch_bounds__(RW_THREADS) void resblock_bwd_rw_k(WnResMsArgs a) {
                     const bool ok = n ? ok1 : ok0;
                     float gz = dz[n][i];
                     if (tl + n >= a.z_lo && tl + n < a.t_hi) gz += cr[i][n];
-                    const float th = wn_tanh(af[n][i]);
-                    const float sg = wn_sigmoid(ag[n][i]);
-                    vz[n] = ok ? th * sg : 0.f;
-                    vf[n] = ok ? gz * sg * (1.0f - th * th) : 0.f;
-                    vg[n] = ok ? gz * th * sg * (1.0f - sg) : 0.f;
+                    const WnGateD gd = wn_gate_d(af[n][i], ag[n][i]);
+                    vz[n] = ok ? gd.z : 0.f;
+                    vf[n] = ok ? gz * gd.dzdf : 0.f;
+                    vg[n] = ok ? gz * gd.dzdg : 0.f;
                 }
                 float* pf = dfg + (size_t)row * a.pitch + tl;
                 float* pg = dfg + (size_t)(CH + row) * a.pitch + tl;

