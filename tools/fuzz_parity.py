@@ -25,6 +25,7 @@ from tests.helpers import scrambled_input  # noqa: E402
 RELU_EPS = 2e-4          # tests/test_gpu_fullsize.py: the band around zero inside which a ReLU's subgradient follows the device
 
 
+GAIN = 2.5               # --gain: every weight times this (default init leaves every probability at 1 / 256)
 EPI = False              # --epi: every case has 256 skip channels (the fused epilogue launches), most of them no biases and 3 or 6 blocks
 
 
@@ -50,7 +51,7 @@ def one_case(rng, k, only=None):
     net = wavenet(**cfg)
     with torch.no_grad():
         for p in net.parameters():
-            p.mul_(2.5)
+            p.mul_(GAIN)
     params = {kk: v.clone() for kk, v in net.state_dict().items()}
     net = net.cuda()
     T = net.receptive_field + extra
@@ -63,7 +64,7 @@ def one_case(rng, k, only=None):
     inter = {}
     with torch.no_grad():
         wo.wavenet_forward(params, dil, x, intermediates=inter)
-    floor = 1e-3 * max(g.abs().max().item() for g in g_ref.values())
+    floor = max(1e-3 * max(g.abs().max().item() for g in g_ref.values()), 1e-30)
     probs = net(x.cuda())
     eng = net._engine
     pre = eng.workspace(B, T)["O"][:B * 256 * W].view(B, 256, W).cpu()
@@ -85,6 +86,9 @@ def one_case(rng, k, only=None):
         if only is not None and e > 3e-4:
             print("   %-40s rel err %.2e" % (name, e))
         worst2 = max(worst2, e)
+    nonfinite = int((~torch.isfinite(eng.flat_grad)).sum()) + int((~torch.isfinite(probs)).sum())
+    if nonfinite and all(torch.isfinite(g).all() for g in g_ref.values()):
+        print("NONFINITE case %3d: %d non-finite device values where the oracle is finite" % (k, nonfinite), flush=True)
     ok = (e_pre <= 1e-3 and e_p <= 1e-3 and abs(loss.item() - l_ref.item()) < 1e-4 and abs(loss2.item() - l_ref.item()) < 1e-4
           and worst <= 3e-4 and worst2 <= 3e-4)
     tie_note = ""
@@ -171,10 +175,11 @@ def main():
     ap.add_argument("--cases", type=int, default=30)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--epi", action="store_true", help="256 skip channels in every case: wn_skip_epilogue_fwd / _bwd on random shapes")
+    ap.add_argument("--gain", type=float, default=2.5, help="weight gain (2.5: the fixtures' conditioning; above ~4 the float32 reference itself is no longer reproducible to 1e-3 - use it to look for non-finite results)")
     ap.add_argument("--only", type=int, default=None, help="run just this case of the stream (prints the failing tensors)")
     args = ap.parse_args()
-    global EPI
-    EPI = args.epi
+    global EPI, GAIN
+    EPI, GAIN = args.epi, args.gain
     rng = np.random.default_rng(args.seed)
     bad = sum(0 if one_case(rng, k, args.only) else 1 for k in range(args.cases))
     print("%d / %d cases failed" % (bad, args.cases))
