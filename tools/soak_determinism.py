@@ -79,6 +79,40 @@ def main():
         torch.manual_seed(3)
         cond = ae._draw_conditioning()               # ONE draw of the conditioning projections for every run
         out["c4"] = soak(lambda: aeng.loss_and_grad(x, target, cond), lambda: aeng.flat_grad, a.reps)
+    if "alt" in a.what:
+        # the other forms of the step on a smaller geometry (3 clips x 9000 samples, 12 blocks): engine switches are read when an engine / a
+        # workspace is built, so every setting gets a fresh module
+        from music_amd.model import wavenet
+        alts = [("default", {}, {}), ("pair_form_blocks", {"WN_PQ_CHAIN": "0"}, {}), ("two_role_blocks", {"WN_PQ_BWD": "0"}, {}),
+                ("three_launch_epilogue", {"WN_EPI_FUSED": "0", "WN_EPI_FUSED_BWD": "0"}, {}), ("biases", {}, {"use_bias": True}),
+                ("32_channels", {}, {"dilation_channels": 32, "residual_channels": 32}),
+                ("ragged_channels", {}, {"dilation_channels": 40, "residual_channels": 48, "skip_channels": 100})]
+        for name, env, kw in alts:
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                cfg = dict(CFG, dilations=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 3, 96], **kw)
+                torch.manual_seed(1)
+                net = wavenet(**cfg)
+                with torch.no_grad():
+                    for p_ in net.parameters():
+                        p_.mul_(2.5)
+                net = net.cuda()
+                eng = net._engine_for(dev)
+                B2 = 4 if name == "32_channels" else 3
+                T2 = 9000
+                codes = torch.from_numpy(rng.integers(0, 256, size=(B2, T2)).astype(np.int32)).cuda()
+                W = T2 - net.receptive_field + 1
+                target = torch.from_numpy(rng.integers(0, 256, size=(B2 * W,)).astype(np.int64)).cuda()
+                out["alt:" + name] = soak(lambda: eng.loss_and_grad_codes(codes, target, scrambled=True), lambda: eng.flat_grad, max(a.reps // 4, 50))
+                del net, eng
+                torch.cuda.empty_cache()
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
     print(json.dumps(out))
     sys.exit(1 if any(v["mismatching_runs"] for v in out.values()) else 0)
 
