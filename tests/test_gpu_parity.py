@@ -1566,6 +1566,33 @@ def test_fused_loss_survives_other_backward_passes_on_the_same_output():
                 assert (a - b).abs().max().item() <= 5e-5 * max(a.abs().max().item(), 1e-3 * gmax), seq.__name__
 
 
+def test_module_without_the_private_torch_hooks_runs_unfused(monkeypatch):
+    """_losshook.AVAILABLE False (a torch without the internals the interception rests on): plain tensor out, torch's own loss, same numbers."""
+    import numpy as np
+    from music_amd import _losshook
+    from tests.helpers import scrambled_input
+    net = _small_net()
+    rng = np.random.default_rng(5)
+    B, W = 2, 300
+    x = scrambled_input(rng.integers(0, 256, size=(B, net.receptive_field + W - 1))).cuda()
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64)).cuda()
+    crit = torch.nn.CrossEntropyLoss()
+    res = []
+    for avail in (True, False):
+        monkeypatch.setattr(_losshook, "AVAILABLE", avail)
+        net.zero_grad()
+        out = net(x)
+        assert (type(out) is _losshook.Probs) == avail
+        loss = crit(out, target)
+        loss.backward()
+        res.append((float(loss.detach()), [p.grad.clone() for p in net.parameters()]))
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0))
+    gmax = max(g.abs().max().item() for g in g0)
+    for a, b in zip(g0, g1):
+        assert (a - b).abs().max().item() <= 5e-5 * max(a.abs().max().item(), 1e-3 * gmax)
+
+
 def test_cross_entropy_on_the_autoencoder_output_runs_fused_and_equals_torchs():
     """The same interception on `wavenet_autoencoder` (its train loop applies nn.CrossEntropyLoss to the output as well): loss and
     every gradient against the unfused module, with the same per-forward conditioning projections (same torch seed)."""

@@ -319,3 +319,20 @@ def test_cpu_quota_is_read_and_respected(monkeypatch):
         assert torch.get_num_threads() == n0
     finally:
         torch.set_num_threads(n0)
+
+
+def test_loss_hook_degrades_when_torch_lacks_its_private_hooks(monkeypatch):
+    """music_amd/_losshook.py intercepts nn.CrossEntropyLoss through three torch internals; on a torch that lacks one of them the module must
+    not fuse (make() -> None: the module then returns a plain tensor and torch's own loss runs) instead of failing inside a backward."""
+    from music_amd import _losshook
+
+    class Eng:
+        fused_loss_ok = True
+    assert _losshook.AVAILABLE is True and _losshook._private_api_present()          # this torch has them
+    assert _losshook.make(Eng(), {"gen": 1}, True) is not None
+    monkeypatch.setattr(_losshook, "AVAILABLE", False)
+    assert _losshook.make(Eng(), {"gen": 1}, True) is None
+    out = torch.ones(2, 3, requires_grad=True)
+    assert _losshook.wrap(out, None) is out
+    monkeypatch.delattr(torch._C, "DisableTorchFunctionSubclass")
+    assert _losshook._private_api_present() is False
