@@ -593,3 +593,39 @@ def test_shipped_config_shipped_batch_window_vs_oracle():
     g1 = eng.flat_grad.clone()
     l2 = eng.loss_and_grad(x, target).item()
     assert l1 == l2 and torch.equal(g1, eng.flat_grad) and np.isfinite(l1)
+
+
+def test_c2_addressing_beyond_4gb():
+    """Config 2's model on FOUR IDENTICAL clips of 300 000 samples: the stacked z / dz tensors are 9.2 GB each and the residual streams 9.5 GB, so
+    clips 2 and 3 live wholly beyond byte offset 2^32 in them (tools/big_offsets.py).  Every clip's probabilities must equal clip 0's AND the
+    one-clip run's bit for bit, and the gradient of the mean loss the one-clip run's to summation-order rounding (four equal clips scale every
+    16-bit operand split by an exact power of two).  A 32-bit offset in any kernel or launcher of the step shows up here and in no 8 x 16000 case."""
+    from music_amd.model import wavenet
+    torch.manual_seed(0)
+    net = wavenet(**C2)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.5)
+    net = net.cuda()
+    eng = net._engine_for(torch.device("cuda", 0))
+    rng = np.random.default_rng(5)
+    T, B = 300000, 4
+    W = T - net.receptive_field + 1
+    one = rng.integers(0, 256, size=(1, T)).astype(np.int32)
+    tgt = rng.integers(0, 256, size=(W,)).astype(np.int64)
+    res = {}
+    for b in (1, B):
+        codes = torch.from_numpy(np.repeat(one, b, axis=0)).cuda()
+        target = torch.from_numpy(np.tile(tgt, b)).cuda()
+        loss = eng.loss_and_grad_codes(codes, target, scrambled=True, want_probs=True)
+        res[b] = (float(loss), eng.flat_grad.clone(), eng.workspace(b, T)["probs"].reshape(b, -1).clone())
+        eng._ws.clear()
+        torch.cuda.empty_cache()
+    (l1, g1, p1), (lb, gb, pb) = res[1], res[B]
+    assert torch.isfinite(gb).all() and torch.isfinite(pb).all()
+    for k in range(B):
+        assert torch.equal(pb[k], p1[0]), "probabilities of clip %d differ" % k
+    assert abs(l1 - lb) < 1e-5
+    rel = float((gb - g1).abs().max() / g1.abs().max())
+    print("  4 x 300000: gradient of the four-clip run against the one-clip run: %.1e of its max" % rel)
+    assert rel < 2e-6
