@@ -984,6 +984,9 @@ class wavenet_autoencoder(nn.Module):
         # nn.CrossEntropyLoss()(net(x), target) with its default arguments runs fused (music_amd/_losshook.py); False: torch's own
         self.fuse_loss = True
         self._last_hook = None
+        # (forward, backward) arithmetic of the matrix-core products, as on `wavenet`; ("bf16x3", "bf16x3") gives the forward float32's exponent range
+        # (an un-normalised ReLU encoder can leave f16's: DESIGN section 5) at 2^-17 instead of 2^-22 per product
+        self.precision = ("f16x3", "bf16x3")
 
     def __getstate__(self):
         # copy.deepcopy / pickle / torch.save(module): the engine (HIP streams, workspaces, ctypes plans) stays behind and is rebuilt
@@ -1021,7 +1024,7 @@ class wavenet_autoencoder(nn.Module):
             raise RuntimeError("music_amd.wavenet_autoencoder runs on an MI355X (ROCm) device only; there is no CPU path")
         eng = self._engine
         p0 = next(self.parameters())
-        if eng is None or eng.device != device or p0.data_ptr() != eng.flat.data_ptr():
+        if eng is None or eng.device != device or p0.data_ptr() != eng.flat.data_ptr() or getattr(eng, "mode_names", None) != tuple(self.precision):
             if any(p.device != device for p in self.parameters()):
                 raise RuntimeError("music_amd.wavenet_autoencoder: parameters and input are on different devices")
             if any(p.dtype != torch.float32 for p in self.parameters()):
@@ -1032,13 +1035,14 @@ class wavenet_autoencoder(nn.Module):
             fast = (self.filter_width == 2 and self.quantization_channel == 256 and
                     max(self.en_residual_channel, self.en_dilation_channel, self.de_residual_channel, self.de_dilation_channel) <= 64)
             if fast:
-                eng = _AutoencoderEngine(self, device)
+                eng = _AutoencoderEngine(self, device, mode=self.precision[0], mode_bwd=self.precision[1])
             else:
                 try:
                     from .ae_generic import GenericAutoencoderEngine
                 except ImportError:
                     from music_amd.ae_generic import GenericAutoencoderEngine
-                eng = GenericAutoencoderEngine(self, device)
+                eng = GenericAutoencoderEngine(self, device, mode=self.precision[0], mode_bwd=self.precision[1])
+            eng.mode_names = tuple(self.precision)
             self._engine = eng
         return eng
 

@@ -671,6 +671,65 @@ def test_autoencoder_backward_vs_oracle():
         print("autoencoder", tag, "worst relative grad err %.2e" % worst)
 
 
+def test_autoencoder_bf16_forward_survives_activations_beyond_f16():
+    """The autoencoder's encoder is an un-normalised ReLU residual net: with its block weights x 12 the residual stream reaches 8e4 - 6e5, beyond
+    f16's 65504.  The default forward arithmetic (f16 hi / lo split) then returns garbage or NaN - a stated limit, DESIGN section 5 - and
+    `net.precision = ("bf16x3", "bf16x3")` (float32's exponent range, 2^-17 per product) must give the oracle's probabilities and finite, close
+    gradients on the same model."""
+    from music_amd.model1 import wavenet_autoencoder
+    from oracle import intops
+    cfg = dict(filter_width=2, quantization_channel=256, dilations=[1, 2, 4, 8, 16, 32, 3], en_residual_channel=64, en_dilation_channel=64,
+               en_bottleneck_width=16, en_pool_kernel_size=50, de_residual_channel=64, de_dilation_channel=64, de_skip_channel=256, use_bias=False)
+    torch.manual_seed(11)
+    net = wavenet_autoencoder(**cfg)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+        net.connection_2.weight.mul_(6.0)
+        for n, p in net.named_parameters():
+            if n.startswith("en_dilation_layer_stack"):
+                p.mul_(12.0)
+        net.bottleneck_layer.weight.mul_(12.0 ** -4)                # (keeps the encoding, and with it the decoder, in its usual range)
+    params = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    rng = np.random.default_rng(12)
+    B, W = 2, 400
+    idx = rng.integers(0, 256, size=(B, net.receptive_field + W - 1))
+    x = torch.from_numpy(np.stack([intops.one_hot_proper(r) for r in idx]))
+    target = torch.from_numpy(rng.integers(0, 256, size=(B * W,)).astype(np.int64))
+    torch.manual_seed(77)
+    cond = wo.draw_conditioning(len(cfg["dilations"]), cfg["en_bottleneck_width"], cfg["de_dilation_channel"], cfg["de_skip_channel"])
+    leaf = {k: v.double().clone().requires_grad_(True) for k, v in params.items()}
+    p_ref, _ = wo.autoencoder_forward(leaf, cfg["dilations"], x.double(), cfg["en_pool_kernel_size"], [(w.double(), b.double()) for (w, b) in cond])
+    l_ref = torch.nn.functional.cross_entropy(p_ref, target)
+    g_ref = torch.autograd.grad(l_ref, list(leaf.values()), allow_unused=True)
+    gmax = max(g.abs().max().item() for g in g_ref if g is not None)
+    out = {}
+    for prec in (("f16x3", "bf16x3"), ("bf16x3", "bf16x3")):
+        net.precision = prec
+        torch.manual_seed(77)
+        net.zero_grad()
+        probs = net(x.cuda())
+        loss = torch.nn.CrossEntropyLoss()(probs, target.cuda())
+        loss.backward()
+        assert net._engine.mode_names == prec
+        xe = net._engine.workspace(B, idx.shape[1])["Xe"]
+        e_p = (probs.detach().cpu().double() - p_ref.detach()).abs().max().item()
+        finite = all(torch.isfinite(p.grad).all().item() for p in net.parameters())
+        worst = 0.0
+        if finite:
+            for (name, p), g in zip(net.named_parameters(), g_ref):
+                g = torch.zeros_like(leaf[name]) if g is None else g
+                worst = max(worst, (p.grad.cpu().double() - g).abs().max().item() / max(g.abs().max().item(), 1e-3 * gmax))
+        out[prec[0]] = (e_p, finite, worst, float(xe[torch.isfinite(xe)].abs().max()))
+        print("  %s forward: largest encoder activation %.2e, probabilities err %.2e, gradients finite %s, worst relative err %.2e" %
+              (prec[0], out[prec[0]][3], e_p, finite, worst))
+    assert out["bf16x3"][3] > 65504.0, "the model of this test must leave f16's range"
+    assert (not out["f16x3"][1]) or out["f16x3"][0] > 1e-2          # the stated limit is real ...
+    e_p, finite, worst, _ = out["bf16x3"]
+    assert finite and e_p <= LOGIT_TOL and worst <= 5e-3             # ... and the bf16 split carries the model through it
+
+
 def test_batched_decode_equals_single_utterances():
     """wn_decode_batch: U utterances side by side in one launch give, row by row, exactly
     the codes of U single-utterance launches (same arithmetic, independent state), with the as-written
