@@ -1022,6 +1022,8 @@ class wavenet_autoencoder(nn.Module):
     def _engine_for(self, device):
         if device.type != "cuda":
             raise RuntimeError("music_amd.wavenet_autoencoder runs on an MI355X (ROCm) device only; there is no CPU path")
+        if not hasattr(self, "precision"):                   # (a module pickled before the attribute existed)
+            self.precision = ("f16x3", "bf16x3")
         eng = self._engine
         p0 = next(self.parameters())
         if eng is None or eng.device != device or p0.data_ptr() != eng.flat.data_ptr() or getattr(eng, "mode_names", None) != tuple(self.precision):
