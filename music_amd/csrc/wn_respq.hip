@@ -807,9 +807,13 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         Ops ops;                                            // (one item ahead: 1.968 vs 1.941 ms for the stack; the conditioned
         constexpr int WD = COND ? 1 : 2;                    // form does that and spends the 32 registers on its bucket sums)
         load_rows(rr, pos_r(0, 0), true);
-        if (WD == 2) load_rows(rr2, pos_r(0, 1), pos_r(0, 1).top);
         convert(ops, rr, pos_r(0, -1));                        // "item -1": zeros (its products meet the zeroed tiles of stage 1)
         __syncthreads();
+        // the SECOND item's rows only now (round 6): every workgroup of a launch starts at once, and what they all request before their first barrier
+        // - 160 KB each, 41 MB per launch - is what that barrier waits 6 us for (the rows it needs arrive with everybody else's prefetch).  These
+        // 32 KB are not needed before iteration 1: stack backward 1.910 -> 1.894, 1.921 -> 1.904 ms (profiles/r06_ab_first_requests.json).  Moving the R
+        // waves' skip-gradient rows behind their first x / dy rows as well, or delaying this role's first requests, gives the gain back.
+        if (WD == 2) load_rows(rr2, pos_r(0, 1), pos_r(0, 1).top);
         // iteration it: products of item it-1 (result tiles of stage (it-1)&1, operands in `ops`); then the raw rows of
         // item it become `ops` and the rows of item it+2 are requested (loop unrolled by two: no register copies)
         // (the conditioned form and the pair-fed chain form have no registers for it; forced on the conditioned form, 12 spilled registers
