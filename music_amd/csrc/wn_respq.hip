@@ -870,8 +870,6 @@ __global__ __launch_bounds__(PQ_THREADS) void resblock_bwd_pq_k(WnResPqArgs a) {
         for (int m = 0; m < 4; ++m)            // 4 consecutive floats of a row per lane: one 16-byte store
             __builtin_nontemporal_store(cd[m], reinterpret_cast<f32x4*>(&sd[(size_t)(16 * g + c) * CH + 16 * m + 4 * q]));
     }
-    if (wv == 4) {
-    }
 }
 
 // slots per workgroup of the conditioning-gradient slabs: a workgroup's items are at most (items_per_wg - 1) x (workgroups of its
