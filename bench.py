@@ -899,6 +899,29 @@ def main():
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port", "sample": "failed",
                                    "error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0:
+        # LAST key, short: the driver keeps the contract keys and the last 2 KB of this line - the side configurations' figures at a glance
+        # (each also sits, with its workload text, under `extra`)
+        def dig(d, *ks):
+            for k in ks:
+                d = d.get(k) if isinstance(d, dict) else None
+            return round(d, 4) if isinstance(d, float) else d
+        ex = out.get("extra", {})
+        out["summary"] = {
+            "c2_ms_per_step": round(out["ms_per_step"], 4), "c2_ms_per_step_median": dig(out, "config", "ms_per_step_median"),
+            "c2_stack_fwd_bwd_frac_of_8TBs": dig(out, "roofline_stack_fwd_bwd", "frac"), "c2_stack_fwd_frac": dig(out, "roofline_stack_fwd", "frac"),
+            "c2_bwd_block_frac": dig(out, "roofline", "frac"),
+            "c4_autoencoder_ms_per_step": dig(ex, "c4_autoencoder", "ms_per_step"), "c4_samples_per_s": dig(ex, "c4_autoencoder", "samples_per_s"),
+            "c4_frac_decoder_fwd": dig(ex, "c4_autoencoder", "roofline_stacks", "frac_decoder_fwd"),
+            "c4_frac_decoder_bwd": dig(ex, "c4_autoencoder", "roofline_stacks", "frac_decoder_bwd"),
+            "c4_frac_encoder_fwd": dig(ex, "c4_autoencoder", "roofline_stacks", "frac_encoder_fwd"),
+            "c4_frac_encoder_bwd": dig(ex, "c4_autoencoder", "roofline_stacks", "frac_encoder_bwd"),
+            "c5_decode_samples_per_s": dig(ex, "c5_decode", "single_stream_samples_per_s"), "c5_batch128_samples_per_s": dig(ex, "c5_decode", "batch128_samples_per_s"),
+            "reference_loop_ms_per_step": dig(ex, "reference_surface_step", "loader_onehot", "ms_per_step"),
+            "shipped_wavenet_ms_per_step": dig(ex, "shipped_params", "wavenet", "ms_per_step"),
+            "shipped_autoencoder_ms_per_step": dig(ex, "shipped_params", "autoencoder", "ms_per_step"),
+            "cpu_baseline_samples_per_s": dig(out, "cpu_baseline", "value"),
+        }
     if use_dist:
         dist.destroy_process_group()
     sys.stdout.flush()
